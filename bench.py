@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - channel-estimates/s of the hot path (LS + DNN real + DNN imag -> complex CSI) on
+MI355X.  One "step" = one pass of the whole path over one batch of synthetic packets that is
+already resident in HBM.
+
+Workload (N = 1): BASELINE.json configs[1] - Nt=32, Nr=4, 500 packets at each of the 8 SNR levels
+{-25..10 dB} = 4000 packets = 512 000 pair-channels per step, shipped model FC 1024x1024 + BN
+(full_pipeline_maMIMO_DNNEst.sh:40,47), fp32.  For N > 1 every rank runs the same per-GPU
+workload on its own packet shard (weak scaling); the weights are broadcast once from rank 0
+over RCCL before the timed region and there is no collective in the data path.
+
+Data: i.i.d. CN(0,1) preambles generated on the device (csi_synth_white) and random-initialised
+weights of the shipped architecture - the reference ships neither datasets nor weights.  The
+arithmetic is data-independent (dense fp32), so noise level does not change the work.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - dominant kernel (pair_dense_gemm) TFLOP/s from HIP events on the library's own
+                 stream, against the 157.3 TFLOP/s fp32 matrix peak of gfx950
+  cpu_baseline - the reference's per-packet naive fp32 loop restated on the host cores
+                 (oracle/cpu_baseline.py), timed on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--nt', type=int, default=32)
+    ap.add_argument('--nr', type=int, default=4)
+    ap.add_argument('--packets', type=int, default=4000, help='packets per GPU per step')
+    ap.add_argument('--hidden', type=int, nargs='+', default=[1024, 1024])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget-s', type=float, default=12.0)
+    ap.add_argument('--no-ls', action='store_true', help='time the DNN only')
+    ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
+    args = ap.parse_args()
+
+    import dl_channel_estimation_mamimo_amd as pkg
+    rank, world, local = pkg.dist.env_rank_world()
+    if world > 1:
+        pkg.dist.init_process_group('nccl')
+    n_gpus = max(args.gpus, world)
+
+    nt, nr, npkt, hidden = args.nt, args.nr, args.packets, tuple(args.hidden)
+    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local)
+
+    # weights: created on rank 0, broadcast as one flat buffer (RCCL over xGMI when world > 1)
+    wts = None
+    if rank == 0:
+        rng = np.random.default_rng(1234)
+        wts = {'real': pkg.synth.make_weights(rng, nt, hidden), 'imag': pkg.synth.make_weights(rng, nt, hidden),
+               'P': {'pilot': pkg.synth.hadamard(nt)}}
+    if world > 1:
+        wts = {k: pkg.dist.broadcast_weights(wts[k] if rank == 0 else None, src=0) for k in ('real', 'imag', 'P')}
+    eng.load_weights('real', wts['real'])
+    eng.load_weights('imag', wts['imag'])
+    eng.set_pilot(wts['P']['pilot'])
+
+    # this rank's packet shard, generated in HBM
+    first = rank * npkt
+    d_re, d_im = eng.empty((npkt, nr, eng.len_ltf)), eng.empty((npkt, nr, eng.len_ltf))
+    eng.synth_white(2024 + 1, first, npkt, d_re, d_im)
+    d_ore, d_oim = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
+    d_hre, d_him = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
+    eng.synchronize()
+
+    def step():
+        if not args.no_ls:
+            eng.ls_estimate_device(d_re, d_im, npkt, d_hre, d_him)
+        eng.predict_device(d_re, d_im, npkt, d_ore, d_oim)
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    eng.profile_enable(True)
+    eng.profile_reset()
+
+    pkg.dist.barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    pkg.dist.barrier()
+    dt = time.perf_counter() - t0
+    dt = pkg.dist.all_reduce_max(dt)
+
+    prof = eng.profile()
+    eng.profile_enable(False)
+    pairs_per_step = npkt * nr * nt * world
+    value = pairs_per_step * args.steps / dt
+
+    # parity spot check after the timed region (never inside it)
+    check = {}
+    if rank == 0 and args.check > 0:
+        from oracle import csi_oracle as o
+        k = min(args.check, npkt)
+        ltf = d_re.download(0, k) + 1j * d_im.download(0, k)
+        r_re, r_im = o.predict_packets(ltf, wts['P']['pilot'], wts['real'], wts['imag'], np.float64, pkt_batch=k)
+        check['dnn_rel_err'] = max(o.row_rel_err(d_ore.download(0, k), r_re), o.row_rel_err(d_oim.download(0, k), r_im))
+        if not args.no_ls:
+            r_ls = o.ls_estimate(ltf, wts['P']['pilot'])
+            check['ls_rel_err'] = max(o.row_rel_err(d_hre.download(0, k), r_ls.real), o.row_rel_err(d_him.download(0, k), r_ls.imag))
+        check['packets'] = k
+
+    if rank != 0:
+        return
+
+    dom = prof['pair_dense_gemm']
+    dom_ms = dom['ms'] / max(dom['launches'], 1)
+    achieved = dom['flops'] / max(dom['ms'], 1e-9) / 1e9          # TFLOP/s
+    kernels = {}
+    for name, p in prof.items():
+        if p['launches']:
+            kernels[name] = dict(launches=p['launches'], ms_total=round(p['ms'], 3),
+                                 ms_avg=round(p['ms'] / p['launches'], 4),
+                                 tflops=round(p['flops'] / max(p['ms'], 1e-9) / 1e9, 2),
+                                 algo_gbs=round(p['bytes'] / max(p['ms'], 1e-9) / 1e6, 1))
+    out = {
+        'metric': 'channel-estimates/sec (Nt=%d,Nr=%d)' % (nt, nr),
+        'value': value,
+        'unit': 'pair-channel estimates/s',
+        'n_gpus': n_gpus,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: Nt=%d Nr=%d, %d packets/GPU/step (8 SNR x 500), LS + DNN(real) + DNN(imag), '
+                               'FC %s + BN, 234 bins' % (nt, nr, npkt, 'x'.join(map(str, hidden))),
+                   'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
+                   'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
+        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                     'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
+        'kernels': kernels,
+        'parity_check': check,
+    }
+    if 'ls_estimate' in kernels:
+        p = prof['ls_estimate']
+        gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
+        out['roofline_ls'] = {'bound': 'hbm', 'kernel': 'ls_estimate', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': gbs / HBM_PEAK_GBS, 'traffic': None}
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline as cb
+        k = min(npkt, 256)
+        ltf = (d_re.download(0, k) + 1j * d_im.download(0, k)).astype(np.complex64)
+        r = cb.time_reference_loop(ltf, wts['P']['pilot'], wts['real'], wts['imag'], budget_s=args.cpu_budget_s)
+        out['cpu_baseline'] = {
+            'value': r['pairs_per_s'], 'unit': 'pair-channel estimates/s', 'cores': r['threads'], 'kind': 'port',
+            'sample': '%d packets one by one (batch = Nt*Nr rows, naive un-shared fp32 network, torch-CPU sgemm, '
+                      'real then imag model) + numpy LS; median per-packet latency; host cpu_count=%d'
+                      % (r['packets'], os.cpu_count()),
+            'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'],
+            'gpu_over_cpu': value / r['pairs_per_s']}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,118 @@
+"""ctypes binding of include/csi_mamimo.h (the C-ABI of the HIP library).
+
+The binding is deliberately thin: one Python attribute per exported symbol, argument types
+copied from the header.  ``load_library()`` raises ``CsiError`` when the shared object has not
+been built - the product path never falls back to a CPU implementation."""
+import ctypes
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG_DIR)
+_SO = os.path.join(_PKG_DIR, 'libcsi_mamimo.so')
+_SRC = os.path.join(_PKG_DIR, 'csrc', 'csi_mamimo.hip')
+
+CSI_MAX_HIDDEN = 8
+CSI_ABI_VERSION = 1
+CSI_DTYPE_F32 = 0
+CSI_DTYPE_BF16 = 1
+
+STATUS_NAMES = {0: 'CSI_OK', -1: 'CSI_ERR_INVALID_ARG', -2: 'CSI_ERR_NOT_READY', -3: 'CSI_ERR_HIP',
+                -4: 'CSI_ERR_NO_DEVICE', -5: 'CSI_ERR_NOMEM'}
+
+
+class CsiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'{STATUS_NAMES.get(code, code)}: {msg}')
+        self.code = code
+
+
+class CsiConfig(ctypes.Structure):
+    _fields_ = [('nt', ctypes.c_int32), ('nr', ctypes.c_int32), ('len_ltf', ctypes.c_int32),
+                ('n_hidden', ctypes.c_int32), ('hidden', ctypes.c_int32 * CSI_MAX_HIDDEN),
+                ('n_out', ctypes.c_int32), ('use_bn', ctypes.c_int32), ('bn_eps', ctypes.c_float),
+                ('dtype', ctypes.c_int32), ('device', ctypes.c_int32), ('workspace_bytes', ctypes.c_int64)]
+
+
+class CsiTensor(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char_p), ('data', ctypes.POINTER(ctypes.c_float)),
+                ('rows', ctypes.c_int64), ('cols', ctypes.c_int64)]
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_ctx = ctypes.c_void_p
+
+# symbol -> (restype, argtypes); must list every function declared in include/csi_mamimo.h
+SYMBOLS = {
+    'csi_abi_version': (ctypes.c_int, []),
+    'csi_create': (ctypes.c_int, [ctypes.POINTER(CsiConfig), ctypes.POINTER(_ctx)]),
+    'csi_destroy': (None, [_ctx]),
+    'csi_last_error': (ctypes.c_char_p, [_ctx]),
+    'csi_load_weights': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(CsiTensor), ctypes.c_int]),
+    'csi_set_pilot': (ctypes.c_int, [_ctx, _fp]),
+    'csi_predict': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, _fp]),
+    'csi_predict_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'csi_predict_samples': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, ctypes.c_int64, _fp]),
+    'csi_ls_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, _fp]),
+    'csi_ls_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'csi_synchronize': (ctypes.c_int, [_ctx]),
+    'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),
+    'csi_device_free': (ctypes.c_int, [_ctx, _vp]),
+    'csi_memcpy_h2d': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64]),
+    'csi_memcpy_d2h': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64]),
+    'csi_synth_white': (ctypes.c_int, [_ctx, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, _vp, _vp]),
+    'csi_profile_enable': (ctypes.c_int, [_ctx, ctypes.c_int]),
+    'csi_profile_reset': (ctypes.c_int, [_ctx]),
+    'csi_profile_num_kernels': (ctypes.c_int, []),
+    'csi_profile_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
+    'csi_profile_query': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/csi_mamimo.hip for gfx950 into the in-tree shared object (hipcc
+    cross-compiles without a GPU).  Returns the path."""
+    srcs = [_SRC] + [os.path.join(_PKG_DIR, 'csrc', f) for f in os.listdir(os.path.join(_PKG_DIR, 'csrc'))]
+    srcs.append(os.path.join(_REPO, 'include', 'csi_mamimo.h'))
+    if not force and os.path.exists(_SO):
+        so_m = os.path.getmtime(_SO)
+        if all(os.path.getmtime(s) <= so_m for s in srcs if os.path.exists(s)):
+            return _SO
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
+           _SRC, '-o', _SO]
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if res.returncode != 0:
+        raise RuntimeError('hipcc failed:\n' + res.stdout)
+    return _SO
+
+
+def load_library():
+    """dlopen the HIP library and attach prototypes.  Raises CsiError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CsiError(-4, f'{_SO} not found: build it with __graft_entry__.build() '
+                           f'(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    lib = ctypes.CDLL(_SO)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.csi_abi_version()
+    if ver != CSI_ABI_VERSION:
+        raise CsiError(-1, f'ABI version mismatch: library {ver}, binding {CSI_ABI_VERSION}')
+    _lib = lib
+    return lib

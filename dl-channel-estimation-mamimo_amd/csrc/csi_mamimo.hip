@@ -1,0 +1,811 @@
+// csi_mamimo.hip - C-ABI (include/csi_mamimo.h) and host-side orchestration of the MI355X
+// channel-estimation hot path.  gfx950 only; built with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csi_mamimo.hip -o libcsi_mamimo.so
+//
+// What runs where (reference call sites in include/csi_mamimo.h):
+//   csi_predict*        layer 0 once per (packet, rx)  -> gemm_f32_kernel<A_PLAIN, EPI_RAW> (split-K)
+//                       (+ splitk_reduce_kernel)          then per pair (packet, rx, tx):
+//                       hidden 1.. and regressor       -> gemm_f32_kernel<A_PAIR|A_PLAIN, ...>
+//   csi_predict_samples literal un-shared network      -> gemm_f32_kernel<A_PLAIN, ...>
+//   csi_ls_estimate*    FFT + despread                 -> ls_estimate_kernel
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/csi_mamimo.h"
+#include "gemm_f32.hip.h"
+#include "ls_estimate.hip.h"
+
+using namespace csi;
+
+namespace {
+
+enum KernelId {
+    K_LAYER0_LTF = 0,    // layer 0, LTF part, once per (packet, rx)
+    K_SPLITK_REDUCE,     // deterministic split-K combine of layer 0
+    K_PAIR_DENSE,        // first per-pair layer, h1 generated in the prologue  (dominant)
+    K_DENSE_HIDDEN,      // further hidden layers
+    K_REGRESSOR,         // fc_regressor
+    K_LS_ESTIMATE,       // FFT + despread
+    K_NAIVE_DENSE0,      // un-shared layer 0 of csi_predict_samples
+    K_SYNTH_WHITE,
+    K_PILOT_TABLE,
+    K_COUNT
+};
+const char* const kKernelNames[K_COUNT] = {
+    "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
+    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table"};
+
+thread_local std::string g_create_error;
+
+struct Layer {
+    float* Wt = nullptr;      // [out][in]  (K-major)
+    float* bias = nullptr;    // [out]
+    float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
+    float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
+    int in = 0, out = 0;
+};
+
+struct Model {
+    std::vector<Layer> layers;   // n_hidden dense layers + regressor (last)
+    float* W0p = nullptr;        // [nt][H1] pilot rows of fc_dense0.kernel, row-major
+    float* T = nullptr;          // [nt][H1] pilot table incl. bias
+    bool loaded = false;
+    bool table_ok = false;
+};
+
+struct ProfSpan {
+    int id;
+    hipEvent_t beg, end;
+};
+
+}  // namespace
+
+struct csi_ctx {
+    csi_config cfg;
+    int d_in = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Model model[2];
+    float* P = nullptr;          // device [nt][nt]
+    bool pilot_ok = false;
+    // LS constants
+    float* tw = nullptr;         // [2][256]
+    int* bin_pos = nullptr;      // [234]
+    float* denom = nullptr;      // [234]
+    // activation workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // staging for host-buffer entry points
+    char* stage = nullptr;
+    size_t stage_bytes = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[K_COUNT] = {0};
+    int64_t prof_launches[K_COUNT] = {0};
+    double prof_flops[K_COUNT] = {0};
+    double prof_bytes[K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(csi_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, CSI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+struct ProfScope {
+    csi_ctx* c;
+    bool on;
+    ProfSpan sp;
+    ProfScope(csi_ctx* ctx, int id, double flops, double bytes) : c(ctx), on(ctx->prof_on) {
+        if (!on) return;
+        sp.id = id;
+        sp.beg = take();
+        sp.end = take();
+        c->prof_launches[id] += 1;
+        c->prof_flops[id] += flops;
+        c->prof_bytes[id] += bytes;
+        hipEventRecord(sp.beg, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(sp.end, c->stream);
+        c->spans.push_back(sp);
+    }
+    hipEvent_t take() {
+        if (!c->ev_pool.empty()) {
+            hipEvent_t e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+};
+
+int prof_collect(csi_ctx* c) {
+    if (c->spans.empty()) return CSI_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.beg, sp.end) == hipSuccess) c->prof_ms[sp.id] += ms;
+        c->ev_pool.push_back(sp.beg);
+        c->ev_pool.push_back(sp.end);
+    }
+    c->spans.clear();
+    return CSI_OK;
+}
+
+int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {
+    if (*have >= need) return CSI_OK;
+    if (*buf) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    if (hipMalloc((void**)buf, need) != hipSuccess) {
+        *buf = nullptr;
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", need);
+    }
+    *have = need;
+    return CSI_OK;
+}
+
+int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess)
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", n * sizeof(float));
+    HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return CSI_OK;
+}
+
+void free_layer(Layer& l) {
+    if (l.Wt) hipFree(l.Wt);
+    if (l.bias) hipFree(l.bias);
+    if (l.scale) hipFree(l.scale);
+    if (l.shift) hipFree(l.shift);
+    l = Layer();
+}
+
+void free_model(Model& m) {
+    for (auto& l : m.layers) free_layer(l);
+    m.layers.clear();
+    if (m.W0p) hipFree(m.W0p);
+    if (m.T) hipFree(m.T);
+    m.W0p = m.T = nullptr;
+    m.loaded = m.table_ok = false;
+}
+
+const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& name) {
+    for (int i = 0; i < n; ++i)
+        if (t[i].name && name == t[i].name) return &t[i];
+    return nullptr;
+}
+
+// ---------------------------------------------------------------- GEMM launch helpers
+template <int AMODE, int EPI>
+int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
+    if (g.M <= 0) return CSI_OK;
+    if ((g.K & 3) || (g.lda & 3) || (g.ldb & 3))
+        return fail(c, CSI_ERR_INVALID_ARG, "gemm: K/lda/ldb must be multiples of 4 (K=%d lda=%d ldb=%d)",
+                    g.K, g.lda, g.ldb);
+    const int tiles_m = (g.M + G_BM - 1) / G_BM;
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double a_rows = (AMODE == A_PAIR) ? (double)g.M / g.nt : (double)g.M;
+    const double bytes = 4.0 * (a_rows * g.K + (double)g.N * g.K + (double)g.M * g.N * splits);
+    ProfScope ps(c, kid, flops, bytes);
+    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int choose_splits(int M, int N, int K, int* k_per_split) {
+    const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    long s = 1024 / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > 8) s = 8;
+    const int ktiles = (K + G_BK - 1) / G_BK;
+    if (s > ktiles) s = ktiles;
+    int kps = (int)((ktiles + s - 1) / s) * G_BK;
+    int splits = (K + kps - 1) / kps;
+    *k_per_split = kps;
+    return splits;
+}
+
+int build_pilot_table(csi_ctx* c, Model& m) {
+    if (!m.loaded || !c->pilot_ok || c->cfg.nt == 0) return CSI_OK;
+    const int nt = c->cfg.nt, h1 = c->cfg.hidden[0];
+    if (!m.T) {
+        if (hipMalloc((void**)&m.T, (size_t)nt * h1 * sizeof(float)) != hipSuccess)
+            return fail(c, CSI_ERR_NOMEM, "pilot table allocation failed");
+    }
+    ProfScope ps(c, K_PILOT_TABLE, 2.0 * nt * nt * h1, 4.0 * (nt * nt + 2.0 * nt * h1));
+    hipLaunchKernelGGL(pilot_table_kernel, dim3((h1 + 255) / 256, nt), dim3(256), 0, c->stream,
+                       c->P, m.W0p, m.layers[0].bias, m.T, nt, h1);
+    HIP_TRY(c, hipGetLastError());
+    m.table_ok = true;
+    return CSI_OK;
+}
+
+// ---------------------------------------------------------------- DNN, shared layer 0
+// d_ltf: [npkt][nr][len_ltf] one component plane; d_out: [npkt][nr][nt][n_out]
+int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float* d_out) {
+    const csi_config& cf = c->cfg;
+    const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
+    int maxh = 0;
+    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    const int smax = 8;
+    const size_t per_pkt = (size_t)nr * h1 * 4 * (smax + 1) +
+                           (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
+    size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)1 << 30);
+    int64_t chunk = (int64_t)(budget / per_pkt);
+    if (chunk < 1) chunk = 1;
+    if (chunk > npkt) chunk = npkt;
+    // keep M = chunk*nr*nt inside int range
+    const int64_t max_chunk = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);
+    if (chunk > max_chunk) chunk = max_chunk;
+    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_pkt * (size_t)chunk);
+    if (rc) return rc;
+
+    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
+        const int64_t np = std::min(chunk, npkt - p0);
+        const int M1 = (int)(np * nr);
+        const int M2 = (int)(np * nr * nt);
+        float* slabs = reinterpret_cast<float*>(c->ws);
+        float* l0sum = slabs + (size_t)chunk * nr * h1 * smax;
+        float* hbuf[2];
+        hbuf[0] = l0sum + (size_t)chunk * nr * h1;
+        hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh;
+
+        // layer 0, LTF part: L0[M1][h1] = ltf[M1][len_ltf] * W0[0:len_ltf, :]
+        int kps = 0;
+        const int splits = choose_splits(M1, h1, cf.len_ltf, &kps);
+        GemmArgs g{};
+        g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
+        g.lda = cf.len_ltf;
+        g.Bt = m.layers[0].Wt;
+        g.ldb = c->d_in;
+        g.C = slabs;
+        g.ldc = h1;
+        g.M = M1; g.N = h1; g.K = cf.len_ltf;
+        g.k_per_split = kps;
+        rc = launch_gemm<A_PLAIN, EPI_RAW>(c, K_LAYER0_LTF, g, splits);
+        if (rc) return rc;
+        const float* l0 = slabs;
+        if (splits > 1) {
+            const size_t n4 = (size_t)M1 * h1 / 4;
+            ProfScope ps(c, K_SPLITK_REDUCE, (double)(splits - 1) * M1 * h1, 4.0 * (splits + 1) * M1 * h1);
+            const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 4096);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, slabs, l0sum, n4, splits);
+            HIP_TRY(c, hipGetLastError());
+            l0 = l0sum;
+        }
+
+        // first per-pair layer: h1 generated in the prologue from L0 + T
+        float* out_chunk = d_out + (size_t)p0 * nr * nt * cf.n_out;
+        GemmArgs p{};
+        p.A = l0; p.lda = h1;
+        p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = m.layers[0].shift; p.nt = nt;
+        p.M = M2; p.K = h1;
+        const Layer& l1 = m.layers[1];
+        p.Bt = l1.Wt; p.ldb = l1.in; p.N = l1.out;
+        p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
+        p.k_per_split = ((h1 + G_BK - 1) / G_BK) * G_BK;
+        if (nh == 1) {
+            p.C = out_chunk; p.ldc = cf.n_out;
+            rc = launch_gemm<A_PAIR, EPI_BIAS>(c, K_REGRESSOR, p, 1);
+            if (rc) return rc;
+            continue;
+        }
+        p.C = hbuf[0]; p.ldc = l1.out;
+        rc = launch_gemm<A_PAIR, EPI_BIAS_RELU_AFFINE>(c, K_PAIR_DENSE, p, 1);
+        if (rc) return rc;
+        int cur = 0;
+        for (int li = 2; li <= nh; ++li) {
+            const Layer& l = m.layers[li];
+            GemmArgs q{};
+            q.A = hbuf[cur]; q.lda = l.in;
+            q.Bt = l.Wt; q.ldb = l.in;
+            q.M = M2; q.N = l.out; q.K = l.in;
+            q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+            q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
+            if (li == nh) {
+                q.C = out_chunk; q.ldc = cf.n_out;
+                rc = launch_gemm<A_PLAIN, EPI_BIAS>(c, K_REGRESSOR, q, 1);
+            } else {
+                q.C = hbuf[cur ^ 1]; q.ldc = l.out;
+                rc = launch_gemm<A_PLAIN, EPI_BIAS_RELU_AFFINE>(c, K_DENSE_HIDDEN, q, 1);
+                cur ^= 1;
+            }
+            if (rc) return rc;
+        }
+    }
+    return CSI_OK;
+}
+
+int check_ready(csi_ctx* c, bool need_models, int model = -1) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): only csi_predict_samples is available");
+    if (!c->pilot_ok) return fail(c, CSI_ERR_NOT_READY, "csi_set_pilot has not been called");
+    if (need_models) {
+        for (int d = 0; d < 2; ++d) {
+            if (model >= 0 && d != model) continue;
+            if (!c->model[d].loaded)
+                return fail(c, CSI_ERR_NOT_READY, "weights of the %s model are not loaded", d ? "imag" : "real");
+            if (!c->model[d].table_ok) {
+                int rc = build_pilot_table(c, c->model[d]);
+                if (rc) return rc;
+            }
+        }
+    }
+    return CSI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int csi_abi_version(void) { return CSI_ABI_VERSION; }
+
+const char* csi_last_error(const csi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int csi_create(const csi_config* cfg, csi_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: null argument");
+    *out = nullptr;
+    if (cfg->nt < 0 || cfg->nr < 1 || cfg->n_out < 1 || cfg->n_hidden < 1 || cfg->n_hidden > CSI_MAX_HIDDEN)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: bad shape nt=%d nr=%d n_hidden=%d n_out=%d",
+                    cfg->nt, cfg->nr, cfg->n_hidden, cfg->n_out);
+    // nt == 0: single-input model without pilot input (DNN.py:180,234); csi_predict_samples only
+    if (cfg->nt > 0 && cfg->len_ltf != LS_SYM * cfg->nt)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: len_ltf (%d) must be 320*nt (%d)", cfg->len_ltf,
+                    LS_SYM * cfg->nt);
+    if (cfg->nt == 0 && (cfg->len_ltf < 4 || cfg->len_ltf % 4))
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: single-input width %d must be a positive multiple of 4", cfg->len_ltf);
+    if (cfg->nt % 4)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: nt must be a multiple of 4 (16-byte rows), got %d", cfg->nt);
+    for (int i = 0; i < cfg->n_hidden; ++i)
+        if (cfg->hidden[i] < 4 || cfg->hidden[i] % 4)
+            return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: hidden[%d]=%d must be a positive multiple of 4", i,
+                        cfg->hidden[i]);
+    if (cfg->dtype != CSI_DTYPE_F32)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: dtype %d not available in this build (fp32 only)", cfg->dtype);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, CSI_ERR_NO_DEVICE, "csi_create: no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: device %d out of range (%d visible)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, CSI_ERR_HIP, "csi_create: hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CSI_ERR_NO_DEVICE, "csi_create: device %d is %s; this library is built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+
+    csi_ctx* c = new csi_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
+    c->d_in = cfg->len_ltf + cfg->nt;
+    auto bail = [&](int code) {
+        g_create_error = c->err;
+        csi_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(cfg->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(CSI_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "hipStreamCreate failed";
+        return bail(CSI_ERR_HIP);
+    }
+    // LS constants.  Twiddles in double on the host so the table is correctly rounded.
+    std::vector<float> tw(2 * LS_FFT);
+    for (int u = 0; u < LS_FFT; ++u) {
+        const double ang = -2.0 * M_PI * u / LS_FFT;
+        tw[u] = (float)std::cos(ang);
+        tw[LS_FFT + u] = (float)std::sin(ang);
+    }
+    // VHT-LTF literal of helperMIMOChannelEstimate.m:16-23 and the data-bin list of
+    // generate_maMIMO_LTF.m:98-102, in fftshift-ed (1-based MATLAB) bin order.
+    static const int ltfL[26] = {1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1};
+    static const int ltfR[26] = {1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1};
+    static const int midA[11] = {-1, -1, -1, 1, 1, -1, 1, -1, 1, 1, -1};
+    static const int midB[9] = {1, -1, 1, -1, 0, 1, -1, -1, 1};
+    std::vector<int> ltf;
+    auto push = [&](const int* v, int n) { ltf.insert(ltf.end(), v, v + n); };
+    auto seg = [&]() { push(ltfL, 26); ltf.push_back(1); push(ltfR, 26); };
+    ltf.assign(7, 0);
+    seg(); push(midA, 11); seg(); push(midB, 9); seg(); push(midA, 11); seg();
+    ltf.insert(ltf.end(), 6, 0);
+    if ((int)ltf.size() != LS_FFT) { c->err = "internal: LTF literal length"; return bail(CSI_ERR_INVALID_ARG); }
+    static const int pilots[8] = {26, 54, 90, 118, 140, 168, 204, 232};
+    std::vector<int> bin_pos;
+    std::vector<float> denom;
+    for (int k1 = 1; k1 <= LS_FFT; ++k1) {
+        bool skip = (k1 <= 7) || (k1 == 129) || (k1 >= 251);
+        for (int pk : pilots) skip = skip || (k1 == pk);
+        if (skip) continue;
+        bin_pos.push_back((k1 - 1 + LS_FFT / 2) % LS_FFT);      // undo fftshift: shifted index -> FFT bin
+        denom.push_back((float)cfg->nt * (float)ltf[k1 - 1]);
+    }
+    if ((int)bin_pos.size() != LS_NDATA) { c->err = "internal: data-bin count"; return bail(CSI_ERR_INVALID_ARG); }
+    if (upload(c, &c->tw, tw.data(), tw.size())) return bail(CSI_ERR_HIP);
+    if (upload(c, &c->denom, denom.data(), denom.size())) return bail(CSI_ERR_HIP);
+    if (hipMalloc((void**)&c->bin_pos, LS_NDATA * sizeof(int)) != hipSuccess ||
+        hipMemcpy(c->bin_pos, bin_pos.data(), LS_NDATA * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        c->err = "bin table upload failed";
+        return bail(CSI_ERR_HIP);
+    }
+    const size_t ls_lds = (size_t)(cfg->nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+    if (cfg->nt > 0 && ls_lds <= 160 * 1024) {
+        if (hipFuncSetAttribute((const void*)ls_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ls_lds) != hipSuccess) {
+            c->err = "hipFuncSetAttribute(ls_estimate_kernel) failed";
+            return bail(CSI_ERR_HIP);
+        }
+    }
+    *out = c;
+    return CSI_OK;
+}
+
+void csi_destroy(csi_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& sp : c->spans) { hipEventDestroy(sp.beg); hipEventDestroy(sp.end); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    free_model(c->model[0]);
+    free_model(c->model[1]);
+    if (c->P) hipFree(c->P);
+    if (c->tw) hipFree(c->tw);
+    if (c->bin_pos) hipFree(c->bin_pos);
+    if (c->denom) hipFree(c->denom);
+    if (c->ws) hipFree(c->ws);
+    if (c->stage) hipFree(c->stage);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (model < 0 || model > 1 || !tensors || n <= 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_load_weights: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const csi_config& cf = c->cfg;
+    Model& m = c->model[model];
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_model(m);
+    m.layers.resize(cf.n_hidden + 1);
+    int fan_in = c->d_in;
+    for (int li = 0; li <= cf.n_hidden; ++li) {
+        const bool reg = li == cf.n_hidden;
+        const std::string base = reg ? std::string("fc_regressor") : "fc_dense" + std::to_string(li);
+        const int out = reg ? cf.n_out : cf.hidden[li];
+        const csi_tensor* k = find_tensor(tensors, n, base + ".kernel");
+        const csi_tensor* b = find_tensor(tensors, n, base + ".bias");
+        if (!k || !b || !k->data || !b->data) return fail(c, CSI_ERR_INVALID_ARG, "csi_load_weights: missing %s.kernel/.bias", base.c_str());
+        if (k->rows != fan_in || k->cols != out || b->rows * b->cols != out)
+            return fail(c, CSI_ERR_INVALID_ARG, "csi_load_weights: %s.kernel is [%lld,%lld], expected [%d,%d]", base.c_str(),
+                        (long long)k->rows, (long long)k->cols, fan_in, out);
+        Layer& L = m.layers[li];
+        L.in = fan_in;
+        L.out = out;
+        // transpose [in][out] -> [out][in] (K-major) on the host, blocked for cache friendliness
+        std::vector<float> wt((size_t)out * fan_in);
+        const int TB = 32;
+        for (int i0 = 0; i0 < fan_in; i0 += TB)
+            for (int o0 = 0; o0 < out; o0 += TB)
+                for (int i = i0; i < std::min(fan_in, i0 + TB); ++i)
+                    for (int o = o0; o < std::min(out, o0 + TB); ++o) wt[(size_t)o * fan_in + i] = k->data[(size_t)i * out + o];
+        int rc = upload(c, &L.Wt, wt.data(), wt.size());
+        if (rc) return rc;
+        rc = upload(c, &L.bias, b->data, out);
+        if (rc) return rc;
+        std::vector<float> sc(out, 1.f), sh(out, 0.f);
+        if (!reg && cf.use_bn) {
+            const std::string bn = "bn" + std::to_string(li);
+            const csi_tensor* ga = find_tensor(tensors, n, bn + ".gamma");
+            const csi_tensor* be = find_tensor(tensors, n, bn + ".beta");
+            const csi_tensor* mu = find_tensor(tensors, n, bn + ".moving_mean");
+            const csi_tensor* va = find_tensor(tensors, n, bn + ".moving_variance");
+            if (!ga || !be || !mu || !va) return fail(c, CSI_ERR_INVALID_ARG, "csi_load_weights: missing %s.* (use_bn=1)", bn.c_str());
+            for (const csi_tensor* t : {ga, be, mu, va})
+                if (!t->data || t->rows * t->cols != out)
+                    return fail(c, CSI_ERR_INVALID_ARG, "csi_load_weights: %s.* must have %d elements", bn.c_str(), out);
+            for (int o = 0; o < out; ++o) {
+                // keras non-fused inference: inv = rsqrt(var + eps) * gamma; y = x*inv + (beta - mean*inv)
+                const float inv = (1.0f / std::sqrt(va->data[o] + cf.bn_eps)) * ga->data[o];
+                sc[o] = inv;
+                sh[o] = be->data[o] - mu->data[o] * inv;
+            }
+        }
+        if (!reg) {
+            rc = upload(c, &L.scale, sc.data(), out);
+            if (rc) return rc;
+            rc = upload(c, &L.shift, sh.data(), out);
+            if (rc) return rc;
+        }
+        if (li == 0 && cf.nt > 0) {
+            // pilot rows of fc_dense0.kernel, [nt][h1] row-major as stored
+            rc = upload(c, &m.W0p, k->data + (size_t)cf.len_ltf * out, (size_t)cf.nt * out);
+            if (rc) return rc;
+        }
+        fan_in = out;
+    }
+    m.loaded = true;
+    m.table_ok = false;
+    return build_pilot_table(c, m);
+}
+
+int csi_set_pilot(csi_ctx* c, const float* P) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!P || c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_set_pilot: null P or single-input context");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = upload(c, &c->P, P, (size_t)c->cfg.nt * c->cfg.nt);
+    if (rc) return rc;
+    c->pilot_ok = true;
+    for (int d = 0; d < 2; ++d) {
+        c->model[d].table_ok = false;
+        rc = build_pilot_table(c, c->model[d]);
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
+int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_out_re,
+                       float* d_out_im) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!d_ltf_re || !d_ltf_im || !d_out_re || !d_out_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_predict_device: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    rc = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+    if (rc) return rc;
+    return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+}
+
+int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_h_re,
+                           float* d_h_im) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!d_ltf_re || !d_ltf_im || !d_h_re || !d_h_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate_device: bad argument");
+    if (npkt == 0) return CSI_OK;
+    const csi_config& cf = c->cfg;
+    const size_t lds = (size_t)(cf.nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate: nt=%d needs %zu B of LDS (>160 KiB); not supported yet", cf.nt, lds);
+    HIP_TRY(c, hipSetDevice(cf.device));
+    const int64_t nblk = npkt * cf.nr;
+    LsArgs a{};
+    a.P = c->P; a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
+    a.nt = cf.nt; a.len_ltf = cf.len_ltf;
+    const int64_t max_grid = 1 << 30;
+    for (int64_t b0 = 0; b0 < nblk; b0 += max_grid) {
+        const int64_t nb = std::min(max_grid, nblk - b0);
+        a.ltf_re = d_ltf_re + (size_t)b0 * cf.len_ltf;
+        a.ltf_im = d_ltf_im + (size_t)b0 * cf.len_ltf;
+        a.h_re = d_h_re + (size_t)b0 * cf.nt * LS_NDATA;
+        a.h_im = d_h_im + (size_t)b0 * cf.nt * LS_NDATA;
+        const double pairs = (double)nb * cf.nt;
+        ProfScope ps(c, K_LS_ESTIMATE, pairs * (10240.0 + 8.0 * LS_NDATA * cf.nt), pairs * (2560.0 + 1872.0));
+        hipLaunchKernelGGL(ls_estimate_kernel, dim3((unsigned)nb), dim3(LS_THREADS), lds, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return CSI_OK;
+}
+
+int csi_synchronize(csi_ctx* c) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+// ---- host-buffer entry points: stage through device memory in packet chunks
+static int host_packets(csi_ctx* c, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im,
+                        int n_out, bool ls) {
+    const csi_config& cf = c->cfg;
+    const size_t in_pkt = (size_t)cf.nr * cf.len_ltf * sizeof(float);
+    const size_t out_pkt = (size_t)cf.nr * cf.nt * n_out * sizeof(float);
+    int64_t chunk = std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)(2 * (in_pkt + out_pkt)));
+    chunk = std::min(chunk, npkt);
+    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, 2 * (in_pkt + out_pkt) * (size_t)chunk);
+    if (rc) return rc;
+    float* d_re = reinterpret_cast<float*>(c->stage);
+    float* d_im = reinterpret_cast<float*>(c->stage + in_pkt * chunk);
+    float* d_ore = reinterpret_cast<float*>(c->stage + 2 * in_pkt * chunk);
+    float* d_oim = reinterpret_cast<float*>(c->stage + 2 * in_pkt * chunk + out_pkt * chunk);
+    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
+        const int64_t np = std::min(chunk, npkt - p0);
+        HIP_TRY(c, hipMemcpyAsync(d_re, re + (size_t)p0 * cf.nr * cf.len_ltf, in_pkt * np, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_im, im + (size_t)p0 * cf.nr * cf.len_ltf, in_pkt * np, hipMemcpyHostToDevice, c->stream));
+        rc = ls ? csi_ls_estimate_device(c, d_re, d_im, np, d_ore, d_oim) : csi_predict_device(c, d_re, d_im, np, d_ore, d_oim);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(o_re + (size_t)p0 * cf.nr * cf.nt * n_out, d_ore, out_pkt * np, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o_im + (size_t)p0 * cf.nr * cf.nt * n_out, d_oim, out_pkt * np, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CSI_OK;
+}
+
+int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* out_re, float* out_im) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!ltf_re || !ltf_im || !out_re || !out_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_predict: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
+}
+
+int csi_ls_estimate(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* h_re, float* h_im) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!ltf_re || !ltf_im || !h_re || !h_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return host_packets(c, ltf_re, ltf_im, npkt, h_re, h_im, LS_NDATA, true);
+}
+
+int csi_predict_samples(csi_ctx* c, int model, const float* x, int64_t B, float* y) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (model < 0 || model > 1) return fail(c, CSI_ERR_INVALID_ARG, "csi_predict_samples: model must be 0 or 1");
+    Model& m = c->model[model];
+    if (!m.loaded) return fail(c, CSI_ERR_NOT_READY, "weights of the %s model are not loaded", model ? "imag" : "real");
+    if (B < 0 || (B > 0 && (!x || !y))) return fail(c, CSI_ERR_INVALID_ARG, "csi_predict_samples: bad argument");
+    if (B == 0) return CSI_OK;
+    const csi_config& cf = c->cfg;
+    HIP_TRY(c, hipSetDevice(cf.device));
+    int maxh = 0;
+    for (int i = 0; i < cf.n_hidden; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    const size_t per_row = ((size_t)c->d_in + 2 * (size_t)maxh + cf.n_out) * sizeof(float);
+    int64_t chunk = std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)per_row);
+    chunk = std::min(chunk, B);
+    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, per_row * (size_t)chunk);
+    if (rc) return rc;
+    float* d_x = reinterpret_cast<float*>(c->stage);
+    float* hb[2];
+    hb[0] = d_x + (size_t)chunk * c->d_in;
+    hb[1] = hb[0] + (size_t)chunk * maxh;
+    float* d_y = hb[1] + (size_t)chunk * maxh;
+    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
+        const int64_t nb = std::min(chunk, B - r0);
+        HIP_TRY(c, hipMemcpyAsync(d_x, x + (size_t)r0 * c->d_in, (size_t)nb * c->d_in * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        const float* cur = d_x;
+        int cur_ld = c->d_in, w = 0;
+        for (int li = 0; li <= cf.n_hidden; ++li) {
+            const Layer& l = m.layers[li];
+            GemmArgs q{};
+            q.A = cur; q.lda = cur_ld;
+            q.Bt = l.Wt; q.ldb = l.in;
+            q.M = (int)nb; q.N = l.out; q.K = l.in;
+            q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+            q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
+            if (li == cf.n_hidden) {
+                q.C = d_y; q.ldc = cf.n_out;
+                rc = launch_gemm<A_PLAIN, EPI_BIAS>(c, K_REGRESSOR, q, 1);
+            } else {
+                q.C = hb[w]; q.ldc = l.out;
+                rc = launch_gemm<A_PLAIN, EPI_BIAS_RELU_AFFINE>(c, li == 0 ? K_NAIVE_DENSE0 : K_DENSE_HIDDEN, q, 1);
+                cur = hb[w];
+                cur_ld = l.out;
+                w ^= 1;
+            }
+            if (rc) return rc;
+        }
+        HIP_TRY(c, hipMemcpyAsync(y + (size_t)r0 * cf.n_out, d_y, (size_t)nb * cf.n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CSI_OK;
+}
+
+// ---- device memory plumbing
+int csi_device_malloc(csi_ctx* c, void** dptr, int64_t bytes) {
+    if (!c || !dptr || bytes < 0) return c ? fail(c, CSI_ERR_INVALID_ARG, "csi_device_malloc: bad argument") : CSI_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    *dptr = nullptr;
+    if (bytes == 0) return CSI_OK;
+    if (hipMalloc(dptr, (size_t)bytes) != hipSuccess) {
+        *dptr = nullptr;
+        return fail(c, CSI_ERR_NOMEM, "csi_device_malloc: %lld bytes failed", (long long)bytes);
+    }
+    return CSI_OK;
+}
+
+int csi_device_free(csi_ctx* c, void* dptr) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!dptr) return CSI_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(dptr));
+    return CSI_OK;
+}
+
+int csi_memcpy_h2d(csi_ctx* c, void* dst_dev, const void* src_host, int64_t bytes) {
+    if (!c || bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) return c ? fail(c, CSI_ERR_INVALID_ARG, "csi_memcpy_h2d: bad argument") : CSI_ERR_INVALID_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+int csi_memcpy_d2h(csi_ctx* c, void* dst_host, const void* src_dev, int64_t bytes) {
+    if (!c || bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) return c ? fail(c, CSI_ERR_INVALID_ARG, "csi_memcpy_d2h: bad argument") : CSI_ERR_INVALID_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+int csi_synth_white(csi_ctx* c, uint64_t seed, int64_t first_pkt, int64_t npkt, float* d_re, float* d_im) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (npkt < 0 || first_pkt < 0 || (npkt > 0 && (!d_re || !d_im))) return fail(c, CSI_ERR_INVALID_ARG, "csi_synth_white: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t per_pkt = (size_t)c->cfg.nr * c->cfg.len_ltf;
+    const size_t n = per_pkt * (size_t)npkt;
+    ProfScope ps(c, K_SYNTH_WHITE, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(synth_white_kernel, dim3(2048), dim3(256), 0, c->stream, seed, (uint64_t)first_pkt * per_pkt, n, d_re, d_im);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// ---- profiling
+int csi_profile_enable(csi_ctx* c, int on) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    int rc = prof_collect(c);
+    c->prof_on = on != 0;
+    return rc;
+}
+
+int csi_profile_reset(csi_ctx* c) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    int rc = prof_collect(c);
+    for (int i = 0; i < K_COUNT; ++i) {
+        c->prof_ms[i] = 0;
+        c->prof_launches[i] = 0;
+        c->prof_flops[i] = 0;
+        c->prof_bytes[i] = 0;
+    }
+    return rc;
+}
+
+int csi_profile_num_kernels(void) { return K_COUNT; }
+
+const char* csi_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+
+int csi_profile_query(csi_ctx* c, int id, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (id < 0 || id >= K_COUNT) return fail(c, CSI_ERR_INVALID_ARG, "csi_profile_query: kernel id %d out of range", id);
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->prof_ms[id];
+    if (launches) *launches = c->prof_launches[id];
+    if (flops) *flops = c->prof_flops[id];
+    if (bytes) *bytes = c->prof_bytes[id];
+    return CSI_OK;
+}
+
+}  // extern "C"

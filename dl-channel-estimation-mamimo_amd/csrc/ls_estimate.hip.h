@@ -1,0 +1,213 @@
+// ls_estimate.hip.h - least-squares pilot estimate of one rx preamble per workgroup.
+//
+// Restates, for the GPU, ofdmdemod + helperMIMOChannelEstimate
+// (packet_generation/phased_arr/generate_maMIMO_LTF.m:336-342, helperMIMOChannelEstimate.m:24-36):
+//   F[s][f]  = sum_n x[s*320 + 64 + n] exp(-2 pi i f n / 256)            (CP dropped, unscaled FFT)
+//   H[j][q]  = sum_s F[s][f(q)] * P[j][s]  /  (Nt * ltf[q])              (P real; Puse = P')
+// for the 234 data bins q (fftshift-ed bin order, nulls and pilots removed).
+//
+// Data flow per workgroup (one (packet, rx) pair, 256 threads):
+//   HBM --float4, coalesced--> registers --digit-reversed scatter--> LDS  [Nt][re|im][256(+pad)]
+//   in-place radix-4 DIT FFT, one wave per LTF symbol (4 stages, natural-order output)
+//   despread = real [Nt x Nt] x [Nt x 234] product per re/im plane on v_mfma_f32_32x32x2_f32
+//   (B operand read straight from the LDS spectrum through the bin table), scaled and written
+//   coalesced to H[(p,r)][j][q].
+// HBM-bound: 2560 B in + 1872 B out per pair; everything else stays in LDS/registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LS_FFT = 256;
+constexpr int LS_CP = 64;
+constexpr int LS_SYM = 320;
+constexpr int LS_NDATA = 234;
+constexpr int LS_PLANE = LS_FFT + 32;        // 4 pad floats per 32 -> stage-2 butterflies conflict-free
+constexpr int LS_THREADS = 256;
+
+struct LsArgs {
+    const float* ltf_re;     // [nblk][len_ltf]
+    const float* ltf_im;
+    const float* P;          // [nt][nt] row j = pilot sequence of tx j
+    const float* tw;         // [2][256] cos / -sin table, exp(-2 pi i u / 256)
+    const int* bin_pos;      // [234] natural-order FFT index f(q) of data bin q
+    const float* denom;      // [234] nt * ltf[q]
+    float* h_re;             // [nblk][nt][234]
+    float* h_im;
+    int nt;
+    int len_ltf;
+};
+
+__device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
+
+__device__ __forceinline__ size_t ls_lds_bytes(int nt) { return (size_t)(nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float); }
+
+__global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw_re = smem;                      // [256]
+    float* tw_im = smem + LS_FFT;             // [256]
+    float* F = smem + 2 * LS_FFT;             // [nt][2][LS_PLANE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nt = a.nt;
+    const size_t blk = blockIdx.x;
+
+    tw_re[tid] = a.tw[tid];
+    tw_im[tid] = a.tw[LS_FFT + tid];
+
+    // ---- load: wave w takes symbols w, w+4, ...; lane loads samples 4*lane..4*lane+3 of the
+    // FFT window and scatters them to their base-4 digit-reversed positions.
+    const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
+    const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);      // lane = d3 d2 d1 -> d1 d2 d3
+    for (int s0 = wave; s0 < nt; s0 += 16) {
+        f32x4 vr[4], vi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < nt) {
+                vr[u] = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
+                vi[u] = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < nt) {
+                float* fr = F + (size_t)s * 2 * LS_PLANE;
+                float* fi = fr + LS_PLANE;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int p = ls_phys(c * 64 + rev3);
+                    fr[p] = vr[u][c];
+                    fi[p] = vi[u][c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- FFT: one wave per symbol, lane = one radix-4 butterfly per stage
+    for (int s = wave; s < nt; s += 4) {
+        float* fr = F + (size_t)s * 2 * LS_PLANE;
+        float* fi = fr + LS_PLANE;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int L = 1 << (2 * st);
+            const int j = lane & (L - 1);
+            const int base = (lane >> (2 * st)) * 4 * L + j;
+            const int tstep = 64 >> (2 * st);               // 256 / (4L)
+            float xr[4], xi[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int p = ls_phys(base + m * L);
+                xr[m] = fr[p];
+                xi[m] = fi[p];
+            }
+            if (st > 0) {
+#pragma unroll
+                for (int m = 1; m < 4; ++m) {
+                    const int u = (j * m * tstep) & 255;
+                    const float c = tw_re[u], sn = tw_im[u];
+                    const float r = xr[m] * c - xi[m] * sn;
+                    const float i = xr[m] * sn + xi[m] * c;
+                    xr[m] = r;
+                    xi[m] = i;
+                }
+            }
+            // 4-point DFT: y_q = sum_m (-i)^(m q) x_m
+            const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
+            const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
+            const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
+            const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
+            float yr[4], yi[4];
+            yr[0] = ar + cr; yi[0] = ai + ci;
+            yr[1] = br + di; yi[1] = bi - dr;       // x0 - i x1 - x2 + i x3
+            yr[2] = ar - cr; yi[2] = ai - ci;
+            yr[3] = br - di; yi[3] = bi + dr;       // x0 + i x1 - x2 - i x3
+            // all lanes of this wave must have read before anyone overwrites
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int p = ls_phys(base + m * L);
+                fr[p] = yr[m];
+                fi[p] = yi[m];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+
+    // ---- despread on the matrix core: D[j][q] = sum_s P[j][s] * F[s][f(q)]
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n_jt = (nt + 31) >> 5;
+    const int ksteps = (nt + 1) >> 1;
+    for (int qt = wave; qt < 8; qt += 4) {
+        const int q = qt * 32 + l31;
+        const bool qok = q < LS_NDATA;
+        const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
+        const float den = a.denom[qok ? q : 0];
+        for (int jt = 0; jt < n_jt; ++jt) {
+            const int ja = jt * 32 + l31;                   // A-operand row of this lane
+            const bool jok = ja < nt;
+            f32x16 dre, dim;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dre[e] = 0.f; dim[e] = 0.f; }
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int s = 2 * ks + hi;
+                const bool sok = s < nt;
+                const float pv = (jok && sok) ? a.P[ja * nt + s] : 0.f;
+                const float* fr = F + (size_t)(sok ? s : 0) * 2 * LS_PLANE;
+                const float bre = sok ? fr[pos] : 0.f;
+                const float bim = sok ? fr[LS_PLANE + pos] : 0.f;
+                dre = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bre, dre, 0, 0, 0);
+                dim = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bim, dim, 0, 0, 0);
+            }
+            if (qok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (j < nt) {
+                        const size_t o = (blk * nt + j) * LS_NDATA + q;
+                        a.h_re[o] = dre[r] / den;
+                        a.h_im[o] = dim[r] / den;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// i.i.d. CN(0,1) samples from a counter-based generator: element index -> splitmix64 ->
+// two uniforms -> Box-Muller.  re/im each have variance 1/2.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void synth_white_kernel(uint64_t seed, uint64_t first_elem, size_t n, float* __restrict__ re,
+                                   float* __restrict__ im) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = splitmix64(seed ^ splitmix64(first_elem + i));
+        const float u1 = ((float)(uint32_t)(h >> 32) + 0.5f) * (1.0f / 4294967296.0f);
+        const float u2 = ((float)(uint32_t)h + 0.5f) * (1.0f / 4294967296.0f);
+        const float rad = sqrtf(-logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        re[i] = rad * cs;
+        im[i] = rad * sn;
+    }
+}
+
+}  // namespace csi

@@ -1,0 +1,100 @@
+"""Multi-GPU plumbing: one process per GPU, packets sharded by index, weights broadcast once.
+
+The path has no steady-state exchange: every packet is independent and the weights are
+read-only.  The only collective is the load-time broadcast of the weight blob
+and the pilot matrix from rank 0 - ``torch.distributed`` with the ``nccl`` backend, which is
+RCCL over xGMI on ROCm (``gloo`` on CPU-only hosts, used by the tests)."""
+import os
+import numpy as np
+
+
+def env_rank_world():
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def shard_range(n, rank, world):
+    """Contiguous packet range [lo, hi) of this rank; the first n % world ranks get one extra."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_process_group(backend=None):
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    rank, world, local = env_rank_world()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def broadcast_weights(weights, src=0, device=None):
+    """Broadcast a {name: float32 ndarray} dict from ``src`` to every rank as ONE flat buffer
+    (a single large collective instead of one per tensor: xGMI rings are per-link bound, so
+    fewer, larger transfers).  Non-source ranks may pass ``None``; the tensor names and shapes
+    travel first as a small object broadcast.  Returns the dict on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return weights
+    rank = dist.get_rank()
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    meta = [None]
+    if rank == src:
+        names = [k for k, v in weights.items() if isinstance(v, np.ndarray)]
+        meta[0] = [(k, tuple(weights[k].shape)) for k in names]
+    dist.broadcast_object_list(meta, src=src)
+    total = int(sum(int(np.prod(s)) for _, s in meta[0]))
+    if rank == src:
+        flat = np.concatenate([np.ascontiguousarray(weights[k], dtype=np.float32).ravel() for k, _ in meta[0]])
+        buf = torch.from_numpy(flat).to(device)
+    else:
+        buf = torch.empty(total, dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    host = buf.cpu().numpy()
+    out, off = {}, 0
+    for k, s in meta[0]:
+        n = int(np.prod(s))
+        out[k] = host[off:off + n].reshape(s).copy()
+        off += n
+    return out
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max(value, device=None):
+    """max over ranks of a python float (used for the max-over-ranks step time)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(value, device=None):
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,213 @@
+"""CsiEngine: one HIP context (one GPU, one stream) holding the two regressors (real, imag),
+the pilot matrix and the activation workspace.  Thin object wrapper over the C-ABI."""
+import ctypes
+import numpy as np
+
+from . import _lib
+from ._lib import CsiError
+
+N_DATA = 234     # data subcarriers, generate_maMIMO_LTF.m:98
+SYM_LEN = 320    # FFT 256 + CP 64, generate_maMIMO_LTF.m:96-97
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+class DeviceArray:
+    """float32 array in HBM owned by an engine (hipMalloc through the C-ABI)."""
+
+    def __init__(self, engine, shape):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * 4
+        p = ctypes.c_void_p()
+        engine._check(engine._lib.csi_device_malloc(engine._ctx, ctypes.byref(p), self.nbytes))
+        self.ptr = p.value or 0
+
+    def upload(self, host):
+        host = _f32c(host)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        self.engine._check(self.engine._lib.csi_memcpy_h2d(self.engine._ctx, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def download(self, first=0, count=None):
+        """Copy back rows [first, first+count) along axis 0 (default: everything)."""
+        n0 = self.shape[0]
+        count = n0 - first if count is None else count
+        row = self.nbytes // max(n0, 1)
+        out = np.empty((count,) + self.shape[1:], dtype=np.float32)
+        self.engine._check(self.engine._lib.csi_memcpy_d2h(self.engine._ctx, out.ctypes.data,
+                                                           self.ptr + first * row, count * row))
+        return out
+
+    def free(self):
+        if self.ptr and self.engine._ctx:
+            self.engine._lib.csi_device_free(self.engine._ctx, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CsiEngine:
+    """Owns a ``csi_ctx``.  Shapes follow the reference: nt tx antennas, nr rx antennas,
+    len_ltf = 320*nt samples per rx preamble, FC hidden widths ``hidden`` (--nn), n_out outputs
+    (massiveMIMO_CSI_prediction_DNN.py:18,227)."""
+
+    def __init__(self, nt, nr, hidden=(1024, 1024), n_out=N_DATA, use_bn=True, bn_eps=1e-3,
+                 device=0, workspace_bytes=0, dtype='f32', len_ltf=None):
+        self._lib = _lib.load_library()
+        self._ctx = None
+        self.nt, self.nr = int(nt), int(nr)
+        # nt == 0: single-input model without pilot input (DNN.py:180,234); only predict_samples
+        self.len_ltf = SYM_LEN * self.nt if self.nt > 0 else int(len_ltf)
+        self.d_in = self.len_ltf + self.nt
+        self.hidden = tuple(int(h) for h in hidden)
+        self.n_out = int(n_out)
+        self.use_bn = bool(use_bn)
+        cfg = _lib.CsiConfig()
+        cfg.nt, cfg.nr, cfg.len_ltf = self.nt, self.nr, self.len_ltf
+        if not 1 <= len(self.hidden) <= _lib.CSI_MAX_HIDDEN:
+            raise CsiError(-1, f'between 1 and {_lib.CSI_MAX_HIDDEN} hidden layers are supported')
+        cfg.n_hidden = len(self.hidden)
+        for i, h in enumerate(self.hidden):
+            cfg.hidden[i] = h
+        cfg.n_out, cfg.use_bn, cfg.bn_eps = self.n_out, int(self.use_bn), float(bn_eps)
+        cfg.dtype = {'f32': _lib.CSI_DTYPE_F32, 'bf16': _lib.CSI_DTYPE_BF16}[dtype]
+        cfg.device, cfg.workspace_bytes = int(device), int(workspace_bytes)
+        ctx = ctypes.c_void_p()
+        rc = self._lib.csi_create(ctypes.byref(cfg), ctypes.byref(ctx))
+        if rc != 0:
+            raise CsiError(rc, (self._lib.csi_last_error(None) or b'').decode())
+        self._ctx = ctx
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise CsiError(rc, (self._lib.csi_last_error(self._ctx) or b'').decode())
+
+    def close(self):
+        if self._ctx:
+            self._lib.csi_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.csi_synchronize(self._ctx))
+
+    def empty(self, shape):
+        return DeviceArray(self, shape)
+
+    def to_device(self, host):
+        host = _f32c(host)
+        return DeviceArray(self, host.shape).upload(host)
+
+    # ------------------------------------------------------------------ model state
+    def load_weights(self, model, weights):
+        """model: 0/'real' or 1/'imag'.  weights: dict keras-name -> ndarray
+        (fc_dense{i}.kernel [in,out], .bias, bn{i}.gamma/beta/moving_mean/moving_variance,
+        fc_regressor.kernel/.bias)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        keep, arr = [], (_lib.CsiTensor * len(weights))()
+        n = 0
+        for name, val in weights.items():
+            if not isinstance(val, np.ndarray):
+                continue
+            a = _f32c(val)
+            keep.append(a)
+            arr[n].name = name.encode()
+            arr[n].data = _fp(a)
+            arr[n].rows = a.shape[0] if a.ndim == 2 else 1
+            arr[n].cols = a.shape[1] if a.ndim == 2 else a.size
+            n += 1
+        self._check(self._lib.csi_load_weights(self._ctx, int(idx), arr, n))
+
+    def set_pilot(self, P):
+        """P [nt, nt], row j = pilot sequence of tx j (= dataset['P'][:, j],
+        massiveMIMO_dataGenerator.py:311)."""
+        P = _f32c(P)
+        if P.shape != (self.nt, self.nt):
+            raise CsiError(-1, f'P must be [{self.nt},{self.nt}], got {P.shape}')
+        self._check(self._lib.csi_set_pilot(self._ctx, _fp(P)))
+
+    # ------------------------------------------------------------------ host-buffer calls
+    def _split(self, ltf, ltf_im=None):
+        if ltf_im is None:
+            ltf = np.asarray(ltf)
+            re, im = _f32c(ltf.real), _f32c(ltf.imag)
+        else:
+            re, im = _f32c(ltf), _f32c(ltf_im)
+        if re.ndim != 3 or re.shape[1:] != (self.nr, self.len_ltf) or im.shape != re.shape:
+            raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {re.shape}')
+        return re, im
+
+    def predict(self, ltf, ltf_im=None):
+        """DNN estimate.  ltf complex [npkt,nr,len_ltf] (or two float planes).
+        Returns (out_real, out_imag) float32 [npkt,nr,nt,n_out]."""
+        re, im = self._split(ltf, ltf_im)
+        npkt = re.shape[0]
+        o_re = np.empty((npkt, self.nr, self.nt, self.n_out), dtype=np.float32)
+        o_im = np.empty_like(o_re)
+        self._check(self._lib.csi_predict(self._ctx, _fp(re), _fp(im), npkt, _fp(o_re), _fp(o_im)))
+        return o_re, o_im
+
+    def ls_estimate(self, ltf, ltf_im=None):
+        """LS estimate, complex64 [npkt,nr,nt,234]."""
+        re, im = self._split(ltf, ltf_im)
+        npkt = re.shape[0]
+        h_re = np.empty((npkt, self.nr, self.nt, N_DATA), dtype=np.float32)
+        h_im = np.empty_like(h_re)
+        self._check(self._lib.csi_ls_estimate(self._ctx, _fp(re), _fp(im), npkt, _fp(h_re), _fp(h_im)))
+        return h_re + 1j * h_im
+
+    def predict_samples(self, model, x):
+        """Literal Model.predict of one component: x [B, len_ltf+nt] -> float32 [B, n_out]."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        x = _f32c(x)
+        if x.ndim != 2 or x.shape[1] != self.d_in:
+            raise CsiError(-1, f'x must be [B,{self.d_in}], got {x.shape}')
+        y = np.empty((x.shape[0], self.n_out), dtype=np.float32)
+        self._check(self._lib.csi_predict_samples(self._ctx, int(idx), _fp(x), x.shape[0], _fp(y)))
+        return y
+
+    # ------------------------------------------------------------------ device-resident calls
+    def predict_device(self, d_re, d_im, npkt, d_out_re, d_out_im):
+        self._check(self._lib.csi_predict_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr))
+
+    def ls_estimate_device(self, d_re, d_im, npkt, d_h_re, d_h_im):
+        self._check(self._lib.csi_ls_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_h_re.ptr, d_h_im.ptr))
+
+    def synth_white(self, seed, first_pkt, npkt, d_re, d_im):
+        self._check(self._lib.csi_synth_white(self._ctx, int(seed), int(first_pkt), int(npkt), d_re.ptr, d_im.ptr))
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on=True):
+        self._check(self._lib.csi_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self._lib.csi_profile_reset(self._ctx))
+
+    def profile(self):
+        """dict kernel-name -> {ms, launches, flops, bytes} since the last reset."""
+        out = {}
+        for k in range(self._lib.csi_profile_num_kernels()):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            self._check(self._lib.csi_profile_query(self._ctx, k, ctypes.byref(ms), ctypes.byref(n),
+                                                    ctypes.byref(fl), ctypes.byref(by)))
+            out[self._lib.csi_profile_kernel_name(k).decode()] = dict(
+                ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out

@@ -1,0 +1,140 @@
+/* csi_mamimo.h - C-ABI of the MI355X (gfx950) massive-MIMO channel-estimation hot path.
+ *
+ * The reference (mauro-belgiovine/DL-channel-estimation-MaMIMO) has no FFI: the path sits
+ * behind two Python call surfaces, which the entry points below replace one for one.
+ * Citations are file:line in the reference repository.
+ *
+ *   reference interface                                             replaced by
+ *   --------------------------------------------------------------  ---------------------------
+ *   model construction, massiveMIMO_CSI_prediction_DNN.py:176-234   csi_create
+ *   Model.load_weights(<d>_weights-improvement.hdf5)   DNN.py:334   csi_load_weights
+ *   keras.models.load_model(<d>_keras_model)     inference.py:15-16  csi_load_weights
+ *   dataset['P'] fed as seq_p     massiveMIMO_dataGenerator.py:311  csi_set_pilot
+ *   Model.predict(generator) over packets, batch = nTX*nRX
+ *        DNN.py:339-346 + sample assembly dataGenerator.py:299-316  csi_predict[_device]
+ *   Model.predict(x, batch_size=bs)              inference.py:29-30
+ *        / DNN.py:434,470  (arbitrary rows [B, lenLTF+Nt])          csi_predict_samples
+ *   ofdmdemod + helperMIMOChannelEstimate
+ *        generate_maMIMO_LTF.m:336-342, helperMIMOChannelEstimate.m:24-36
+ *                                                                   csi_ls_estimate[_device]
+ *   --execTime profiler loop                       DNN.py:441-475   csi_profile_*
+ *
+ * Conventions: every function returns 0 on success or a negative csi_status; it never calls
+ * exit().  All buffers are caller-owned, row-major, contiguous float32.  A context is bound
+ * to one GPU and one HIP stream and is not thread-safe; use one context per GPU.  Host-buffer
+ * entry points are synchronous.  *_device entry points take device pointers, enqueue on the
+ * context's stream and return without waiting; call csi_synchronize before reading results.
+ *
+ * Sample / output order everywhere: s = p*Nr*Nt + iRx*Nt + iTx
+ * (create_massiveMIMO_CSIest_dnn_dataset.py:62), i.e. outputs are [Npkt][Nr][Nt][n_out],
+ * which is MATLAB CSI(:, iTx, iRx) of packet p (BER_test_maMIMO_LTF.m:191-195).
+ */
+#ifndef CSI_MAMIMO_H
+#define CSI_MAMIMO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSI_MAX_HIDDEN 8
+#define CSI_ABI_VERSION 1
+
+typedef enum {
+    CSI_OK = 0,
+    CSI_ERR_INVALID_ARG = -1,   /* null pointer, bad shape, unsupported size              */
+    CSI_ERR_NOT_READY = -2,     /* predict before weights / pilot were loaded             */
+    CSI_ERR_HIP = -3,           /* a HIP runtime call failed; text in csi_last_error       */
+    CSI_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                                */
+    CSI_ERR_NOMEM = -5          /* device allocation failed                                */
+} csi_status;
+
+typedef enum {
+    CSI_DTYPE_F32 = 0,          /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out    */
+    CSI_DTYPE_BF16 = 1          /* bf16 operands, fp32 accumulate MFMA, fp32 out            */
+} csi_dtype;
+
+/* Model + problem shape.  n_out = 234 and hidden = {1024, 1024} in the shipped pipeline
+ * (full_pipeline_maMIMO_DNNEst.sh:40,47). */
+typedef struct {
+    int32_t nt;                      /* tx antennas = LTF symbols = pilot-row length        */
+    int32_t nr;                      /* rx antennas per packet                              */
+    int32_t len_ltf;                 /* samples per rx preamble, 320*nt                     */
+    int32_t n_hidden;                /* number of Dense+relu(+BN) layers, 1..CSI_MAX_HIDDEN */
+    int32_t hidden[CSI_MAX_HIDDEN];  /* their widths (--nn)                                 */
+    int32_t n_out;                   /* fc_regressor width (nSubCarr)                       */
+    int32_t use_bn;                  /* --useBN                                             */
+    float   bn_eps;                  /* keras BatchNormalization epsilon, 1e-3              */
+    int32_t dtype;                   /* csi_dtype                                           */
+    int32_t device;                  /* HIP device ordinal                                  */
+    int64_t workspace_bytes;         /* cap for activation workspace; 0 = default (1 GiB)   */
+} csi_config;
+
+/* One named weight tensor on the host.  Names are the keras ones:
+ *   fc_dense<i>.kernel [in,out]   fc_dense<i>.bias [out]
+ *   bn<i>.gamma / .beta / .moving_mean / .moving_variance [out]      (iff use_bn)
+ *   fc_regressor.kernel [in,n_out]   fc_regressor.bias [n_out]
+ * Rows 0..len_ltf-1 of fc_dense0.kernel multiply the LTF samples, rows len_ltf..len_ltf+nt-1
+ * the pilot row (Concatenate([flatten, seq_p]), DNN.py:207-208). */
+typedef struct {
+    const char*  name;
+    const float* data;
+    int64_t      rows;               /* 1 for vectors                                       */
+    int64_t      cols;
+} csi_tensor;
+
+typedef struct csi_ctx csi_ctx;
+
+int  csi_abi_version(void);
+int  csi_create(const csi_config* cfg, csi_ctx** out);
+void csi_destroy(csi_ctx* ctx);
+const char* csi_last_error(const csi_ctx* ctx);      /* ctx may be NULL: last create error  */
+
+/* model: 0 = real, 1 = imag.  Tensors are copied (and re-laid-out) to the device. */
+int  csi_load_weights(csi_ctx* ctx, int model, const csi_tensor* tensors, int n);
+/* P [nt][nt], row j = pilot sequence of tx antenna j = MATLAB P(j,:) = dataset['P'][:, j]. */
+int  csi_set_pilot(csi_ctx* ctx, const float* P);
+
+/* DNN estimate of npkt packets.  ltf_re / ltf_im [npkt][nr][len_ltf]; out_re / out_im
+ * [npkt][nr][nt][n_out].  Layer 0 is evaluated once per (packet, rx) and shared by the nt
+ * pairs (the reference stores each rx preamble once for the same reason, mk.py:50-63). */
+int  csi_predict(csi_ctx* ctx, const float* ltf_re, const float* ltf_im, int64_t npkt,
+                 float* out_re, float* out_im);
+int  csi_predict_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
+                        float* d_out_re, float* d_out_im);
+
+/* Literal Model.predict: x [B][len_ltf+nt] -> y [B][n_out] through the un-shared network. */
+int  csi_predict_samples(csi_ctx* ctx, int model, const float* x, int64_t B, float* y);
+
+/* LS estimate: h_re / h_im [npkt][nr][nt][234]. */
+int  csi_ls_estimate(csi_ctx* ctx, const float* ltf_re, const float* ltf_im, int64_t npkt,
+                     float* h_re, float* h_im);
+int  csi_ls_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
+                            float* d_h_re, float* d_h_im);
+
+int  csi_synchronize(csi_ctx* ctx);
+
+/* Device-memory plumbing so that a host program needs no other GPU runtime. */
+int  csi_device_malloc(csi_ctx* ctx, void** dptr, int64_t bytes);
+int  csi_device_free(csi_ctx* ctx, void* dptr);
+int  csi_memcpy_h2d(csi_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int  csi_memcpy_d2h(csi_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+/* i.i.d. CN(0,1) preambles generated on the device by a counter-based RNG (element index
+ * -> value), for workloads too large to stage through the host (SURVEY.md 8d 'white'). */
+int  csi_synth_white(csi_ctx* ctx, uint64_t seed, int64_t first_pkt, int64_t npkt,
+                     float* d_ltf_re, float* d_ltf_im);
+
+/* Per-kernel HIP-event timing on the context's stream (the reference's --execTime). */
+int  csi_profile_enable(csi_ctx* ctx, int on);
+int  csi_profile_reset(csi_ctx* ctx);
+int  csi_profile_num_kernels(void);
+const char* csi_profile_kernel_name(int kernel_id);
+/* total_ms / launches / flops / bytes accumulated since the last reset. */
+int  csi_profile_query(csi_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches,
+                       double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSI_MAMIMO_H */

@@ -1,0 +1,74 @@
+"""CPU baseline timer for bench.py's ``cpu_baseline`` leg.  TEST/BENCH INFRASTRUCTURE ONLY.
+
+What is timed is the reference's own test loop restated (massiveMIMO_CSI_prediction_DNN.py:
+339-346): ONE batch of Nt*Nr rows per packet through the NAIVE three-layer fp32 network (no
+layer-0 sharing), for the real and then the imag model - with torch-CPU matmuls (oneDNN/MKL
+sgemm, the kernel class TF-CPU uses; TensorFlow itself is not installable here) on all host
+cores, plus the numpy LS estimate of the same packets.  The reference's Python sample-assembly
+loop (massiveMIMO_dataGenerator.py:307-314) is excluded: inputs are pre-assembled float32."""
+import time
+import numpy as np
+
+from . import csi_oracle as o
+
+
+def _torch_model(w):
+    import torch
+    t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in w.items() if isinstance(v, np.ndarray)}
+    eps = float(w.get('bn_eps', o.BN_EPS))
+    layers = []
+    i = 0
+    while f'fc_dense{i}.kernel' in t:
+        bn = None
+        if f'bn{i}.gamma' in t:
+            inv = t[f'bn{i}.gamma'] * torch.rsqrt(t[f'bn{i}.moving_variance'] + eps)
+            bn = (inv, t[f'bn{i}.beta'] - t[f'bn{i}.moving_mean'] * inv)
+        layers.append((t[f'fc_dense{i}.kernel'], t[f'fc_dense{i}.bias'], bn))
+        i += 1
+
+    def forward(x):
+        h = x
+        for k, b, bn in layers:
+            h = torch.relu(h @ k + b)
+            if bn is not None:
+                h = h * bn[0] + bn[1]
+        return h @ t['fc_regressor.kernel'] + t['fc_regressor.bias']
+
+    return forward
+
+
+def time_reference_loop(ltf, P, w_re, w_im, budget_s=12.0, min_packets=8):
+    """ltf complex64 [n, nr, len_ltf].  Runs packets one by one until ``budget_s`` seconds of
+    DNN time have elapsed (at least min_packets).  Returns a dict with pairs/s for DNN-only,
+    LS-only and both, the packet count and the thread count used."""
+    import torch
+    nt = P.shape[0]
+    n, nr, _ = ltf.shape
+    f_re, f_im = _torch_model(w_re), _torch_model(w_im)
+    Pf = np.asarray(P, dtype=np.float32)
+    xs = []
+    for p in range(n):       # pre-assembled, outside the timed region
+        xs.append((torch.from_numpy(o.samples_from_packets(ltf[p:p + 1], Pf, 'real')),
+                   torch.from_numpy(o.samples_from_packets(ltf[p:p + 1], Pf, 'imag'))))
+    with torch.no_grad():
+        for p in range(min(3, n)):                      # warm-up
+            f_re(xs[p][0]); f_im(xs[p][1])
+        done, t_dnn, per_pkt = 0, 0.0, []
+        while done < n and (done < min_packets or t_dnn < budget_s):
+            t0 = time.perf_counter()
+            f_re(xs[done][0]); f_im(xs[done][1])
+            per_pkt.append(time.perf_counter() - t0)
+            t_dnn += per_pkt[-1]
+            done += 1
+    ls_t = []
+    for p in range(min(done, 16)):
+        t0 = time.perf_counter()
+        o.ls_estimate(ltf[p:p + 1], P)
+        ls_t.append(time.perf_counter() - t0)
+    # median per-packet latency: robust against scheduling noise on a shared host, and it
+    # favours the CPU (the baseline is never under-reported)
+    med_dnn, med_ls = float(np.median(per_pkt)), float(np.median(ls_t))
+    ppp = nr * nt
+    return dict(packets=done, pairs=done * ppp, threads=torch.get_num_threads(), dnn_s=t_dnn,
+                dnn_ms_per_packet=med_dnn * 1e3, ls_ms_per_packet=med_ls * 1e3,
+                dnn_pairs_per_s=ppp / med_dnn, ls_pairs_per_s=ppp / med_ls, pairs_per_s=ppp / (med_dnn + med_ls))

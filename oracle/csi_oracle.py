@@ -1,0 +1,332 @@
+"""CPU oracle for the massive-MIMO channel-estimation hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference algorithm (reference repo
+mauro-belgiovine/DL-channel-estimation-MaMIMO, mounted read-only at /root/reference
+in the build container; paths below are relative to it).  Nothing here is shipped
+in the product path: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.
+
+PARITY PIN STATUS (see DESIGN.md "Oracle"):
+  * sample assembly / ordering (a-3) and the CSIPredictor pre/post-processing and
+    real/imag recombination (a-8, a-9) are PINNED: ``tests/golden/make_golden.py``
+    imported the reference's own pure-numpy code (``massiveMIMO_dataGenerator.py``,
+    ``inference.py``) in the build container and the outputs are committed under
+    ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them.
+  * the Dense / BatchNormalization / Dropout arithmetic (a-4..a-7) lives in TensorFlow
+    2.3 (README.md:27-28) and the LS estimate (a-1, a-2) in MATLAB R2020b + toolboxes
+    (README.md:29-30); neither is vendored nor installable here and the reference has
+    no tests, golden vectors or weights.  For those rows: PARITY UNPINNED.  They are
+    restated from the call sites and the published layer definitions, and checked by
+    exact identities (LS known-answer round trip, torch.nn.functional cross-check).
+
+Shapes follow the reference: a "sample" is one (packet p, rx antenna r, tx antenna t)
+link with index ``s = p*Nr*Nt + r*Nt + t`` (create_massiveMIMO_CSIest_dnn_dataset.py:62).
+"""
+import numpy as np
+
+# ---------------------------------------------------------------------------
+# OFDM constants  (packet_generation/phased_arr/generate_maMIMO_LTF.m:96-102)
+# ---------------------------------------------------------------------------
+FFT_LEN = 256            # prm.FFTLength                      generate_maMIMO_LTF.m:96
+CP_LEN = 64              # prm.CyclicPrefixLength             generate_maMIMO_LTF.m:97
+SYM_LEN = FFT_LEN + CP_LEN
+N_DATA = 234             # prm.numCarriers                    generate_maMIMO_LTF.m:98
+BN_EPS = 1e-3            # keras BatchNormalization() default epsilon (DNN.py:217)
+
+
+def null_carrier_indices():
+    """1-based guard + DC bins, generate_maMIMO_LTF.m:99  ``[1:7 129 256-5:256]'``."""
+    return np.array(list(range(1, 8)) + [129] + list(range(251, 257)), dtype=np.int64)
+
+
+def pilot_carrier_indices():
+    """1-based pilot bins, generate_maMIMO_LTF.m:100."""
+    return np.array([26, 54, 90, 118, 140, 168, 204, 232], dtype=np.int64)
+
+
+def data_carrier_indices():
+    """1-based data bins ``prm.CarriersLocations`` = setdiff(1:256, nulls U pilots),
+    generate_maMIMO_LTF.m:101-102.  Returned sorted ascending, length 234."""
+    non_data = set(null_carrier_indices().tolist()) | set(pilot_carrier_indices().tolist())
+    idx = np.array([k for k in range(1, FFT_LEN + 1) if k not in non_data], dtype=np.int64)
+    assert idx.size == N_DATA
+    return idx
+
+
+def vht_ltf_256():
+    """The 256-bin VHT-LTF frequency sequence literal of helperMIMOChannelEstimate.m:16-23
+    (index 0 here = MATLAB index 1 = most negative frequency after fftshift)."""
+    ltf_left = [1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1,
+                1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1]
+    ltf_right = [1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1,
+                 -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1]
+    mid_a = [-1, -1, -1, 1, 1, -1, 1, -1, 1, 1, -1]
+    mid_b = [1, -1, 1, -1, 0, 1, -1, -1, 1]
+    seq = ([0] * 7 + ltf_left + [1] + ltf_right + mid_a
+           + ltf_left + [1] + ltf_right + mid_b
+           + ltf_left + [1] + ltf_right + mid_a
+           + ltf_left + [1] + ltf_right + [0] * 6)
+    seq = np.array(seq, dtype=np.float64)
+    assert seq.size == FFT_LEN
+    return seq
+
+
+# ---------------------------------------------------------------------------
+# a-1  OFDM demodulation (MATLAB ofdmdemod call sites generate_maMIMO_LTF.m:336-338,
+#      BER_test_maMIMO_LTF.m:324-326; python convention massiveMIMO_dataGenerator.py:437-453)
+# ---------------------------------------------------------------------------
+def ofdm_demod(ltf, nt):
+    """ltf: complex [..., lenLTF] time-domain preamble of ONE rx antenna, lenLTF = 320*nt.
+    Returns rxsym complex [..., 234, nt] (data bins x LTF symbol), i.e. MATLAB
+    ``rxOFDM(:, 1:numTx, iRx)``.
+
+    Convention: column-major split into nt symbols of 320 samples
+    (massiveMIMO_dataGenerator.py:437-439); symbol offset = CP length so the FFT window
+    is samples 64..319 of each symbol (:442-443); unscaled 256-point FFT (:452); fftshift
+    ALONG THE FREQUENCY AXIS ONLY so DC lands on 1-based bin 129 (generate_maMIMO_LTF.m:99;
+    :453 of the python file shifts both axes, which is a bug in dead code); keep the 234
+    data bins (generate_maMIMO_LTF.m:98-102)."""
+    ltf = np.asarray(ltf)
+    assert ltf.shape[-1] == SYM_LEN * nt
+    sym = ltf.reshape(ltf.shape[:-1] + (nt, SYM_LEN))          # [..., s, n]
+    win = sym[..., CP_LEN:CP_LEN + FFT_LEN]
+    spec = np.fft.fft(win, n=FFT_LEN, axis=-1)
+    spec = np.fft.fftshift(spec, axes=-1)                      # index i <-> MATLAB bin i+1
+    data = spec[..., data_carrier_indices() - 1]               # [..., s, 234]
+    return np.swapaxes(data, -1, -2)                           # [..., 234, s]
+
+
+# ---------------------------------------------------------------------------
+# a-2  LS channel estimate  (helperMIMOChannelEstimate.m:8-41)
+# ---------------------------------------------------------------------------
+def ls_from_rxsym(rxsym, P):
+    """rxsym complex [..., 234, nt] (bins x symbol);  P [nt, nt] with ROW j = pilot mapping
+    sequence of tx antenna j over the nt LTF symbols (MATLAB ``P(j,:)``).
+    hD(:,j,i) = rxsym * Puse(:,j) ./ denom,  Puse = P'  (conjugate transpose, :24),
+    denom = nltf .* ltf(CarriersLocations) (:26-27,:33-36).
+    Returns H complex [..., 234, nt] (bins x tx)."""
+    P = np.asarray(P)
+    nt = P.shape[0]
+    puse = P.conj().T                                           # [s, j]
+    denom = nt * vht_ltf_256()[data_carrier_indices() - 1]      # [234]
+    return (rxsym @ puse) / denom[:, None]
+
+
+def ls_estimate(ltf, P):
+    """Full LS path of one or many rx-antenna preambles.
+    ltf complex [..., lenLTF]  ->  H complex [..., nt, 234]   (tx-major rows, matching the
+    DNN output layout ``H[pkt, iRx, iTx, k]``, BER_test_maMIMO_LTF.m:191-195)."""
+    nt = np.asarray(P).shape[0]
+    h = ls_from_rxsym(ofdm_demod(ltf, nt), P)                   # [..., 234, nt]
+    return np.swapaxes(h, -1, -2)
+
+
+# ---------------------------------------------------------------------------
+# a-3  sample assembly  (massiveMIMO_dataGenerator.py:299-316)
+# ---------------------------------------------------------------------------
+def assemble_batch(dataset, d, list_ids, len_ltf=None):
+    """Mirror of DataGenerator.__data_generation for datasource 'matlab_maMimo',
+    method 'default'.  ``dataset`` is the pickle dict written by
+    create_massiveMIMO_CSIest_dnn_dataset.py:125 ({X:[N,2] (key,iTx), y:{real,imag},
+    LTF:{key:{real,imag}}, P, simParams}).  Returns (Xsig [B,lenLTF,1], Xp [B,nTX], y [B,234])
+    as float64 (np.empty default dtype, :303-305)."""
+    n = len(list_ids)
+    first_key = dataset['X'][list_ids[0], 0]
+    if len_ltf is None:
+        len_ltf = dataset['LTF'][first_key][d].shape[0]          # loadDataset :27
+    nt = dataset['simParams']['nTX']
+    xsig = np.empty((n, len_ltf, 1))
+    xp = np.empty((n, nt))
+    y = np.empty((n, dataset['y'][d].shape[1]))
+    for i, six in enumerate(list_ids):
+        xsig[i] = dataset['LTF'][dataset['X'][six, 0]][d][0:len_ltf][:, np.newaxis]   # :307-308
+        xp[i] = dataset['P'][:, dataset['X'][six, 1]]                                  # :311
+        y[i] = dataset['y'][d][six, :]                                                 # :314
+    return xsig, xp, y
+
+
+def pilot_rows_from_dataset_P(P_py):
+    """dataset['P'] is the h5py read of the MATLAB matrix, i.e. its transpose
+    (create_massiveMIMO_CSIest_dnn_dataset.py:37); the DNN sees ``P_py[:, iTx]`` =
+    MATLAB ``P(iTx, :)``.  Returns the [nt, nt] array whose ROW t is that vector."""
+    return np.ascontiguousarray(np.asarray(P_py).T)
+
+
+def samples_from_packets(ltf, P, d):
+    """Packed-array twin of assemble_batch.  ltf complex [Npkt, Nr, lenLTF]; P [nt,nt]
+    with row t = pilot sequence of tx t.  Returns X [Npkt*Nr*Nt, lenLTF+Nt] = the
+    Flatten+Concatenate input of the FC model (DNN.py:207-208) in dataset sample order
+    s = p*Nr*Nt + r*Nt + t (create_massiveMIMO_CSIest_dnn_dataset.py:62)."""
+    ltf = np.asarray(ltf)
+    npkt, nr, len_ltf = ltf.shape
+    nt = P.shape[0]
+    part = ltf.real if d == 'real' else ltf.imag
+    x = np.empty((npkt, nr, nt, len_ltf + nt), dtype=part.dtype)
+    x[..., :len_ltf] = part[:, :, None, :]
+    x[..., len_ltf:] = np.asarray(P, dtype=part.dtype)[None, None, :, :]
+    return x.reshape(npkt * nr * nt, len_ltf + nt)
+
+
+# ---------------------------------------------------------------------------
+# a-4..a-7  the FC regressor  (massiveMIMO_CSI_prediction_DNN.py:176-234)
+# ---------------------------------------------------------------------------
+def bn_inference(x, gamma, beta, mean, var, eps=BN_EPS):
+    """keras BatchNormalization at inference on a 2-D input (non-fused path):
+    inv = gamma * rsqrt(var + eps);  y = x*inv + (beta - mean*inv)."""
+    dt = x.dtype
+    inv = (gamma / np.sqrt(var + dt.type(eps))).astype(dt)
+    return x * inv + (beta - mean * inv).astype(dt)
+
+
+def fc_forward(x, w, dtype=np.float64):
+    """Forward of ONE model (real or imag).  x [B, lenLTF+Nt] already flattened and
+    concatenated ([flatten(seq_in), seq_p], DNN.py:207-208).  ``w`` is a dict with keras
+    names: fc_dense{i}.kernel [in,out], fc_dense{i}.bias, optional bn{i}.gamma/beta/
+    moving_mean/moving_variance, fc_regressor.kernel/bias, and 'bn_eps'.
+    Dense relu (DNN.py:211-214) -> BatchNormalization (:215-219, applied AFTER the relu)
+    -> Dropout (:222, identity at inference) ... -> Dense linear (:227)."""
+    h = np.asarray(x, dtype=dtype)
+    eps = float(w.get('bn_eps', BN_EPS))
+    cv = lambda a: np.asarray(a, dtype=dtype)          # no copy when already of that dtype
+    i = 0
+    while f'fc_dense{i}.kernel' in w:
+        h = h @ cv(w[f'fc_dense{i}.kernel']) + cv(w[f'fc_dense{i}.bias'])
+        h = np.maximum(h, dtype(0))
+        if f'bn{i}.gamma' in w:
+            h = bn_inference(h, cv(w[f'bn{i}.gamma']), cv(w[f'bn{i}.beta']), cv(w[f'bn{i}.moving_mean']),
+                             cv(w[f'bn{i}.moving_variance']), eps)
+        i += 1
+    return h @ cv(w['fc_regressor.kernel']) + cv(w['fc_regressor.bias'])
+
+
+# ---------------------------------------------------------------------------
+# a-8  predict over packets in dataset order; real/imag recombination
+#      (DNN.py:339-346; inference.py:29-31; output layout BER_test_maMIMO_LTF.m:191-195)
+# ---------------------------------------------------------------------------
+def predict_packets(ltf, P, w_real, w_imag, dtype=np.float64, pkt_batch=None):
+    """Literal restatement of the reference test loop: one batch of Nt*Nr rows per packet
+    (set_batchsize(nTX*nRX), DNN.py:339) through the NAIVE network (no layer-1 sharing),
+    for the real then the imag model.  Returns (out_real, out_imag) float [Npkt,Nr,Nt,234]."""
+    ltf = np.asarray(ltf)
+    npkt, nr, _ = ltf.shape
+    nt = P.shape[0]
+    outs = []
+    for d, w in (('real', w_real), ('imag', w_imag)):
+        n_out = w['fc_regressor.bias'].shape[0]
+        out = np.empty((npkt, nr, nt, n_out), dtype=dtype)
+        step = pkt_batch or 1
+        for p0 in range(0, npkt, step):
+            x = samples_from_packets(ltf[p0:p0 + step], np.asarray(P), d)
+            y = fc_forward(x, w, dtype)
+            out[p0:p0 + step] = y.reshape(-1, nr, nt, n_out)
+        outs.append(out)
+    return outs[0], outs[1]
+
+
+def recombine(out_real, out_imag):
+    """inference.py:31  ``output_real + 1j * output_imag``."""
+    return out_real + 1j * out_imag
+
+
+# ---------------------------------------------------------------------------
+# a-9  CSIPredictor pre/post-processing  (inference.py:35-68)
+# ---------------------------------------------------------------------------
+def preprocess_rice_renew(input_batch):
+    """inference.py:39-44: requires complex128, otherwise the reference prints an error
+    and exits(-1); here a ValueError carries the same message."""
+    if np.asarray(input_batch).dtype != np.complex128:
+        raise ValueError('[CSIPredictor] ERROR: Input batch must be of type np.complex128')
+    return input_batch
+
+
+def postprocess_rice_renew(output_batch):
+    """inference.py:52-66: 52 outputs -> 64 bins [0*6 | o[0:26] | 0 | o[26:52] | 0*5],
+    then ifftshift along axis 1."""
+    output_batch = np.asarray(output_batch)
+    if output_batch.shape[1] != 52:
+        raise ValueError('[CSIPredictor] ERROR: Output samples must have size 52 (assuming FFTLen = 64).')
+    b = output_batch.shape[0]
+    tmp = np.concatenate((np.zeros((b, 6)), output_batch[:, 0:26], np.zeros((b, 1)),
+                          output_batch[:, 26:], np.zeros((b, 5))), axis=1)
+    return np.fft.ifftshift(tmp, axes=1)
+
+
+# ---------------------------------------------------------------------------
+# a-12  per-link NMSE  (BER_test_maMIMO_LTF.m:675-686)
+# ---------------------------------------------------------------------------
+def nmse_subk(h_ref, h_est):
+    """h_* complex [..., Nr, Nt, 234] (or any [..., link, 234]): per link
+    ||ref-est||^2 / ||ref||^2 over the bins, mean over all links."""
+    diff = np.asarray(h_ref) - np.asarray(h_est)
+    num = np.sum(np.abs(diff) ** 2, axis=-1)
+    den = np.sum(np.abs(np.asarray(h_ref)) ** 2, axis=-1)
+    return float(np.mean(num / den))
+
+
+def row_rel_err(y, y_ref):
+    """Norm-relative error per output row, the form the 1e-5 fp32 contract is stated in
+    (SURVEY.md section 7 'hard parts'): max over rows of ||y-ref||2 / ||ref||2."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1, np.asarray(y).shape[-1])
+    r = np.asarray(y_ref, dtype=np.float64).reshape(y.shape)
+    return float(np.max(np.linalg.norm(y - r, axis=1) / np.linalg.norm(r, axis=1)))
+
+
+# ---------------------------------------------------------------------------
+# Synthetic data (the reference ships no weights and no datasets)
+# ---------------------------------------------------------------------------
+def hadamard(n):
+    """Sylvester-Hadamard matrix; stand-in for the un-vendored helperGetP(numSTS)
+    (helperMIMOChannelEstimate.m:13).  In the real pipeline P is read from the dataset."""
+    assert n & (n - 1) == 0
+    h = np.array([[1.0]])
+    while h.shape[0] < n:
+        h = np.block([[h, h], [h, -h]])
+    return h
+
+
+def make_weights(rng, d_in, hidden, n_out, use_bn=True, dtype=np.float32):
+    """Keras-initialiser-like random weights: glorot-uniform kernels (DNN.py:213,227),
+    small biases, non-trivial BN statistics so that folding errors would show."""
+    w = {'bn_eps': BN_EPS}
+    fan_in = d_in
+    for i, h in enumerate(hidden):
+        lim = np.sqrt(6.0 / (fan_in + h))
+        w[f'fc_dense{i}.kernel'] = rng.uniform(-lim, lim, (fan_in, h)).astype(dtype)
+        w[f'fc_dense{i}.bias'] = (0.01 * rng.standard_normal(h)).astype(dtype)
+        if use_bn:
+            w[f'bn{i}.gamma'] = rng.uniform(0.5, 1.5, h).astype(dtype)
+            w[f'bn{i}.beta'] = (0.1 * rng.standard_normal(h)).astype(dtype)
+            w[f'bn{i}.moving_mean'] = (0.1 * rng.standard_normal(h)).astype(dtype)
+            w[f'bn{i}.moving_variance'] = rng.uniform(0.5, 1.5, h).astype(dtype)
+        fan_in = h
+    lim = np.sqrt(6.0 / (fan_in + n_out))
+    w['fc_regressor.kernel'] = rng.uniform(-lim, lim, (fan_in, n_out)).astype(dtype)
+    w['fc_regressor.bias'] = (0.01 * rng.standard_normal(n_out)).astype(dtype)
+    return w
+
+
+def make_structured_packets(rng, npkt, nr, P, snr_db=None, n_taps=8):
+    """Packets with a KNOWN channel: H[k,j,i] = FFT of an n_taps complex Gaussian CIR per
+    link; rx[k,s,i] = ltf[k] * sum_j H[k,j,i] P[j,s] on all non-null bins; OFDM-modulated
+    (ifftshift -> ifft -> CP); the amplitude scaling of generate_maMIMO_LTF.m:303-304 is left
+    out so that the known answer is H itself.  Returns
+    (ltf complex128 [npkt,nr,320*nt], H complex128 [npkt,nr,nt,234]).  With snr_db=None the
+    LS estimate of the returned preamble equals H to rounding when P P^H = nt I."""
+    P = np.asarray(P, dtype=np.float64)
+    nt = P.shape[0]
+    cir = (rng.standard_normal((npkt, nr, nt, n_taps)) + 1j * rng.standard_normal((npkt, nr, nt, n_taps)))
+    cir *= np.exp(-0.5 * np.arange(n_taps))[None, None, None, :] / np.sqrt(2.0)
+    hfull = np.fft.fftshift(np.fft.fft(cir, n=FFT_LEN, axis=-1), axes=-1)     # [p,r,j,256]
+    ltf_seq = vht_ltf_256()
+    # frequency-domain LTF symbols: X[p,r,s,k] = ltf[k] * sum_j H[p,r,j,k] P[j,s]
+    xf = np.einsum('prjk,js->prsk', hfull, P) * ltf_seq[None, None, None, :]
+    xt = np.fft.ifft(np.fft.ifftshift(xf, axes=-1), axis=-1)                  # [p,r,s,256]
+    sym = np.concatenate([xt[..., -CP_LEN:], xt], axis=-1)                    # CP + body
+    ltf = sym.reshape(npkt, nr, nt * SYM_LEN)
+    if snr_db is not None:
+        sig_pow = np.mean(np.abs(ltf) ** 2)
+        npow = sig_pow / (10.0 ** (snr_db / 10.0))
+        noise = (rng.standard_normal(ltf.shape) + 1j * rng.standard_normal(ltf.shape)) * np.sqrt(npow / 2.0)
+        ltf = ltf + noise
+    h_true = hfull[..., data_carrier_indices() - 1]                           # [p,r,j,234]
+    return ltf, h_true

@@ -1,0 +1,335 @@
+"""GPU parity tests (-m gpu): every call goes through the C-ABI of libcsi_mamimo.so and is
+checked against the numpy oracle on identical seeded inputs.
+
+Tolerance: the contract is 1e-5 norm-relative per output row in fp32 (BASELINE.json north_star;
+SURVEY.md section 7 'hard parts' defines the norm-relative form), measured against the fp64
+evaluation of the oracle.  TOL below is that number; nothing is loosened per test."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _weights(oracle, seed, nt, hidden, use_bn=True, n_out=234):
+    rng = np.random.default_rng(seed)
+    d_in = 320 * nt + nt
+    return (oracle.make_weights(rng, d_in, list(hidden), n_out, use_bn=use_bn),
+            oracle.make_weights(rng, d_in, list(hidden), n_out, use_bn=use_bn))
+
+
+def _pilot(rng, nt, orthogonal=True):
+    from oracle import csi_oracle as o
+    if orthogonal:
+        P = o.hadamard(nt)
+        return (P[rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[:, None]).astype(np.float64)
+    return rng.integers(-3, 4, (nt, nt)).astype(np.float64)
+
+
+def _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn=True, n_out=234, **kw):
+    e = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=n_out, use_bn=use_bn, **kw)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    return e
+
+
+# ------------------------------------------------------------------------------------ LS
+@pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 3), (8, 1, 5), (16, 3, 2), (32, 4, 4), (64, 4, 2)])
+def test_ls_matches_oracle_and_known_channel(pkg, oracle, nt, nr, npkt):
+    rng = np.random.default_rng(100 + nt)
+    P = _pilot(rng, nt)
+    ltf, H = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=None)
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    e.set_pilot(P)
+    h = e.ls_estimate(ltf)
+    assert h.shape == (npkt, nr, nt, 234) and h.dtype == np.complex64
+    ref = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    # known-answer: noiseless structured packet -> LS == H
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([H.real, H.imag], -1)) < TOL
+
+
+def test_ls_noisy_generic_pilot_and_linearity(pkg, oracle):
+    rng = np.random.default_rng(7)
+    nt, nr, npkt = 8, 2, 6
+    P = _pilot(rng, nt, orthogonal=False)            # generic real P: no Hadamard assumption
+    a = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=0.0)[0]
+    b = (rng.standard_normal(a.shape) + 1j * rng.standard_normal(a.shape))
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    e.set_pilot(P)
+    ha, hb = e.ls_estimate(a), e.ls_estimate(b)
+    ref = oracle.ls_estimate(a, P)
+    assert rel_rows(np.concatenate([ha.real, ha.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    hab = e.ls_estimate(2.0 * a - 0.5 * b)
+    lin = 2.0 * ha.astype(np.complex128) - 0.5 * hb.astype(np.complex128)
+    assert rel_rows(np.concatenate([hab.real, hab.imag], -1), np.concatenate([lin.real, lin.imag], -1)) < 5e-6
+
+
+def test_ls_empty_batch(pkg):
+    e = pkg.CsiEngine(4, 2, hidden=(8,))
+    e.set_pilot(np.eye(4))
+    h = e.ls_estimate(np.zeros((0, 2, 1280), dtype=np.complex128))
+    assert h.shape == (0, 2, 4, 234)
+
+
+# ------------------------------------------------------------------------------------ DNN
+CASES = [
+    # nt, nr, npkt, hidden, use_bn
+    (4, 2, 3, (64, 64), True),          # the small fixture shape of SURVEY.md 8c
+    (4, 2, 37, (64, 64), True),         # ragged: M2 = 296 rows, not a multiple of the 128 tile
+    (8, 3, 5, (100, 36), True),         # widths that are not multiples of the 32 / 128 tiles
+    (8, 2, 4, (64,), True),             # single hidden layer (regressor fed by the pair prologue)
+    (4, 1, 6, (32, 48, 40), True),      # three hidden layers (ping-pong buffers)
+    (8, 2, 4, (64, 64), False),         # --useBN off
+    (32, 4, 2, (1024, 1024), True),     # the shipped model (pipe.sh:40,47), 2 packets
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden,use_bn', CASES)
+def test_predict_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden, use_bn):
+    rng = np.random.default_rng(nt * 1000 + npkt)
+    w_re, w_im = _weights(oracle, 1234 + nt, nt, hidden, use_bn)
+    P = _pilot(rng, nt, orthogonal=(nt != 8))
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0]
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn)
+    o_re, o_im = e.predict(ltf)
+    assert o_re.shape == (npkt, nr, nt, 234) and o_re.dtype == np.float32
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(o_re, r_re) < TOL
+    assert rel_rows(o_im, r_im) < TOL
+    # accuracy metric of the reference evaluation (BER_test_maMIMO_LTF.m:675-686)
+    assert oracle.nmse_subk(r_re + 1j * r_im, o_re + 1j * o_im) < 1e-10
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(4, 2, 5, (64, 64)), (32, 4, 1, (1024, 1024))])
+def test_literal_predict_equals_shared_layer0_path(pkg, oracle, nt, nr, npkt, hidden):
+    """Key structural identity: the packet path (layer 0 once per rx antenna + pilot table) and
+    the literal Keras predict over [Xsig | Xp] rows agree to rounding, and both match fp64."""
+    rng = np.random.default_rng(55 + nt)
+    w_re, w_im = _weights(oracle, 99, nt, hidden)
+    P = _pilot(rng, nt, orthogonal=False)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    o_re, o_im = e.predict(ltf)
+    for d, w, fast in (('real', w_re, o_re), ('imag', w_im, o_im)):
+        x = oracle.samples_from_packets(ltf, P.astype(np.float32), d)
+        y = e.predict_samples(d, x)
+        ref = oracle.fc_forward(x, w, np.float64)
+        assert rel_rows(y, ref) < TOL
+        assert rel_rows(fast.reshape(y.shape), ref) < TOL
+        assert rel_rows(fast.reshape(y.shape), y) < TOL
+
+
+def test_keras_model_surface_with_reference_batches(pkg, oracle, golden_dir):
+    """CSIModel.predict driven exactly like DNN.py:339-346: a Sequence yielding
+    ([Xsig (B,lenLTF,1), Xp (B,Nt)], y, None) with B = nTX*nRX, batches taken from the golden
+    vectors the reference's DataGenerator produced."""
+    g = np.load(os.path.join(golden_dir, 'ref_datagen_nt4.npz'))
+    nt, nr, npkt = int(g['nt']), int(g['nr']), int(g['npkt'])
+    w_re, w_im = _weights(oracle, 4321, nt, (64, 64))
+    P_rows = g['P_matlab']
+    e = _engine(pkg, nt, nr, (64, 64), w_re, w_im, P_rows)
+
+    class Seq:                                   # stands in for the reference DataGenerator
+        def __init__(self, d):
+            self.d = d
+
+        def __len__(self):
+            return npkt
+
+        def __getitem__(self, b):
+            return [g[f'{self.d}_Xsig'][b], g[f'{self.d}_Xp'][b]], g[f'{self.d}_y'][b], None
+
+    ltf = (g['ds_ltf_real'] + 1j * g['ds_ltf_imag']).reshape(npkt, nr, 320 * nt)
+    fast_re, fast_im = e.predict(ltf)
+    for d, w, fast in (('real', w_re, fast_re), ('imag', w_im, fast_im)):
+        model = pkg.CSIModel(e, d).load_weights(w)
+        csi_out = model.predict(Seq(d))
+        assert csi_out.shape == (npkt * nt * nr, 234) and csi_out.dtype == np.float32
+        x = np.concatenate([g[f'{d}_Xsig'][..., 0], g[f'{d}_Xp']], axis=-1).reshape(npkt * nr * nt, -1)
+        ref = oracle.fc_forward(x, w, np.float64)
+        assert rel_rows(csi_out, ref) < TOL
+        assert rel_rows(fast.reshape(csi_out.shape), ref) < TOL      # packet path, same samples
+
+
+def test_predict_chunking_is_invisible(pkg, oracle):
+    """A tiny workspace forces many packet chunks; results must be bitwise those of one chunk
+    whenever the split-K factor is the same, and within tolerance always."""
+    rng = np.random.default_rng(77)
+    nt, nr, npkt, hidden = 4, 2, 23, (64, 64)
+    w_re, w_im = _weights(oracle, 5, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    big = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    small = _engine(pkg, nt, nr, hidden, w_re, w_im, P, workspace_bytes=5 * (2 * 64 * 4 * 9 + 2 * 4 * 64 * 4))
+    a_re, a_im = big.predict(ltf)
+    b_re, b_im = small.predict(ltf)
+    assert rel_rows(a_re, b_re) < 1e-6 and rel_rows(a_im, b_im) < 1e-6
+    r_re, _ = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(b_re, r_re) < TOL
+
+
+def test_predict_is_deterministic(pkg, oracle):
+    rng = np.random.default_rng(78)
+    nt, nr, npkt, hidden = 8, 2, 9, (64, 64)
+    w_re, w_im = _weights(oracle, 6, nt, hidden)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, _pilot(rng, nt))
+    ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+    a = e.predict(ltf)
+    b = e.predict(ltf)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_zero_kernels_give_bias(pkg, oracle):
+    nt, nr, hidden = 4, 2, (32,)
+    w_re, w_im = _weights(oracle, 9, nt, hidden, use_bn=False)
+    for w in (w_re, w_im):
+        w['fc_regressor.kernel'] = np.zeros_like(w['fc_regressor.kernel'])
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, np.eye(nt), use_bn=False)
+    ltf = pkg.synth.white_packets(np.random.default_rng(1), 3, nr, nt)
+    o_re, o_im = e.predict(ltf)
+    np.testing.assert_array_equal(o_re, np.broadcast_to(w_re['fc_regressor.bias'], o_re.shape))
+    np.testing.assert_array_equal(o_im, np.broadcast_to(w_im['fc_regressor.bias'], o_im.shape))
+
+
+def test_empty_and_error_paths(pkg, oracle):
+    nt, nr, hidden = 4, 2, (32, 32)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    ltf = pkg.synth.white_packets(np.random.default_rng(1), 2, nr, nt)
+    with pytest.raises(pkg.CsiError) as ex:         # nothing loaded yet
+        e.predict(ltf)
+    assert ex.value.code == -2
+    w_re, w_im = _weights(oracle, 9, nt, hidden)
+    e.load_weights('real', w_re)
+    e.set_pilot(np.eye(nt))
+    with pytest.raises(pkg.CsiError) as ex:         # imag model missing
+        e.predict(ltf)
+    assert ex.value.code == -2
+    e.load_weights('imag', w_im)
+    o_re, o_im = e.predict(np.zeros((0, nr, 320 * nt), dtype=np.complex64))
+    assert o_re.shape == (0, nr, nt, 234)
+    bad = dict(w_re)
+    bad['fc_dense1.kernel'] = bad['fc_dense1.kernel'][:, :16]
+    with pytest.raises(pkg.CsiError) as ex:
+        e.load_weights('real', bad)
+    assert ex.value.code == -1
+    with pytest.raises(pkg.CsiError):
+        e.predict(np.zeros((1, nr, 7), dtype=np.complex64))
+
+
+# ------------------------------------------------------------------------------------ twin
+def test_csipredictor_twin_mamimo_end_to_end(pkg, oracle, tmp_path):
+    rng = np.random.default_rng(31)
+    nt, nr, npkt, hidden = 8, 2, 4, (64, 64)
+    w_re, w_im = _weights(oracle, 17, nt, hidden)
+    P = _pilot(rng, nt)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    for d, w in (('real', w_re), ('imag', w_im)):
+        pkg.CSIModel(e, d).load_weights(w).save(str(tmp_path / f'{d}_keras_model'), pilot=P)   # DNN.py:411
+    pred = pkg.CSIPredictor(str(tmp_path), experiment='matlab_maMimo')
+    ltf, H = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=10.0)
+    csi = pred.inference(ltf)
+    assert csi.shape == (npkt, nr, nt, 234) and csi.dtype == np.complex64
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    ref = oracle.recombine(r_re, r_im)
+    assert rel_rows(np.concatenate([csi.real, csi.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    h_ls = pred.ls_estimate(ltf)
+    ref_ls = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h_ls.real, h_ls.imag], -1), np.concatenate([ref_ls.real, ref_ls.imag], -1)) < TOL
+    with pytest.raises(SystemExit) as ex:
+        pred.inference(ltf.astype(np.complex64))
+    assert ex.value.code == -1
+
+
+def test_csipredictor_twin_rice_renew_single_input(pkg, oracle, golden_dir, tmp_path):
+    """The reference's implemented experiment: single-input FC model, 52 outputs re-inserted
+    into 64 bins.  Input/recombination/post-processing behaviour is pinned by the golden
+    vectors recorded from the reference class itself."""
+    import json
+    g = np.load(os.path.join(golden_dir, 'ref_inference_rice.npz'), allow_pickle=True)
+    x = g['x']
+    n_in = x.shape[1]
+    rng = np.random.default_rng(3)
+    ws = {}
+    for d in ('real', 'imag'):
+        w = oracle.make_weights(rng, n_in, [32], 52, use_bn=True)
+        ws[d] = w
+        p = tmp_path / f'{d}_keras_model'
+        p.mkdir()
+        pkg.save_weight_file(str(p / 'weights.safetensors'), w)
+        (p / 'config.json').write_text(json.dumps(dict(nt=0, nr=1, len_ltf=n_in, hidden=[32], n_out=52, use_bn=True)))
+    pred = pkg.CSIPredictor(str(tmp_path))                       # experiment='RICE_RENEW' default
+    y = pred.inference(x)
+    assert y.shape == (x.shape[0], 64) and y.dtype == np.complex128
+    ref = oracle.postprocess_rice_renew(oracle.recombine(oracle.fc_forward(x.real, ws['real'], np.float64),
+                                                          oracle.fc_forward(x.imag, ws['imag'], np.float64)))
+    np.testing.assert_array_equal(y == 0, g['y'] == 0)            # same null pattern as the reference
+    nz = ref[:, 1:27]
+    assert rel_rows(np.concatenate([y[:, 1:27].real, y[:, 1:27].imag], -1), np.concatenate([nz.real, nz.imag], -1)) < TOL
+
+
+# ------------------------------------------------------------------------------------ device path
+def test_device_resident_path_and_profile(pkg, oracle):
+    rng = np.random.default_rng(41)
+    nt, nr, npkt, hidden = 8, 2, 16, (64, 64)
+    w_re, w_im = _weights(oracle, 23, nt, hidden)
+    P = _pilot(rng, nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
+    e.synth_white(2024, 0, npkt, d_re, d_im)
+    d_ore, d_oim = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    d_hre, d_him = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.profile_enable(True)
+    e.profile_reset()
+    e.predict_device(d_re, d_im, npkt, d_ore, d_oim)
+    e.ls_estimate_device(d_re, d_im, npkt, d_hre, d_him)
+    e.synchronize()
+    prof = e.profile()
+    assert prof['pair_dense_gemm']['launches'] == 2 and prof['pair_dense_gemm']['ms'] > 0
+    assert prof['ls_estimate']['launches'] == 1 and prof['regressor_gemm']['launches'] == 2
+    ltf = d_re.download() + 1j * d_im.download()
+    # white generator: unit-variance circular Gaussian, reproducible, offset-consistent
+    assert abs(np.mean(np.abs(ltf) ** 2) - 1.0) < 0.02 and abs(np.mean(ltf)) < 0.01
+    d_re2, d_im2 = e.empty((4, nr, e.len_ltf)), e.empty((4, nr, e.len_ltf))
+    e.synth_white(2024, 5, 4, d_re2, d_im2)
+    np.testing.assert_array_equal(d_re2.download(), ltf.real[5:9].astype(np.float32))
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(d_ore.download(), r_re) < TOL and rel_rows(d_oim.download(), r_im) < TOL
+    ref_ls = oracle.ls_estimate(ltf, P)
+    assert rel_rows(d_hre.download(), ref_ls.real) < TOL and rel_rows(d_him.download(), ref_ls.imag) < TOL
+
+
+def test_full_size_properties_config2_slice(pkg, oracle):
+    """BASELINE config 2 shape (Nt=32, Nr=4, shipped model) on 64 device-generated packets:
+    checked through size-independent properties plus the oracle on a random subset of packets.
+      * packets are independent: the result of a packet does not depend on its batch
+      * LS is linear
+      * a sampled subset matches the fp64 oracle within the contract."""
+    rng = np.random.default_rng(2026)
+    nt, nr, npkt, hidden = 32, 4, 64, (1024, 1024)
+    w_re, w_im = _weights(oracle, 1234, nt, hidden)
+    P = oracle.hadamard(nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
+    e.synth_white(99, 0, npkt, d_re, d_im)
+    d_ore, d_oim = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, d_ore, d_oim)
+    e.synchronize()
+    o_re, o_im = d_ore.download(), d_oim.download()
+    assert np.isfinite(o_re).all() and np.isfinite(o_im).all()
+    pick = sorted(rng.choice(npkt, 3, replace=False).tolist())
+    ltf = (d_re.download() + 1j * d_im.download())[pick]
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=len(pick))
+    assert rel_rows(o_re[pick], r_re) < TOL and rel_rows(o_im[pick], r_im) < TOL
+    # batch independence (different chunk / split-K geometry): same packets alone
+    s_re, s_im = e.predict(ltf)
+    assert rel_rows(s_re, o_re[pick]) < 2e-6 and rel_rows(s_im, o_im[pick]) < 2e-6
+    h = e.ls_estimate(ltf)
+    ref = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL

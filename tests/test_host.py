@@ -1,0 +1,154 @@
+"""CPU tests (-m "not gpu") of the host side: the C-ABI library loads and exports every symbol
+include/csi_mamimo.h declares (no compute call is made), the CSIPredictor twin's pre/post
+processing equals the reference's recorded behaviour, weight container round trip, packet
+sharding, and the world_size-2 weight broadcast over gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(pkg):
+    so = pkg.build_library()
+    assert os.path.exists(so)
+    lib = pkg.load_library()
+    header = open(os.path.join(REPO, 'include', 'csi_mamimo.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(csi_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 20
+    from dl_channel_estimation_mamimo_amd import _lib
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.csi_abi_version() == 1
+    n = lib.csi_profile_num_kernels()
+    names = [lib.csi_profile_kernel_name(i).decode() for i in range(n)]
+    assert 'pair_dense_gemm' in names and 'ls_estimate' in names
+
+
+def test_library_contains_gfx950_code_object(pkg):
+    so = pkg.build_library()
+    blob = open(so, 'rb').read()
+    assert b'gfx950' in blob and b'gemm_f32_kernel' in blob and b'ls_estimate_kernel' in blob
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    """On a box without a gfx950 device the engine must refuse to construct - never compute on
+    the CPU.  (On a GPU box this test only checks that bad shapes are rejected.)"""
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg.CsiError) as e:
+            pkg.CsiEngine(4, 2, hidden=(64, 64))
+        assert e.value.code == -4
+    with pytest.raises(pkg.CsiError):
+        pkg.CsiEngine(4, 2, hidden=())
+
+
+def test_product_package_never_imports_oracle():
+    pk = os.path.join(REPO, 'dl-channel-estimation-mamimo_amd')
+    for root, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert '/root/reference' not in src, f
+
+
+def _bare_predictor(pkg, experiment):
+    p = object.__new__(pkg.CSIPredictor)       # host logic only: no engine, no GPU
+    p.experiment = experiment
+    p.verbose = False
+    p.engine = None
+    return p
+
+
+def test_twin_postprocess_matches_reference_golden(pkg, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_inference_rice.npz'), allow_pickle=True)
+    p = _bare_predictor(pkg, 'RICE_RENEW')
+    post = p.postprocess_data(g['ramp'])
+    np.testing.assert_array_equal(post, g['post_ramp'])
+    assert str(post.dtype) == str(g['post_ramp_dtype'])
+    assert p.preprocess_data(g['x']) is not None
+
+
+def test_twin_error_behaviour_matches_reference(pkg, golden_dir, capsys):
+    g = np.load(os.path.join(golden_dir, 'ref_inference_rice.npz'), allow_pickle=True)
+    p = _bare_predictor(pkg, 'RICE_RENEW')
+    with pytest.raises(SystemExit) as e:
+        p.preprocess_data(g['x'].astype(np.complex64))
+    assert e.value.code == int(g['exit_bad_dtype']) == -1
+    assert '[CSIPredictor] ERROR: Input batch must be of type np.complex128' in capsys.readouterr().out
+    with pytest.raises(SystemExit) as e:
+        p.postprocess_data(np.zeros((2, 51), dtype=np.complex64))
+    assert e.value.code == int(g['exit_bad_width']) == -1
+    assert 'Output samples must have size 52' in capsys.readouterr().out
+
+
+def test_weight_container_roundtrip(pkg, tmp_path):
+    rng = np.random.default_rng(0)
+    w = pkg.synth.make_weights(rng, 4, hidden=(16, 8), n_out=234)
+    for ext in ('safetensors', 'pt'):
+        f = str(tmp_path / f'w.{ext}')
+        pkg.save_weight_file(f, w)
+        w2 = pkg.load_weight_file(f)
+        assert set(w2) == set(w)
+        for k in w:
+            np.testing.assert_array_equal(w[k], w2[k])
+    from dl_channel_estimation_mamimo_amd.model import config_from_weights
+    assert config_from_weights(w, 4) == dict(hidden=[16, 8], n_out=234, use_bn=True)
+
+
+def test_shard_range_partitions_all_packets(pkg):
+    for n in (0, 1, 7, 500, 50000):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                lo, hi = pkg.dist.shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n
+                got.extend(range(lo, hi))
+            assert got == list(range(n))
+            sizes = [pkg.dist.shard_range(n, r, world)[1] - pkg.dist.shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import dl_channel_estimation_mamimo_amd as m
+d = m.dist.init_process_group('gloo')
+rank = d.get_rank()
+rng = np.random.default_rng(123)
+w = m.synth.make_weights(rng, 4, hidden=(16, 8), n_out=234) if rank == 0 else None
+w = m.dist.broadcast_weights(w, src=0)
+ref = m.synth.make_weights(np.random.default_rng(123), 4, hidden=(16, 8), n_out=234)
+assert set(w) == set(ref)
+for k in ref:
+    assert np.array_equal(w[k], ref[k]), k
+lo, hi = m.dist.shard_range(11, rank, d.get_world_size())
+tot = m.dist.all_reduce_sum(hi - lo)
+mx = m.dist.all_reduce_max(float(rank + 1))
+assert tot == 11 and mx == 2.0, (tot, mx)
+m.dist.barrier()
+print('rank', rank, 'ok', lo, hi)
+'''
+
+
+def test_two_rank_weight_broadcast_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    port = 29600 + os.getpid() % 300
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, universal_newlines=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert 'rank 0 ok 0 6' in outs[0] and 'rank 1 ok 6 11' in outs[1]

@@ -1,0 +1,166 @@
+"""CPU tests (-m "not gpu"): the oracle against the committed golden vectors that were produced
+by running the reference's own numpy code (tests/golden/make_golden.py), and against exact
+identities for the rows the reference cannot pin (LS, Dense/BN)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _dataset_from_golden(g):
+    keys = g['ds_keys'].tolist()
+    ltf = {k: {'real': g['ds_ltf_real'][i], 'imag': g['ds_ltf_imag'][i]} for i, k in enumerate(keys)}
+    nt, nr = int(g['nt']), int(g['nr'])
+    sim = {'nTX': nt, 'nRX': nr, 'lenLTF': 320 * nt, 'nSubCarr': 234}
+    return {'X': g['ds_X'], 'y': {'real': g['ds_y_real'], 'imag': g['ds_y_imag']}, 'LTF': ltf, 'P': g['ds_P'],
+            'simParams': sim}
+
+
+def test_sample_assembly_matches_reference_datagenerator(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_datagen_nt4.npz'))
+    ds = _dataset_from_golden(g)
+    nt, nr, npkt = int(g['nt']), int(g['nr']), int(g['npkt'])
+    bs = nt * nr
+    for d in ('real', 'imag'):
+        assert int(g[f'{d}_len']) == npkt            # one batch per packet (DNN.py:339)
+        assert int(g[f'{d}_len_bs5']) == (npkt * bs) // 5
+        for b in range(npkt):
+            ids = list(range(b * bs, (b + 1) * bs))
+            xsig, xp, y = oracle.assemble_batch(ds, d, ids)
+            np.testing.assert_array_equal(xsig, g[f'{d}_Xsig'][b])
+            np.testing.assert_array_equal(xp, g[f'{d}_Xp'][b])
+            np.testing.assert_array_equal(y, g[f'{d}_y'][b])
+
+
+def test_packed_layout_equals_reference_sample_order(oracle, golden_dir):
+    """[Npkt,Nr,lenLTF] planes + P rows reproduce the reference's [Xsig | Xp] rows in dataset
+    order s = p*Nr*Nt + r*Nt + t, including the P orientation (P_py[:, t] = MATLAB P(t,:))."""
+    g = np.load(os.path.join(golden_dir, 'ref_datagen_nt4.npz'))
+    nt, nr, npkt = int(g['nt']), int(g['nr']), int(g['npkt'])
+    ltf = (g['ds_ltf_real'] + 1j * g['ds_ltf_imag']).reshape(npkt, nr, 320 * nt)
+    P_rows = oracle.pilot_rows_from_dataset_P(g['ds_P'])
+    np.testing.assert_array_equal(P_rows, g['P_matlab'])
+    for d in ('real', 'imag'):
+        x = oracle.samples_from_packets(ltf, P_rows, d)
+        ref = np.concatenate([g[f'{d}_Xsig'][..., 0], g[f'{d}_Xp']], axis=-1).reshape(npkt * nr * nt, -1)
+        np.testing.assert_array_equal(x, ref)
+    # transposed P must NOT match (the fixture's P is deliberately non-symmetric)
+    assert not np.array_equal(oracle.samples_from_packets(ltf, P_rows.T, 'real'), ref)
+
+
+def test_inference_recombine_and_postprocess_match_reference(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_inference_rice.npz'), allow_pickle=True)
+    x = g['x']
+    out_re = (x.real.astype(np.float32) @ g['A_re'].astype(np.float32) + g['b_re'].astype(np.float32)).astype(np.float32)
+    out_im = (x.imag.astype(np.float32) @ g['A_im'].astype(np.float32) + g['b_im'].astype(np.float32)).astype(np.float32)
+    y = oracle.postprocess_rice_renew(oracle.recombine(out_re, out_im))
+    assert str(y.dtype) == str(g['y_dtype'])
+    np.testing.assert_allclose(y, g['y'], rtol=0, atol=1e-5)       # float32 matmul order only
+    np.testing.assert_array_equal(y == 0, g['y'] == 0)              # null pattern exact
+    post = oracle.postprocess_rice_renew(g['ramp'])
+    np.testing.assert_array_equal(post, g['post_ramp'])
+    assert str(post.dtype) == str(g['post_ramp_dtype'])
+    assert int(g['exit_bad_dtype']) == -1 and int(g['exit_bad_width']) == -1
+    with pytest.raises(ValueError):
+        oracle.preprocess_rice_renew(x.astype(np.complex64))
+    with pytest.raises(ValueError):
+        oracle.postprocess_rice_renew(np.zeros((2, 51), dtype=np.complex64))
+    # the reference hands float64 planes and batch_size=bs to the models
+    assert list(g['model_calls_real']) == ['<f8', str(x.shape[0])]
+
+
+def test_postprocess_index_map(oracle):
+    o = np.arange(1, 53)[None, :].astype(np.complex128)
+    y = oracle.postprocess_rice_renew(o).real.astype(int)[0]
+    assert y[0] == 0 and list(y[1:27]) == list(range(27, 53)) and not y[27:38].any() and list(y[38:]) == list(range(1, 27))
+
+
+def test_ofdm_constants(oracle):
+    idx = oracle.data_carrier_indices()
+    assert idx.size == 234 and idx[0] == 8 and idx[-1] == 250 and 129 not in idx and 26 not in idx
+    ltf = oracle.vht_ltf_256()
+    assert ltf.size == 256 and not ltf[:7].any() and not ltf[-6:].any() and ltf[128] == 0
+    assert set(np.unique(ltf[idx - 1]).tolist()) == {-1.0, 1.0}
+
+
+@pytest.mark.parametrize('nt', [4, 8, 32])
+def test_ls_known_answer(oracle, nt):
+    """LS(x) == H exactly (to fp64 rounding) when the packet is synthesised from H and
+    P P^H = Nt I (follows from helperMIMOChannelEstimate.m:24-36)."""
+    rng = np.random.default_rng(nt)
+    P = oracle.hadamard(nt)
+    perm = rng.permutation(nt)
+    P = P[perm] * rng.choice([-1.0, 1.0], nt)[:, None]              # non-symmetric, still orthogonal
+    ltf, H = oracle.make_structured_packets(rng, 2, 3, P)
+    np.testing.assert_allclose(oracle.ls_estimate(ltf, P), H, rtol=0, atol=1e-12)
+    if nt > 4:
+        assert np.abs(oracle.ls_estimate(ltf, P.T) - H).max() > 1e-3  # orientation matters
+
+
+def test_ls_is_linear_and_ignores_cp(oracle):
+    rng = np.random.default_rng(5)
+    nt = 8
+    P = oracle.hadamard(nt)
+    a = rng.standard_normal((2, 1, 320 * nt)) + 1j * rng.standard_normal((2, 1, 320 * nt))
+    b = rng.standard_normal((2, 1, 320 * nt)) + 1j * rng.standard_normal((2, 1, 320 * nt))
+    lhs = oracle.ls_estimate(2.0 * a - 3j * b, P)
+    np.testing.assert_allclose(lhs, 2.0 * oracle.ls_estimate(a, P) - 3j * oracle.ls_estimate(b, P), atol=1e-10)
+    a2 = a.copy().reshape(2, 1, nt, 320)
+    a2[..., :64] = 0                                                 # the CP samples are not used
+    np.testing.assert_allclose(oracle.ls_estimate(a2.reshape(a.shape), P), oracle.ls_estimate(a, P), atol=1e-12)
+
+
+def test_fc_forward_against_torch_layers(oracle):
+    """Dense/BN semantics cross-checked against an independent implementation
+    (torch.nn.functional.linear / batch_norm in eval mode, eps=1e-3)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    nt = 4
+    w = oracle.make_weights(rng, 320 * nt + nt, [48, 40], 234, use_bn=True, dtype=np.float64)
+    x = rng.standard_normal((9, 320 * nt + nt))
+    y = oracle.fc_forward(x, w, np.float64)
+    h = torch.from_numpy(x)
+    for i in range(2):
+        h = F.relu(F.linear(h, torch.from_numpy(w[f'fc_dense{i}.kernel'].T.copy()), torch.from_numpy(w[f'fc_dense{i}.bias'])))
+        h = F.batch_norm(h, torch.from_numpy(w[f'bn{i}.moving_mean']), torch.from_numpy(w[f'bn{i}.moving_variance']),
+                         torch.from_numpy(w[f'bn{i}.gamma']), torch.from_numpy(w[f'bn{i}.beta']), training=False, eps=1e-3)
+    yt = F.linear(h, torch.from_numpy(w['fc_regressor.kernel'].T.copy()), torch.from_numpy(w['fc_regressor.bias'])).numpy()
+    np.testing.assert_allclose(y, yt, rtol=1e-12, atol=1e-12)
+
+
+def test_fc_forward_identities(oracle):
+    rng = np.random.default_rng(3)
+    nt = 4
+    d_in = 320 * nt + nt
+    w = oracle.make_weights(rng, d_in, [16], 234, use_bn=False, dtype=np.float64)
+    x = rng.standard_normal((5, d_in))
+    w0 = {k: (np.zeros_like(v) if k.endswith('kernel') else v) for k, v in w.items()}
+    # zero kernels: output = regressor bias
+    np.testing.assert_allclose(oracle.fc_forward(x, w0), np.broadcast_to(w['fc_regressor.bias'], (5, 234)))
+    # fp32 evaluation stays within the fp32 contract of the fp64 one
+    w32 = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) else v) for k, v in w.items()}
+    assert oracle.row_rel_err(oracle.fc_forward(x, w32, np.float32), oracle.fc_forward(x, w32, np.float64)) < 1e-5
+
+
+def test_predict_packets_layout(oracle):
+    """Row s of the literal predict equals H[p, r, t] with s = p*Nr*Nt + r*Nt + t."""
+    rng = np.random.default_rng(8)
+    nt, nr, npkt = 4, 2, 3
+    P = rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+    w_re = oracle.make_weights(rng, 320 * nt + nt, [24, 24], 234)
+    w_im = oracle.make_weights(rng, 320 * nt + nt, [24, 24], 234)
+    ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+    o_re, o_im = oracle.predict_packets(ltf, P, w_re, w_im)
+    x = oracle.samples_from_packets(ltf, P, 'imag')
+    y = oracle.fc_forward(x, w_im)
+    p, r, t = 2, 1, 3
+    np.testing.assert_allclose(o_im[p, r, t], y[p * nr * nt + r * nt + t], rtol=1e-12)
+    assert o_re.shape == (npkt, nr, nt, 234)
+
+
+def test_nmse(oracle):
+    rng = np.random.default_rng(2)
+    h = rng.standard_normal((2, 2, 4, 234)) + 1j * rng.standard_normal((2, 2, 4, 234))
+    assert oracle.nmse_subk(h, h) == 0.0
+    assert abs(oracle.nmse_subk(h, 0.9 * h) - 0.01) < 1e-12
