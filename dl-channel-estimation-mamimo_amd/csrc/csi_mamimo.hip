@@ -44,7 +44,8 @@ const char* const kKernelNames[K_COUNT] = {
 thread_local std::string g_create_error;
 
 struct Layer {
-    float* Wt = nullptr;      // [out][in]  (K-major)
+    float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)
+    int ldw = 0;
     float* bias = nullptr;    // [out]
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
     float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
@@ -166,18 +167,24 @@ int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {
         *buf = nullptr;
         *have = 0;
     }
-    if (hipMalloc((void**)buf, need) != hipSuccess) {
+    const size_t bytes = need + G_SLACK_FLOATS * sizeof(float);
+    if (hipMalloc((void**)buf, bytes) != hipSuccess) {
         *buf = nullptr;
-        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", need);
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
     }
+    HIP_TRY(c, hipMemsetAsync(*buf, 0, bytes, c->stream));     // never-written parts must be finite
     *have = need;
     return CSI_OK;
 }
 
+// Every device array a GEMM may read as its A side (or as a per-column vector) is followed by
+// G_SLACK_FLOATS zeroed floats: the K tail of the last tile over-reads into finite memory.
 int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
     if (*dst) { hipFree(*dst); *dst = nullptr; }
-    if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess)
-        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", n * sizeof(float));
+    const size_t bytes = (n + G_SLACK_FLOATS) * sizeof(float);
+    if (hipMalloc((void**)dst, bytes) != hipSuccess)
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+    HIP_TRY(c, hipMemset(*dst, 0, bytes));
     HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
     return CSI_OK;
 }
@@ -209,8 +216,8 @@ const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& nam
 template <int AMODE, int EPI>
 int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     if (g.M <= 0) return CSI_OK;
-    if ((g.K & 3) || (g.lda & 3) || (g.ldb & 3))
-        return fail(c, CSI_ERR_INVALID_ARG, "gemm: K/lda/ldb must be multiples of 4 (K=%d lda=%d ldb=%d)",
+    if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
+        return fail(c, CSI_ERR_INVALID_ARG, "gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
                     g.K, g.lda, g.ldb);
     const int tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
@@ -219,30 +226,59 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     const double a_rows = (AMODE == A_PAIR) ? (double)g.M / g.nt : (double)g.M;
     const double bytes = 4.0 * (a_rows * g.K + (double)g.N * g.K + (double)g.M * g.N * splits);
     ProfScope ps(c, kid, flops, bytes);
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, G_BK, 2, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
 
+// first per-pair layer: fragment-time h1 kernel for 4 <= nt <= 128, register-staged one otherwise
+template <int EPI>
+int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
+    if (g.nt < 4 || g.nt > 128) return launch_gemm<A_PAIR, EPI>(c, kid, g, 1);
+    if (g.M <= 0) return CSI_OK;
+    if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
+        return fail(c, CSI_ERR_INVALID_ARG, "pair gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
+                    g.K, g.lda, g.ldb);
+    const int tiles_m = (g.M + G_BM - 1) / G_BM;
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 4.0 * ((double)g.M / g.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    ProfScope ps(c, kid, flops, bytes);
+    hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), dim3((unsigned)(tiles_m * g.tiles_n)), dim3(G_THREADS), 0, c->stream, g);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// Split-K factor of layer 0.  The grid should fill whole rounds of the 512 resident workgroups
+// (256 CUs x 2): pick the smallest factor whose last round is >= 90 % full, else the fullest.
 int choose_splits(int M, int N, int K, int* k_per_split) {
     const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-    long s = 1024 / (tiles > 0 ? tiles : 1);
-    if (s < 1) s = 1;
-    if (s > 8) s = 8;
     const int ktiles = (K + G_BK - 1) / G_BK;
-    if (s > ktiles) s = ktiles;
-    int kps = (int)((ktiles + s - 1) / s) * G_BK;
-    int splits = (K + kps - 1) / kps;
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s : cand) {
+        if (s > 1 && ktiles / s < 16) break;          // keep >= 16 k-tiles per block
+        const int kps = (ktiles + s - 1) / s;
+        const int real = (ktiles + kps - 1) / kps;
+        const double rounds = (double)tiles * real / 512.0;
+        const double eff = rounds / std::ceil(rounds);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+        if (eff >= 0.9) { best = s; break; }
+    }
+    const int kps = (ktiles + best - 1) / best * G_BK;
     *k_per_split = kps;
-    return splits;
+    return (K + kps - 1) / kps;
 }
 
 int build_pilot_table(csi_ctx* c, Model& m) {
     if (!m.loaded || !c->pilot_ok || c->cfg.nt == 0) return CSI_OK;
     const int nt = c->cfg.nt, h1 = c->cfg.hidden[0];
     if (!m.T) {
-        if (hipMalloc((void**)&m.T, (size_t)nt * h1 * sizeof(float)) != hipSuccess)
+        const size_t bytes = ((size_t)nt * h1 + G_SLACK_FLOATS) * sizeof(float);
+        if (hipMalloc((void**)&m.T, bytes) != hipSuccess)
             return fail(c, CSI_ERR_NOMEM, "pilot table allocation failed");
+        HIP_TRY(c, hipMemsetAsync(m.T, 0, bytes, c->stream));
     }
     ProfScope ps(c, K_PILOT_TABLE, 2.0 * nt * nt * h1, 4.0 * (nt * nt + 2.0 * nt * h1));
     hipLaunchKernelGGL(pilot_table_kernel, dim3((h1 + 255) / 256, nt), dim3(256), 0, c->stream,
@@ -259,17 +295,38 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
     int maxh = 0;
     for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
-    const int smax = 8;
-    const size_t per_pkt = (size_t)nr * h1 * 4 * (smax + 1) +
-                           (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)1 << 30);
-    int64_t chunk = (int64_t)(budget / per_pkt);
-    if (chunk < 1) chunk = 1;
-    if (chunk > npkt) chunk = npkt;
-    // keep M = chunk*nr*nt inside int range
-    const int64_t max_chunk = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);
-    if (chunk > max_chunk) chunk = max_chunk;
-    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_pkt * (size_t)chunk);
+    // Packet chunks: as few as the workspace allows, all of (nearly) the same size so that every
+    // chunk fills the machine equally well.  Per packet: layer-0 slabs + their sum, and the
+    // ping-pong buffers of the hidden activations.
+    const int smax = 16;                                  // upper bound of choose_splits
+    const size_t hid_pkt = (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
+    size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);   // 1.5 GiB
+    int64_t chunk = npkt;
+    int splits_max = 1;
+    for (int iter = 0; iter < 64; ++iter) {
+        int kps_tmp;
+        splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
+        const size_t per_pkt_try = (size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt;
+        const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / per_pkt_try));
+        const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
+        const int64_t cap = std::min(fit, max_rows);
+        if (chunk <= cap) break;
+        const int64_t nchunks = (npkt + cap - 1) / cap;
+        const int64_t balanced = (npkt + nchunks - 1) / nchunks;
+        if (balanced == chunk) break;
+        chunk = balanced;
+    }
+    (void)smax;
+    // the tail chunk may want a different split factor; size the slabs for the larger of the two
+    {
+        int kps_tmp;
+        splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
+        const int64_t tail = npkt % chunk;
+        if (tail) splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
+    }
+    const size_t slab_floats = (size_t)chunk * nr * h1;
+    const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk;
+    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_chunk);
     if (rc) return rc;
 
     for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
@@ -277,9 +334,9 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         const int M1 = (int)(np * nr);
         const int M2 = (int)(np * nr * nt);
         float* slabs = reinterpret_cast<float*>(c->ws);
-        float* l0sum = slabs + (size_t)chunk * nr * h1 * smax;
+        float* l0sum = slabs + slab_floats * splits_max;              // unused when splits_max == 1
         float* hbuf[2];
-        hbuf[0] = l0sum + (size_t)chunk * nr * h1;
+        hbuf[0] = slabs + slab_floats * (splits_max > 1 ? splits_max + 1 : 1);
         hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh;
 
         // layer 0, LTF part: L0[M1][h1] = ltf[M1][len_ltf] * W0[0:len_ltf, :]
@@ -289,7 +346,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
         g.lda = cf.len_ltf;
         g.Bt = m.layers[0].Wt;
-        g.ldb = c->d_in;
+        g.ldb = m.layers[0].ldw;
         g.C = slabs;
         g.ldc = h1;
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
@@ -313,24 +370,24 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = m.layers[0].shift; p.nt = nt;
         p.M = M2; p.K = h1;
         const Layer& l1 = m.layers[1];
-        p.Bt = l1.Wt; p.ldb = l1.in; p.N = l1.out;
+        p.Bt = l1.Wt; p.ldb = l1.ldw; p.N = l1.out;
         p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
         p.k_per_split = ((h1 + G_BK - 1) / G_BK) * G_BK;
         if (nh == 1) {
             p.C = out_chunk; p.ldc = cf.n_out;
-            rc = launch_gemm<A_PAIR, EPI_BIAS>(c, K_REGRESSOR, p, 1);
+            rc = launch_pair<EPI_BIAS>(c, K_REGRESSOR, p);
             if (rc) return rc;
             continue;
         }
         p.C = hbuf[0]; p.ldc = l1.out;
-        rc = launch_gemm<A_PAIR, EPI_BIAS_RELU_AFFINE>(c, K_PAIR_DENSE, p, 1);
+        rc = launch_pair<EPI_BIAS_RELU_AFFINE>(c, K_PAIR_DENSE, p);
         if (rc) return rc;
         int cur = 0;
         for (int li = 2; li <= nh; ++li) {
             const Layer& l = m.layers[li];
             GemmArgs q{};
             q.A = hbuf[cur]; q.lda = l.in;
-            q.Bt = l.Wt; q.ldb = l.in;
+            q.Bt = l.Wt; q.ldb = l.ldw;
             q.M = M2; q.N = l.out; q.K = l.in;
             q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
             q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
@@ -512,13 +569,15 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
         Layer& L = m.layers[li];
         L.in = fan_in;
         L.out = out;
-        // transpose [in][out] -> [out][in] (K-major) on the host, blocked for cache friendliness
-        std::vector<float> wt((size_t)out * fan_in);
+        // transpose [in][out] -> [out][ldw] (K-major, K zero-padded to a multiple of the k-tile) on
+        // the host, blocked for cache friendliness
+        L.ldw = (fan_in + G_BK - 1) / G_BK * G_BK;
+        std::vector<float> wt((size_t)out * L.ldw, 0.f);
         const int TB = 32;
         for (int i0 = 0; i0 < fan_in; i0 += TB)
             for (int o0 = 0; o0 < out; o0 += TB)
                 for (int i = i0; i < std::min(fan_in, i0 + TB); ++i)
-                    for (int o = o0; o < std::min(out, o0 + TB); ++o) wt[(size_t)o * fan_in + i] = k->data[(size_t)i * out + o];
+                    for (int o = o0; o < std::min(out, o0 + TB); ++o) wt[(size_t)o * L.ldw + i] = k->data[(size_t)i * out + o];
         int rc = upload(c, &L.Wt, wt.data(), wt.size());
         if (rc) return rc;
         rc = upload(c, &L.bias, b->data, out);
@@ -702,7 +761,7 @@ int csi_predict_samples(csi_ctx* c, int model, const float* x, int64_t B, float*
             const Layer& l = m.layers[li];
             GemmArgs q{};
             q.A = cur; q.lda = cur_ld;
-            q.Bt = l.Wt; q.ldb = l.in;
+            q.Bt = l.Wt; q.ldb = l.ldw;
             q.M = (int)nb; q.N = l.out; q.K = l.in;
             q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
             q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;

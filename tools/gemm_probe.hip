@@ -1,0 +1,93 @@
+// gemm_probe.hip - within-process A/B of gemm_f32_kernel variants at the bench shapes.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o /tmp/gemm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+#include "../dl-channel-estimation-mamimo_amd/csrc/gemm_f32.hip.h"
+using namespace csi;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+static float* dalloc(size_t n, bool rnd, float scale = 1.f) {
+    float* d; CK(hipMalloc(&d, (n + 64) * 4)); CK(hipMemset(d, 0, (n + 64) * 4));
+    if (rnd) { std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() & 0xffff) / 32768.f - 1.f);
+        CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice)); }
+    return d;
+}
+
+template <int AMODE, int EPI, int BK, int MINW>
+double run(const char* name, GemmArgs g, int splits, int iters, std::vector<float>* out = nullptr) {
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n, 1, splits);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, BK, 2, MINW>), grid, dim3(256), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, BK, 2, MINW>), grid, dim3(256), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], mn = ts[0];
+    double fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s BK=%d minw=%d  med %.3f ms  %.1f TF   (best %.1f TF)\n", name, BK, MINW, med, fl / med / 1e9, fl / mn / 1e9);
+    if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
+    return med;
+}
+
+template <int EPI>
+double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s fragment-time h1   med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
+    return med;
+}
+
+int main() {
+    const int nt = 32, M1 = 8192, M2 = M1 * nt, H = 1024, KL = 10240, NO = 234;
+    float* ltf = dalloc((size_t)M1 * KL, true);
+    float* W0 = dalloc((size_t)H * 10272, true, 0.02f);
+    float* L0 = dalloc((size_t)M1 * H * 2, true);
+    float* T = dalloc((size_t)nt * H, true);
+    float* s0 = dalloc(H, true); float* t0 = dalloc(H, true);
+    float* W1 = dalloc((size_t)H * H, true, 0.05f);
+    float* W2 = dalloc((size_t)NO * H, true, 0.05f);
+    float* bias = dalloc(H, true); float* sc = dalloc(H, true); float* sh = dalloc(H, true);
+    float* h2 = dalloc((size_t)M2 * H, false);
+    float* out = dalloc((size_t)M2 * NO, false);
+    GemmArgs p{}; p.A = L0; p.lda = H; p.T = T; p.s0 = s0; p.t0 = t0; p.nt = nt; p.M = M2; p.K = H; p.N = H;
+    p.Bt = W1; p.ldb = H; p.bias = bias; p.scale = sc; p.shift = sh; p.C = h2; p.ldc = H; p.k_per_split = H;
+    GemmArgs l{}; l.A = ltf; l.lda = KL; l.Bt = W0; l.ldb = 10272; l.C = L0; l.ldc = H; l.M = M1; l.N = H; l.K = KL; l.k_per_split = 5120;
+    GemmArgs r{}; r.A = h2; r.lda = H; r.Bt = W2; r.ldb = H; r.M = M2; r.N = NO; r.K = H; r.bias = bias; r.C = out; r.ldc = NO; r.k_per_split = H;
+    std::vector<float> o1, o2, o3;
+    for (int rep = 0; rep < 2; ++rep) {
+        run<A_PAIR, EPI_BIAS_RELU_AFFINE, 32, 2>("pair_dense", p, 1, 7, &o1);
+        run_pair<EPI_BIAS_RELU_AFFINE>("pair_dense", p, 7, &o2);
+        o3 = o2;
+        double d = 0; for (int i = 0; i < 256; ++i) d = std::max(d, (double)std::fabs(o1[i] - o2[i]) + std::fabs(o1[i] - o3[i]));
+        printf("   max |diff| between variants on first 256 outputs: %g (values ~%g)\n", d, o1[5]);
+        run<A_PLAIN, EPI_RAW, 32, 2>("layer0 (split 2)", l, 2, 7);
+        run<A_PLAIN, EPI_BIAS, 32, 2>("regressor", r, 1, 7);
+    }
+    return 0;
+}
