@@ -3,10 +3,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csi_mamimo.hip -o libcsi_mamimo.so
 //
 // What runs where (reference call sites in include/csi_mamimo.h):
-//   csi_predict*        layer 0 once per (packet, rx)  -> gemm_f32_kernel<A_PLAIN, EPI_RAW> (split-K)
+//   csi_predict*        layer 0 once per (packet, rx)  -> gemm_f32_kernel<EPI_RAW> (optional split-K)
 //                       (+ splitk_reduce_kernel)          then per pair (packet, rx, tx):
-//                       hidden 1.. and regressor       -> gemm_f32_kernel<A_PAIR|A_PLAIN, ...>
-//   csi_predict_samples literal un-shared network      -> gemm_f32_kernel<A_PLAIN, ...>
+//                       hidden 1.. and regressor       -> pair_gemm_f32_kernel / gemm_f32_kernel
+//   csi_predict_samples literal un-shared network      -> gemm_f32_kernel
 //   csi_ls_estimate*    FFT + despread                 -> ls_estimate_kernel
 #include <hip/hip_runtime.h>
 
@@ -213,7 +213,7 @@ const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& nam
 }
 
 // ---------------------------------------------------------------- GEMM launch helpers
-template <int AMODE, int EPI>
+template <int EPI>
 int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     if (g.M <= 0) return CSI_OK;
     if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
@@ -223,18 +223,19 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
     const double flops = 2.0 * (double)g.M * g.N * g.K;
-    const double a_rows = (AMODE == A_PAIR) ? (double)g.M / g.nt : (double)g.M;
+    const double a_rows = (double)g.M;
     const double bytes = 4.0 * (a_rows * g.K + (double)g.N * g.K + (double)g.M * g.N * splits);
     ProfScope ps(c, kid, flops, bytes);
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, G_BK, 2, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
 
-// first per-pair layer: fragment-time h1 kernel for 4 <= nt <= 128, register-staged one otherwise
+// first per-pair layer (fragment-time h1 kernel, 4 <= nt <= 128)
 template <int EPI>
 int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
-    if (g.nt < 4 || g.nt > 128) return launch_gemm<A_PAIR, EPI>(c, kid, g, 1);
+    if (g.nt < 4 || g.nt > 128)
+        return fail(c, CSI_ERR_INVALID_ARG, "the per-pair layer supports 4 <= nt <= 128 (got %d)", g.nt);
     if (g.M <= 0) return CSI_OK;
     if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
         return fail(c, CSI_ERR_INVALID_ARG, "pair gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
@@ -244,7 +245,9 @@ int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M / g.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
-    hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), dim3((unsigned)(tiles_m * g.tiles_n)), dim3(G_THREADS), 0, c->stream, g);
+    const dim3 grid((unsigned)(tiles_m * g.tiles_n));
+    if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
+    else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -351,7 +354,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         g.ldc = h1;
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
         g.k_per_split = kps;
-        rc = launch_gemm<A_PLAIN, EPI_RAW>(c, K_LAYER0_LTF, g, splits);
+        rc = launch_gemm<EPI_RAW>(c, K_LAYER0_LTF, g, splits);
         if (rc) return rc;
         const float* l0 = slabs;
         if (splits > 1) {
@@ -393,10 +396,10 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
             q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
             if (li == nh) {
                 q.C = out_chunk; q.ldc = cf.n_out;
-                rc = launch_gemm<A_PLAIN, EPI_BIAS>(c, K_REGRESSOR, q, 1);
+                rc = launch_gemm<EPI_BIAS>(c, K_REGRESSOR, q, 1);
             } else {
                 q.C = hbuf[cur ^ 1]; q.ldc = l.out;
-                rc = launch_gemm<A_PLAIN, EPI_BIAS_RELU_AFFINE>(c, K_DENSE_HIDDEN, q, 1);
+                rc = launch_gemm<EPI_BIAS_RELU_AFFINE>(c, K_DENSE_HIDDEN, q, 1);
                 cur ^= 1;
             }
             if (rc) return rc;
@@ -767,10 +770,10 @@ int csi_predict_samples(csi_ctx* c, int model, const float* x, int64_t B, float*
             q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
             if (li == cf.n_hidden) {
                 q.C = d_y; q.ldc = cf.n_out;
-                rc = launch_gemm<A_PLAIN, EPI_BIAS>(c, K_REGRESSOR, q, 1);
+                rc = launch_gemm<EPI_BIAS>(c, K_REGRESSOR, q, 1);
             } else {
                 q.C = hb[w]; q.ldc = l.out;
-                rc = launch_gemm<A_PLAIN, EPI_BIAS_RELU_AFFINE>(c, li == 0 ? K_NAIVE_DENSE0 : K_DENSE_HIDDEN, q, 1);
+                rc = launch_gemm<EPI_BIAS_RELU_AFFINE>(c, li == 0 ? K_NAIVE_DENSE0 : K_DENSE_HIDDEN, q, 1);
                 cur = hb[w];
                 cur_ld = l.out;
                 w ^= 1;

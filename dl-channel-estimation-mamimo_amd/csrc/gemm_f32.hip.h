@@ -1,31 +1,43 @@
 // gemm_f32.hip.h - fp32 dense layers of the per-pair CSI regressor on CDNA4 matrix cores.
 //
-// One kernel template covers every Dense layer of the reference model
+// Two kernels cover every Dense layer of the reference model
 // (massiveMIMO_CSI_prediction_DNN.py:211-227):   C[M,N] = epilogue( A[M,K] * W[K,N] )
+//
+//   gemm_f32_kernel       A is a plain row-major matrix (layer 0 over the rx preambles, hidden
+//                         layers 2.., fc_regressor, and the literal un-shared network).
+//   pair_gemm_f32_kernel  first per-pair layer; its A operand
+//                             h1[(p,r,t), k] = bn0( relu( L0[(p,r), k] + T[t, k] ) )
+//                         is generated at fragment-read time from two small LDS images (the
+//                         layer-0 LTF product L0, computed once per (packet, rx) and shared by the
+//                         Nt pairs, and the pilot table T = P * W0[lenLTF:, :] + b0).  h1 never
+//                         exists in HBM, nor as a tile in LDS.
+//
+// Common structure
 //   * W is held K-major on the device (Bt[N][ldb], transposed and zero-padded in K to a
-//     multiple of 32 once at load time) so that both operands are read from LDS with one
-//     ds_read_b128 per four k-steps.
+//     multiple of 32 once at load time); both operands are read from LDS with one ds_read_b128
+//     per four k-steps.
 //   * arithmetic: v_mfma_f32_32x32x2_f32 - exact fp32 products, fp32 accumulate (a k-ordered
-//     fmaf chain), i.e. the same number format the reference's TF-CPU float32 kernels use.
-//   * block tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles,
-//     LDS double-buffered (2 x 32 KiB), one barrier per k-tile, 2 workgroups per CU.
-//   * operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip).
-//     The LDS image is lane-linear (128-B rows, no padding); bank conflicts of the fragment
-//     reads are removed by an XOR swizzle of the 16-B chunk index with (row>>1)&7, applied on
-//     the per-lane SOURCE address of the DMA and on the ds_read address.
-//   * A_PAIR mode builds the layer-1 activations on the fly in the A-operand prologue:
-//        h1[(p,r,t), k] = bn0( relu( L0[(p,r), k] + T[t, k] ) )
-//     where L0 = LTF part of layer 0 (computed once per (packet, rx) and shared by the Nt
-//     pairs) and T = P * W0[lenLTF:, :] + b0 (Nt x H1 table).  h1 never exists in HBM.
+//     fmaf chain), i.e. the number format of the reference's TF-CPU float32 kernels.
+//   * block tile 128x128, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles,
+//     2 workgroups per CU.
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into
+//     a ring of R_NS = 4 stages of R_BK = 16 k-columns.  The DMA of k-tile t+3 is issued while
+//     k-tile t is multiplied; a counted s_waitcnt vmcnt(N) + one raw s_barrier per k-tile hand a
+//     stage over, so neither the DMA issue cost nor its landing latency (measured: -10 % when
+//     exposed) sits on the matrix pipe's critical path.
+//   * the LDS images are lane-linear (64-B rows, no padding); bank conflicts of the fragment
+//     reads are removed by XOR-ing the 16-B chunk index with (row>>2)&3, applied on the per-lane
+//     SOURCE address of the DMA and on the ds_read address.
 //   * epilogue: + bias, relu, BatchNormalization affine applied AFTER the relu as in
 //     DNN.py:211-219 (y = relu(z) * inv + (beta - mean * inv)).
 //
 // Bounds: rows are clamped to the last valid row (results of clamped rows are never stored);
-// the K tail of a tile (K % 32 != 0) multiplies zero-padded weight columns, and every A-side
-// buffer carries >= 128 B of zeroed slack so that the over-read stays in bounds and finite.
+// the K tail of a tile multiplies zero-padded weight columns, and every A-side buffer carries
+// >= 256 B of zeroed slack so that the over-read stays in bounds and finite.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace csi {
 
@@ -38,18 +50,23 @@ constexpr int G_BK = 32;                       // K granularity the host pads / 
 constexpr int G_THREADS = 256;
 constexpr int G_SLACK_FLOATS = 64;             // zeroed slack behind every A-side buffer
 
-enum AMode { A_PLAIN = 0, A_PAIR = 1 };
+constexpr int R_BK = 16;                       // k-columns per ring stage
+constexpr int R_NS = 4;                        // ring stages
+constexpr int R_D = R_NS - 1;                  // prefetch distance in k-tiles
+constexpr int R_CH = R_BK / 4;                 // 16-B chunks per image row (4)
+constexpr int R_RPP = 64 / R_CH;               // image rows per 1-KiB DMA piece (16)
+
 enum Epi { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU_AFFINE = 2 };
 
 struct GemmArgs {
-    const float* A;        // A_PLAIN: [M][lda].  A_PAIR: L0 [M/nt][lda] (pre-bias layer-0 LTF product)
+    const float* A;        // plain: [M][lda].  pair: L0 [M/nt][lda] (pre-bias layer-0 LTF product)
     const float* Bt;       // [N][ldb], K contiguous, ldb % 32 == 0, columns >= K are zero
     float* C;              // [M][ldc]; EPI_RAW split z writes slab C + z*M*ldc
     int M, N, K;
     int lda, ldb, ldc;
     int k_per_split;       // multiple of G_BK
     int tiles_n;
-    // A_PAIR only
+    // pair kernel only
     const float* T;        // [nt][lda] pilot table, includes the layer-0 bias
     const float* s0;       // [K] layer-0 BN scale   (1 when the model has no BN)
     const float* t0;       // [K] layer-0 BN shift   (0 when the model has no BN)
@@ -60,13 +77,25 @@ struct GemmArgs {
     const float* shift;    // [N]
 };
 
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
 // 16 bytes per lane, HBM/L2 -> LDS, destination = wave-uniform base + lane*16
 __device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+__device__ __forceinline__ int r_swz(int row) { return (row >> 2) & (R_CH - 1); }
+
+// Stage hand-over: wait until at most `groups` of this wave's DMA groups (P instructions each)
+// are still in flight, retire this wave's LDS reads, then meet the other waves.  The counted
+// vmcnt keeps the younger k-tiles' DMA in flight ACROSS the barrier; __syncthreads() would
+// drain them (vmcnt(0)).
+template <int P>
+__device__ __forceinline__ void ring_handover(int groups) {
+    if (groups >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * P) : "memory");
+    else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+static_assert(R_D == 3, "ring_handover covers 0..2 groups in flight");
 
 // Epilogue shared by the GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Kept free of per-element branches: the per-column
@@ -116,27 +145,39 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const G
     }
 }
 
-// Tile geometry for a k-tile of BK floats (16 or 32):
-//   CH   = 16-byte chunks per tile row                       (BK/4)
-//   RPP  = tile rows covered by one 1-KiB DMA piece          (64/CH)
-//   NPW  = DMA pieces each wave issues per operand tile      (128/RPP/4)
-//   swizzle of the chunk index: f(row) = (row / (16/CH)) % CH  - 16 consecutive rows then hit
-//   16 distinct 16-B slots of the 256-B LDS bank row, so ds_read_b128 is conflict-free.
-template <int BK>
-struct TileGeom {
-    static constexpr int CH = BK / 4;
-    static constexpr int RPP = 64 / CH;
-    static constexpr int NPW = 128 / RPP / 4;
-    static constexpr int TILE = 128 * BK;
-    static constexpr int RSH = (CH == 8) ? 1 : 2;       // log2(16/CH)
-    __device__ static __forceinline__ int swz(int row) { return (row >> RSH) & (CH - 1); }
-};
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
 
-template <int AMODE, int EPI, int BK, int STAGES, int MINW>
-__global__ __launch_bounds__(G_THREADS, MINW) void gemm_f32_kernel(const GemmArgs g) {
-    using TG = TileGeom<BK>;
-    constexpr int TILE = TG::TILE;
-    __shared__ __attribute__((aligned(16))) float lds[STAGES * 2 * TILE];   // [stage][A|B][128][BK]
+// 16 MFMAs: one 8-deep k-chunk of the wave's 64x64 tile.  k-permutation inside the chunk:
+// lanes 0-31 hold k = 0..3, lanes 32-63 k = 4..7; step s consumes component s of both
+// operands, so A and B agree on k.
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[2][2], const f32x4& a0, const f32x4& a1, const f32x4& b0,
+                                           const f32x4& b1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+    }
+}
+
+// =============================================================================================
+// plain GEMM.  Ring stage = [A image 128x16 | B image 128x16]; each wave issues 2 + 2 DMA
+// pieces (16 rows x 64 B each) per k-tile.
+// =============================================================================================
+constexpr int GP_STAGE = 2 * 128 * R_BK;       // floats per stage (16 KiB)
+constexpr int GP_P = 4;                        // DMA instructions per wave per k-tile
+
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[R_NS * GP_STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,159 +190,83 @@ __global__ __launch_bounds__(G_THREADS, MINW) void gemm_f32_kernel(const GemmArg
     const int m0 = tm * G_BM, n0 = tn * G_BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
-    const int nkt = (kend - kbeg + BK - 1) / BK;
+    const int nkt = (kend - kbeg + R_BK - 1) / R_BK;
 
-    // ---- LDS-DMA map: wave w issues pieces j = NPW*w .. NPW*w+NPW-1; piece j = tile rows
-    // RPP*j .. RPP*j+RPP-1; lane -> row RPP*j + lane/CH, physical chunk lane%CH, which holds
-    // logical chunk (lane%CH) ^ swz(row) of that row.
-    const float* bsrc[TG::NPW];
-    const float* asrc[TG::NPW];
+    // DMA map: wave w issues pieces 2w, 2w+1 of each image; piece j = image rows 16j..16j+15;
+    // lane -> row 16j + lane/4, physical chunk lane%4 holding logical chunk (lane%4) ^ swz(row)
+    const float* asrc[2];
+    const float* bsrc[2];
 #pragma unroll
-    for (int u = 0; u < TG::NPW; ++u) {
-        const int row = TG::RPP * (TG::NPW * wave + u) + lane / TG::CH;
-        const int clog = (lane % TG::CH) ^ TG::swz(row);
+    for (int u = 0; u < 2; ++u) {
+        const int row = R_RPP * (2 * wave + u) + (lane >> 2);
+        const int clog = (lane & 3) ^ r_swz(row);
+        asrc[u] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + clog * 4 + kbeg;
         bsrc[u] = g.Bt + (size_t)min(n0 + row, g.N - 1) * g.ldb + clog * 4 + kbeg;
-        if (AMODE == A_PLAIN) asrc[u] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + clog * 4 + kbeg;
-        else asrc[u] = nullptr;
     }
+    auto issue = [&](int kt, int u, bool b_side) {
+        float* st = lds + (kt & (R_NS - 1)) * GP_STAGE + (b_side ? 128 * R_BK : 0) + (2 * wave + u) * 256;
+        dma16((b_side ? bsrc[u] : asrc[u]) + kt * R_BK, st);
+    };
 
-    // ---- A_PAIR register-staged map: thread -> chunk c4 of rows r0 + (256/CH)*i, i < CH/2
-    constexpr int PR = TG::CH / 2;                // rows per thread
-    constexpr int RSTEP = G_THREADS / TG::CH;     // row stride between a thread's rows
-    const int c4 = tid % TG::CH;
-    const int r0 = tid / TG::CH;
-    const float* lptr[PR];
-    const float* tptr[PR];
-    int awoff[PR];
-    if (AMODE == A_PAIR) {
+    // fragment read offsets inside a stage
+    const int arow = wm * 64 + l31, brow = wn * 64 + l31;
+    int aoff[2], boff[2];
 #pragma unroll
-        for (int i = 0; i < PR; ++i) {
-            const int row = r0 + RSTEP * i;
-            const int m = min(m0 + row, g.M - 1);
-            const int pr = m / g.nt;
-            const int t = m - pr * g.nt;
-            lptr[i] = g.A + (size_t)pr * g.lda + c4 * 4 + kbeg;
-            tptr[i] = g.T + (size_t)t * g.lda + c4 * 4 + kbeg;
-            awoff[i] = row * BK + ((c4 ^ TG::swz(row)) << 2);
-        }
+    for (int c = 0; c < 2; ++c) {
+        aoff[c] = arow * R_BK + (((2 * c + hi) ^ r_swz(arow)) << 2);
+        boff[c] = 128 * R_BK + brow * R_BK + (((2 * c + hi) ^ r_swz(brow)) << 2);
     }
-    const float* sptr = (AMODE == A_PAIR) ? g.s0 + c4 * 4 + kbeg : nullptr;
-    const float* hptr = (AMODE == A_PAIR) ? g.t0 + c4 * 4 + kbeg : nullptr;
-
-    f32x4 pa[PR], pt[PR], ps, psh;
-
-    // one DMA piece pair (B, and A when plain) of k-tile kt into stage buffer `buf`
-    auto issue_dma_piece = [&](int kt, int buf, int u) {
-        float* As = lds + buf * (2 * TILE);
-        float* Bs = As + TILE;
-        const int k = kt * BK;
-        const int piece = (TG::NPW * wave + u) * 256;     // floats per 1-KiB piece
-        dma16(bsrc[u] + k, Bs + piece);
-        if (AMODE == A_PLAIN) dma16(asrc[u] + k, As + piece);
-    };
-    auto load_pair = [&](int kt) {
-        const int k = kt * BK;
-#pragma unroll
-        for (int i = 0; i < PR; ++i) {
-            pa[i] = ldg4(lptr[i] + k);
-            pt[i] = ldg4(tptr[i] + k);
-        }
-        ps = ldg4(sptr + k);
-        psh = ldg4(hptr + k);
-    };
-    auto store_pair = [&](int buf) {
-        float* As = lds + buf * (2 * TILE);
-#pragma unroll
-        for (int i = 0; i < PR; ++i) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(pa[i][e] + pt[i][e], 0.f), ps[e], psh[e]);
-            *reinterpret_cast<f32x4*>(As + awoff[i]) = v;
-        }
-    };
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    zero_acc(acc);
 
-    // fragment read offsets (floats): row*BK + ((2c+hi) ^ swz)*4, swz identical for row and row+32
-    const int arow = wm * 64 + l31, brow = wn * 64 + l31;
-    int aoff[BK / 8], boff[BK / 8];
-#pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-        aoff[c] = arow * BK + (((2 * c + hi) ^ TG::swz(arow)) << 2);
-        boff[c] = brow * BK + (((2 * c + hi) ^ TG::swz(brow)) << 2);
+    const int npro = min(nkt, R_D);
+    for (int t = 0; t < npro; ++t) {
+        issue(t, 0, false); issue(t, 1, false); issue(t, 0, true); issue(t, 1, true);
     }
-
-    // multiply k-tile in stage `buf`; the DMA pieces of k-tile `kt_next` (if >= 0) are issued
-    // between the MFMA groups so that their issue cost hides under the matrix pipe.
-    auto compute_tile = [&](int buf, int kt_next, int buf_next) {
-        const float* As = lds + buf * (2 * TILE);
-        const float* Bs = As + TILE;
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const float* st = lds + (kt & (R_NS - 1)) * GP_STAGE;
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            // k-permutation inside each 8-chunk: lanes 0-31 take k = 0..3, lanes 32-63 k = 4..7;
-            // MFMA step s consumes component s of both operands, so A and B agree on k.
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(As + aoff[c]);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(As + aoff[c] + 32 * BK);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + boff[c]);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + boff[c] + 32 * BK);
-            if (kt_next >= 0 && c < TG::NPW) issue_dma_piece(kt_next, buf_next, c);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-            }
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + aoff[c]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + aoff[c] + 32 * R_BK);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + boff[c]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(st + boff[c] + 32 * R_BK);
+            if (MORE) { issue(kt + R_D, c, false); issue(kt + R_D, c, true); }
+            mfma_chunk(acc, a0, a1, b0, b1);
         }
     };
-    static_assert(TG::NPW <= BK / 8, "one DMA piece per MFMA group");
-
-    if (nkt > 0) {
-#pragma unroll
-        for (int u = 0; u < TG::NPW; ++u) issue_dma_piece(0, 0, u);
-        if (AMODE == A_PAIR) {
-            load_pair(0);
-            store_pair(0);
-        }
+    int kt = 0;
+    for (; kt < nkt - R_D; ++kt) {          // steady state: 2 younger groups stay in flight
+        ring_handover<GP_P>(R_D - 1);
+        ktile(kt, std::true_type{});
     }
-    __syncthreads();          // drains the LDS-DMA (vmcnt) and publishes the ds_writes
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1) < nkt;
-        if (more && AMODE == A_PAIR) load_pair(kt + 1);
-        compute_tile(kt & 1, more ? kt + 1 : -1, (kt + 1) & 1);
-        if (more && AMODE == A_PAIR) store_pair((kt + 1) & 1);
-        __syncthreads();
+    for (; kt < nkt; ++kt) {                // drain
+        ring_handover<GP_P>(nkt - 1 - kt);
+        ktile(kt, std::false_type{});
     }
-
     gemm_epilogue<EPI>(acc, g, m0, n0, wm, wn, l31, hi);
 }
 
-// ---------------------------------------------------------------------------------------------
-// First per-pair layer with the layer-1 activations generated AT FRAGMENT-READ TIME.
-//   C[(p,r,t), n] = epi( sum_k h1[(p,r,t), k] * W[k, n] ),
-//   h1[(p,r,t), k] = bn0( relu( L0[(p,r), k] + T[t, k] ) )
-// Instead of a 128-row A tile the k-tile stage holds three small images, all filled by LDS-DMA:
-//   Ls  [PL_LROWS][32]  rows 0..NL-1 = the L0 rows of the (packet, rx) pairs this block touches,
-//                       row NL = bn0 scale slice, row NL+1 = bn0 shift slice
-//   Ts  [nt (<=128)][32] the pilot table slice (every t of the block is a row of it)
-//   Bs  [128][32]        the weight tile
-// and each lane builds its A fragment as fma(max(L + T, 0), s, t) right before the MFMAs
-// (24 VALU per 16 MFMA, hidden under the matrix pipe).  No h1 tile is ever written anywhere,
-// not even to LDS.  Requires 4 <= nt <= 128.
-constexpr int PL_LROWS = 40;                   // 128/4 + 1 L0 rows + 2 vector rows, rounded to 8
-constexpr int PL_STAGE = 128 * 32 + 128 * 32 + PL_LROWS * 32;    // floats per stage
-
-template <int EPI>
+// =============================================================================================
+// pair GEMM (first per-pair layer).  Ring stage = three images, all filled by LDS-DMA:
+//   Bs [128][16]   weight tile
+//   Ts [128][16]   pilot-table slice, row t (rows >= nt are unused duplicates)
+//   Ls [48][16]    rows 0..NL-1 = the L0 rows of the (packet, rx) pairs this block touches,
+//                  row NL = bn0 scale slice, row NL+1 = bn0 shift slice
+// Each lane builds its A fragment as fma(max(L + T, 0), s, t) right before the MFMAs (24 VALU
+// per 16 MFMA, hidden under the matrix pipe).  Every wave issues exactly 2 B + TPW T + 1 L DMA
+// pieces per k-tile so that the counted vmcnt is the same constant for all waves (TPW = 1
+// covers nt <= 64, TPW = 2 nt <= 128; a wave whose piece lies beyond the image repeats the
+// last one - same bytes, same destination).  Requires 4 <= nt <= 128.
+// =============================================================================================
+constexpr int PL_LROWS = 48;                                   // 128/4 + 1 L0 rows + 2 vector rows -> 3 pieces
+constexpr int PL_STAGE = (128 + 128 + PL_LROWS) * R_BK;        // floats per stage (19 KiB)
+template <int EPI, int TPW>
 __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BK = 32;
-    using TG = TileGeom<BK>;
-    __shared__ __attribute__((aligned(16))) float lds[2 * PL_STAGE];     // [stage][Bs | Ts | Ls]
+    constexpr int PL_P = 2 + TPW + 1;
+    __shared__ __attribute__((aligned(16))) float lds[R_NS * PL_STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -312,113 +277,110 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
     const int tile = blockIdx.x;
     const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
     const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int nkt = (g.K + BK - 1) / BK;
+    const int nkt = (g.K + R_BK - 1) / R_BK;
     const int nt = g.nt;
     const int pr_base = m0 / nt;
-    const int pr_last = min(m0 + G_BM - 1, g.M - 1) / nt;
-    const int NL = pr_last - pr_base + 1;                // <= 33
-    const int nL = (NL + 2 + 7) >> 3;                    // DMA pieces of the L image
-    const int nT = (nt + 7) >> 3;                        // DMA pieces of the T image
+    const int NL = min(m0 + G_BM - 1, g.M - 1) / nt - pr_base + 1;       // <= 33
 
-    // ---- DMA sources.  Piece j covers image rows 8j..8j+7; lane -> row 8j + lane/8, physical
-    // chunk lane%8 holding logical chunk (lane%8) ^ swz(row).  Wave w issues B pieces 4w..4w+3,
-    // T pieces w, w+4, w+8, w+12 and L pieces w, w+4 (when they exist).
-    const int prow = lane >> 3, pch = lane & 7;
-    const float* bsrc[4];
-    const float* tsrc[4];
-    const float* lsrc[2];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int rb = 8 * (4 * wave + u) + prow;
-        bsrc[u] = g.Bt + (size_t)min(n0 + rb, g.N - 1) * g.ldb + ((pch ^ TG::swz(rb)) << 2);
-        const int rt = 8 * (wave + 4 * u) + prow;
-        tsrc[u] = g.T + (size_t)min(rt, nt - 1) * g.lda + ((pch ^ TG::swz(rt)) << 2);
-    }
+    // ---- DMA sources (piece = 16 image rows; lane -> row 16j + lane/4, chunk lane%4)
+    const int prow = lane >> 2, pch = lane & 3;
+    const float* bsrc[2];
+    const float* tsrc[TPW];
+    const float* lsrc;
+    const int nT = (nt + R_RPP - 1) / R_RPP;                   // pieces of the T image that exist
+    int tpiece[TPW];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int rl = 8 * (wave + 4 * u) + prow;
-        const int cl = (pch ^ TG::swz(rl)) << 2;
+        const int rb = R_RPP * (2 * wave + u) + prow;
+        bsrc[u] = g.Bt + (size_t)min(n0 + rb, g.N - 1) * g.ldb + ((pch ^ r_swz(rb)) << 2);
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        tpiece[u] = min(wave + 4 * u, nT - 1);                 // T pieces w (and w+4)
+        const int rt = R_RPP * tpiece[u] + prow;
+        tsrc[u] = g.T + (size_t)min(rt, nt - 1) * g.lda + ((pch ^ r_swz(rt)) << 2);
+    }
+    const int lpiece = min(wave, PL_LROWS / R_RPP - 1);        // wave 3 repeats piece 2 (same bytes)
+    {
+        const int rl = R_RPP * lpiece + prow;
         const float* p = g.A + (size_t)(pr_base + min(rl, NL - 1)) * g.lda;
         if (rl == NL) p = g.s0;
         if (rl == NL + 1) p = g.t0;
-        lsrc[u] = p + cl;
+        lsrc = p + ((pch ^ r_swz(rl)) << 2);
     }
-
-    auto issue_piece = [&](int kt, int buf, int u) {      // u in 0..3: the u-th piece group of this wave
-        float* Bs = lds + buf * PL_STAGE;
-        float* Ts = Bs + 128 * BK;
-        float* Ls = Ts + 128 * BK;
-        const int k = kt * BK;
-        dma16(bsrc[u] + k, Bs + (4 * wave + u) * 256);
-        if (wave + 4 * u < nT) dma16(tsrc[u] + k, Ts + (wave + 4 * u) * 256);
-        if (u < 2 && wave + 4 * u < nL) dma16(lsrc[u] + k, Ls + (wave + 4 * u) * 256);
+    // u = 0/1: {B piece, T piece};  u = 2: the L piece
+    auto issue = [&](int kt, int u) {
+        float* st = lds + (kt & (R_NS - 1)) * PL_STAGE;
+        const int k = kt * R_BK;
+        if (u < 2) {
+            dma16(bsrc[u] + k, st + (2 * wave + u) * 256);
+            if (u < TPW) dma16(tsrc[u] + k, st + 128 * R_BK + tpiece[u] * 256);
+        } else {
+            dma16(lsrc + k, st + 256 * R_BK + lpiece * 256);
+        }
     };
 
     // ---- per-lane fragment addressing (rows are fixed for the whole kernel)
-    int loff[2], lswz[2], toff[2], tswz[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = min(m0 + wm * 64 + mi * 32 + l31, g.M - 1);
-        const int pr = m / nt;
-        const int t = m - pr * nt;
-        const int lr = pr - pr_base;
-        loff[mi] = lr * BK; lswz[mi] = TG::swz(lr);
-        toff[mi] = t * BK;  tswz[mi] = TG::swz(t);
-    }
+    int loff[2][2], toff[2][2], boff[2], soff[2], hoff[2];
     const int brow = wn * 64 + l31;
-    const int bswz = TG::swz(brow);
-    const int soff = NL * BK, hoff = (NL + 1) * BK;
-    const int sswz = TG::swz(NL), hswz = TG::swz(NL + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = 2 * c + hi;                       // logical 16-B chunk of this lane
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = min(m0 + wm * 64 + mi * 32 + l31, g.M - 1);
+            const int pr = m / nt;
+            const int t = m - pr * nt;
+            const int lr = pr - pr_base;
+            loff[mi][c] = 256 * R_BK + lr * R_BK + ((ch ^ r_swz(lr)) << 2);
+            toff[mi][c] = 128 * R_BK + t * R_BK + ((ch ^ r_swz(t)) << 2);
+        }
+        boff[c] = brow * R_BK + ((ch ^ r_swz(brow)) << 2);
+        soff[c] = 256 * R_BK + NL * R_BK + ((ch ^ r_swz(NL)) << 2);
+        hoff[c] = 256 * R_BK + (NL + 1) * R_BK + ((ch ^ r_swz(NL + 1)) << 2);
+    }
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    zero_acc(acc);
 
-    auto compute_tile = [&](int buf, int kt_next, int buf_next) {
-        const float* Bs = lds + buf * PL_STAGE;
-        const float* Ts = Bs + 128 * BK;
-        const float* Ls = Ts + 128 * BK;
+    const int npro = min(nkt, R_D);
+    for (int t = 0; t < npro; ++t) {
+        issue(t, 0); issue(t, 1); issue(t, 2);
+    }
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const float* st = lds + (kt & (R_NS - 1)) * PL_STAGE;
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            const int ch = 2 * c + hi;                    // logical 16-B chunk of this lane
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(Ls + soff + ((ch ^ sswz) << 2));
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(Ls + hoff + ((ch ^ hswz) << 2));
-            const f32x4 l0 = *reinterpret_cast<const f32x4*>(Ls + loff[0] + ((ch ^ lswz[0]) << 2));
-            const f32x4 l1 = *reinterpret_cast<const f32x4*>(Ls + loff[1] + ((ch ^ lswz[1]) << 2));
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(Ts + toff[0] + ((ch ^ tswz[0]) << 2));
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(Ts + toff[1] + ((ch ^ tswz[1]) << 2));
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + brow * BK + ((ch ^ bswz) << 2));
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + (brow + 32) * BK + ((ch ^ bswz) << 2));
-            if (kt_next >= 0) issue_piece(kt_next, buf_next, c);
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(st + soff[c]);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(st + hoff[c]);
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(st + loff[0][c]);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(st + loff[1][c]);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(st + toff[0][c]);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(st + toff[1][c]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + boff[c]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(st + boff[c] + 32 * R_BK);
+            if (MORE) {
+                issue(kt + R_D, c);
+                if (c == 1) issue(kt + R_D, 2);
+            }
             f32x4 a0, a1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a0[e] = fmaf(fmaxf(l0[e] + t0[e], 0.f), sv[e], hv[e]);
                 a1[e] = fmaf(fmaxf(l1[e] + t1[e], 0.f), sv[e], hv[e]);
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-            }
+            mfma_chunk(acc, a0, a1, b0, b1);
         }
     };
-
-    if (nkt > 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+    int kt = 0;
+    for (; kt < nkt - R_D; ++kt) {          // steady state: 2 younger groups stay in flight
+        ring_handover<PL_P>(R_D - 1);
+        ktile(kt, std::true_type{});
     }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1) < nkt;
-        compute_tile(kt & 1, more ? kt + 1 : -1, (kt + 1) & 1);
-        __syncthreads();
+    for (; kt < nkt; ++kt) {                // drain
+        ring_handover<PL_P>(nkt - 1 - kt);
+        ktile(kt, std::false_type{});
     }
     gemm_epilogue<EPI>(acc, g, m0, n0, wm, wn, l31, hi);
 }

@@ -18,47 +18,46 @@ static float* dalloc(size_t n, bool rnd, float scale = 1.f) {
     return d;
 }
 
-template <int AMODE, int EPI, int BK, int MINW>
+template <int EPI>
 double run(const char* name, GemmArgs g, int splits, int iters, std::vector<float>* out = nullptr) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n, 1, splits);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, BK, 2, MINW>), grid, dim3(256), 0, 0, g);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
     CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < iters; ++i) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, EPI, BK, 2, MINW>), grid, dim3(256), 0, 0, g);
-        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
-    }
-    CK(hipGetLastError());
-    std::sort(ts.begin(), ts.end());
-    double med = ts[ts.size() / 2], mn = ts[0];
-    double fl = 2.0 * g.M * g.N * g.K;
-    printf("%-34s BK=%d minw=%d  med %.3f ms  %.1f TF   (best %.1f TF)\n", name, BK, MINW, med, fl / med / 1e9, fl / mn / 1e9);
-    if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
-    return med;
-}
-
-template <int EPI>
-double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
-    g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n);
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
-    CK(hipDeviceSynchronize());
-    std::vector<float> ts;
-    for (int i = 0; i < iters; ++i) {
-        CK(hipEventRecord(a));
-        hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
     }
     CK(hipGetLastError());
     std::sort(ts.begin(), ts.end());
     double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
-    printf("%-34s fragment-time h1   med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    printf("%-34s med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
+    return med;
+}
+
+template <int EPI, int TPW>
+double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, TPW>), grid, dim3(256), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, TPW>), grid, dim3(256), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
     if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
     return med;
 }
@@ -80,14 +79,11 @@ int main() {
     GemmArgs l{}; l.A = ltf; l.lda = KL; l.Bt = W0; l.ldb = 10272; l.C = L0; l.ldc = H; l.M = M1; l.N = H; l.K = KL; l.k_per_split = 5120;
     GemmArgs r{}; r.A = h2; r.lda = H; r.Bt = W2; r.ldb = H; r.M = M2; r.N = NO; r.K = H; r.bias = bias; r.C = out; r.ldc = NO; r.k_per_split = H;
     std::vector<float> o1, o2, o3;
-    for (int rep = 0; rep < 2; ++rep) {
-        run<A_PAIR, EPI_BIAS_RELU_AFFINE, 32, 2>("pair_dense", p, 1, 7, &o1);
-        run_pair<EPI_BIAS_RELU_AFFINE>("pair_dense", p, 7, &o2);
-        o3 = o2;
-        double d = 0; for (int i = 0; i < 256; ++i) d = std::max(d, (double)std::fabs(o1[i] - o2[i]) + std::fabs(o1[i] - o3[i]));
-        printf("   max |diff| between variants on first 256 outputs: %g (values ~%g)\n", d, o1[5]);
-        run<A_PLAIN, EPI_RAW, 32, 2>("layer0 (split 2)", l, 2, 7);
-        run<A_PLAIN, EPI_BIAS, 32, 2>("regressor", r, 1, 7);
+    for (int rep = 0; rep < 3; ++rep) {
+        run_pair<EPI_BIAS_RELU_AFFINE, 1>("pair_dense tpw1", p, 7, &o1);
+        run_pair<EPI_BIAS_RELU_AFFINE, 2>("pair_dense tpw2", p, 7, &o2);
+        run<EPI_RAW>("layer0 (split 2)", l, 2, 7);
+        run<EPI_BIAS>("regressor", r, 1, 7);
     }
     return 0;
 }
