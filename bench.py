@@ -120,6 +120,24 @@ def main():
     if rank != 0:
         return
 
+    # HBM traffic per launch comes from the committed rocprofv3 PMC summary of this same command
+    # (profiles/rNN_traffic.json, written by tools/profile_summarize.py); it cannot be measured
+    # from inside the process.
+    traffic = {}
+    pdir = os.path.join(REPO, 'profiles')
+    if os.path.isdir(pdir):
+        files = sorted(f for f in os.listdir(pdir) if f.endswith('_traffic.json'))
+        if files:
+            with open(os.path.join(pdir, files[-1])) as f:
+                traffic = json.load(f)
+            traffic['_file'] = 'profiles/' + files[-1]
+
+    def hbm_per_launch(prefix):
+        for k, v in traffic.items():
+            if k.startswith(prefix):
+                return v.get('hbm_bytes_per_launch')
+        return None
+
     dom = prof['pair_dense_gemm']
     dom_ms = dom['ms'] / max(dom['launches'], 1)
     achieved = dom['flops'] / max(dom['ms'], 1e-9) / 1e9          # TFLOP/s
@@ -148,7 +166,9 @@ def main():
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS,
+                     'traffic': hbm_per_launch('pair_gemm_f32_kernel'), 'traffic_unit': 'HBM bytes per launch (PMC)',
+                     'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,
         'parity_check': check,
@@ -157,7 +177,8 @@ def main():
         p = prof['ls_estimate']
         gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
         out['roofline_ls'] = {'bound': 'hbm', 'kernel': 'ls_estimate', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': gbs / HBM_PEAK_GBS, 'traffic': None}
+                              'frac': gbs / HBM_PEAK_GBS, 'traffic': hbm_per_launch('ls_estimate_kernel'),
+                              'algorithmic_bytes_per_launch': p['bytes'] / max(p['launches'], 1)}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
