@@ -47,16 +47,21 @@ def main():
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
     ap.add_argument('--no-ls', action='store_true', help='time the DNN only')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
+    ap.add_argument('--host-path', type=int, default=0,
+                    help='also time the host-buffer (PCIe-inclusive) entry points on this many packets')
     args = ap.parse_args()
 
     import dl_channel_estimation_mamimo_amd as pkg
     rank, world, local = pkg.dist.env_rank_world()
     if world > 1:
-        pkg.dist.init_process_group('nccl')
+        # RCCL over xGMI; CSI_DIST_BACKEND=gloo lets several ranks share one GPU for a dry run
+        pkg.dist.init_process_group(os.environ.get('CSI_DIST_BACKEND', 'nccl'))
     n_gpus = max(args.gpus, world)
 
     nt, nr, npkt, hidden = args.nt, args.nr, args.packets, tuple(args.hidden)
-    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local)
+    import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev)
 
     # weights: created on rank 0, broadcast as one flat buffer (RCCL over xGMI when world > 1)
     wts = None
@@ -117,6 +122,18 @@ def main():
             check['ls_rel_err'] = max(o.row_rel_err(d_hre.download(0, k), r_ls.real), o.row_rel_err(d_him.download(0, k), r_ls.imag))
         check['packets'] = k
 
+    host_path = None
+    if rank == 0 and args.host_path > 0:
+        k = min(args.host_path, npkt)
+        h_re, h_im = d_re.download(0, k), d_im.download(0, k)
+        eng.predict(h_re, h_im); eng.ls_estimate(h_re, h_im)          # warm-up (staging buffers)
+        t0 = time.perf_counter()
+        eng.ls_estimate(h_re, h_im)
+        eng.predict(h_re, h_im)
+        t1 = time.perf_counter() - t0
+        host_path = {'packets': k, 'pairs_per_s': k * nr * nt / t1, 'ms': t1 * 1e3,
+                     'note': 'csi_ls_estimate + csi_predict with pageable host buffers: H2D + kernels + D2H, synchronous'}
+
     if rank != 0:
         return
 
@@ -161,8 +178,9 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'configs[1]: Nt=%d Nr=%d, %d packets/GPU/step (8 SNR x 500), LS + DNN(real) + DNN(imag), '
-                               'FC %s + BN, 234 bins' % (nt, nr, npkt, 'x'.join(map(str, hidden))),
+        'config': {'workload': '%sNt=%d Nr=%d, %d packets/GPU/step%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
+                       'configs[1]: ' if (nt, nr, npkt) == (32, 4, 4000) else '', nt, nr, npkt,
+                       ' (8 SNR x 500)' if npkt == 4000 else '', 'x'.join(map(str, hidden))),
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS,
@@ -173,6 +191,8 @@ def main():
         'kernels': kernels,
         'parity_check': check,
     }
+    if host_path:
+        out['host_path_pcie_inclusive'] = host_path
     if 'ls_estimate' in kernels:
         p = prof['ls_estimate']
         gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6

@@ -520,10 +520,12 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
         return bail(CSI_ERR_HIP);
     }
     const size_t ls_lds = (size_t)(cfg->nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-    if (cfg->nt > 0 && ls_lds <= 160 * 1024) {
-        if (hipFuncSetAttribute((const void*)ls_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ls_lds) != hipSuccess) {
-            c->err = "hipFuncSetAttribute(ls_estimate_kernel) failed";
+    if (cfg->nt > 0) {
+        const bool fft_first = cfg->nt <= 64;
+        const size_t bytes = fft_first ? ls_lds : (size_t)(LSD_ROWS * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+        const void* fn = fft_first ? (const void*)ls_estimate_kernel : (const void*)ls_despread_first_kernel;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            c->err = "hipFuncSetAttribute(LS kernel) failed";
             return bail(CSI_ERR_HIP);
         }
     }
@@ -658,15 +660,15 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate_device: bad argument");
     if (npkt == 0) return CSI_OK;
     const csi_config& cf = c->cfg;
-    const size_t lds = (size_t)(cf.nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-    if (lds > 160 * 1024)
-        return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate: nt=%d needs %zu B of LDS (>160 KiB); not supported yet", cf.nt, lds);
+    const bool fft_first = cf.nt <= 64;        // Nt spectra fit the LDS; otherwise despread first
+    const size_t lds = (size_t)((fft_first ? cf.nt : LSD_ROWS) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+    const int n_jc = (cf.nt + LSD_ROWS - 1) / LSD_ROWS;
     HIP_TRY(c, hipSetDevice(cf.device));
     const int64_t nblk = npkt * cf.nr;
     LsArgs a{};
     a.P = c->P; a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
     a.nt = cf.nt; a.len_ltf = cf.len_ltf;
-    const int64_t max_grid = 1 << 30;
+    const int64_t max_grid = ((int64_t)1 << 30) / n_jc;
     for (int64_t b0 = 0; b0 < nblk; b0 += max_grid) {
         const int64_t nb = std::min(max_grid, nblk - b0);
         a.ltf_re = d_ltf_re + (size_t)b0 * cf.len_ltf;
@@ -675,7 +677,10 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         a.h_im = d_h_im + (size_t)b0 * cf.nt * LS_NDATA;
         const double pairs = (double)nb * cf.nt;
         ProfScope ps(c, K_LS_ESTIMATE, pairs * (10240.0 + 8.0 * LS_NDATA * cf.nt), pairs * (2560.0 + 1872.0));
-        hipLaunchKernelGGL(ls_estimate_kernel, dim3((unsigned)nb), dim3(LS_THREADS), lds, c->stream, a);
+        if (fft_first)
+            hipLaunchKernelGGL(ls_estimate_kernel, dim3((unsigned)nb), dim3(LS_THREADS), lds, c->stream, a);
+        else
+            hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), lds, c->stream, a, n_jc);
         HIP_TRY(c, hipGetLastError());
     }
     return CSI_OK;

@@ -13,6 +13,7 @@
 //   (B operand read straight from the LDS spectrum through the bin table), scaled and written
 //   coalesced to H[(p,r)][j][q].
 // HBM-bound: 2560 B in + 1872 B out per pair; everything else stays in LDS/registers.
+// Nt <= 64 uses this FFT-first kernel; larger Nt the despread-first kernel further down.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,7 +45,58 @@ struct LsArgs {
 
 __device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
 
-__device__ __forceinline__ size_t ls_lds_bytes(int nt) { return (size_t)(nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float); }
+
+// In-place 256-point radix-4 DIT FFT of one LDS row pair (re, im) by ONE wave; the input must sit
+// at base-4 digit-reversed positions, the output is in natural bin order.  lane = one radix-4
+// butterfly per stage.  Positions go through ls_phys() (4 pad floats per 32).
+__device__ __forceinline__ void ls_fft256_wave(float* fr, float* fi, const float* tw_re, const float* tw_im, int lane) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int L = 1 << (2 * st);
+        const int j = lane & (L - 1);
+        const int base = (lane >> (2 * st)) * 4 * L + j;
+        const int tstep = 64 >> (2 * st);               // 256 / (4L)
+        float xr[4], xi[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int p = ls_phys(base + m * L);
+            xr[m] = fr[p];
+            xi[m] = fi[p];
+        }
+        if (st > 0) {
+#pragma unroll
+            for (int m = 1; m < 4; ++m) {
+                const int u = (j * m * tstep) & 255;
+                const float c = tw_re[u], sn = tw_im[u];
+                const float r = xr[m] * c - xi[m] * sn;
+                const float i = xr[m] * sn + xi[m] * c;
+                xr[m] = r;
+                xi[m] = i;
+            }
+        }
+        // 4-point DFT: y_q = sum_m (-i)^(m q) x_m
+        const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
+        const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
+        const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
+        const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
+        float yr[4], yi[4];
+        yr[0] = ar + cr; yi[0] = ai + ci;
+        yr[1] = br + di; yi[1] = bi - dr;       // x0 - i x1 - x2 + i x3
+        yr[2] = ar - cr; yi[2] = ai - ci;
+        yr[3] = br - di; yi[3] = bi + dr;       // x0 + i x1 - x2 - i x3
+        // all lanes of this wave must have read before anyone overwrites
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int p = ls_phys(base + m * L);
+            fr[p] = yr[m];
+            fi[p] = yi[m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 
 __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -93,56 +145,10 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a)
     }
     __syncthreads();
 
-    // ---- FFT: one wave per symbol, lane = one radix-4 butterfly per stage
+    // ---- FFT: one wave per symbol
     for (int s = wave; s < nt; s += 4) {
         float* fr = F + (size_t)s * 2 * LS_PLANE;
-        float* fi = fr + LS_PLANE;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int L = 1 << (2 * st);
-            const int j = lane & (L - 1);
-            const int base = (lane >> (2 * st)) * 4 * L + j;
-            const int tstep = 64 >> (2 * st);               // 256 / (4L)
-            float xr[4], xi[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int p = ls_phys(base + m * L);
-                xr[m] = fr[p];
-                xi[m] = fi[p];
-            }
-            if (st > 0) {
-#pragma unroll
-                for (int m = 1; m < 4; ++m) {
-                    const int u = (j * m * tstep) & 255;
-                    const float c = tw_re[u], sn = tw_im[u];
-                    const float r = xr[m] * c - xi[m] * sn;
-                    const float i = xr[m] * sn + xi[m] * c;
-                    xr[m] = r;
-                    xi[m] = i;
-                }
-            }
-            // 4-point DFT: y_q = sum_m (-i)^(m q) x_m
-            const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
-            const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
-            const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
-            const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
-            float yr[4], yi[4];
-            yr[0] = ar + cr; yi[0] = ai + ci;
-            yr[1] = br + di; yi[1] = bi - dr;       // x0 - i x1 - x2 + i x3
-            yr[2] = ar - cr; yi[2] = ai - ci;
-            yr[3] = br - di; yi[3] = bi + dr;       // x0 + i x1 - x2 - i x3
-            // all lanes of this wave must have read before anyone overwrites
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int p = ls_phys(base + m * L);
-                fr[p] = yr[m];
-                fi[p] = yi[m];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        ls_fft256_wave(fr, fr + LS_PLANE, tw_re, tw_im, lane);
     }
     __syncthreads();
 
@@ -182,6 +188,118 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a)
                     }
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-Nt variant (Nt > 64, where Nt spectra no longer fit the 160 KiB LDS): by linearity the
+// despread is done FIRST, in the time domain, and only the despread rows are transformed:
+//   Y[j][n] = sum_s P[j][s] x[s][64+n]          H[j][q] = FFT(Y[j])[f(q)] / (Nt ltf[q])
+// One workgroup = one (packet, rx, chunk of 32 tx antennas).  The symbols stream through LDS in
+// chunks of 32 (B operand of v_mfma_f32_32x32x2_f32, A operand = the 32x32 block of P), the 32
+// despread rows stay in the accumulators, are then scattered (digit-reversed) into the same LDS
+// buffer, transformed by ls_fft256_wave and written out.  The input of a (packet, rx) is read by
+// Nt/32 workgroups (L2 / Infinity Cache absorb the re-reads); LDS = 64 KiB + tables.
+constexpr int LSD_ROWS = 32;
+
+__global__ __launch_bounds__(LS_THREADS) void ls_despread_first_kernel(const LsArgs a, int n_jc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw_re = smem;
+    float* tw_im = smem + LS_FFT;
+    float* X = smem + 2 * LS_FFT;             // [32][2][LS_PLANE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = a.nt;
+    const size_t blk = blockIdx.x / n_jc;
+    const int jc = blockIdx.x % n_jc;
+
+    tw_re[tid] = a.tw[tid];
+    tw_im[tid] = a.tw[LS_FFT + tid];
+
+    // accumulators: wave w owns sample tiles {w, w+4} of both planes
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][p][e] = 0.f;
+
+    const int ja = jc * LSD_ROWS + l31;                   // A-operand row (tx antenna) of this lane
+    const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
+    const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
+    for (int s0 = 0; s0 < nt; s0 += LSD_ROWS) {
+        __syncthreads();                                   // previous chunk fully consumed
+        // load 32 symbols (natural sample order), wave w takes rows w, w+4, ...
+#pragma unroll
+        for (int u = 0; u < LSD_ROWS / 4; ++u) {
+            const int r = wave + 4 * u;
+            const int s = s0 + r;
+            f32x4 vr = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+            if (s < nt) {
+                vr = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
+                vi = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
+            }
+            float* xr = X + (size_t)r * 2 * LS_PLANE;
+            float* xi = xr + LS_PLANE;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = ls_phys(4 * lane + c);
+                xr[p] = vr[c];
+                xi[p] = vi[c];
+            }
+        }
+        __syncthreads();
+        for (int ks = 0; ks < LSD_ROWS / 2; ++ks) {
+            const int r = 2 * ks + hi;
+            const int s = s0 + r;
+            const float pv = (ja < nt && s < nt) ? a.P[ja * nt + s] : 0.f;
+            const float* xr = X + (size_t)r * 2 * LS_PLANE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = ls_phys((wave + 4 * i) * 32 + l31);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, xr[p], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, xr[LS_PLANE + p], acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // scatter Y[j][n] (C/D layout: col = lane&31 <-> n, row <-> j) to digit-reversed positions
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = (wave + 4 * i) * 32 + l31;
+        const int rev = ((n & 3) << 6) | (((n >> 2) & 3) << 4) | (((n >> 4) & 3) << 2) | (n >> 6);
+        const int p = ls_phys(rev);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float* yr = X + (size_t)j * 2 * LS_PLANE;
+            yr[p] = acc[i][0][r];
+            yr[LS_PLANE + p] = acc[i][1][r];
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < LSD_ROWS; j += 4) {
+        float* fr = X + (size_t)j * 2 * LS_PLANE;
+        ls_fft256_wave(fr, fr + LS_PLANE, tw_re, tw_im, lane);
+    }
+    __syncthreads();
+    // pick the 234 data bins, scale, store coalesced
+    for (int idx = tid; idx < LSD_ROWS * LS_NDATA; idx += LS_THREADS) {
+        const int j = idx / LS_NDATA;
+        const int q = idx - j * LS_NDATA;
+        const int jt = jc * LSD_ROWS + j;
+        if (jt < nt) {
+            const int p = ls_phys(a.bin_pos[q]);
+            const float den = a.denom[q];
+            const float* fr = X + (size_t)j * 2 * LS_PLANE;
+            const size_t o = (blk * nt + jt) * LS_NDATA + q;
+            a.h_re[o] = fr[p] / den;
+            a.h_im[o] = fr[LS_PLANE + p] / den;
         }
     }
 }

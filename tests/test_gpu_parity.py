@@ -39,7 +39,7 @@ def _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn=True, n_out=234, **kw):
 
 
 # ------------------------------------------------------------------------------------ LS
-@pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 3), (8, 1, 5), (16, 3, 2), (32, 4, 4), (64, 4, 2)])
+@pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 3), (8, 1, 5), (16, 3, 2), (32, 4, 4), (64, 4, 2), (128, 2, 2)])
 def test_ls_matches_oracle_and_known_channel(pkg, oracle, nt, nr, npkt):
     rng = np.random.default_rng(100 + nt)
     P = _pilot(rng, nt)
@@ -70,6 +70,20 @@ def test_ls_noisy_generic_pilot_and_linearity(pkg, oracle):
     assert rel_rows(np.concatenate([hab.real, hab.imag], -1), np.concatenate([lin.real, lin.imag], -1)) < 5e-6
 
 
+@pytest.mark.parametrize('nt', [12, 72, 96])
+def test_ls_non_power_of_two_nt_generic_pilot(pkg, oracle, nt):
+    """Nt that is not a power of two (partial 32-row MFMA tiles, and for Nt > 64 the
+    despread-first kernel with a partial last chunk), generic real P."""
+    rng = np.random.default_rng(nt)
+    P = rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+    ltf = rng.standard_normal((2, 2, 320 * nt)) + 1j * rng.standard_normal((2, 2, 320 * nt))
+    e = pkg.CsiEngine(nt, 2, hidden=(8,))
+    e.set_pilot(P)
+    h = e.ls_estimate(ltf)
+    ref = oracle.ls_estimate(ltf.astype(np.complex64), P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+
+
 def test_ls_empty_batch(pkg):
     e = pkg.CsiEngine(4, 2, hidden=(8,))
     e.set_pilot(np.eye(4))
@@ -87,6 +101,9 @@ CASES = [
     (4, 1, 6, (32, 48, 40), True),      # three hidden layers (ping-pong buffers)
     (8, 2, 4, (64, 64), False),         # --useBN off
     (32, 4, 2, (1024, 1024), True),     # the shipped model (pipe.sh:40,47), 2 packets
+    (64, 2, 3, (64, 32), True),         # BASELINE configs 3/4 antenna count
+    (128, 2, 2, (64, 64), True),        # BASELINE config 5 antenna count (two T pieces per wave)
+    (12, 2, 7, (40,), True),            # Nt not a power of two
 ]
 
 
@@ -94,8 +111,12 @@ CASES = [
 def test_predict_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden, use_bn):
     rng = np.random.default_rng(nt * 1000 + npkt)
     w_re, w_im = _weights(oracle, 1234 + nt, nt, hidden, use_bn)
-    P = _pilot(rng, nt, orthogonal=(nt != 8))
-    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0]
+    pow2 = (nt & (nt - 1)) == 0
+    P = _pilot(rng, nt, orthogonal=(pow2 and nt != 8))
+    if pow2:
+        ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0]
+    else:
+        ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn)
     o_re, o_im = e.predict(ltf)
     assert o_re.shape == (npkt, nr, nt, 234) and o_re.dtype == np.float32
