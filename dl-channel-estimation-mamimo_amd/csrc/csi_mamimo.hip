@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,6 +86,7 @@ struct csi_ctx {
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
+    int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256 (tests exercise both kernels)
     // profiling
     bool prof_on = false;
     std::vector<ProfSpan> spans;
@@ -240,14 +242,25 @@ int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
     if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
         return fail(c, CSI_ERR_INVALID_ARG, "pair gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
                     g.K, g.lda, g.ldb);
-    const int tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M / g.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
-    const dim3 grid((unsigned)(tiles_m * g.tiles_n));
-    if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
-    else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
+    // 256-row tiles halve the LDS-DMA instructions per MFMA; use them once they fill the 512
+    // resident workgroup slots, 128-row tiles (more workgroups) below that.
+    const int tiles_m256 = (g.M + P2_BM - 1) / P2_BM;
+    const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n >= 512);
+    if (big) {
+        const dim3 grid((unsigned)(tiles_m256 * g.tiles_n));
+        if (g.nt < 8) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
+        else if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
+        else hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 2, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
+    } else {
+        const int tiles_m = (g.M + G_BM - 1) / G_BM;
+        const dim3 grid((unsigned)(tiles_m * g.tiles_n));
+        if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
+        else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
+    }
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -471,6 +484,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     c->d_in = cfg->len_ltf + cfg->nt;
+    if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);

@@ -102,11 +102,12 @@ static_assert(R_D == 3, "ring_handover covers 0..2 groups in flight");
 // vectors are loaded unconditionally from a clamped index and interior row tiles store
 // straight-line (a branch per store makes hipcc wait vmcnt(0) before every store, which
 // serialises the whole tail).
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, int m0, int n0,
+template <int EPI, int MI = 2, int BMT = G_BM>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][2], const GemmArgs& g, int m0, int n0,
                                               int wm, int wn, int l31, int hi) {
     float* Cz = g.C + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0);
-    const bool full_rows = (m0 + G_BM) <= g.M;          // block-uniform
+    const bool full_rows = (m0 + BMT) <= g.M;           // block-uniform
+    const int wrow = m0 + wm * (MI * 32) + 4 * hi;      // first row this lane stores
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int col = n0 + wn * 64 + nj * 32 + l31;
@@ -115,11 +116,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const G
         float bias = 0.f, sc = 1.f, sh = 0.f;
         if (EPI != EPI_RAW) bias = g.bias[colc];
         if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-        float* cbase = Cz + (size_t)(m0 + wm * 64 + 4 * hi) * g.ldc + col;
+        float* cbase = Cz + (size_t)wrow * g.ldc + col;
         if (full_rows) {
             if (cok) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[mi][nj][r];
@@ -131,14 +132,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const G
             }
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
                     float v = acc[mi][nj][r];
                     if (EPI == EPI_BIAS) v += bias;
                     if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
-                    if (cok && (m0 + wm * 64 + 4 * hi + rr) < g.M) cbase[(size_t)rr * g.ldc] = v;
+                    if (cok && (wrow + rr) < g.M) cbase[(size_t)rr * g.ldc] = v;
                 }
             }
         }
@@ -383,6 +384,153 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
         ktile(kt, std::false_type{});
     }
     gemm_epilogue<EPI>(acc, g, m0, n0, wm, wn, l31, hi);
+}
+
+// =============================================================================================
+// pair GEMM, 256x128 block tile.  The A side of this layer costs (almost) no DMA - the pilot-table
+// slice is the same for every row tile and the L0 rows are 1/Nt of the rows - so doubling the row
+// tile halves the LDS-DMA instructions per MFMA, which is what limits the 128x128 kernel
+// (tools/gemm_probe.hip).  4 waves (2x2), wave tile 128x64 = 4x2 MFMA tiles (128 accumulator
+// registers), 2 workgroups per CU.  Ring stage = Bs [128][16] | Ts [64*TPW][16] | Ls [64*LPW][16];
+// every wave issues 2 B + TPW T + LPW L pieces per k-tile (TPW = 1: nt <= 64, LPW = 1: nt >= 8).
+// =============================================================================================
+constexpr int P2_BM = 256;
+
+template <int EPI, int TPW, int LPW>
+__global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const GemmArgs g) {
+    constexpr int TROWS = 64 * TPW, LROWS = 64 * LPW;
+    constexpr int STAGE = (128 + TROWS + LROWS) * R_BK;             // floats
+    constexpr int NS = (TPW + LPW == 2) ? 4 : 3;                    // 64 KiB / 60 KiB of LDS
+    constexpr int D = NS - 1;
+    constexpr int P = 2 + TPW + LPW;
+    constexpr int TOFF = 128 * R_BK, LOFF = (128 + TROWS) * R_BK;
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+    const int m0 = tm * P2_BM, n0 = tn * G_BN;
+    const int nkt = (g.K + R_BK - 1) / R_BK;
+    const int nt = g.nt;
+    const int pr_base = m0 / nt;
+    const int NL = min(m0 + P2_BM - 1, g.M - 1) / nt - pr_base + 1;      // <= 65
+    const int nT = (nt + R_RPP - 1) / R_RPP;
+    const int nL = (NL + 2 + R_RPP - 1) / R_RPP;
+
+    // ---- DMA sources (piece = 16 image rows; lane -> row 16j + lane/4, chunk lane%4)
+    const int prow = lane >> 2, pch = lane & 3;
+    const float* bsrc[2];
+    const float* tsrc[TPW];
+    const float* lsrc[LPW];
+    int tpiece[TPW], lpiece[LPW];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rb = R_RPP * (2 * wave + u) + prow;
+        bsrc[u] = g.Bt + (size_t)min(n0 + rb, g.N - 1) * g.ldb + ((pch ^ r_swz(rb)) << 2);
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        tpiece[u] = min(wave + 4 * u, nT - 1);
+        const int rt = R_RPP * tpiece[u] + prow;
+        tsrc[u] = g.T + (size_t)min(rt, nt - 1) * g.lda + ((pch ^ r_swz(rt)) << 2);
+    }
+#pragma unroll
+    for (int u = 0; u < LPW; ++u) {
+        lpiece[u] = min(wave + 4 * u, nL - 1);
+        const int rl = R_RPP * lpiece[u] + prow;
+        const float* p = g.A + (size_t)(pr_base + min(rl, NL - 1)) * g.lda;
+        if (rl == NL) p = g.s0;
+        if (rl == NL + 1) p = g.t0;
+        lsrc[u] = p + ((pch ^ r_swz(rl)) << 2);
+    }
+    // one call = this wave's pieces of k-tile kt, part u (0, 1): {B piece u, T piece u, L piece u}
+    auto issue = [&](int kt, int u) {
+        float* st = lds + (kt % NS) * STAGE;
+        const int k = kt * R_BK;
+        dma16(bsrc[u] + k, st + (2 * wave + u) * 256);
+        if (u < TPW) dma16(tsrc[u] + k, st + TOFF + tpiece[u] * 256);
+        if (u < LPW) dma16(lsrc[u] + k, st + LOFF + lpiece[u] * 256);
+    };
+
+    // ---- per-lane fragment addressing
+    int loff[4][2], toff[4][2], boff[2], soff[2], hoff[2];
+    const int brow = wn * 64 + l31;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = 2 * c + hi;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = min(m0 + wm * 128 + mi * 32 + l31, g.M - 1);
+            const int pr = m / nt;
+            const int t = m - pr * nt;
+            const int lr = pr - pr_base;
+            loff[mi][c] = LOFF + lr * R_BK + ((ch ^ r_swz(lr)) << 2);
+            toff[mi][c] = TOFF + t * R_BK + ((ch ^ r_swz(t)) << 2);
+        }
+        boff[c] = brow * R_BK + ((ch ^ r_swz(brow)) << 2);
+        soff[c] = LOFF + NL * R_BK + ((ch ^ r_swz(NL)) << 2);
+        hoff[c] = LOFF + (NL + 1) * R_BK + ((ch ^ r_swz(NL + 1)) << 2);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int npro = min(nkt, D);
+    for (int t = 0; t < npro; ++t) { issue(t, 0); issue(t, 1); }
+
+    auto handover = [&](int groups) {
+        if (groups >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * P) : "memory");
+        else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const float* st = lds + (kt % NS) * STAGE;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(st + soff[c]);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(st + hoff[c]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + boff[c]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(st + boff[c] + 32 * R_BK);
+            f32x4 a[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const f32x4 l = *reinterpret_cast<const f32x4*>(st + loff[mi][c]);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(st + toff[mi][c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[mi][e] = fmaf(fmaxf(l[e] + t[e], 0.f), sv[e], hv[e]);
+            }
+            if (MORE) issue(kt + D, c);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b0[s], acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b1[s], acc[mi][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    int kt = 0;
+    for (; kt < nkt - D; ++kt) {
+        handover(D - 1);
+        ktile(kt, std::true_type{});
+    }
+    for (; kt < nkt; ++kt) {
+        handover(nkt - 1 - kt);
+        ktile(kt, std::false_type{});
+    }
+    gemm_epilogue<EPI, 4, P2_BM>(acc, g, m0, n0, wm, wn, l31, hi);
 }
 
 // out[i] = sum_z slab_z[i]  (deterministic order z = 0..S-1); n4 = number of float4

@@ -127,6 +127,23 @@ def test_predict_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden, use_bn):
     assert oracle.nmse_subk(r_re + 1j * r_im, o_re + 1j * o_im) < 1e-10
 
 
+@pytest.mark.parametrize('tile', ['128', '256'])
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(4, 2, 70, (64, 48)), (32, 2, 9, (96, 64)), (128, 1, 3, (64, 64)),
+                                               (12, 3, 11, (40, 24)), (8, 2, 5, (64,))])
+def test_both_pair_tile_kernels(pkg, oracle, monkeypatch, tile, nt, nr, npkt, hidden):
+    """The first per-pair layer has a 128-row and a 256-row tile kernel (chosen by grid size);
+    force each one on ragged row counts and every (T pieces, L pieces) template variant."""
+    monkeypatch.setenv('CSI_FORCE_PAIR_TILE', tile)
+    rng = np.random.default_rng(nt + npkt)
+    w_re, w_im = _weights(oracle, 77 + nt, nt, hidden)
+    P = _pilot(rng, nt, orthogonal=False)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    o_re, o_im = e.predict(ltf)
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
+
+
 @pytest.mark.parametrize('nt,nr,npkt,hidden', [(4, 2, 5, (64, 64)), (32, 4, 1, (1024, 1024))])
 def test_literal_predict_equals_shared_layer0_path(pkg, oracle, nt, nr, npkt, hidden):
     """Key structural identity: the packet path (layer 0 once per rx antenna + pilot table) and

@@ -62,6 +62,28 @@ double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out
     return med;
 }
 
+template <int EPI>
+double run_pair256(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid(((g.M + P2_BM - 1) / P2_BM) * g.tiles_n);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(256), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(256), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    if (out) { out->resize(256); CK(hipMemcpy(out->data(), g.C, 256 * 4, hipMemcpyDeviceToHost)); }
+    return med;
+}
+
 int main() {
     const int nt = 32, M1 = 8192, M2 = M1 * nt, H = 1024, KL = 10240, NO = 234;
     float* ltf = dalloc((size_t)M1 * KL, true);
@@ -81,7 +103,8 @@ int main() {
     std::vector<float> o1, o2, o3;
     for (int rep = 0; rep < 3; ++rep) {
         run_pair<EPI_BIAS_RELU_AFFINE, 1>("pair_dense tpw1", p, 7, &o1);
-        run_pair<EPI_BIAS_RELU_AFFINE, 2>("pair_dense tpw2", p, 7, &o2);
+        run_pair256<EPI_BIAS_RELU_AFFINE>("pair_dense 256x128", p, 7, &o2);
+        { double d = 0; for (int i = 0; i < 256; ++i) d = std::max(d, (double)std::fabs(o1[i] - o2[i])); printf("   max |diff| 128 vs 256 tile: %g (value %g)\n", d, o1[7]); }
         run<EPI_RAW>("layer0 (split 2)", l, 2, 7);
         run<EPI_BIAS>("regressor", r, 1, 7);
     }
