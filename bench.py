@@ -32,6 +32,7 @@ sys.path.insert(0, REPO)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense, v_mfma_f32_32x32x16_bf16
 
 
 def main():
@@ -46,6 +47,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
     ap.add_argument('--no-ls', action='store_true', help='time the DNN only')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32 = the headline fp32 path; bf16 = BASELINE config 3 (use with --nt 64 --packets 5000)')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
     ap.add_argument('--host-path', type=int, default=0,
                     help='also time the host-buffer (PCIe-inclusive) entry points on this many packets')
@@ -61,7 +64,7 @@ def main():
     nt, nr, npkt, hidden = args.nt, args.nr, args.packets, tuple(args.hidden)
     import torch
     ndev = max(torch.cuda.device_count(), 1)
-    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev)
+    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev, dtype=args.dtype)
 
     # weights: created on rank 0, broadcast as one flat buffer (RCCL over xGMI when world > 1)
     wts = None
@@ -116,7 +119,12 @@ def main():
         k = min(args.check, npkt)
         ltf = d_re.download(0, k) + 1j * d_im.download(0, k)
         r_re, r_im = o.predict_packets(ltf, wts['P']['pilot'], wts['real'], wts['imag'], np.float64, pkt_batch=k)
-        check['dnn_rel_err'] = max(o.row_rel_err(d_ore.download(0, k), r_re), o.row_rel_err(d_oim.download(0, k), r_im))
+        g_re, g_im = d_ore.download(0, k), d_oim.download(0, k)
+        check['dnn_rel_err'] = max(o.row_rel_err(g_re, r_re), o.row_rel_err(g_im, r_im))
+        check['dnn_nmse_vs_fp64'] = o.nmse_subk(r_re + 1j * r_im, g_re + 1j * g_im)
+        if args.dtype == 'bf16':
+            b_re, b_im = o.predict_packets_bf16(ltf, wts['P']['pilot'], wts['real'], wts['imag'])
+            check['dnn_rel_err_vs_bf16_emulation'] = max(o.row_rel_err(g_re, b_re), o.row_rel_err(g_im, b_im))
         if not args.no_ls:
             r_ls = o.ls_estimate(ltf, wts['P']['pilot'])
             check['ls_rel_err'] = max(o.row_rel_err(d_hre.download(0, k), r_ls.real), o.row_rel_err(d_him.download(0, k), r_ls.imag))
@@ -158,6 +166,7 @@ def main():
     dom = prof['pair_dense_gemm']
     dom_ms = dom['ms'] / max(dom['launches'], 1)
     achieved = dom['flops'] / max(dom['ms'], 1e-9) / 1e9          # TFLOP/s
+    mfma_peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MATRIX_PEAK_TFLOPS
     kernels = {}
     for name, p in prof.items():
         if p['launches']:
@@ -176,16 +185,16 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': args.dtype,
         'data': 'synthetic',
         'config': {'workload': '%sNt=%d Nr=%d, %d packets/GPU/step%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
-                       'configs[1]: ' if (nt, nr, npkt) == (32, 4, 4000) else '', nt, nr, npkt,
+                       'configs[1]: ' if (nt, nr, npkt, args.dtype) == (32, 4, 4000, 'f32') else ('configs[2]: ' if (nt, nr, npkt, args.dtype) == (64, 4, 5000, 'bf16') else ''), nt, nr, npkt,
                        ' (8 SNR x 500)' if npkt == 4000 else '', 'x'.join(map(str, hidden))),
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
-        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     'traffic': hbm_per_launch('pair_gemm_f32_kernel'), 'traffic_unit': 'HBM bytes per launch (PMC)',
+        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,
+                     'unit': 'TFLOP/s', 'frac': achieved / mfma_peak,
+                     'traffic': hbm_per_launch('pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,

@@ -20,6 +20,7 @@
 
 #include "../../include/csi_mamimo.h"
 #include "gemm_f32.hip.h"
+#include "gemm_bf16.hip.h"
 #include "ls_estimate.hip.h"
 
 using namespace csi;
@@ -36,17 +37,21 @@ enum KernelId {
     K_NAIVE_DENSE0,      // un-shared layer 0 of csi_predict_samples
     K_SYNTH_WHITE,
     K_PILOT_TABLE,
+    K_CAST_BF16,         // fp32 -> bf16 of the preambles (bf16 mode)
+    K_PAIR_H1_BF16,      // materialise h1 in bf16 (bf16 mode)
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
-    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table"};
+    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16"};
 
 thread_local std::string g_create_error;
 
 struct Layer {
-    float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)
+    float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)   fp32 mode
     int ldw = 0;
+    bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
+    int ldwb = 0;
     float* bias = nullptr;    // [out]
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
     float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
@@ -193,6 +198,7 @@ int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
 
 void free_layer(Layer& l) {
     if (l.Wt) hipFree(l.Wt);
+    if (l.Wb) hipFree(l.Wb);
     if (l.bias) hipFree(l.bias);
     if (l.scale) hipFree(l.scale);
     if (l.shift) hipFree(l.shift);
@@ -421,6 +427,116 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     return CSI_OK;
 }
 
+// ---------------------------------------------------------------- bf16 mode
+template <int EPI, bool OUT_BF16>
+int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
+    if (g.M <= 0) return CSI_OK;
+    if ((g.lda & 7) || (g.ldb % B_BK))
+        return fail(c, CSI_ERR_INVALID_ARG, "bf16 gemm: lda must be a multiple of 8 and ldb of 64 (lda=%d ldb=%d)", g.lda, g.ldb);
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (OUT_BF16 ? 2.0 : 4.0) * (double)g.M * g.N * splits;
+    ProfScope ps(c, kid, flops, bytes);
+    // 256x256 tiles (8 waves) once they fill the 256 CUs, 128x128 tiles (4 waves, 2 per CU) below
+    const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splits;
+    if (big_tiles >= 256) {
+        g.tiles_n = (g.N + 255) / 256;
+        dim3 grid((unsigned)(((g.M + 255) / 256) * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 4, 4, 2, 2>), grid, dim3(512), 0, c->stream, g);
+    } else {
+        g.tiles_n = (g.N + 127) / 128;
+        dim3 grid((unsigned)(((g.M + 127) / 128) * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, c->stream, g);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
+    ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * n);
+    const size_t n8 = n / 8;
+    const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 8192);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, src, dst, n8);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// hidden layers 1.. and the regressor on a bf16 activation matrix hin [M][l.in]; writes d_out fp32
+int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_t* hb1, float* d_out, int first_layer) {
+    const csi_config& cf = c->cfg;
+    bf16_t* hb[2] = {hb0, hb1};
+    const bf16_t* cur = hin;
+    int w = 0;
+    for (int li = first_layer; li <= cf.n_hidden; ++li) {
+        const Layer& l = m.layers[li];
+        GemmBf16Args q{};
+        q.A = cur; q.lda = l.in;
+        q.Bt = l.Wb; q.ldb = l.ldwb;
+        q.M = M; q.N = l.out; q.K = l.in;
+        q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+        q.k_per_split = l.ldwb;
+        int rc;
+        if (li == cf.n_hidden) {
+            q.C = d_out; q.ldc = cf.n_out;
+            rc = launch_gemm_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, 1);
+        } else {
+            q.C = hb[w]; q.ldc = l.out;
+            rc = launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN, q, 1);
+            cur = hb[w];
+            w ^= 1;
+        }
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
+int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float* d_out) {
+    const csi_config& cf = c->cfg;
+    const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
+    int maxh = 0;
+    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    // per packet: bf16 preamble copy, fp32 layer-0 product, bf16 h1, bf16 ping-pong hidden buffers
+    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 + (size_t)nr * nt * h1 * 2 +
+                           (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
+    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);
+    int64_t cap = std::max<int64_t>(1, (int64_t)(budget / per_pkt));
+    cap = std::min(cap, (int64_t)0x7fffffff / ((int64_t)nr * nt * 2));
+    const int64_t nchunks = (npkt + cap - 1) / cap;
+    const int64_t chunk = (npkt + nchunks - 1) / nchunks;
+    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_pkt * (size_t)chunk + 1024);
+    if (rc) return rc;
+    char* base = c->ws;
+    bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
+    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4;
+    bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
+    bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
+    bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
+    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
+        const int64_t np = std::min(chunk, npkt - p0);
+        const int M1 = (int)(np * nr), M2 = (int)(np * nr * nt);
+        rc = cast_bf16(c, d_ltf + (size_t)p0 * nr * cf.len_ltf, xb, (size_t)M1 * cf.len_ltf);
+        if (rc) return rc;
+        GemmBf16Args g{};
+        g.A = xb; g.lda = cf.len_ltf;
+        g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
+        g.C = l0; g.ldc = h1;
+        g.M = M1; g.N = h1; g.K = cf.len_ltf;
+        g.k_per_split = cf.len_ltf;
+        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, 1);
+        if (rc) return rc;
+        {
+            ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
+            const size_t total = (size_t)M2 * (h1 / 8);
+            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
+            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, l0, 1, (size_t)0, m.T,
+                               m.layers[0].scale, m.layers[0].shift, h1b, M2, nt, h1);
+            HIP_TRY(c, hipGetLastError());
+        }
+        rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
 int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): only csi_predict_samples is available");
@@ -466,8 +582,13 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
         if (cfg->hidden[i] < 4 || cfg->hidden[i] % 4)
             return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: hidden[%d]=%d must be a positive multiple of 4", i,
                         cfg->hidden[i]);
-    if (cfg->dtype != CSI_DTYPE_F32)
-        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: dtype %d not available in this build (fp32 only)", cfg->dtype);
+    if (cfg->dtype != CSI_DTYPE_F32 && cfg->dtype != CSI_DTYPE_BF16)
+        return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: unknown dtype %d", cfg->dtype);
+    if (cfg->dtype == CSI_DTYPE_BF16) {
+        for (int i = 0; i < cfg->n_hidden; ++i)
+            if (cfg->hidden[i] % 8)
+                return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_create: bf16 needs hidden widths that are multiples of 8 (hidden[%d]=%d)", i, cfg->hidden[i]);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, CSI_ERR_NO_DEVICE, "csi_create: no HIP device visible");
@@ -597,8 +718,27 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             for (int o0 = 0; o0 < out; o0 += TB)
                 for (int i = i0; i < std::min(fan_in, i0 + TB); ++i)
                     for (int o = o0; o < std::min(out, o0 + TB); ++o) wt[(size_t)o * L.ldw + i] = k->data[(size_t)i * out + o];
-        int rc = upload(c, &L.Wt, wt.data(), wt.size());
-        if (rc) return rc;
+        int rc = CSI_OK;
+        const bool bf16 = cf.dtype == CSI_DTYPE_BF16;
+        auto rne = [](float f) {                       // fp32 -> bf16, round to nearest even
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        if (bf16) {
+            L.ldwb = (fan_in + B_BK - 1) / B_BK * B_BK;
+            std::vector<uint16_t> wb((size_t)out * L.ldwb, 0);
+            for (int o = 0; o < out; ++o)
+                for (int i = 0; i < fan_in; ++i) wb[(size_t)o * L.ldwb + i] = rne(wt[(size_t)o * L.ldw + i]);
+            const size_t bytes = wb.size() * 2 + 256;
+            if (hipMalloc((void**)&L.Wb, bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
+            HIP_TRY(c, hipMemset(L.Wb, 0, bytes));
+            HIP_TRY(c, hipMemcpy(L.Wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            rc = upload(c, &L.Wt, wt.data(), wt.size());
+            if (rc) return rc;
+        }
         rc = upload(c, &L.bias, b->data, out);
         if (rc) return rc;
         std::vector<float> sc(out, 1.f), sh(out, 0.f);
@@ -626,8 +766,12 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             if (rc) return rc;
         }
         if (li == 0 && cf.nt > 0) {
-            // pilot rows of fc_dense0.kernel, [nt][h1] row-major as stored
-            rc = upload(c, &m.W0p, k->data + (size_t)cf.len_ltf * out, (size_t)cf.nt * out);
+            // pilot rows of fc_dense0.kernel, [nt][h1] row-major as stored (bf16 mode: rounded like
+            // every other weight, the table itself is evaluated in fp32)
+            std::vector<float> w0p(k->data + (size_t)cf.len_ltf * out, k->data + (size_t)(cf.len_ltf + cf.nt) * out);
+            if (bf16)
+                for (float& v : w0p) { const uint32_t u = (uint32_t)rne(v) << 16; std::memcpy(&v, &u, 4); }
+            rc = upload(c, &m.W0p, w0p.data(), w0p.size());
             if (rc) return rc;
         }
         fan_in = out;
@@ -661,6 +805,11 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         return fail(c, CSI_ERR_INVALID_ARG, "csi_predict_device: bad argument");
     if (npkt == 0) return CSI_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->cfg.dtype == CSI_DTYPE_BF16) {
+        rc = predict_plane_bf16(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        if (rc) return rc;
+        return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
+    }
     rc = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
     if (rc) return rc;
     return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
@@ -764,6 +913,45 @@ int csi_predict_samples(csi_ctx* c, int model, const float* x, int64_t B, float*
     HIP_TRY(c, hipSetDevice(cf.device));
     int maxh = 0;
     for (int i = 0; i < cf.n_hidden; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    if (cf.dtype == CSI_DTYPE_BF16) {
+        const int ldx = (c->d_in + B_BK - 1) / B_BK * B_BK;
+        const size_t per_row_b = (size_t)c->d_in * 4 + (size_t)ldx * 2 + 2 * (size_t)maxh * 2 + (size_t)cf.n_out * 4;
+        int64_t chunk_b = std::min<int64_t>(B, std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)per_row_b));
+        int rcb = ensure_bytes(c, &c->stage, &c->stage_bytes, per_row_b * (size_t)chunk_b + 1024);
+        if (rcb) return rcb;
+        char* base = c->stage;
+        float* d_xf = reinterpret_cast<float*>(base);      base += (size_t)chunk_b * c->d_in * 4;
+        float* d_yf = reinterpret_cast<float*>(base);      base += (size_t)chunk_b * cf.n_out * 4;
+        bf16_t* d_xb = reinterpret_cast<bf16_t*>(base);    base += (size_t)chunk_b * ldx * 2;
+        bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);     base += (size_t)chunk_b * maxh * 2;
+        bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
+        for (int64_t r0 = 0; r0 < B; r0 += chunk_b) {
+            const int nb = (int)std::min(chunk_b, B - r0);
+            HIP_TRY(c, hipMemcpyAsync(d_xf, x + (size_t)r0 * c->d_in, (size_t)nb * c->d_in * 4, hipMemcpyHostToDevice, c->stream));
+            {
+                ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * nb * c->d_in);
+                const unsigned blocks = (unsigned)std::min<size_t>(((size_t)nb * ldx + 255) / 256, 8192);
+                hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, d_xf, d_xb, nb, c->d_in, ldx);
+                HIP_TRY(c, hipGetLastError());
+            }
+            const Layer& l0 = m.layers[0];
+            GemmBf16Args q{};
+            q.A = d_xb; q.lda = ldx;
+            q.Bt = l0.Wb; q.ldb = l0.ldwb;
+            q.C = hb0; q.ldc = l0.out;
+            q.M = nb; q.N = l0.out; q.K = c->d_in;
+            q.bias = l0.bias; q.scale = l0.scale; q.shift = l0.shift;
+            q.k_per_split = l0.ldwb;
+            rcb = launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, K_NAIVE_DENSE0, q, 1);
+            if (rcb) return rcb;
+            // hidden layers 1.. ping-pong starting from hb1, so layer 1 never overwrites its input
+            rcb = bf16_tail(c, m, hb0, nb, hb1, hb0, d_yf, 1);
+            if (rcb) return rcb;
+            HIP_TRY(c, hipMemcpyAsync(y + (size_t)r0 * cf.n_out, d_yf, (size_t)nb * cf.n_out * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        return CSI_OK;
+    }
     const size_t per_row = ((size_t)c->d_in + 2 * (size_t)maxh + cf.n_out) * sizeof(float);
     int64_t chunk = std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)per_row);
     chunk = std::min(chunk, B);

@@ -223,6 +223,47 @@ def predict_packets(ltf, P, w_real, w_imag, dtype=np.float64, pkt_batch=None):
     return outs[0], outs[1]
 
 
+# ---------------------------------------------------------------------------
+# bf16-operand emulation (BASELINE.json config 3).  Not a reference behaviour: the reference
+# runs fp32.  It defines what the CSI_DTYPE_BF16 kernels are expected to compute - operands
+# (inputs, weights, hidden activations) rounded to bfloat16 round-to-nearest-even, exact
+# products, wide accumulation, fp32 bias / relu / BN epilogue - so that their error against the
+# fp64 oracle can be split into 'format' and 'implementation' parts.
+# ---------------------------------------------------------------------------
+def bf16_round(x):
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def fc_forward_bf16(x, w):
+    """Literal network with bf16 operands.  x [B, lenLTF+Nt] float."""
+    eps = float(w.get('bn_eps', BN_EPS))
+    h = bf16_round(x).astype(np.float64)
+    i = 0
+    while f'fc_dense{i}.kernel' in w:
+        z = h @ bf16_round(w[f'fc_dense{i}.kernel']).astype(np.float64) + w[f'fc_dense{i}.bias'].astype(np.float64)
+        z = np.maximum(z.astype(np.float32), np.float32(0))
+        if f'bn{i}.gamma' in w:
+            z = bn_inference(z, w[f'bn{i}.gamma'].astype(np.float32), w[f'bn{i}.beta'].astype(np.float32),
+                             w[f'bn{i}.moving_mean'].astype(np.float32), w[f'bn{i}.moving_variance'].astype(np.float32), eps)
+        h = bf16_round(z).astype(np.float64)
+        i += 1
+    return (h @ bf16_round(w['fc_regressor.kernel']).astype(np.float64) + w['fc_regressor.bias'].astype(np.float64)).astype(np.float32)
+
+
+def predict_packets_bf16(ltf, P, w_real, w_imag):
+    ltf = np.asarray(ltf)
+    npkt, nr, _ = ltf.shape
+    nt = P.shape[0]
+    outs = []
+    for d, w in (('real', w_real), ('imag', w_imag)):
+        x = samples_from_packets(ltf, np.asarray(P, dtype=np.float32), d)
+        outs.append(fc_forward_bf16(x, w).reshape(npkt, nr, nt, -1))
+    return outs[0], outs[1]
+
+
 def recombine(out_real, out_imag):
     """inference.py:31  ``output_real + 1j * output_imag``."""
     return out_real + 1j * out_imag

@@ -261,6 +261,51 @@ def test_empty_and_error_paths(pkg, oracle):
         e.predict(np.zeros((1, nr, 7), dtype=np.complex64))
 
 
+# ------------------------------------------------------------------------------------ bf16 mode
+BF16_TOL_IMPL = 4e-3     # vs the bf16-operand emulation: only accumulation-order induced bf16 re-roundings
+BF16_TOL_FMT = 3e-2      # vs the fp64 oracle: the format error of 8-bit-mantissa operands (NOT the fp32 contract)
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(8, 2, 6, (64, 64)), (4, 2, 40, (72, 40)), (64, 2, 3, (128, 64)),
+                                               (16, 2, 5, (64,)), (8, 1, 9, (64, 32, 48))])
+def test_bf16_mode_matches_bf16_emulation(pkg, oracle, nt, nr, npkt, hidden):
+    """BASELINE config 3 dtype: bf16 operands, fp32 accumulate.  Checked against the oracle's
+    bf16-operand emulation (tight) and against the fp64 oracle (format error, reported as NMSE)."""
+    rng = np.random.default_rng(nt + 31 * npkt)
+    w_re, w_im = _weights(oracle, 500 + nt, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    o_re, o_im = e.predict(ltf)
+    b_re, b_im = oracle.predict_packets_bf16(ltf, P, w_re, w_im)
+    assert rel_rows(o_re, b_re) < BF16_TOL_IMPL and rel_rows(o_im, b_im) < BF16_TOL_IMPL
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(o_re, r_re) < BF16_TOL_FMT and rel_rows(o_im, r_im) < BF16_TOL_FMT
+    assert oracle.nmse_subk(r_re + 1j * r_im, o_re + 1j * o_im) < 1e-3
+    # literal (un-shared) network in bf16
+    x = oracle.samples_from_packets(ltf, P.astype(np.float32), 'real')
+    y = e.predict_samples('real', x)
+    assert rel_rows(y, oracle.fc_forward_bf16(x, w_re)) < BF16_TOL_IMPL
+    # LS is unaffected by the DNN dtype
+    h = e.ls_estimate(ltf)
+    ref = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+
+
+def test_bf16_mode_shipped_model_slice(pkg, oracle):
+    """Nt=64, Nr=4 (config 3 shape), shipped 1024x1024 model, a few packets: exercises the 256x256
+    tile kernel through the layer sizes of the real model."""
+    rng = np.random.default_rng(64)
+    nt, nr, npkt, hidden = 64, 4, 4, (1024, 1024)
+    w_re, w_im = _weights(oracle, 640, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    o_re, o_im = e.predict(ltf)
+    b_re, b_im = oracle.predict_packets_bf16(ltf[:2], P, w_re, w_im)
+    assert rel_rows(o_re[:2], b_re) < BF16_TOL_IMPL and rel_rows(o_im[:2], b_im) < BF16_TOL_IMPL
+
+
 # ------------------------------------------------------------------------------------ twin
 def test_csipredictor_twin_mamimo_end_to_end(pkg, oracle, tmp_path):
     rng = np.random.default_rng(31)

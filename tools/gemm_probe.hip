@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 #include <cmath>
 #include <algorithm>
 #include "../dl-channel-estimation-mamimo_amd/csrc/gemm_f32.hip.h"
+#include "../dl-channel-estimation-mamimo_amd/csrc/gemm_bf16.hip.h"
 using namespace csi;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -84,7 +87,55 @@ double run_pair256(const char* name, GemmArgs g, int iters, std::vector<float>* 
     return med;
 }
 
-int main() {
+template <int EPI, bool OB, int WM, int WN, int MI, int NJ, int NS>
+double run_bf16(const char* name, GemmBf16Args g, int splits, int iters) {
+    constexpr int BM = WM * MI * 32, BN = WN * NJ * 32;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    dim3 grid(((g.M + BM - 1) / BM) * g.tiles_n, 1, splits);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OB, WM, WN, MI, NJ, NS>), grid, dim3(64 * WM * WN), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OB, WM, WN, MI, NJ, NS>), grid, dim3(64 * WM * WN), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("bf16 %-22s %dx%d waves %dx%d tiles/wave NS=%d  med %.3f ms  %.0f TF (best %.0f)\n", name, WM, WN, MI, NJ, NS, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    return med;
+}
+
+static bf16_t* dalloc_bf16(size_t n, float scale) {
+    bf16_t* d; CK(hipMalloc(&d, (n + 128) * 2)); CK(hipMemset(d, 0, (n + 128) * 2));
+    std::vector<bf16_t> h(n);
+    for (size_t i = 0; i < n; ++i) { float f = scale * ((rand() & 0xffff) / 32768.f - 1.f); uint32_t u; memcpy(&u, &f, 4); h[i] = (bf16_t)(u >> 16); }
+    CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "bf16") {
+        const int M = 262144, H = 1024;
+        bf16_t* A = dalloc_bf16((size_t)M * H, 1.f);
+        bf16_t* W = dalloc_bf16((size_t)H * H, 0.05f);
+        float* bias = dalloc(H, true); float* sc = dalloc(H, true); float* sh = dalloc(H, true);
+        bf16_t* C; CK(hipMalloc(&C, (size_t)M * H * 2));
+        GemmBf16Args g{}; g.A = A; g.Bt = W; g.C = C; g.M = M; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.k_per_split = H;
+        g.bias = bias; g.scale = sc; g.shift = sh;
+        for (int rep = 0; rep < 2; ++rep) {
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 2, 2, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 2, 2, 4>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 2, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 2, 3>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 2, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 4, 2>("hidden 1024x1024", g, 1, 7);
+        }
+        return 0;
+    }
     const int nt = 32, M1 = 8192, M2 = M1 * nt, H = 1024, KL = 10240, NO = 234;
     float* ltf = dalloc((size_t)M1 * KL, true);
     float* W0 = dalloc((size_t)H * 10272, true, 0.02f);
