@@ -91,6 +91,7 @@ struct csi_ctx {
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
+    int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
     int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256 (tests exercise both kernels)
     // profiling
     bool prof_on = false;
@@ -606,6 +607,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     c->d_in = cfg->len_ltf + cfg->nt;
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
+    if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);
@@ -656,9 +658,10 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     }
     const size_t ls_lds = (size_t)(cfg->nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
     if (cfg->nt > 0) {
-        const bool fft_first = cfg->nt <= 64;
+        const bool fft_first = cfg->nt <= c->ls_fft_first_max;
         const size_t bytes = fft_first ? ls_lds : (size_t)(LSD_ROWS * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-        const void* fn = fft_first ? (const void*)ls_estimate_kernel : (const void*)ls_despread_first_kernel;
+        const void* fn = !fft_first ? (const void*)ls_despread_first_kernel
+                         : (cfg->nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             c->err = "hipFuncSetAttribute(LS kernel) failed";
             return bail(CSI_ERR_HIP);
@@ -823,7 +826,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate_device: bad argument");
     if (npkt == 0) return CSI_OK;
     const csi_config& cf = c->cfg;
-    const bool fft_first = cf.nt <= 64;        // Nt spectra fit the LDS; otherwise despread first
+    const bool fft_first = cf.nt <= c->ls_fft_first_max;   // spectra of all Nt symbols in LDS, else despread first
     const size_t lds = (size_t)((fft_first ? cf.nt : LSD_ROWS) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
     const int n_jc = (cf.nt + LSD_ROWS - 1) / LSD_ROWS;
     HIP_TRY(c, hipSetDevice(cf.device));
@@ -831,7 +834,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
     LsArgs a{};
     a.P = c->P; a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
     a.nt = cf.nt; a.len_ltf = cf.len_ltf;
-    const int64_t max_grid = ((int64_t)1 << 30) / n_jc;
+    const int64_t max_grid = ((int64_t)1 << 30) / n_jc;      // also keeps nb inside an int
     for (int64_t b0 = 0; b0 < nblk; b0 += max_grid) {
         const int64_t nb = std::min(max_grid, nblk - b0);
         a.ltf_re = d_ltf_re + (size_t)b0 * cf.len_ltf;
@@ -840,9 +843,13 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         a.h_im = d_h_im + (size_t)b0 * cf.nt * LS_NDATA;
         const double pairs = (double)nb * cf.nt;
         ProfScope ps(c, K_LS_ESTIMATE, pairs * (10240.0 + 8.0 * LS_NDATA * cf.nt), pairs * (2560.0 + 1872.0));
-        if (fft_first)
-            hipLaunchKernelGGL(ls_estimate_kernel, dim3((unsigned)nb), dim3(LS_THREADS), lds, c->stream, a);
-        else
+        if (fft_first) {
+            // persistent grid: as many workgroups as the LDS lets reside (x256 CUs)
+            const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
+            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)256 * per_cu);
+            if (cf.nt <= 32) hipLaunchKernelGGL((ls_estimate_kernel<8>), dim3(grid), dim3(LS_THREADS), lds, c->stream, a, (int)nb);
+            else hipLaunchKernelGGL((ls_estimate_kernel<16>), dim3(grid), dim3(LS_THREADS), lds, c->stream, a, (int)nb);
+        } else
             hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), lds, c->stream, a, n_jc);
         HIP_TRY(c, hipGetLastError());
     }

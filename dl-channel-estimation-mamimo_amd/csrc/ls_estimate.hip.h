@@ -46,59 +46,93 @@ struct LsArgs {
 __device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
 
 
-// In-place 256-point radix-4 DIT FFT of one LDS row pair (re, im) by ONE wave; the input must sit
-// at base-4 digit-reversed positions, the output is in natural bin order.  lane = one radix-4
-// butterfly per stage.  Positions go through ls_phys() (4 pad floats per 32).
-__device__ __forceinline__ void ls_fft256_wave(float* fr, float* fi, const float* tw_re, const float* tw_im, int lane) {
+// In-place 256-point radix-4 DIT FFT of NS LDS row pairs (re, im) by ONE wave, the NS transforms
+// interleaved in one instruction stream (independent chains hide the LDS round-trip latency of
+// each stage).  Inputs sit at base-4 digit-reversed positions, outputs are in natural bin order.
+// lane = one radix-4 butterfly per stage.  Positions go through ls_phys() (4 pad floats per 32).
+template <int NS>
+__device__ __forceinline__ void ls_fft256_wave(float* const (&fr)[NS], const float* tw_re, const float* tw_im, int lane) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int L = 1 << (2 * st);
         const int j = lane & (L - 1);
         const int base = (lane >> (2 * st)) * 4 * L + j;
         const int tstep = 64 >> (2 * st);               // 256 / (4L)
-        float xr[4], xi[4];
+        int p[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int p = ls_phys(base + m * L);
-            xr[m] = fr[p];
-            xi[m] = fi[p];
-        }
+        for (int m = 0; m < 4; ++m) p[m] = ls_phys(base + m * L);
+        float xr[NS][4], xi[NS][4];
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                xr[n][m] = fr[n][p[m]];
+                xi[n][m] = fr[n][LS_PLANE + p[m]];
+            }
+        float yr[NS][4], yi[NS][4];
+        float twc[4], tws[4];
         if (st > 0) {
 #pragma unroll
             for (int m = 1; m < 4; ++m) {
                 const int u = (j * m * tstep) & 255;
-                const float c = tw_re[u], sn = tw_im[u];
-                const float r = xr[m] * c - xi[m] * sn;
-                const float i = xr[m] * sn + xi[m] * c;
-                xr[m] = r;
-                xi[m] = i;
+                twc[m] = tw_re[u];
+                tws[m] = tw_im[u];
             }
         }
-        // 4-point DFT: y_q = sum_m (-i)^(m q) x_m
-        const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
-        const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
-        const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
-        const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
-        float yr[4], yi[4];
-        yr[0] = ar + cr; yi[0] = ai + ci;
-        yr[1] = br + di; yi[1] = bi - dr;       // x0 - i x1 - x2 + i x3
-        yr[2] = ar - cr; yi[2] = ai - ci;
-        yr[3] = br - di; yi[3] = bi + dr;       // x0 + i x1 - x2 - i x3
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            if (st > 0) {
+#pragma unroll
+                for (int m = 1; m < 4; ++m) {
+                    const float r = xr[n][m] * twc[m] - xi[n][m] * tws[m];
+                    const float i = xr[n][m] * tws[m] + xi[n][m] * twc[m];
+                    xr[n][m] = r;
+                    xi[n][m] = i;
+                }
+            }
+            // 4-point DFT: y_q = sum_m (-i)^(m q) x_m
+            const float ar = xr[n][0] + xr[n][2], ai = xi[n][0] + xi[n][2];
+            const float br = xr[n][0] - xr[n][2], bi = xi[n][0] - xi[n][2];
+            const float cr = xr[n][1] + xr[n][3], ci = xi[n][1] + xi[n][3];
+            const float dr = xr[n][1] - xr[n][3], di = xi[n][1] - xi[n][3];
+            yr[n][0] = ar + cr; yi[n][0] = ai + ci;
+            yr[n][1] = br + di; yi[n][1] = bi - dr;       // x0 - i x1 - x2 + i x3
+            yr[n][2] = ar - cr; yi[n][2] = ai - ci;
+            yr[n][3] = br - di; yi[n][3] = bi + dr;       // x0 + i x1 - x2 - i x3
+        }
         // all lanes of this wave must have read before anyone overwrites
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int p = ls_phys(base + m * L);
-            fr[p] = yr[m];
-            fi[p] = yi[m];
-        }
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                fr[n][p[m]] = yr[n][m];
+                fr[n][LS_PLANE + p[m]] = yi[n][m];
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-__global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a) {
+// FFT of rows first, first+4, ... < n of an image [n][2][LS_PLANE] by this wave, two at a time
+__device__ __forceinline__ void ls_fft_rows(float* F, int first, int n, const float* tw_re, const float* tw_im, int lane) {
+    int s = first;
+    for (; s + 4 < n; s += 8) {
+        float* const pr[2] = {F + (size_t)s * 2 * LS_PLANE, F + (size_t)(s + 4) * 2 * LS_PLANE};
+        ls_fft256_wave<2>(pr, tw_re, tw_im, lane);
+    }
+    if (s < n) {
+        float* const pr[1] = {F + (size_t)s * 2 * LS_PLANE};
+        ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
+    }
+}
+
+// Persistent: gridDim.x workgroups walk the (packet, rx) items; while item i is transformed and
+// despread, the samples of item i + gridDim.x are already in flight into registers (SPW symbols
+// per wave, 2 x float4 each), so the HBM stream does not stop during the compute phases.
+template <int SPW>     // symbols per wave held in registers: 8 covers nt <= 32, 16 covers nt <= 64
+__global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a, int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw_re = smem;                      // [256]
     float* tw_im = smem + LS_FFT;             // [256]
@@ -107,30 +141,35 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
     const int nt = a.nt;
-    const size_t blk = blockIdx.x;
+    const int n_jt = (nt + 31) >> 5;
+    const int ksteps = (nt + 1) >> 1;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);      // lane = d3 d2 d1 -> d1 d2 d3
 
     tw_re[tid] = a.tw[tid];
     tw_im[tid] = a.tw[LS_FFT + tid];
 
-    // ---- load: wave w takes symbols w, w+4, ...; lane loads samples 4*lane..4*lane+3 of the
-    // FFT window and scatters them to their base-4 digit-reversed positions.
-    const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
-    const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
-    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);      // lane = d3 d2 d1 -> d1 d2 d3
-    for (int s0 = wave; s0 < nt; s0 += 16) {
-        f32x4 vr[4], vi[4];
+    // wave w owns symbols w, w+4, ...; lane holds samples 4*lane..4*lane+3 of each FFT window
+    f32x4 vr[SPW], vi[SPW];
+    auto fetch = [&](size_t blk) {
+        const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
+        const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + 4 * u;
-            if (s < nt) {
-                vr[u] = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
-                vi[u] = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
-            }
+        for (int u = 0; u < SPW; ++u) {
+            const int s = min(wave + 4 * u, nt - 1);          // clamp: surplus slots re-read a valid symbol
+            vr[u] = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
+            vi[u] = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
         }
+    };
+
+    size_t blk = blockIdx.x;
+    if (blk < (size_t)nblk) fetch(blk);
+    for (; blk < (size_t)nblk; blk += gridDim.x) {
+        // ---- registers -> LDS at base-4 digit-reversed positions
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + 4 * u;
+        for (int u = 0; u < SPW; ++u) {
+            const int s = wave + 4 * u;
             if (s < nt) {
                 float* fr = F + (size_t)s * 2 * LS_PLANE;
                 float* fi = fr + LS_PLANE;
@@ -142,53 +181,61 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a)
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        // ---- next item's samples start streaming now
+        const size_t nxt = blk + gridDim.x;
+        if (nxt < (size_t)nblk) fetch(nxt);
 
-    // ---- FFT: one wave per symbol
-    for (int s = wave; s < nt; s += 4) {
-        float* fr = F + (size_t)s * 2 * LS_PLANE;
-        ls_fft256_wave(fr, fr + LS_PLANE, tw_re, tw_im, lane);
-    }
-    __syncthreads();
+        // ---- FFT: wave w transforms symbols w, w+4, ...
+        ls_fft_rows(F, wave, nt, tw_re, tw_im, lane);
+        __syncthreads();
 
-    // ---- despread on the matrix core: D[j][q] = sum_s P[j][s] * F[s][f(q)]
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int n_jt = (nt + 31) >> 5;
-    const int ksteps = (nt + 1) >> 1;
-    for (int qt = wave; qt < 8; qt += 4) {
-        const int q = qt * 32 + l31;
-        const bool qok = q < LS_NDATA;
-        const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
-        const float den = a.denom[qok ? q : 0];
-        for (int jt = 0; jt < n_jt; ++jt) {
-            const int ja = jt * 32 + l31;                   // A-operand row of this lane
-            const bool jok = ja < nt;
-            f32x16 dre, dim;
+        // ---- despread on the matrix core: D[j][q] = sum_s P[j][s] * F[s][f(q)]
+        for (int qt = wave; qt < 8; qt += 4) {
+            const int q = qt * 32 + l31;
+            const bool qok = q < LS_NDATA;
+            const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
+            const float den = a.denom[qok ? q : 0];
+            for (int jt = 0; jt < n_jt; ++jt) {
+                const int ja = jt * 32 + l31;                   // A-operand row of this lane
+                const bool jok = ja < nt;
+                f32x16 dre, dim;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { dre[e] = 0.f; dim[e] = 0.f; }
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const int s = 2 * ks + hi;
-                const bool sok = s < nt;
-                const float pv = (jok && sok) ? a.P[ja * nt + s] : 0.f;
-                const float* fr = F + (size_t)(sok ? s : 0) * 2 * LS_PLANE;
-                const float bre = sok ? fr[pos] : 0.f;
-                const float bim = sok ? fr[LS_PLANE + pos] : 0.f;
-                dre = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bre, dre, 0, 0, 0);
-                dim = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bim, dim, 0, 0, 0);
-            }
-            if (qok) {
+                for (int e = 0; e < 16; ++e) { dre[e] = 0.f; dim[e] = 0.f; }
+                // this lane's pilot entries P[ja][hi], P[ja][2+hi], ... fetched up front (independent
+                // loads) instead of one L1 round trip per MFMA step
+                float pvs[2 * SPW];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (j < nt) {
-                        const size_t o = (blk * nt + j) * LS_NDATA + q;
-                        a.h_re[o] = dre[r] / den;
-                        a.h_im[o] = dim[r] / den;
+                for (int ks = 0; ks < 2 * SPW; ++ks) {
+                    const int s = 2 * ks + hi;
+                    pvs[ks] = (jok && s < nt) ? a.P[ja * nt + s] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2 * SPW; ++ks) {
+                    if (ks >= ksteps) break;
+                    const int s = 2 * ks + hi;
+                    const bool sok = s < nt;
+                    const float pv = pvs[ks];
+                    const float* fr = F + (size_t)(sok ? s : 0) * 2 * LS_PLANE;
+                    const float bre = sok ? fr[pos] : 0.f;
+                    const float bim = sok ? fr[LS_PLANE + pos] : 0.f;
+                    dre = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bre, dre, 0, 0, 0);
+                    dim = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, bim, dim, 0, 0, 0);
+                }
+                if (qok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (j < nt) {
+                            const size_t o = (blk * nt + j) * LS_NDATA + q;
+                            a.h_re[o] = dre[r] / den;
+                            a.h_im[o] = dim[r] / den;
+                        }
                     }
                 }
             }
         }
+        __syncthreads();          // spectra consumed; LDS may be overwritten by the next item
     }
 }
 
@@ -283,10 +330,7 @@ __global__ __launch_bounds__(LS_THREADS) void ls_despread_first_kernel(const LsA
         }
     }
     __syncthreads();
-    for (int j = wave; j < LSD_ROWS; j += 4) {
-        float* fr = X + (size_t)j * 2 * LS_PLANE;
-        ls_fft256_wave(fr, fr + LS_PLANE, tw_re, tw_im, lane);
-    }
+    ls_fft_rows(X, wave, LSD_ROWS, tw_re, tw_im, lane);
     __syncthreads();
     // pick the 234 data bins, scale, store coalesced
     for (int idx = tid; idx < LSD_ROWS * LS_NDATA; idx += LS_THREADS) {

@@ -84,6 +84,21 @@ def test_ls_non_power_of_two_nt_generic_pilot(pkg, oracle, nt):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
 
 
+@pytest.mark.parametrize('thr', ['0', '64'])
+def test_ls_both_kernels_agree(pkg, oracle, monkeypatch, thr):
+    """The FFT-first and the despread-first LS kernels are interchangeable for Nt <= 64 (the
+    default switches at Nt = 32 on measured speed); force each one."""
+    monkeypatch.setenv('CSI_LS_FFT_FIRST_MAX', thr)
+    rng = np.random.default_rng(int(thr) + 3)
+    for nt, nr in ((8, 2), (32, 3), (64, 2)):
+        P = _pilot(rng, nt)
+        ltf, H = oracle.make_structured_packets(rng, 3, nr, P, snr_db=None)
+        e = pkg.CsiEngine(nt, nr, hidden=(8,))
+        e.set_pilot(P)
+        h = e.ls_estimate(ltf)
+        assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([H.real, H.imag], -1)) < TOL
+
+
 def test_ls_empty_batch(pkg):
     e = pkg.CsiEngine(4, 2, hidden=(8,))
     e.set_pilot(np.eye(4))
