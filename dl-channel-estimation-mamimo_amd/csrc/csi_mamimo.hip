@@ -88,6 +88,9 @@ struct csi_ctx {
     // activation workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    // split-K slabs of the small-batch path
+    char* skbuf = nullptr;
+    size_t skbuf_bytes = 0;
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
@@ -222,6 +225,26 @@ const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& nam
 }
 
 // ---------------------------------------------------------------- GEMM launch helpers
+// Small-batch latency path: a GEMM with few output tiles (the reference's literal one-packet call
+// has 8) is split along K over ~256 workgroups and combined by splitk_epilogue_kernel.
+int small_batch_splits(long tiles, int K) {
+    if (tiles >= 96 || K < 256) return 1;
+    long s = 384 / std::max<long>(tiles, 1);
+    s = std::min<long>(s, K / 64);           // >= 4 ring k-tiles per workgroup
+    return (int)std::max<long>(s, 1);
+}
+
+template <int EPI>
+int launch_splitk_epilogue(csi_ctx* c, const GemmArgs& g, const float* slabs, int S) {
+    ProfScope ps(c, K_SPLITK_REDUCE, (double)S * g.M * g.N, 4.0 * (S + 1) * (double)g.M * g.N);
+    const size_t total = (size_t)g.M * g.N;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<EPI>), dim3(blocks), dim3(256), 0, c->stream, slabs, S, g.M, g.N, g.C, g.ldc,
+                       g.bias, g.scale, g.shift);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
 template <int EPI>
 int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     if (g.M <= 0) return CSI_OK;
@@ -230,6 +253,24 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
                     g.K, g.lda, g.ldb);
     const int tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    if (EPI != EPI_RAW && splits == 1) {
+        const int S = small_batch_splits((long)tiles_m * g.tiles_n, g.K);
+        if (S > 1) {
+            int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)S * g.M * g.N * sizeof(float));
+            if (rc) return rc;
+            GemmArgs r = g;
+            r.C = reinterpret_cast<float*>(c->skbuf);
+            r.ldc = g.N;
+            r.k_per_split = ((g.K + G_BK - 1) / G_BK + S - 1) / S * G_BK;
+            const int real = (g.K + r.k_per_split - 1) / r.k_per_split;
+            {
+                ProfScope ps(c, kid, 2.0 * (double)g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * real));
+                hipLaunchKernelGGL((gemm_f32_kernel<EPI_RAW>), dim3((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)real), dim3(G_THREADS), 0, c->stream, r);
+                HIP_TRY(c, hipGetLastError());
+            }
+            return launch_splitk_epilogue<EPI>(c, g, r.C, real);
+        }
+    }
     dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double a_rows = (double)g.M;
@@ -240,7 +281,7 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     return CSI_OK;
 }
 
-// first per-pair layer (fragment-time h1 kernel, 4 <= nt <= 128)
+// first per-pair layer (fragment-time h1 kernels, 4 <= nt <= 128)
 template <int EPI>
 int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
     if (g.nt < 4 || g.nt > 128)
@@ -250,12 +291,34 @@ int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
         return fail(c, CSI_ERR_INVALID_ARG, "pair gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
                     g.K, g.lda, g.ldb);
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    const int tiles_m = (g.M + G_BM - 1) / G_BM;
+    const int tiles_m256 = (g.M + P2_BM - 1) / P2_BM;
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M / g.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
+
+    // small batch: split K over the chip, combine + epilogue in a second (tiny) kernel
+    const int S = c->force_pair_tile ? 1 : small_batch_splits((long)tiles_m * g.tiles_n, g.K);
+    if (S > 1) {
+        int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)S * g.M * g.N * sizeof(float));
+        if (rc) return rc;
+        GemmArgs r = g;
+        r.C = reinterpret_cast<float*>(c->skbuf);
+        r.ldc = g.N;
+        r.k_per_split = ((g.K + G_BK - 1) / G_BK + S - 1) / S * G_BK;
+        const int real = (g.K + r.k_per_split - 1) / r.k_per_split;
+        {
+            ProfScope ps(c, kid, flops, bytes);
+            const dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)real);
+            if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI_RAW, 1>), grid, dim3(G_THREADS), 0, c->stream, r);
+            else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI_RAW, 2>), grid, dim3(G_THREADS), 0, c->stream, r);
+            HIP_TRY(c, hipGetLastError());
+        }
+        return launch_splitk_epilogue<EPI>(c, g, r.C, real);
+    }
+
     ProfScope ps(c, kid, flops, bytes);
     // 256-row tiles halve the LDS-DMA instructions per MFMA; use them once they fill the 512
     // resident workgroup slots, 128-row tiles (more workgroups) below that.
-    const int tiles_m256 = (g.M + P2_BM - 1) / P2_BM;
     const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n >= 512);
     if (big) {
         const dim3 grid((unsigned)(tiles_m256 * g.tiles_n));
@@ -263,8 +326,8 @@ int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
         else if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
         else hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 2, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
     } else {
-        const int tiles_m = (g.M + G_BM - 1) / G_BM;
         const dim3 grid((unsigned)(tiles_m * g.tiles_n));
+        g.k_per_split = (g.K + G_BK - 1) / G_BK * G_BK;
         if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
         else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
     }
@@ -277,11 +340,11 @@ int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
 int choose_splits(int M, int N, int K, int* k_per_split) {
     const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     const int ktiles = (K + G_BK - 1) / G_BK;
-    static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32, 40};
     int best = 1;
     double best_eff = -1.0;
     for (int s : cand) {
-        if (s > 1 && ktiles / s < 16) break;          // keep >= 16 k-tiles per block
+        if (s > 1 && ktiles / s < 8) break;           // keep >= 8 k-tiles (of 32) per block
         const int kps = (ktiles + s - 1) / s;
         const int real = (ktiles + kps - 1) / kps;
         const double rounds = (double)tiles * real / 512.0;
@@ -321,7 +384,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     // Packet chunks: as few as the workspace allows, all of (nearly) the same size so that every
     // chunk fills the machine equally well.  Per packet: layer-0 slabs + their sum, and the
     // ping-pong buffers of the hidden activations.
-    const int smax = 16;                                  // upper bound of choose_splits
+    const int smax = 40;                                  // upper bound of choose_splits
     const size_t hid_pkt = (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
     size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);   // 1.5 GiB
     int64_t chunk = npkt;
@@ -685,6 +748,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->denom) hipFree(c->denom);
     if (c->ws) hipFree(c->ws);
     if (c->stage) hipFree(c->stage);
+    if (c->skbuf) hipFree(c->skbuf);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -278,7 +278,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
     const int tile = blockIdx.x;
     const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
     const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int nkt = (g.K + R_BK - 1) / R_BK;
+    const int kbeg = blockIdx.z * g.k_per_split;           // split-K (small-batch latency path)
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nkt = (kend - kbeg + R_BK - 1) / R_BK;
     const int nt = g.nt;
     const int pr_base = m0 / nt;
     const int NL = min(m0 + G_BM - 1, g.M - 1) / nt - pr_base + 1;       // <= 33
@@ -293,13 +295,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int rb = R_RPP * (2 * wave + u) + prow;
-        bsrc[u] = g.Bt + (size_t)min(n0 + rb, g.N - 1) * g.ldb + ((pch ^ r_swz(rb)) << 2);
+        bsrc[u] = g.Bt + (size_t)min(n0 + rb, g.N - 1) * g.ldb + ((pch ^ r_swz(rb)) << 2) + kbeg;
     }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         tpiece[u] = min(wave + 4 * u, nT - 1);                 // T pieces w (and w+4)
         const int rt = R_RPP * tpiece[u] + prow;
-        tsrc[u] = g.T + (size_t)min(rt, nt - 1) * g.lda + ((pch ^ r_swz(rt)) << 2);
+        tsrc[u] = g.T + (size_t)min(rt, nt - 1) * g.lda + ((pch ^ r_swz(rt)) << 2) + kbeg;
     }
     const int lpiece = min(wave, PL_LROWS / R_RPP - 1);        // wave 3 repeats piece 2 (same bytes)
     {
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
         const float* p = g.A + (size_t)(pr_base + min(rl, NL - 1)) * g.lda;
         if (rl == NL) p = g.s0;
         if (rl == NL + 1) p = g.t0;
-        lsrc = p + ((pch ^ r_swz(rl)) << 2);
+        lsrc = p + ((pch ^ r_swz(rl)) << 2) + kbeg;
     }
     // u = 0/1: {B piece, T piece};  u = 2: the L piece
     auto issue = [&](int kt, int u) {
@@ -538,12 +540,44 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
                                      size_t n4, int S) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        // loads of 8 slabs in flight at a time; the sum itself stays in z order (deterministic)
         f32x4 v = reinterpret_cast<const f32x4*>(slabs)[i];
-        for (int z = 1; z < S; ++z) {
-            f32x4 w = reinterpret_cast<const f32x4*>(slabs)[i + (size_t)z * n4];
-            v += w;
+        int z = 1;
+        for (; z + 8 <= S; z += 8) {
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = reinterpret_cast<const f32x4*>(slabs)[i + (size_t)(z + u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += w[u];
         }
+        for (; z < S; ++z) v += reinterpret_cast<const f32x4*>(slabs)[i + (size_t)z * n4];
         reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+// out[m][n] = epilogue( sum_z slab_z[m][n] ), slabs compact [S][M][N]; one thread per element.
+// Used by the small-batch path, where split-K spreads a short GEMM over the whole chip.
+template <int EPI>
+__global__ void splitk_epilogue_kernel(const float* __restrict__ slabs, int S, int M, int N, float* __restrict__ out,
+                                       int ldc, const float* __restrict__ bias, const float* __restrict__ scale,
+                                       const float* __restrict__ shift) {
+    const size_t total = (size_t)M * N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+        float v = slabs[i];
+        int z = 1;
+        for (; z + 8 <= S; z += 8) {            // 8 loads in flight, summed in z order
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = slabs[(size_t)(z + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += w[u];
+        }
+        for (; z < S; ++z) v += slabs[(size_t)z * total + i];
+        if (EPI == EPI_BIAS) v += bias[n];
+        if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias[n], 0.f), scale[n], shift[n]);
+        out[(size_t)m * ldc + n] = v;
     }
 }
 

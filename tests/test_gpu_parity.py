@@ -119,6 +119,8 @@ CASES = [
     (64, 2, 3, (64, 32), True),         # BASELINE configs 3/4 antenna count
     (128, 2, 2, (64, 64), True),        # BASELINE config 5 antenna count (two T pieces per wave)
     (12, 2, 7, (40,), True),            # Nt not a power of two
+    (8, 2, 3, (512, 320), True),        # small batch, K >= 256: split-K latency path of every layer
+    (8, 2, 1, (256,), False),           # one packet, single hidden layer, no BN, split-K regressor
 ]
 
 
