@@ -374,6 +374,31 @@ def test_csipredictor_twin_rice_renew_single_input(pkg, oracle, golden_dir, tmp_
     assert rel_rows(np.concatenate([y[:, 1:27].real, y[:, 1:27].imag], -1), np.concatenate([nz.real, nz.imag], -1)) < TOL
 
 
+def test_dataset_label_self_consistency(pkg, oracle):
+    """dataset labels are the LS estimate of the same noisy preamble; a dataset in the
+    reference's pickle layout, packed by the host code, must satisfy LS(ltf) == labels on the GPU."""
+    rng = np.random.default_rng(12)
+    nt, nr, npkt = 8, 2, 3
+    P_rows = _pilot(rng, nt)
+    ltf, _ = oracle.make_structured_packets(rng, npkt, nr, P_rows, snr_db=3.0)
+    y = oracle.ls_estimate(ltf, P_rows).reshape(npkt * nr * nt, 234)          # what MATLAB stores as label
+    X = np.zeros((npkt * nr * nt, 2), dtype=int)
+    LTF = {}
+    for p in range(npkt):
+        for r in range(nr):
+            key = 1000 + p * nr + r
+            LTF[key] = {'real': ltf[p, r].real.copy(), 'imag': ltf[p, r].imag.copy()}
+            for t in range(nt):
+                X[p * nr * nt + r * nt + t] = [key, t]
+    ds = {'X': X, 'y': {'real': y.real.copy(), 'imag': y.imag.copy()}, 'LTF': LTF, 'P': P_rows.T.copy(),
+          'simParams': {'nTX': nt, 'nRX': nr}}
+    packed = pkg.dataset.packets_from_dataset(ds)
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    assert pkg.dataset.label_consistency(e, packed) < TOL
+    packed['pilot'] = packed['pilot'].T.copy()                                # wrong orientation must show
+    assert pkg.dataset.label_consistency(e, packed) > 1e-2
+
+
 # ------------------------------------------------------------------------------------ device path
 def test_device_resident_path_and_profile(pkg, oracle):
     rng = np.random.default_rng(41)

@@ -103,6 +103,62 @@ def test_weight_container_roundtrip(pkg, tmp_path):
     assert config_from_weights(w, 4) == dict(hidden=[16, 8], n_out=234, use_bn=True)
 
 
+def _golden_dataset(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_datagen_nt4.npz'))
+    keys = g['ds_keys'].tolist()
+    ltf = {k: {'real': g['ds_ltf_real'][i], 'imag': g['ds_ltf_imag'][i]} for i, k in enumerate(keys)}
+    nt, nr = int(g['nt']), int(g['nr'])
+    ds = {'X': g['ds_X'], 'y': {'real': g['ds_y_real'], 'imag': g['ds_y_imag']}, 'LTF': ltf, 'P': g['ds_P'],
+          'simParams': {'nTX': nt, 'nRX': nr}}
+    return g, ds
+
+
+def test_dataset_packing_matches_reference_generator_view(pkg, golden_dir, tmp_path):
+    """The packed arrays must be what the reference DataGenerator hands to the DNN, sample by
+    sample (golden vectors recorded from the reference's own generator)."""
+    import pickle
+    g, ds = _golden_dataset(golden_dir)
+    f = tmp_path / 'ds.b'
+    with open(f, 'wb') as fh:
+        pickle.dump(ds, fh)
+    packed = pkg.dataset.packets_from_dataset(pkg.dataset.load_dataset(str(f)))
+    nt, nr, npkt = packed['nt'], packed['nr'], packed['npkt']
+    assert (nt, nr, npkt) == (int(g['nt']), int(g['nr']), int(g['npkt']))
+    np.testing.assert_array_equal(packed['pilot'], g['P_matlab'])
+    for d, part in (('real', packed['ltf'].real), ('imag', packed['ltf'].imag)):
+        xsig = g[f'{d}_Xsig'][..., 0].reshape(npkt, nr, nt, -1)           # [pkt, rx, tx, lenLTF]
+        for t in range(nt):
+            np.testing.assert_array_equal(part, xsig[:, :, t, :])         # same preamble for every tx
+        xp = g[f'{d}_Xp'].reshape(npkt, nr, nt, nt)
+        np.testing.assert_array_equal(xp, np.broadcast_to(packed['pilot'], xp.shape))
+        lab = packed['labels'].real if d == 'real' else packed['labels'].imag
+        np.testing.assert_array_equal(lab.reshape(npkt, nr * nt, -1), g[f'{d}_y'])
+    bad = dict(ds, X=ds['X'][::-1].copy())
+    with pytest.raises(ValueError):
+        pkg.dataset.packets_from_dataset(bad)
+
+
+def test_mat_export_layout(pkg, golden_dir, tmp_path):
+    """Per-packet .mat files as DNN.py:401-409 writes them and BER_test_maMIMO_LTF.m:197-217 reads
+    them: struct all_pkts_csi_nn_out with x, y, true_y, rows (iRX-1)*nTX + iTX."""
+    from scipy.io import loadmat
+    g, ds = _golden_dataset(golden_dir)
+    packed = pkg.dataset.packets_from_dataset(ds)
+    nt, nr, npkt = packed['nt'], packed['nr'], packed['npkt']
+    rng = np.random.default_rng(0)
+    o_re = rng.standard_normal((npkt, nr, nt, 234)).astype(np.float32)
+    o_im = rng.standard_normal((npkt, nr, nt, 234)).astype(np.float32)
+    files = pkg.dataset.export_predictions(str(tmp_path), packed, o_re, o_im)
+    assert [os.path.basename(f) for f in files['real']] == [f'test_csi_predictions_real_{i}.mat' for i in range(1, npkt + 1)]
+    m = loadmat(files['imag'][1])['all_pkts_csi_nn_out'][0, 0]
+    np.testing.assert_array_equal(m['y'], o_im[1].reshape(nr * nt, 234))
+    np.testing.assert_array_equal(m['true_y'], g['imag_y'][1])
+    np.testing.assert_array_equal(m['x'], g['imag_Xsig'][1][..., 0])
+    # MATLAB reassembly CSI(:, iTX, iRX) = pred((iRX-1)*nTX + iTX, :)
+    iRX, iTX = 2, 3
+    np.testing.assert_array_equal(m['y'][(iRX - 1) * nt + (iTX - 1)], o_im[1, iRX - 1, iTX - 1])
+
+
 def test_shard_range_partitions_all_packets(pkg):
     for n in (0, 1, 7, 500, 50000):
         for world in (1, 2, 3, 8):
