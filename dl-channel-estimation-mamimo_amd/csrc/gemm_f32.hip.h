@@ -160,6 +160,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // operands, so A and B agree on k.
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[2][2], const f32x4& a0, const f32x4& a1, const f32x4& b0,
                                            const f32x4& b1) {
+    // no s_setprio here: measured -4 % on the 128x128 kernels (16-MFMA clusters), +4 % on the
+    // 256-row pair kernel (32-MFMA clusters), which raises its priority itself
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const Ge
                 for (int e = 0; e < 4; ++e) a[mi][e] = fmaf(fmaxf(l[e] + t[e], 0.f), sv[e], hv[e]);
             }
             if (MORE) issue(kt + D, c);
+            __builtin_amdgcn_s_setprio(1);      // the MFMA cluster outranks the other workgroup's loads/VALU (+4 %)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const Ge
                     acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b1[s], acc[mi][1], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
     };
     int kt = 0;
