@@ -95,7 +95,7 @@ struct csi_ctx {
     char* stage = nullptr;
     size_t stage_bytes = 0;
     int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
-    int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256 (tests exercise both kernels)
+    int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
     // profiling
     bool prof_on = false;
     std::vector<ProfSpan> spans;
@@ -254,7 +254,7 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     const int tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     if (EPI != EPI_RAW && splits == 1) {
-        const int S = small_batch_splits((long)tiles_m * g.tiles_n, g.K);
+        const int S = c->force_pair_tile ? 1 : small_batch_splits((long)tiles_m * g.tiles_n, g.K);
         if (S > 1) {
             int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)S * g.M * g.N * sizeof(float));
             if (rc) return rc;
@@ -271,12 +271,20 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
             return launch_splitk_epilogue<EPI>(c, g, r.C, real);
         }
     }
-    dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double a_rows = (double)g.M;
     const double bytes = 4.0 * (a_rows * g.K + (double)g.N * g.K + (double)g.M * g.N * splits);
     ProfScope ps(c, kid, flops, bytes);
-    hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    // 256-row tiles (fewer LDS-DMA instructions per MFMA) once they fill the 512 resident slots
+    const int tiles_m256 = (g.M + G2_BM - 1) / G2_BM;
+    const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n * splits >= 512);
+    if (big) {
+        dim3 grid((unsigned)(tiles_m256 * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    } else {
+        dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    }
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }

@@ -253,6 +253,110 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_f32_kernel(const GemmArgs g
 }
 
 // =============================================================================================
+// plain GEMM, 256x128 block tile: 4 waves (2x2), wave tile 128x64 = 4x2 MFMA tiles, ring of 3
+// stages [A image 256x16 | B image 128x16] (72 KiB, 2 workgroups per CU), 6 DMA pieces per wave
+// per k-tile of 64 MFMAs (0.094 per MFMA against 0.125 for the 128x128 kernel).  No s_setprio:
+// with the A operand streaming from HBM it starves the other workgroup's DMA (measured -9 %).
+// Used when the grid fills the chip (+1.5-2 %); the 128x128 kernel otherwise.
+// =============================================================================================
+constexpr int G2_BM = 256;
+
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm256_f32_kernel(const GemmArgs g) {
+    constexpr int NS = 3, D = NS - 1, P = 6;
+    constexpr int STAGE = (G2_BM + 128) * R_BK;                    // floats (24 KiB)
+    constexpr int BOFF = G2_BM * R_BK;
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+    const int m0 = tm * G2_BM, n0 = tn * G_BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nkt = (kend - kbeg + R_BK - 1) / R_BK;
+
+    // DMA: 24 pieces of 16 image rows per stage (16 A, 8 B); wave w issues pieces 6w .. 6w+5
+    const float* src[P];
+    int dst[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        const int piece = P * wave + u;
+        const int row = R_RPP * piece + (lane >> 2);               // image row (A rows 0..255, then B rows)
+        const int clog = (lane & 3) ^ r_swz(row);
+        if (piece < G2_BM / R_RPP) src[u] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + clog * 4 + kbeg;
+        else src[u] = g.Bt + (size_t)min(n0 + row - G2_BM, g.N - 1) * g.ldb + clog * 4 + kbeg;
+        dst[u] = piece * 256;
+    }
+    auto issue = [&](int kt, int u) { dma16(src[u] + kt * R_BK, lds + (kt % NS) * STAGE + dst[u]); };
+
+    int aoff[2], boff[2];
+    const int arow = wm * 128 + l31, brow = wn * 64 + l31;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        aoff[c] = arow * R_BK + (((2 * c + hi) ^ r_swz(arow)) << 2);
+        boff[c] = BOFF + brow * R_BK + (((2 * c + hi) ^ r_swz(brow)) << 2);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int npro = min(nkt, D);
+    for (int t = 0; t < npro; ++t)
+#pragma unroll
+        for (int u = 0; u < P; ++u) issue(t, u);
+
+    auto handover = [&](int groups) {
+        if (groups >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const float* st = lds + (kt % NS) * STAGE;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(st + aoff[c] + mi * 32 * R_BK);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + boff[c]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(st + boff[c] + 32 * R_BK);
+            if (MORE) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) issue(kt + D, 3 * c + u);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b0[s], acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b1[s], acc[mi][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    int kt = 0;
+    for (; kt < nkt - D; ++kt) {
+        handover(D - 1);
+        ktile(kt, std::true_type{});
+    }
+    for (; kt < nkt; ++kt) {
+        handover(nkt - 1 - kt);
+        ktile(kt, std::false_type{});
+    }
+    gemm_epilogue<EPI, 4, G2_BM>(acc, g, m0, n0, wm, wn, l31, hi);
+}
+
+// =============================================================================================
 // pair GEMM (first per-pair layer).  Ring stage = three images, all filled by LDS-DMA:
 //   Bs [128][16]   weight tile
 //   Ts [128][16]   pilot-table slice, row t (rows >= nt are unused duplicates)

@@ -146,10 +146,11 @@ def test_predict_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden, use_bn):
 
 @pytest.mark.parametrize('tile', ['128', '256'])
 @pytest.mark.parametrize('nt,nr,npkt,hidden', [(4, 2, 70, (64, 48)), (32, 2, 9, (96, 64)), (128, 1, 3, (64, 64)),
-                                               (12, 3, 11, (40, 24)), (8, 2, 5, (64,))])
+                                               (12, 3, 11, (40, 24)), (8, 2, 5, (64,)), (8, 1, 40, (72, 136, 200))])
 def test_both_pair_tile_kernels(pkg, oracle, monkeypatch, tile, nt, nr, npkt, hidden):
-    """The first per-pair layer has a 128-row and a 256-row tile kernel (chosen by grid size);
-    force each one on ragged row counts and every (T pieces, L pieces) template variant."""
+    """Every GEMM has a 128-row and a 256-row tile kernel (chosen by grid size); force each one on
+    ragged row counts, every (T pieces, L pieces) template variant of the pair kernel, and the
+    plain kernels of layer 0 / hidden layers / regressor."""
     monkeypatch.setenv('CSI_FORCE_PAIR_TILE', tile)
     rng = np.random.default_rng(nt + npkt)
     w_re, w_im = _weights(oracle, 77 + nt, nt, hidden)

@@ -43,6 +43,27 @@ double run(const char* name, GemmArgs g, int splits, int iters, std::vector<floa
     return med;
 }
 
+template <int EPI>
+double run256(const char* name, GemmArgs g, int splits, int iters) {
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    dim3 grid(((g.M + G2_BM - 1) / G2_BM) * g.tiles_n, 1, splits);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("%-34s med %.3f ms  %.1f TF   (best %.1f TF)\n", name, med, fl / med / 1e9, fl / ts[0] / 1e9);
+    return med;
+}
+
 template <int EPI, int TPW>
 double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
@@ -157,7 +178,9 @@ int main(int argc, char** argv) {
         run_pair256<EPI_BIAS_RELU_AFFINE>("pair_dense 256x128", p, 7, &o2);
         { double d = 0; for (int i = 0; i < 256; ++i) d = std::max(d, (double)std::fabs(o1[i] - o2[i])); printf("   max |diff| 128 vs 256 tile: %g (value %g)\n", d, o1[7]); }
         run<EPI_RAW>("layer0 (split 2)", l, 2, 7);
+        run256<EPI_RAW>("layer0 (split 2) 256x128", l, 2, 7);
         run<EPI_BIAS>("regressor", r, 1, 7);
+        run256<EPI_BIAS>("regressor 256x128", r, 1, 7);
     }
     return 0;
 }
