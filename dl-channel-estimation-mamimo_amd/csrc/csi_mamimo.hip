@@ -66,6 +66,13 @@ struct Model {
     bool table_ok = false;
 };
 
+struct GraphEntry {           // one captured csi_predict_device call
+    const void* in_re; const void* in_im; void* out_re; void* out_im;
+    int64_t npkt;
+    int seen;                 // eager runs with this key so far (capture happens on the 2nd call)
+    hipGraphExec_t exec;
+};
+
 struct ProfSpan {
     int id;
     hipEvent_t beg, end;
@@ -94,6 +101,8 @@ struct csi_ctx {
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
+    bool use_graph = false;
+    std::vector<GraphEntry> graphs;
     int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
     int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
     // profiling
@@ -170,8 +179,15 @@ int prof_collect(csi_ctx* c) {
     return CSI_OK;
 }
 
+void drop_graphs(csi_ctx* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
 int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {
     if (*have >= need) return CSI_OK;
+    drop_graphs(c);           // captured launches point into the old buffer
     if (*buf) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipFree(*buf));
@@ -748,6 +764,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& sp : c->spans) { hipEventDestroy(sp.beg); hipEventDestroy(sp.end); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    drop_graphs(c);
     free_model(c->model[0]);
     free_model(c->model[1]);
     if (c->P) hipFree(c->P);
@@ -768,6 +785,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
     const csi_config& cf = c->cfg;
     Model& m = c->model[model];
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graphs(c);
     free_model(m);
     m.layers.resize(cf.n_hidden + 1);
     int fan_in = c->d_in;
@@ -861,6 +879,7 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
     if (!P || c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_set_pilot: null P or single-input context");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graphs(c);
     int rc = upload(c, &c->P, P, (size_t)c->cfg.nt * c->cfg.nt);
     if (rc) return rc;
     c->pilot_ok = true;
@@ -880,14 +899,48 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         return fail(c, CSI_ERR_INVALID_ARG, "csi_predict_device: bad argument");
     if (npkt == 0) return CSI_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if (c->cfg.dtype == CSI_DTYPE_BF16) {
-        rc = predict_plane_bf16(c, c->model[0], d_ltf_re, npkt, d_out_re);
-        if (rc) return rc;
-        return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
+    auto run = [&]() -> int {
+        if (c->cfg.dtype == CSI_DTYPE_BF16) {
+            int r = predict_plane_bf16(c, c->model[0], d_ltf_re, npkt, d_out_re);
+            if (r) return r;
+            return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
+        }
+        int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        if (r) return r;
+        return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+    };
+    if (!c->use_graph || c->prof_on) return run();
+
+    // hipGraph replay: 1st call with a key runs eagerly (sizes every buffer), 2nd call captures,
+    // later calls replay.  Any reallocation / weight / pilot change drops the cache.
+    GraphEntry* ge = nullptr;
+    for (auto& g : c->graphs)
+        if (g.in_re == d_ltf_re && g.in_im == d_ltf_im && g.out_re == d_out_re && g.out_im == d_out_im && g.npkt == npkt) ge = &g;
+    if (!ge) {
+        if (c->graphs.size() >= 16) drop_graphs(c);
+        c->graphs.push_back(GraphEntry{d_ltf_re, d_ltf_im, d_out_re, d_out_im, npkt, 0, nullptr});
+        ge = &c->graphs.back();
     }
-    rc = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
-    if (rc) return rc;
-    return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+    if (ge->exec) {
+        HIP_TRY(c, hipGraphLaunch(ge->exec, c->stream));
+        return CSI_OK;
+    }
+    if (ge->seen++ == 0) return run();
+    const GraphEntry key = *ge;               // run() may not reallocate now, but keep a copy anyway
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    rc = run();
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e_end != hipSuccess) return fail(c, CSI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) return fail(c, CSI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e_inst));
+    for (auto& g : c->graphs)
+        if (g.in_re == key.in_re && g.in_im == key.in_im && g.out_re == key.out_re && g.out_im == key.out_im && g.npkt == key.npkt) g.exec = exec;
+    HIP_TRY(c, hipGraphLaunch(exec, c->stream));
+    return CSI_OK;
 }
 
 int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_h_re,
@@ -924,6 +977,33 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         } else
             hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), lds, c->stream, a, n_jc);
         HIP_TRY(c, hipGetLastError());
+    }
+    return CSI_OK;
+}
+
+int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!name) return fail(c, CSI_ERR_INVALID_ARG, "csi_set_option: null name");
+    const std::string n(name);
+    if (n == "use_graph") {
+        if (!value) drop_graphs(c);
+        c->use_graph = value != 0;
+    } else if (n == "force_tile") {
+        if (value != 0 && value != 128 && value != 256) return fail(c, CSI_ERR_INVALID_ARG, "force_tile must be 0, 128 or 256");
+        drop_graphs(c);
+        c->force_pair_tile = (int)value;
+    } else if (n == "ls_fft_first_max") {
+        if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
+        c->ls_fft_first_max = (int)value;
+        if (c->cfg.nt > 0) {
+            const bool fft_first = c->cfg.nt <= c->ls_fft_first_max;
+            const size_t bytes = (size_t)((fft_first ? c->cfg.nt : LSD_ROWS) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+            const void* fn = !fft_first ? (const void*)ls_despread_first_kernel
+                             : (c->cfg.nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>);
+            HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        }
+    } else {
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_set_option: unknown option '%s'", name);
     }
     return CSI_OK;
 }

@@ -115,6 +115,14 @@ int  csi_ls_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_
 
 int  csi_synchronize(csi_ctx* ctx);
 
+/* Tuning / debug knobs (no reference counterpart).  name:
+ *   "use_graph"        1: csi_predict_device replays a captured hipGraph when it is called again
+ *                         with the same pointers and packet count (the reference's per-packet loop,
+ *                         DNN.py:346, repeats one launch sequence); 0 (default): eager launches
+ *   "force_tile"       128 | 256: row-tile height of every GEMM (0 = chosen by grid size)
+ *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 32, max 64) */
+int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
+
 /* Device-memory plumbing so that a host program needs no other GPU runtime. */
 int  csi_device_malloc(csi_ctx* ctx, void** dptr, int64_t bytes);
 int  csi_device_free(csi_ctx* ctx, void* dptr);

@@ -431,6 +431,46 @@ def test_device_resident_path_and_profile(pkg, oracle):
     assert rel_rows(d_hre.download(), ref_ls.real) < TOL and rel_rows(d_him.download(), ref_ls.imag) < TOL
 
 
+def test_hipgraph_replay_matches_eager(pkg, oracle):
+    """use_graph: the 2nd identical csi_predict_device call is captured, later ones replay the
+    hipGraph.  Results must equal the eager ones bit for bit, follow new input data written into
+    the same buffers, and survive a re-allocation (larger batch) and a weight reload."""
+    rng = np.random.default_rng(5)
+    nt, nr, npkt, hidden = 8, 2, 6, (256, 64)
+    w_re, w_im = _weights(oracle, 41, nt, hidden)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, _pilot(rng, nt))
+    a = pkg.synth.white_packets(rng, npkt, nr, nt)
+    b = pkg.synth.white_packets(rng, npkt, nr, nt)
+    d_re, d_im = e.to_device(a.real), e.to_device(a.imag)
+    o_re, o_im = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+    eager_a = (o_re.download(), o_im.download())
+    eager_b = e.predict(b)
+    e.set_option('use_graph', 1)
+    for it in range(4):                       # eager, capture, replay, replay
+        o_re.upload(np.zeros((npkt, nr, nt, 234), np.float32))
+        e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+        np.testing.assert_array_equal(o_re.download(), eager_a[0])
+        np.testing.assert_array_equal(o_im.download(), eager_a[1])
+    d_re.upload(b.real); d_im.upload(b.imag)  # same pointers, new data -> the graph must see it
+    e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+    np.testing.assert_array_equal(o_re.download(), eager_b[0])
+    big = pkg.synth.white_packets(rng, 40, nr, nt)      # forces a workspace re-allocation
+    e.predict(big)
+    e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+    np.testing.assert_array_equal(o_im.download(), eager_b[1])
+    w2_re, w2_im = _weights(oracle, 42, nt, hidden)     # new weights drop the cached graphs
+    e.load_weights('real', w2_re); e.load_weights('imag', w2_im)
+    for it in range(3):
+        e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+    e.set_option('use_graph', 0)
+    ref = e.predict(b)
+    np.testing.assert_array_equal(o_re.download(), ref[0])
+    np.testing.assert_array_equal(o_im.download(), ref[1])
+    with pytest.raises(pkg.CsiError):
+        e.set_option('no_such_option', 1)
+
+
 def test_full_size_properties_config2_slice(pkg, oracle):
     """BASELINE config 2 shape (Nt=32, Nr=4, shipped model) on 64 device-generated packets:
     checked through size-independent properties plus the oracle on a random subset of packets.

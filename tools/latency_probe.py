@@ -12,7 +12,9 @@ eng = pkg.CsiEngine(nt, nr, hidden=hidden)
 eng.load_weights('real', pkg.synth.make_weights(rng, nt, hidden))
 eng.load_weights('imag', pkg.synth.make_weights(rng, nt, hidden))
 eng.set_pilot(pkg.synth.hadamard(nt))
-for npkt in (1, 2, 8, 32, 128, 512):
+import itertools
+for graph, npkt in itertools.product((0, 1), (1, 2, 8, 32, 128, 512)):
+    eng.set_option('use_graph', graph)
     d_re, d_im = eng.empty((npkt, nr, eng.len_ltf)), eng.empty((npkt, nr, eng.len_ltf))
     eng.synth_white(1, 0, npkt, d_re, d_im)
     o_re, o_im = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
@@ -31,5 +33,5 @@ for npkt in (1, 2, 8, 32, 128, 512):
     eng.ls_estimate_device(d_re, d_im, npkt, h_re, h_im); eng.predict_device(d_re, d_im, npkt, o_re, o_im); eng.synchronize()
     prof = {k: round(v['ms'] * 1e3, 1) for k, v in eng.profile().items() if v['launches']}
     eng.profile_enable(False)
-    print('npkt=%4d  median %.1f us  min %.1f us  -> %.0f pairs/s   kernels(us)=%s' % (
-        npkt, np.median(ts) * 1e6, min(ts) * 1e6, npkt * nr * nt / np.median(ts), prof))
+    print('graph=%d npkt=%4d  median %.1f us  min %.1f us  -> %.0f pairs/s   kernels(us)=%s' % (
+        graph, npkt, np.median(ts) * 1e6, min(ts) * 1e6, npkt * nr * nt / np.median(ts), prof))
