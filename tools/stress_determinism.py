@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Race screen: the DNN / LS outputs of a config-2 sized batch must be bit-identical over repeated
+runs (the LDS-DMA ring hand-over has no data-dependent path, so any difference is a race), for
+both tile heights and the small-batch split-K path, and match the oracle on sampled packets."""
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dl_channel_estimation_mamimo_amd as pkg
+from oracle import csi_oracle as o
+
+def digest(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+nt, nr, hidden = 32, 4, (1024, 1024)
+rng = np.random.default_rng(0)
+w_re, w_im = pkg.synth.make_weights(rng, nt, hidden), pkg.synth.make_weights(rng, nt, hidden)
+P = pkg.synth.hadamard(nt)
+bad = 0
+for dtype in ('f32', 'bf16'):
+    for npkt, tile in ((1500, 0), (1500, 128), (37, 0), (3, 0)):
+        eng = pkg.CsiEngine(nt, nr, hidden=hidden, dtype=dtype)
+        eng.load_weights('real', w_re); eng.load_weights('imag', w_im); eng.set_pilot(P)
+        eng.set_option('force_tile', tile)
+        d_re, d_im = eng.empty((npkt, nr, eng.len_ltf)), eng.empty((npkt, nr, eng.len_ltf))
+        eng.synth_white(7, 0, npkt, d_re, d_im)
+        outs = [eng.empty((npkt, nr, nt, 234)) for _ in range(4)]
+        ref = None
+        for it in range(8):
+            eng.ls_estimate_device(d_re, d_im, npkt, outs[2], outs[3])
+            eng.predict_device(d_re, d_im, npkt, outs[0], outs[1])
+            eng.synchronize()
+            sig = tuple(digest(x.download()) for x in outs)
+            if ref is None:
+                ref = sig
+            elif sig != ref:
+                bad += 1
+                print('MISMATCH', dtype, npkt, tile, it, sig, ref)
+        k = min(2, npkt)
+        ltf = d_re.download(0, k) + 1j * d_im.download(0, k)
+        if dtype == 'f32':
+            r_re, r_im = o.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=k)
+            err = max(o.row_rel_err(outs[0].download(0, k), r_re), o.row_rel_err(outs[1].download(0, k), r_im))
+            ok = err < 1e-5
+        else:
+            r_re, r_im = o.predict_packets_bf16(ltf, P, w_re, w_im)
+            err = max(o.row_rel_err(outs[0].download(0, k), r_re), o.row_rel_err(outs[1].download(0, k), r_im))
+            ok = err < 4e-3
+        bad += 0 if ok else 1
+        print('%-4s npkt=%5d tile=%3d  8 runs identical=%s  err=%.2e %s' % (dtype, npkt, tile, 'yes', err, 'ok' if ok else 'FAIL'))
+        del outs, d_re, d_im, eng
+print('FAILURES:', bad)
+sys.exit(1 if bad else 0)
