@@ -61,6 +61,7 @@ struct Layer {
 struct Model {
     std::vector<Layer> layers;   // n_hidden dense layers + regressor (last)
     float* W0p = nullptr;        // [nt][H1] pilot rows of fc_dense0.kernel, row-major
+    float* W0rm = nullptr;       // [lenLTF][H1] LTF rows of fc_dense0.kernel as stored (skinny layer-0 kernel)
     float* T = nullptr;          // [nt][H1] pilot table incl. bias
     bool loaded = false;
     bool table_ok = false;
@@ -95,6 +96,9 @@ struct csi_ctx {
     // activation workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    // layer-0 slabs + sum of the one-packet (skinny) path
+    char* l0skinny = nullptr;
+    size_t l0skinny_bytes = 0;
     // split-K slabs of the small-batch path
     char* skbuf = nullptr;
     size_t skbuf_bytes = 0;
@@ -229,6 +233,8 @@ void free_model(Model& m) {
     for (auto& l : m.layers) free_layer(l);
     m.layers.clear();
     if (m.W0p) hipFree(m.W0p);
+    if (m.W0rm) hipFree(m.W0rm);
+    m.W0rm = nullptr;
     if (m.T) hipFree(m.T);
     m.W0p = m.T = nullptr;
     m.loaded = m.table_ok = false;
@@ -450,8 +456,30 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh;
 
         // layer 0, LTF part: L0[M1][h1] = ltf[M1][len_ltf] * W0[0:len_ltf, :]
+        const float* l0 = nullptr;
+        if (M1 <= 8 && m.W0rm && !c->force_pair_tile) {
+            // a handful of preambles: stream W0 once (HBM-bound) instead of running a GEMM
+            const int S = (cf.len_ltf + 4 * SK_KS - 1) / (4 * SK_KS);
+            rc = ensure_bytes(c, &c->l0skinny, &c->l0skinny_bytes, (size_t)(S + 1) * 8 * h1 * sizeof(float));
+            if (rc) return rc;
+            float* sl = reinterpret_cast<float*>(c->l0skinny);
+            float* sum = sl + (size_t)S * M1 * h1;
+            {
+                ProfScope ps(c, K_LAYER0_LTF, 2.0 * M1 * h1 * cf.len_ltf, 4.0 * ((double)cf.len_ltf * h1 + (double)M1 * cf.len_ltf + (double)S * M1 * h1));
+                hipLaunchKernelGGL((layer0_skinny_kernel<8>), dim3((unsigned)S, (unsigned)((h1 + 255) / 256)), dim3(256), 0, c->stream,
+                                   d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, m.W0rm, h1, cf.len_ltf, sl);
+                HIP_TRY(c, hipGetLastError());
+            }
+            {
+                const size_t n4 = (size_t)M1 * h1 / 4;
+                ProfScope ps(c, K_SPLITK_REDUCE, (double)(S - 1) * M1 * h1, 4.0 * (S + 1) * M1 * h1);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64), 0, c->stream, sl, sum, n4, S);
+                HIP_TRY(c, hipGetLastError());
+            }
+            l0 = sum;
+        }
         int kps = 0;
-        const int splits = choose_splits(M1, h1, cf.len_ltf, &kps);
+        const int splits = l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps);
         GemmArgs g{};
         g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
         g.lda = cf.len_ltf;
@@ -461,9 +489,11 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         g.ldc = h1;
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
         g.k_per_split = kps;
-        rc = launch_gemm<EPI_RAW>(c, K_LAYER0_LTF, g, splits);
-        if (rc) return rc;
-        const float* l0 = slabs;
+        if (!l0) {
+            rc = launch_gemm<EPI_RAW>(c, K_LAYER0_LTF, g, splits);
+            if (rc) return rc;
+            l0 = slabs;
+        }
         if (splits > 1) {
             const size_t n4 = (size_t)M1 * h1 / 4;
             ProfScope ps(c, K_SPLITK_REDUCE, (double)(splits - 1) * M1 * h1, 4.0 * (splits + 1) * M1 * h1);
@@ -774,6 +804,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->ws) hipFree(c->ws);
     if (c->stage) hipFree(c->stage);
     if (c->skbuf) hipFree(c->skbuf);
+    if (c->l0skinny) hipFree(c->l0skinny);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -866,6 +897,10 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 for (float& v : w0p) { const uint32_t u = (uint32_t)rne(v) << 16; std::memcpy(&v, &u, 4); }
             rc = upload(c, &m.W0p, w0p.data(), w0p.size());
             if (rc) return rc;
+            if (!bf16) {
+                rc = upload(c, &m.W0rm, k->data, (size_t)cf.len_ltf * out);
+                if (rc) return rc;
+            }
         }
         fan_in = out;
     }

@@ -643,6 +643,61 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const Ge
     gemm_epilogue<EPI, 4, P2_BM>(acc, g, m0, n0, wm, wn, l31, hi);
 }
 
+// Layer 0 for a handful of preambles (the reference's literal one-packet call has M1 = Nr = 4
+// rows): a weight-streaming kernel instead of a GEMM.  W0 is read ONCE, row-major [K][h1] as keras
+// stores it (n contiguous -> 16 B per lane, coalesced).  Workgroup (z, y) owns 4*SK_KS consecutive
+// k rows and 256 columns: wave w streams rows w*SK_KS.., lane 4 columns, MR accumulator rows;
+// the four waves are combined in LDS (fixed order) and the workgroup writes slab z, which
+// splitk_reduce_kernel sums in fixed order.  HBM-bound: 4*K*h1 bytes.
+constexpr int SK_KS = 40;                      // k rows per wave; 160 per workgroup (320*nt / 160 = 2*nt slabs)
+
+template <int MR>
+__global__ __launch_bounds__(256) void layer0_skinny_kernel(const float* __restrict__ x, int lda, int M,
+                                                            const float* __restrict__ W, int h1, int K,
+                                                            float* __restrict__ slabs) {
+    __shared__ float xs[4][MR * SK_KS];
+    __shared__ __attribute__((aligned(16))) float red[4][MR][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = (blockIdx.x * 4 + wave) * SK_KS;
+    const int kn = max(0, min(SK_KS, K - k0));
+    for (int i = lane; i < MR * SK_KS; i += 64) {
+        const int m = i / SK_KS, k = i - m * SK_KS;
+        xs[wave][i] = (m < M && k < kn) ? x[(size_t)m * lda + k0 + k] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = blockIdx.y * 256 + lane * 4;
+    const bool nok = n < h1;
+    f32x4 acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (size_t)k0 * h1 + (nok ? n : 0);
+#pragma unroll 8
+    for (int k = 0; k < SK_KS; ++k) {
+        if (k < kn) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wp + (size_t)k * h1);
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float xv = xs[wave][m * SK_KS + k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[m][e] = fmaf(xv, w[e], acc[m][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) *reinterpret_cast<f32x4*>(&red[wave][m][lane * 4]) = acc[m];
+    __syncthreads();
+    // 256 threads: thread t sums column t of every accumulator row over the four waves
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    if (col < h1) {
+        float* out = slabs + (size_t)blockIdx.x * M * h1 + col;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            if (m < M) out[(size_t)m * h1] = (red[0][m][threadIdx.x] + red[1][m][threadIdx.x]) + (red[2][m][threadIdx.x] + red[3][m][threadIdx.x]);
+    }
+}
+
 // out[i] = sum_z slab_z[i]  (deterministic order z = 0..S-1); n4 = number of float4
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                      size_t n4, int S) {
