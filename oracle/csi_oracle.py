@@ -264,6 +264,35 @@ def predict_packets_bf16(ltf, P, w_real, w_imag):
     return outs[0], outs[1]
 
 
+def predict_packets_shared(ltf, P, w_real, w_imag, dtype=np.float64):
+    """Same function as predict_packets evaluated with layer 0 shared across the Nt pairs of an rx
+    antenna (z0 = LTF.W0[:lenLTF] + P_t.W0[lenLTF:] + b0) - algebraically identical, Nt times
+    cheaper; used where the literal form is too slow for the checker (Nt = 128 shapes)."""
+    ltf = np.asarray(ltf)
+    npkt, nr, len_ltf = ltf.shape
+    nt = P.shape[0]
+    outs = []
+    for d, w in (('real', w_real), ('imag', w_imag)):
+        eps = float(w.get('bn_eps', BN_EPS))
+        part = (ltf.real if d == 'real' else ltf.imag).astype(dtype).reshape(npkt * nr, len_ltf)
+        k0 = w['fc_dense0.kernel'].astype(dtype)
+        l0 = part @ k0[:len_ltf]
+        t = np.asarray(P, dtype=dtype) @ k0[len_ltf:] + w['fc_dense0.bias'].astype(dtype)
+        h = np.maximum(l0[:, None, :] + t[None, :, :], 0).reshape(npkt * nr * nt, -1)
+        i = 0
+        while True:
+            if f'bn{i}.gamma' in w:
+                h = bn_inference(h, w[f'bn{i}.gamma'].astype(dtype), w[f'bn{i}.beta'].astype(dtype),
+                                 w[f'bn{i}.moving_mean'].astype(dtype), w[f'bn{i}.moving_variance'].astype(dtype), eps)
+            i += 1
+            if f'fc_dense{i}.kernel' not in w:
+                break
+            h = np.maximum(h @ w[f'fc_dense{i}.kernel'].astype(dtype) + w[f'fc_dense{i}.bias'].astype(dtype), 0)
+        y = h @ w['fc_regressor.kernel'].astype(dtype) + w['fc_regressor.bias'].astype(dtype)
+        outs.append(y.reshape(npkt, nr, nt, -1))
+    return outs[0], outs[1]
+
+
 def recombine(out_real, out_imag):
     """inference.py:31  ``output_real + 1j * output_imag``."""
     return out_real + 1j * out_imag

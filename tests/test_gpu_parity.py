@@ -520,6 +520,32 @@ def test_full_size_properties_config2(pkg, oracle):
     assert float(np.max(num / den)) < 5e-6
 
 
+def test_config5_shape_long_accumulation(pkg, oracle):
+    """BASELINE config 5 shape: Nt=128, Nr=16, shipped model.  Layer 0 accumulates K = 40 960
+    products per output; with 512 packets its grid fills the chip without split-K, i.e. the
+    LONGEST single fp32 accumulation chain the path can produce.  Sampled packets must still
+    meet the contract, the LS estimate (despread-first kernel) too."""
+    rng = np.random.default_rng(128)
+    nt, nr, npkt, hidden = 128, 16, 512, (1024, 1024)
+    w_re, w_im = _weights(oracle, 128, nt, hidden)
+    P = oracle.hadamard(nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
+    e.synth_white(11, 0, npkt, d_re, d_im)
+    d_ore, d_oim = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, d_ore, d_oim)
+    e.synchronize()
+    pick = [0, npkt - 1]
+    for p in pick:
+        ltf = d_re.download(p, 1) + 1j * d_im.download(p, 1)
+        r_re, r_im = oracle.predict_packets_shared(ltf, P, w_re, w_im)
+        assert rel_rows(d_ore.download(p, 1), r_re) < TOL and rel_rows(d_oim.download(p, 1), r_im) < TOL
+    ltf = d_re.download(3, 2) + 1j * d_im.download(3, 2)
+    h = e.ls_estimate(ltf)
+    ref = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+
+
 def test_full_size_properties_config3_bf16(pkg, oracle):
     """BASELINE config 3 shape (Nt=64, Nr=4, bf16) on 1000 device-generated packets = 256 000 pairs:
     run-to-run determinism and the bf16-emulation oracle on sampled packets."""

@@ -159,6 +159,19 @@ def test_predict_packets_layout(oracle):
     assert o_re.shape == (npkt, nr, nt, 234)
 
 
+def test_shared_layer0_oracle_equals_literal(oracle):
+    rng = np.random.default_rng(21)
+    nt, nr, npkt = 8, 2, 3
+    P = rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+    w_re = oracle.make_weights(rng, 320 * nt + nt, [24, 16, 20], 234)
+    w_im = oracle.make_weights(rng, 320 * nt + nt, [24], 234, use_bn=False)
+    ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+    a = oracle.predict_packets(ltf, P, w_re, w_im)
+    b = oracle.predict_packets_shared(ltf, P, w_re, w_im)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-11, atol=1e-11)
+
+
 def test_nmse(oracle):
     rng = np.random.default_rng(2)
     h = rng.standard_normal((2, 2, 4, 234)) + 1j * rng.standard_normal((2, 2, 4, 234))
