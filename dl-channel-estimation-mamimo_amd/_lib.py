@@ -56,6 +56,8 @@ SYMBOLS = {
     'csi_predict_samples': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, ctypes.c_int64, _fp]),
     'csi_ls_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, _fp]),
     'csi_ls_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'csi_lmmse_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, ctypes.c_int, _fp, _fp, _fp]),
+    'csi_lmmse_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'csi_synchronize': (ctypes.c_int, [_ctx]),
     'csi_set_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
     'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),

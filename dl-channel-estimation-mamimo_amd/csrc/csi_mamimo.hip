@@ -22,6 +22,7 @@
 #include "gemm_f32.hip.h"
 #include "gemm_bf16.hip.h"
 #include "ls_estimate.hip.h"
+#include "lmmse.hip.h"
 
 using namespace csi;
 
@@ -39,11 +40,12 @@ enum KernelId {
     K_PILOT_TABLE,
     K_CAST_BF16,         // fp32 -> bf16 of the preambles (bf16 mode)
     K_PAIR_H1_BF16,      // materialise h1 in bf16 (bf16 mode)
+    K_LMMSE,             // Levinson solve of the LMMSE smoother
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
-    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16"};
+    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson"};
 
 thread_local std::string g_create_error;
 
@@ -1012,6 +1014,71 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         } else
             hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), lds, c->stream, a, n_jc);
         HIP_TRY(c, hipGetLastError());
+    }
+    return CSI_OK;
+}
+
+int csi_lmmse_estimate_device(csi_ctx* c, const float* d_h_re, const float* d_h_im, int64_t npkt, const float* d_hvec, int L,
+                              const float* d_snr_db, float* d_out_re, float* d_out_im) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): no LMMSE estimate");
+    if (npkt < 0 || L < 1 || (npkt > 0 && (!d_h_re || !d_h_im || !d_hvec || !d_snr_db || !d_out_re || !d_out_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_lmmse_estimate_device: bad argument");
+    if (npkt == 0) return CSI_OK;
+    const csi_config& cf = c->cfg;
+    HIP_TRY(c, hipSetDevice(cf.device));
+    const int n_jc = (cf.nt + LM_RHS - 1) / LM_RHS;
+    const int64_t nblk = npkt * cf.nr;
+    const int64_t max_items = ((int64_t)1 << 30) / n_jc / cf.nr * cf.nr;      // whole packets per launch
+    for (int64_t b0 = 0; b0 < nblk; b0 += max_items) {
+        const int64_t nb = std::min(max_items, nblk - b0);
+        LmmseArgs a{};
+        a.h_re = d_h_re + (size_t)b0 * cf.nt * LM_N;
+        a.h_im = d_h_im + (size_t)b0 * cf.nt * LM_N;
+        a.hvec = d_hvec + (size_t)(b0 / cf.nr) * L;
+        a.snr_db = d_snr_db + b0;
+        a.o_re = d_out_re + (size_t)b0 * cf.nt * LM_N;
+        a.o_im = d_out_im + (size_t)b0 * cf.nt * LM_N;
+        a.nt = cf.nt; a.nr = cf.nr; a.L = L;
+        // per right-hand side: 2 * n^2 complex multiply-adds = 16 n^2 flop (fp64)
+        ProfScope ps(c, K_LMMSE, (double)nb * (cf.nt + n_jc) * 16.0 * LM_N * LM_N, (double)nb * cf.nt * LM_N * 16.0);
+        hipLaunchKernelGGL(lmmse_levinson_kernel, dim3((unsigned)(nb * n_jc)), dim3(LM_THREADS), 0, c->stream, a, n_jc);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return CSI_OK;
+}
+
+int csi_lmmse_estimate(csi_ctx* c, const float* h_re, const float* h_im, int64_t npkt, const float* hvec, int L,
+                       const float* snr_db, float* out_re, float* out_im) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (npkt < 0 || L < 1 || (npkt > 0 && (!h_re || !h_im || !hvec || !snr_db || !out_re || !out_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_lmmse_estimate: bad argument");
+    if (npkt == 0) return CSI_OK;
+    const csi_config& cf = c->cfg;
+    HIP_TRY(c, hipSetDevice(cf.device));
+    const size_t pkt_f = (size_t)cf.nr * cf.nt * LM_N;                     // floats per packet and plane
+    int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)(4 * pkt_f * sizeof(float)));
+    chunk = std::min(chunk, npkt);
+    const size_t need = (4 * pkt_f + (size_t)L + cf.nr) * sizeof(float) * (size_t)chunk;
+    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, need);
+    if (rc) return rc;
+    float* d_re = reinterpret_cast<float*>(c->stage);
+    float* d_im = d_re + pkt_f * chunk;
+    float* d_ore = d_im + pkt_f * chunk;
+    float* d_oim = d_ore + pkt_f * chunk;
+    float* d_hv = d_oim + pkt_f * chunk;
+    float* d_snr = d_hv + (size_t)L * chunk;
+    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
+        const int64_t np = std::min(chunk, npkt - p0);
+        HIP_TRY(c, hipMemcpyAsync(d_re, h_re + p0 * pkt_f, pkt_f * np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_im, h_im + p0 * pkt_f, pkt_f * np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_hv, hvec + p0 * L, (size_t)L * np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_snr, snr_db + p0 * cf.nr, (size_t)cf.nr * np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        rc = csi_lmmse_estimate_device(c, d_re, d_im, np, d_hv, L, d_snr, d_ore, d_oim);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(out_re + p0 * pkt_f, d_ore, pkt_f * np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out_im + p0 * pkt_f, d_oim, pkt_f * np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return CSI_OK;
 }

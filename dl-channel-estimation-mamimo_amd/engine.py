@@ -177,6 +177,22 @@ class CsiEngine:
         self._check(self._lib.csi_ls_estimate(self._ctx, _fp(re), _fp(im), npkt, _fp(h_re), _fp(h_im)))
         return h_re + 1j * h_im
 
+    def lmmse_estimate(self, h_ls, hvec, snr_db):
+        """LMMSE smoothing (LMMSE_ce.m) of an LS estimate.  h_ls complex [npkt,nr,nt,234]; hvec
+        [npkt, L] (the reference's 'h' argument); snr_db [npkt, nr].  Returns complex64."""
+        h_ls = np.asarray(h_ls)
+        re, im = _f32c(h_ls.real), _f32c(h_ls.imag)
+        npkt = re.shape[0]
+        if re.shape != (npkt, self.nr, self.nt, N_DATA):
+            raise CsiError(-1, f'h_ls must be [npkt,{self.nr},{self.nt},{N_DATA}], got {re.shape}')
+        hvec, snr_db = _f32c(hvec), _f32c(snr_db)
+        if hvec.ndim != 2 or hvec.shape[0] != npkt or snr_db.shape != (npkt, self.nr):
+            raise CsiError(-1, 'hvec must be [npkt, L] and snr_db [npkt, nr]')
+        o_re, o_im = np.empty_like(re), np.empty_like(re)
+        self._check(self._lib.csi_lmmse_estimate(self._ctx, _fp(re), _fp(im), npkt, _fp(hvec), hvec.shape[1], _fp(snr_db),
+                                                 _fp(o_re), _fp(o_im)))
+        return o_re + 1j * o_im
+
     def predict_samples(self, model, x):
         """Literal Model.predict of one component: x [B, len_ltf+nt] -> float32 [B, n_out]."""
         idx = {'real': 0, 'imag': 1}.get(model, model)

@@ -17,6 +17,7 @@
  *   ofdmdemod + helperMIMOChannelEstimate
  *        generate_maMIMO_LTF.m:336-342, helperMIMOChannelEstimate.m:24-36
  *                                                                   csi_ls_estimate[_device]
+ *   LMMSE_ce per link   helperMIMOChannelEstimate.m:37-39, LMMSE_ce.m  csi_lmmse_estimate[_device]
  *   --execTime profiler loop                       DNN.py:441-475   csi_profile_*
  *
  * Conventions: every function returns 0 on success or a negative csi_status; it never calls
@@ -112,6 +113,15 @@ int  csi_ls_estimate(csi_ctx* ctx, const float* ltf_re, const float* ltf_im, int
                      float* h_re, float* h_im);
 int  csi_ls_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
                             float* d_h_re, float* d_h_im);
+
+/* LMMSE smoothing of an LS estimate (the 'hDmmse' output of helperMIMOChannelEstimate.m:37-39,
+ * LMMSE_ce.m:23-39 with Nfft = Np = 234, Nps = 1).  h_re / h_im: LS estimate [npkt][nr][nt][234];
+ * hvec [npkt][L]: the vector the reference passes as LMMSE_ce's 'h' (generate_maMIMO_LTF.m:342
+ * hands it the scatterer delays h_tau); snr_db [npkt][nr]: SNR(i) in dB; out like h. */
+int  csi_lmmse_estimate(csi_ctx* ctx, const float* h_re, const float* h_im, int64_t npkt, const float* hvec, int L,
+                        const float* snr_db, float* out_re, float* out_im);
+int  csi_lmmse_estimate_device(csi_ctx* ctx, const float* d_h_re, const float* d_h_im, int64_t npkt, const float* d_hvec,
+                               int L, const float* d_snr_db, float* d_out_re, float* d_out_im);
 
 int  csi_synchronize(csi_ctx* ctx);
 

@@ -322,6 +322,48 @@ def postprocess_rice_renew(output_batch):
 
 
 # ---------------------------------------------------------------------------
+# SURVEY 8f-3  LMMSE smoothing of an LS estimate  (LMMSE_ce.m:23-39, called per link from
+#              helperMIMOChannelEstimate.m:37-39 with Nfft = Np = 234, Nps = 1)
+# ---------------------------------------------------------------------------
+def lmmse_ce(h_tilde, nfft, np_, nps, h, snr_db):
+    """Literal restatement of LMMSE_ce.m.  h_tilde complex [Np] (one link's LS estimate), h the
+    vector the reference passes as 'channel impulse response' (generate_maMIMO_LTF.m:342 hands it
+    the scatterer delays h_tau), snr_db scalar.  Returns complex [Nfft]."""
+    h = np.asarray(h, dtype=np.complex128).reshape(-1)
+    snr = 10.0 ** (snr_db * 0.1)                                       # :23
+    k = np.arange(h.size)                                              # :27
+    hh = np.vdot(h, h)                                                 # h*h'
+    tmp = h * np.conj(h) * k                                           # :28
+    r = np.sum(tmp) / hh
+    r2 = (tmp @ k) / hh                                                # :29
+    tau_rms = np.sqrt(r2 - r ** 2)                                     # :30
+    df = 1.0 / nfft                                                    # :31
+    j2pi_tau_df = 1j * 2 * np.pi * tau_rms * df                        # :32
+    K1 = np.arange(nfft)[:, None]
+    K2 = np.arange(np_)[None, :]
+    rf = 1.0 / (1.0 + j2pi_tau_df * (K1 - K2 * nps))                   # :33-34
+    K3 = np.arange(np_)[:, None]
+    K4 = np.arange(np_)[None, :]
+    rf2 = 1.0 / (1.0 + j2pi_tau_df * nps * (K3 - K4))                  # :35-36
+    rpp = rf2 + np.eye(np_) / snr                                      # :38
+    return rf @ np.linalg.inv(rpp) @ np.asarray(h_tilde, dtype=np.complex128)   # :39
+
+
+def lmmse_estimate(h_ls, h, snr_db):
+    """helperMIMOChannelEstimate.m:33-39 with isMMSE: every link (tx j, rx i) of every packet is
+    smoothed on its own.  h_ls complex [npkt, nr, nt, 234]; h [npkt, L]; snr_db [npkt, nr]
+    (SNR(i) per rx antenna).  Returns complex128 [npkt, nr, nt, 234]."""
+    h_ls = np.asarray(h_ls)
+    npkt, nr, nt, n = h_ls.shape
+    out = np.empty(h_ls.shape, dtype=np.complex128)
+    for p in range(npkt):
+        for i in range(nr):
+            for j in range(nt):
+                out[p, i, j] = lmmse_ce(h_ls[p, i, j], n, n, 1, h[p], snr_db[p, i])
+    return out
+
+
+# ---------------------------------------------------------------------------
 # a-12  per-link NMSE  (BER_test_maMIMO_LTF.m:675-686)
 # ---------------------------------------------------------------------------
 def nmse_subk(h_ref, h_est):

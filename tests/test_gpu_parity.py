@@ -99,6 +99,27 @@ def test_ls_both_kernels_agree(pkg, oracle, monkeypatch, thr):
         assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([H.real, H.imag], -1)) < TOL
 
 
+@pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 2), (32, 2, 1), (40, 1, 1)])
+def test_lmmse_matches_reference_formula(pkg, oracle, nt, nr, npkt):
+    """LMMSE smoothing (LMMSE_ce.m, one 234x234 inverse per link in the reference; one Levinson solve
+    per (packet, rx) here) against the literal restatement of the reference formula in fp64."""
+    rng = np.random.default_rng(900 + nt)
+    P = oracle.hadamard(nt) if nt & (nt - 1) == 0 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+    ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    e.set_pilot(P)
+    h_ls = e.ls_estimate(ltf)
+    hvec = np.sort(np.abs(rng.standard_normal((npkt, 100)))).astype(np.float32) * 1e-7     # like the delays h_tau
+    snr_db = rng.choice([-10.0, 0.0, 10.0, 25.0], size=(npkt, nr)).astype(np.float32)
+    got = e.lmmse_estimate(h_ls, hvec, snr_db)
+    assert got.shape == h_ls.shape and got.dtype == np.complex64
+    ref = oracle.lmmse_estimate(h_ls, hvec.astype(np.float64), snr_db.astype(np.float64))
+    assert rel_rows(np.concatenate([got.real, got.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    # smoothing must actually change the estimate, and shrink it
+    assert np.linalg.norm(got - h_ls) > 1e-2 * np.linalg.norm(h_ls)
+    assert np.linalg.norm(got) < np.linalg.norm(h_ls)
+
+
 def test_ls_empty_batch(pkg):
     e = pkg.CsiEngine(4, 2, hidden=(8,))
     e.set_pilot(np.eye(4))
