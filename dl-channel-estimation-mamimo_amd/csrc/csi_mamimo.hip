@@ -414,33 +414,27 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     int maxh = 0;
     for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
     // Packet chunks: as few as the workspace allows, all of (nearly) the same size so that every
-    // chunk fills the machine equally well.  Per packet: layer-0 slabs + their sum, and the
-    // ping-pong buffers of the hidden activations.
-    const int smax = 40;                                  // upper bound of choose_splits
+    // chunk fills the machine equally well.  Per packet: layer-0 slabs (+ their sum when split-K
+    // is on - the factor depends on the chunk size, hence the loop) and the ping-pong buffers of
+    // the hidden activations.
     const size_t hid_pkt = (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);   // 1.5 GiB
-    int64_t chunk = npkt;
+    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);   // 1.5 GiB
+    const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
+    int64_t nchunks = 1, chunk = npkt;
     int splits_max = 1;
-    for (int iter = 0; iter < 64; ++iter) {
+    for (;;) {
+        chunk = (npkt + nchunks - 1) / nchunks;
         int kps_tmp;
         splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
-        const size_t per_pkt_try = (size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt;
-        const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / per_pkt_try));
-        const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
-        const int64_t cap = std::min(fit, max_rows);
-        if (chunk <= cap) break;
-        const int64_t nchunks = (npkt + cap - 1) / cap;
-        const int64_t balanced = (npkt + nchunks - 1) / nchunks;
-        if (balanced == chunk) break;
-        chunk = balanced;
+        const size_t need = ((size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt) * (size_t)chunk;
+        if ((need <= budget && chunk <= max_rows) || chunk == 1) break;
+        nchunks = std::max(nchunks + 1, (int64_t)((double)nchunks * (double)need / (double)budget));
     }
-    (void)smax;
-    // the tail chunk may want a different split factor; size the slabs for the larger of the two
-    {
+    {   // the last chunk can be shorter and may want a different split factor
         int kps_tmp;
-        splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
-        const int64_t tail = npkt % chunk;
-        if (tail) splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
+        const int64_t tail = npkt - (nchunks - 1) * chunk;
+        if (tail > 0 && tail != chunk)
+            splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
     }
     const size_t slab_floats = (size_t)chunk * nr * h1;
     const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk;
