@@ -421,6 +421,46 @@ def test_dataset_label_self_consistency(pkg, oracle):
     assert pkg.dataset.label_consistency(e, packed) > 1e-2
 
 
+def test_cli_test_run_end_to_end(pkg, oracle, tmp_path, capsys):
+    """The command-line twin of `DNN.py --test`: pickle dataset + saved models in, evaluate() figure
+    and per-packet .mat files out."""
+    import pickle
+    from scipy.io import loadmat
+    rng = np.random.default_rng(77)
+    nt, nr, npkt, hidden = 8, 2, 3, (64, 32)
+    P_rows = _pilot(rng, nt)
+    ltf, _ = oracle.make_structured_packets(rng, npkt, nr, P_rows, snr_db=3.0)
+    y = oracle.ls_estimate(ltf, P_rows).reshape(npkt * nr * nt, 234)
+    X = np.zeros((npkt * nr * nt, 2), dtype=int)
+    LTF = {}
+    for p in range(npkt):
+        for r in range(nr):
+            key = 500 + p * nr + r
+            LTF[key] = {'real': ltf[p, r].real.copy(), 'imag': ltf[p, r].imag.copy()}
+            for t in range(nt):
+                X[p * nr * nt + r * nt + t] = [key, t]
+    ds = {'X': X, 'y': {'real': y.real.copy(), 'imag': y.imag.copy()}, 'LTF': LTF, 'P': P_rows.T.copy(),
+          'simParams': {'nTX': nt, 'nRX': nr}}
+    with open(tmp_path / 'test.b', 'wb') as f:
+        pickle.dump(ds, f)
+    w_re, w_im = _weights(oracle, 3, nt, hidden)
+    model_dir, work = tmp_path / 'model', tmp_path / 'out'
+    model_dir.mkdir(); work.mkdir()
+    pkg.save_weight_file(str(model_dir / 'real_weights-improvement.safetensors'), w_re)
+    pkg.save_weight_file(str(model_dir / 'imag_weights-improvement.safetensors'), w_im)
+    from dl_channel_estimation_mamimo_amd import cli
+    rc = cli.main(['--test', '-x', str(tmp_path / 'test.b'), '--modeldir', str(model_dir), '-d', str(work), '--nn', '64', '32',
+                   '--useBN', '--datasource', 'matlab_maMimo', '--execTime'])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert 'loss (mse vs labels)' in out and 'LS(GPU) vs stored LS labels' in out and 'pair_dense_gemm' in out
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P_rows, w_re, w_im, np.float64, pkt_batch=npkt)
+    for n in range(npkt):
+        m = loadmat(str(work / f'test_csi_predictions_imag_{n + 1}.mat'))['all_pkts_csi_nn_out'][0, 0]
+        assert rel_rows(m['y'], r_im[n].reshape(nr * nt, 234)) < TOL
+        np.testing.assert_array_equal(m['true_y'], y.imag.reshape(npkt, nr * nt, 234)[n])
+
+
 # ------------------------------------------------------------------------------------ device path
 def test_device_resident_path_and_profile(pkg, oracle):
     rng = np.random.default_rng(41)
