@@ -107,6 +107,7 @@ struct csi_ctx {
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
+    int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
     bool use_graph = false;
     std::vector<GraphEntry> graphs;
     int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
@@ -289,6 +290,7 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
             const int real = (g.K + r.k_per_split - 1) / r.k_per_split;
             {
                 ProfScope ps(c, kid, 2.0 * (double)g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * real));
+                r.tiles_m = 0;           // few tiles: linear order
                 hipLaunchKernelGGL((gemm_f32_kernel<EPI_RAW>), dim3((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)real), dim3(G_THREADS), 0, c->stream, r);
                 HIP_TRY(c, hipGetLastError());
             }
@@ -302,13 +304,15 @@ int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
     // 256-row tiles (fewer LDS-DMA instructions per MFMA) once they fill the 512 resident slots
     const int tiles_m256 = (g.M + G2_BM - 1) / G2_BM;
     const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n * splits >= 512);
-    if (big) {
-        dim3 grid((unsigned)(tiles_m256 * g.tiles_n), 1, (unsigned)splits);
-        hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
-    } else {
-        dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)splits);
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
-    }
+    const int tm_used = big ? tiles_m256 : tiles_m;
+    // measured: traffic -50..60 %, time neutral for 8 column tiles and for the 256-row kernel,
+    // -10 % for the 128-row kernel with 2 column tiles (not used there)
+    const bool xcd_order = c->xcd_order >= 0 ? c->xcd_order != 0
+                                             : (g.tiles_n >= 8 || big) && tile_map_pays(tm_used, g.tiles_n, splits);
+    g.tiles_m = xcd_order ? tm_used : 0;
+    const dim3 grid(xcd_order ? tile_map_grid(tm_used, g.tiles_n) : (unsigned)(tm_used * g.tiles_n), 1, (unsigned)splits);
+    if (big) hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -1088,6 +1092,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value != 0 && value != 128 && value != 256) return fail(c, CSI_ERR_INVALID_ARG, "force_tile must be 0, 128 or 256");
         drop_graphs(c);
         c->force_pair_tile = (int)value;
+    } else if (n == "xcd_order") {
+        if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "xcd_order must be -1 (auto), 0 or 1");
+        drop_graphs(c);
+        c->xcd_order = (int)value;
     } else if (n == "ls_fft_first_max") {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;

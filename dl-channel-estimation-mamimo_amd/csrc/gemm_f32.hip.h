@@ -66,6 +66,7 @@ struct GemmArgs {
     int lda, ldb, ldc;
     int k_per_split;       // multiple of G_BK
     int tiles_n;
+    int tiles_m;           // plain kernels: row tiles; > 0 selects the XCD super-tile order, 0 the linear one
     // pair kernel only
     const float* T;        // [nt][lda] pilot table, includes the layer-0 bias
     const float* s0;       // [K] layer-0 BN scale   (1 when the model has no BN)
@@ -76,6 +77,52 @@ struct GemmArgs {
     const float* scale;    // [N]
     const float* shift;    // [N]
 };
+
+// XCD-aware tile order of the plain GEMMs.  Workgroup b runs on XCD b % 8 (observed dispatch
+// order; used for speed only).  Each XCD works through 'super-tiles' of 64 output tiles - exactly
+// its 32 CUs x 2 resident workgroups - shaped SR row tiles x SC column tiles (SC = min(tiles_n, 8)):
+// the 64 workgroups march through K together, so every A k-slice is fetched into that XCD's L2
+// once for SC column tiles and every W k-slice once for SR row tiles (layer 0: 2.8 -> ~0.5 GB of
+// fabric traffic per launch).  Ragged edges map to tiles outside the matrix; those workgroups exit.
+struct TileMap {
+    int sc, sr, ncg, nsuper;
+};
+__host__ __device__ __forceinline__ TileMap make_tile_map(int tiles_m, int tiles_n) {
+    TileMap t;
+    t.sc = tiles_n >= 8 ? 8 : (tiles_n >= 4 ? 4 : (tiles_n >= 2 ? 2 : 1));
+    t.sr = 64 / t.sc;
+    t.ncg = (tiles_n + t.sc - 1) / t.sc;
+    t.nsuper = ((tiles_m + t.sr - 1) / t.sr) * t.ncg;
+    return t;
+}
+// The super-tile order is used only where it balances the 8 XCDs at least as well as the linear
+// order fills the 512 workgroup slots (few super-tiles would leave whole XCDs idle).
+__host__ __forceinline__ bool tile_map_pays(int tiles_m, int tiles_n, int splits) {
+    const TileMap t = make_tile_map(tiles_m, tiles_n);
+    const double tiles = (double)tiles_m * tiles_n;
+    const double eff_super = (tiles / 512.0) / (double)((t.nsuper + 7) / 8);        // every split repeats the order
+    const long blocks = (long)tiles_m * tiles_n * splits;
+    const double eff_linear = ((double)blocks / 512.0) / (double)((blocks + 511) / 512);
+    return eff_super >= eff_linear - 0.01;
+}
+__host__ __forceinline__ unsigned tile_map_grid(int tiles_m, int tiles_n) {
+    const TileMap t = make_tile_map(tiles_m, tiles_n);
+    return (unsigned)(8 * 64 * ((t.nsuper + 7) / 8));
+}
+__device__ __forceinline__ bool tile_map(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if (tiles_m <= 0) {                      // linear order, column tile fastest
+        tn = b % tiles_n;
+        tm = b / tiles_n;
+        return true;
+    }
+    const TileMap t = make_tile_map(tiles_m, tiles_n);
+    const int xcd = b & 7, idx = b >> 3;
+    const int S = (idx >> 6) * 8 + xcd, w = idx & 63;
+    const int rg = S / t.ncg, cg = S - rg * t.ncg;
+    tm = rg * t.sr + w / t.sc;
+    tn = cg * t.sc + w % t.sc;
+    return tm < tiles_m && tn < tiles_n;
+}
 
 // 16 bytes per lane, HBM/L2 -> LDS, destination = wave-uniform base + lane*16
 __device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
@@ -188,8 +235,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_f32_kernel(const GemmArgs g
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int tile = blockIdx.x;
-    const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+    int tm, tn;
+    if (!tile_map(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn)) return;      // block-uniform
     const int m0 = tm * G_BM, n0 = tn * G_BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -274,8 +321,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm256_f32_kernel(const GemmArg
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int tile = blockIdx.x;
-    const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+    int tm, tn;
+    if (!tile_map(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn)) return;      // block-uniform
     const int m0 = tm * G2_BM, n0 = tn * G_BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);

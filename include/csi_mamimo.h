@@ -130,6 +130,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         with the same pointers and packet count (the reference's per-packet loop,
  *                         DNN.py:346, repeats one launch sequence); 0 (default): eager launches
  *   "force_tile"       128 | 256: row-tile height of every GEMM (0 = chosen by grid size)
+ *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
+ *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 32, max 64) */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
 

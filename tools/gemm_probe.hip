@@ -24,7 +24,9 @@ static float* dalloc(size_t n, bool rnd, float scale = 1.f) {
 template <int EPI>
 double run(const char* name, GemmArgs g, int splits, int iters, std::vector<float>* out = nullptr) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    dim3 grid(((g.M + G_BM - 1) / G_BM) * g.tiles_n, 1, splits);
+    const int tmm = (g.M + G_BM - 1) / G_BM;
+    g.tiles_m = ((g.tiles_n >= 8) && tile_map_pays(tmm, g.tiles_n, splits)) ? tmm : 0;
+    dim3 grid(g.tiles_m ? tile_map_grid(tmm, g.tiles_n) : tmm * g.tiles_n, 1, splits);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
     CK(hipDeviceSynchronize());
@@ -46,7 +48,9 @@ double run(const char* name, GemmArgs g, int splits, int iters, std::vector<floa
 template <int EPI>
 double run256(const char* name, GemmArgs g, int splits, int iters) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    dim3 grid(((g.M + G2_BM - 1) / G2_BM) * g.tiles_n, 1, splits);
+    const int tmm = (g.M + G2_BM - 1) / G2_BM;
+    g.tiles_m = tile_map_pays(tmm, g.tiles_n, splits) ? tmm : 0;
+    dim3 grid(g.tiles_m ? tile_map_grid(tmm, g.tiles_n) : tmm * g.tiles_n, 1, splits);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(256), 0, 0, g);
     CK(hipDeviceSynchronize());
