@@ -1,0 +1,245 @@
+// csi_context.hpp - the csi_ctx object behind include/csi_mamimo.h and the host-side plumbing every
+// entry point shares: error reporting, per-kernel HIP-event profiling, device buffers, weight storage.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/csi_mamimo.h"
+#include "gemm_f32.hip.h"
+#include "gemm_bf16.hip.h"
+#include "ls_estimate.hip.h"
+#include "lmmse.hip.h"
+
+using namespace csi;
+
+namespace {
+
+enum KernelId {
+    K_LAYER0_LTF = 0,    // layer 0, LTF part, once per (packet, rx)
+    K_SPLITK_REDUCE,     // deterministic split-K combine of layer 0
+    K_PAIR_DENSE,        // first per-pair layer, h1 generated in the prologue  (dominant)
+    K_DENSE_HIDDEN,      // further hidden layers
+    K_REGRESSOR,         // fc_regressor
+    K_LS_ESTIMATE,       // FFT + despread
+    K_NAIVE_DENSE0,      // un-shared layer 0 of csi_predict_samples
+    K_SYNTH_WHITE,
+    K_PILOT_TABLE,
+    K_CAST_BF16,         // fp32 -> bf16 of the preambles (bf16 mode)
+    K_PAIR_H1_BF16,      // materialise h1 in bf16 (bf16 mode)
+    K_LMMSE,             // Levinson solve of the LMMSE smoother
+    K_COUNT
+};
+const char* const kKernelNames[K_COUNT] = {
+    "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
+    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson"};
+
+thread_local std::string g_create_error;
+
+struct Layer {
+    float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)   fp32 mode
+    int ldw = 0;
+    bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
+    int ldwb = 0;
+    float* bias = nullptr;    // [out]
+    float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
+    float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
+    int in = 0, out = 0;
+};
+
+struct Model {
+    std::vector<Layer> layers;   // n_hidden dense layers + regressor (last)
+    float* W0p = nullptr;        // [nt][H1] pilot rows of fc_dense0.kernel, row-major
+    float* W0rm = nullptr;       // [lenLTF][H1] LTF rows of fc_dense0.kernel as stored (skinny layer-0 kernel)
+    float* T = nullptr;          // [nt][H1] pilot table incl. bias
+    bool loaded = false;
+    bool table_ok = false;
+};
+
+struct GraphEntry {           // one captured csi_predict_device call
+    const void* in_re; const void* in_im; void* out_re; void* out_im;
+    int64_t npkt;
+    int seen;                 // eager runs with this key so far (capture happens on the 2nd call)
+    hipGraphExec_t exec;
+};
+
+struct ProfSpan {
+    int id;
+    hipEvent_t beg, end;
+};
+
+}  // namespace
+
+struct csi_ctx {
+    csi_config cfg;
+    int d_in = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Model model[2];
+    float* P = nullptr;          // device [nt][nt]
+    bool pilot_ok = false;
+    // LS constants
+    float* tw = nullptr;         // [2][256]
+    int* bin_pos = nullptr;      // [234]
+    float* denom = nullptr;      // [234]
+    // activation workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // layer-0 slabs + sum of the one-packet (skinny) path
+    char* l0skinny = nullptr;
+    size_t l0skinny_bytes = 0;
+    // split-K slabs of the small-batch path
+    char* skbuf = nullptr;
+    size_t skbuf_bytes = 0;
+    // staging for host-buffer entry points
+    char* stage = nullptr;
+    size_t stage_bytes = 0;
+    int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
+    bool use_graph = false;
+    std::vector<GraphEntry> graphs;
+    int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
+    int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[K_COUNT] = {0};
+    int64_t prof_launches[K_COUNT] = {0};
+    double prof_flops[K_COUNT] = {0};
+    double prof_bytes[K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(csi_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, CSI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+struct ProfScope {
+    csi_ctx* c;
+    bool on;
+    ProfSpan sp;
+    ProfScope(csi_ctx* ctx, int id, double flops, double bytes) : c(ctx), on(ctx->prof_on) {
+        if (!on) return;
+        sp.id = id;
+        sp.beg = take();
+        sp.end = take();
+        c->prof_launches[id] += 1;
+        c->prof_flops[id] += flops;
+        c->prof_bytes[id] += bytes;
+        hipEventRecord(sp.beg, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(sp.end, c->stream);
+        c->spans.push_back(sp);
+    }
+    hipEvent_t take() {
+        if (!c->ev_pool.empty()) {
+            hipEvent_t e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+};
+
+int prof_collect(csi_ctx* c) {
+    if (c->spans.empty()) return CSI_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.beg, sp.end) == hipSuccess) c->prof_ms[sp.id] += ms;
+        c->ev_pool.push_back(sp.beg);
+        c->ev_pool.push_back(sp.end);
+    }
+    c->spans.clear();
+    return CSI_OK;
+}
+
+void drop_graphs(csi_ctx* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
+int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {
+    if (*have >= need) return CSI_OK;
+    drop_graphs(c);           // captured launches point into the old buffer
+    if (*buf) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    const size_t bytes = need + G_SLACK_FLOATS * sizeof(float);
+    if (hipMalloc((void**)buf, bytes) != hipSuccess) {
+        *buf = nullptr;
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+    }
+    HIP_TRY(c, hipMemsetAsync(*buf, 0, bytes, c->stream));     // never-written parts must be finite
+    *have = need;
+    return CSI_OK;
+}
+
+// Every device array a GEMM may read as its A side (or as a per-column vector) is followed by
+// G_SLACK_FLOATS zeroed floats: the K tail of the last tile over-reads into finite memory.
+int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    const size_t bytes = (n + G_SLACK_FLOATS) * sizeof(float);
+    if (hipMalloc((void**)dst, bytes) != hipSuccess)
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+    HIP_TRY(c, hipMemset(*dst, 0, bytes));
+    HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return CSI_OK;
+}
+
+void free_layer(Layer& l) {
+    if (l.Wt) hipFree(l.Wt);
+    if (l.Wb) hipFree(l.Wb);
+    if (l.bias) hipFree(l.bias);
+    if (l.scale) hipFree(l.scale);
+    if (l.shift) hipFree(l.shift);
+    l = Layer();
+}
+
+void free_model(Model& m) {
+    for (auto& l : m.layers) free_layer(l);
+    m.layers.clear();
+    if (m.W0p) hipFree(m.W0p);
+    if (m.W0rm) hipFree(m.W0rm);
+    m.W0rm = nullptr;
+    if (m.T) hipFree(m.T);
+    m.W0p = m.T = nullptr;
+    m.loaded = m.table_ok = false;
+}
+
+const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& name) {
+    for (int i = 0; i < n; ++i)
+        if (t[i].name && name == t[i].name) return &t[i];
+    return nullptr;
+}
+
+}  // namespace

@@ -1,0 +1,117 @@
+// csi_dnn_bf16.hpp - host orchestration of the bf16-operand DNN path (BASELINE config 3).
+#pragma once
+#include "csi_context.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- bf16 mode
+template <int EPI, bool OUT_BF16>
+int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
+    if (g.M <= 0) return CSI_OK;
+    if ((g.lda & 7) || (g.ldb % B_BK))
+        return fail(c, CSI_ERR_INVALID_ARG, "bf16 gemm: lda must be a multiple of 8 and ldb of 64 (lda=%d ldb=%d)", g.lda, g.ldb);
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (OUT_BF16 ? 2.0 : 4.0) * (double)g.M * g.N * splits;
+    ProfScope ps(c, kid, flops, bytes);
+    // 256x256 tiles (8 waves) once they fill the 256 CUs, 128x128 tiles (4 waves, 2 per CU) below
+    const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splits;
+    if (big_tiles >= 256) {
+        g.tiles_n = (g.N + 255) / 256;
+        dim3 grid((unsigned)(((g.M + 255) / 256) * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 4, 4, 2, 2>), grid, dim3(512), 0, c->stream, g);
+    } else {
+        g.tiles_n = (g.N + 127) / 128;
+        dim3 grid((unsigned)(((g.M + 127) / 128) * g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, c->stream, g);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
+    ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * n);
+    const size_t n8 = n / 8;
+    const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 8192);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, src, dst, n8);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// hidden layers 1.. and the regressor on a bf16 activation matrix hin [M][l.in]; writes d_out fp32
+int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_t* hb1, float* d_out, int first_layer) {
+    const csi_config& cf = c->cfg;
+    bf16_t* hb[2] = {hb0, hb1};
+    const bf16_t* cur = hin;
+    int w = 0;
+    for (int li = first_layer; li <= cf.n_hidden; ++li) {
+        const Layer& l = m.layers[li];
+        GemmBf16Args q{};
+        q.A = cur; q.lda = l.in;
+        q.Bt = l.Wb; q.ldb = l.ldwb;
+        q.M = M; q.N = l.out; q.K = l.in;
+        q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+        q.k_per_split = l.ldwb;
+        int rc;
+        if (li == cf.n_hidden) {
+            q.C = d_out; q.ldc = cf.n_out;
+            rc = launch_gemm_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, 1);
+        } else {
+            q.C = hb[w]; q.ldc = l.out;
+            rc = launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN, q, 1);
+            cur = hb[w];
+            w ^= 1;
+        }
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
+int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float* d_out) {
+    const csi_config& cf = c->cfg;
+    const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
+    int maxh = 0;
+    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    // per packet: bf16 preamble copy, fp32 layer-0 product, bf16 h1, bf16 ping-pong hidden buffers
+    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 + (size_t)nr * nt * h1 * 2 +
+                           (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
+    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);
+    int64_t cap = std::max<int64_t>(1, (int64_t)(budget / per_pkt));
+    cap = std::min(cap, (int64_t)0x7fffffff / ((int64_t)nr * nt * 2));
+    const int64_t nchunks = (npkt + cap - 1) / cap;
+    const int64_t chunk = (npkt + nchunks - 1) / nchunks;
+    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_pkt * (size_t)chunk + 1024);
+    if (rc) return rc;
+    char* base = c->ws;
+    bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
+    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4;
+    bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
+    bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
+    bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
+    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
+        const int64_t np = std::min(chunk, npkt - p0);
+        const int M1 = (int)(np * nr), M2 = (int)(np * nr * nt);
+        rc = cast_bf16(c, d_ltf + (size_t)p0 * nr * cf.len_ltf, xb, (size_t)M1 * cf.len_ltf);
+        if (rc) return rc;
+        GemmBf16Args g{};
+        g.A = xb; g.lda = cf.len_ltf;
+        g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
+        g.C = l0; g.ldc = h1;
+        g.M = M1; g.N = h1; g.K = cf.len_ltf;
+        g.k_per_split = cf.len_ltf;
+        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, 1);
+        if (rc) return rc;
+        {
+            ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
+            const size_t total = (size_t)M2 * (h1 / 8);
+            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
+            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, l0, 1, (size_t)0, m.T,
+                               m.layers[0].scale, m.layers[0].shift, h1b, M2, nt, h1);
+            HIP_TRY(c, hipGetLastError());
+        }
+        rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
+}  // namespace

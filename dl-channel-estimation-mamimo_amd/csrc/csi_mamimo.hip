@@ -8,652 +8,11 @@
 //                       hidden 1.. and regressor       -> pair_gemm_f32_kernel / gemm_f32_kernel
 //   csi_predict_samples literal un-shared network      -> gemm_f32_kernel
 //   csi_ls_estimate*    FFT + despread                 -> ls_estimate_kernel
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/csi_mamimo.h"
-#include "gemm_f32.hip.h"
-#include "gemm_bf16.hip.h"
-#include "ls_estimate.hip.h"
-#include "lmmse.hip.h"
-
-using namespace csi;
+#include "csi_context.hpp"
+#include "csi_dnn_f32.hpp"
+#include "csi_dnn_bf16.hpp"
 
 namespace {
-
-enum KernelId {
-    K_LAYER0_LTF = 0,    // layer 0, LTF part, once per (packet, rx)
-    K_SPLITK_REDUCE,     // deterministic split-K combine of layer 0
-    K_PAIR_DENSE,        // first per-pair layer, h1 generated in the prologue  (dominant)
-    K_DENSE_HIDDEN,      // further hidden layers
-    K_REGRESSOR,         // fc_regressor
-    K_LS_ESTIMATE,       // FFT + despread
-    K_NAIVE_DENSE0,      // un-shared layer 0 of csi_predict_samples
-    K_SYNTH_WHITE,
-    K_PILOT_TABLE,
-    K_CAST_BF16,         // fp32 -> bf16 of the preambles (bf16 mode)
-    K_PAIR_H1_BF16,      // materialise h1 in bf16 (bf16 mode)
-    K_LMMSE,             // Levinson solve of the LMMSE smoother
-    K_COUNT
-};
-const char* const kKernelNames[K_COUNT] = {
-    "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
-    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson"};
-
-thread_local std::string g_create_error;
-
-struct Layer {
-    float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)   fp32 mode
-    int ldw = 0;
-    bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
-    int ldwb = 0;
-    float* bias = nullptr;    // [out]
-    float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
-    float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
-    int in = 0, out = 0;
-};
-
-struct Model {
-    std::vector<Layer> layers;   // n_hidden dense layers + regressor (last)
-    float* W0p = nullptr;        // [nt][H1] pilot rows of fc_dense0.kernel, row-major
-    float* W0rm = nullptr;       // [lenLTF][H1] LTF rows of fc_dense0.kernel as stored (skinny layer-0 kernel)
-    float* T = nullptr;          // [nt][H1] pilot table incl. bias
-    bool loaded = false;
-    bool table_ok = false;
-};
-
-struct GraphEntry {           // one captured csi_predict_device call
-    const void* in_re; const void* in_im; void* out_re; void* out_im;
-    int64_t npkt;
-    int seen;                 // eager runs with this key so far (capture happens on the 2nd call)
-    hipGraphExec_t exec;
-};
-
-struct ProfSpan {
-    int id;
-    hipEvent_t beg, end;
-};
-
-}  // namespace
-
-struct csi_ctx {
-    csi_config cfg;
-    int d_in = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    Model model[2];
-    float* P = nullptr;          // device [nt][nt]
-    bool pilot_ok = false;
-    // LS constants
-    float* tw = nullptr;         // [2][256]
-    int* bin_pos = nullptr;      // [234]
-    float* denom = nullptr;      // [234]
-    // activation workspace
-    char* ws = nullptr;
-    size_t ws_bytes = 0;
-    // layer-0 slabs + sum of the one-packet (skinny) path
-    char* l0skinny = nullptr;
-    size_t l0skinny_bytes = 0;
-    // split-K slabs of the small-batch path
-    char* skbuf = nullptr;
-    size_t skbuf_bytes = 0;
-    // staging for host-buffer entry points
-    char* stage = nullptr;
-    size_t stage_bytes = 0;
-    int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
-    bool use_graph = false;
-    std::vector<GraphEntry> graphs;
-    int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
-    int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
-    // profiling
-    bool prof_on = false;
-    std::vector<ProfSpan> spans;
-    std::vector<hipEvent_t> ev_pool;
-    double prof_ms[K_COUNT] = {0};
-    int64_t prof_launches[K_COUNT] = {0};
-    double prof_flops[K_COUNT] = {0};
-    double prof_bytes[K_COUNT] = {0};
-};
-
-namespace {
-
-int fail(csi_ctx* ctx, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                      \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(ctx, CSI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                    \
-    } while (0)
-
-struct ProfScope {
-    csi_ctx* c;
-    bool on;
-    ProfSpan sp;
-    ProfScope(csi_ctx* ctx, int id, double flops, double bytes) : c(ctx), on(ctx->prof_on) {
-        if (!on) return;
-        sp.id = id;
-        sp.beg = take();
-        sp.end = take();
-        c->prof_launches[id] += 1;
-        c->prof_flops[id] += flops;
-        c->prof_bytes[id] += bytes;
-        hipEventRecord(sp.beg, c->stream);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        hipEventRecord(sp.end, c->stream);
-        c->spans.push_back(sp);
-    }
-    hipEvent_t take() {
-        if (!c->ev_pool.empty()) {
-            hipEvent_t e = c->ev_pool.back();
-            c->ev_pool.pop_back();
-            return e;
-        }
-        hipEvent_t e;
-        hipEventCreate(&e);
-        return e;
-    }
-};
-
-int prof_collect(csi_ctx* c) {
-    if (c->spans.empty()) return CSI_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (auto& sp : c->spans) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, sp.beg, sp.end) == hipSuccess) c->prof_ms[sp.id] += ms;
-        c->ev_pool.push_back(sp.beg);
-        c->ev_pool.push_back(sp.end);
-    }
-    c->spans.clear();
-    return CSI_OK;
-}
-
-void drop_graphs(csi_ctx* c) {
-    for (auto& g : c->graphs)
-        if (g.exec) hipGraphExecDestroy(g.exec);
-    c->graphs.clear();
-}
-
-int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {
-    if (*have >= need) return CSI_OK;
-    drop_graphs(c);           // captured launches point into the old buffer
-    if (*buf) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipFree(*buf));
-        *buf = nullptr;
-        *have = 0;
-    }
-    const size_t bytes = need + G_SLACK_FLOATS * sizeof(float);
-    if (hipMalloc((void**)buf, bytes) != hipSuccess) {
-        *buf = nullptr;
-        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
-    }
-    HIP_TRY(c, hipMemsetAsync(*buf, 0, bytes, c->stream));     // never-written parts must be finite
-    *have = need;
-    return CSI_OK;
-}
-
-// Every device array a GEMM may read as its A side (or as a per-column vector) is followed by
-// G_SLACK_FLOATS zeroed floats: the K tail of the last tile over-reads into finite memory.
-int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
-    if (*dst) { hipFree(*dst); *dst = nullptr; }
-    const size_t bytes = (n + G_SLACK_FLOATS) * sizeof(float);
-    if (hipMalloc((void**)dst, bytes) != hipSuccess)
-        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
-    HIP_TRY(c, hipMemset(*dst, 0, bytes));
-    HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
-    return CSI_OK;
-}
-
-void free_layer(Layer& l) {
-    if (l.Wt) hipFree(l.Wt);
-    if (l.Wb) hipFree(l.Wb);
-    if (l.bias) hipFree(l.bias);
-    if (l.scale) hipFree(l.scale);
-    if (l.shift) hipFree(l.shift);
-    l = Layer();
-}
-
-void free_model(Model& m) {
-    for (auto& l : m.layers) free_layer(l);
-    m.layers.clear();
-    if (m.W0p) hipFree(m.W0p);
-    if (m.W0rm) hipFree(m.W0rm);
-    m.W0rm = nullptr;
-    if (m.T) hipFree(m.T);
-    m.W0p = m.T = nullptr;
-    m.loaded = m.table_ok = false;
-}
-
-const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& name) {
-    for (int i = 0; i < n; ++i)
-        if (t[i].name && name == t[i].name) return &t[i];
-    return nullptr;
-}
-
-// ---------------------------------------------------------------- GEMM launch helpers
-// Small-batch latency path: a GEMM with few output tiles (the reference's literal one-packet call
-// has 8) is split along K over ~256 workgroups and combined by splitk_epilogue_kernel.
-int small_batch_splits(long tiles, int K) {
-    if (tiles >= 96 || K < 256) return 1;
-    long s = 384 / std::max<long>(tiles, 1);
-    s = std::min<long>(s, K / 64);           // >= 4 ring k-tiles per workgroup
-    return (int)std::max<long>(s, 1);
-}
-
-template <int EPI>
-int launch_splitk_epilogue(csi_ctx* c, const GemmArgs& g, const float* slabs, int S) {
-    ProfScope ps(c, K_SPLITK_REDUCE, (double)S * g.M * g.N, 4.0 * (S + 1) * (double)g.M * g.N);
-    const size_t total = (size_t)g.M * g.N;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL((splitk_epilogue_kernel<EPI>), dim3(blocks), dim3(256), 0, c->stream, slabs, S, g.M, g.N, g.C, g.ldc,
-                       g.bias, g.scale, g.shift);
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
-}
-
-template <int EPI>
-int launch_gemm(csi_ctx* c, int kid, GemmArgs g, int splits) {
-    if (g.M <= 0) return CSI_OK;
-    if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
-        return fail(c, CSI_ERR_INVALID_ARG, "gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
-                    g.K, g.lda, g.ldb);
-    const int tiles_m = (g.M + G_BM - 1) / G_BM;
-    g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    if (EPI != EPI_RAW && splits == 1) {
-        const int S = c->force_pair_tile ? 1 : small_batch_splits((long)tiles_m * g.tiles_n, g.K);
-        if (S > 1) {
-            int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)S * g.M * g.N * sizeof(float));
-            if (rc) return rc;
-            GemmArgs r = g;
-            r.C = reinterpret_cast<float*>(c->skbuf);
-            r.ldc = g.N;
-            r.k_per_split = ((g.K + G_BK - 1) / G_BK + S - 1) / S * G_BK;
-            const int real = (g.K + r.k_per_split - 1) / r.k_per_split;
-            {
-                ProfScope ps(c, kid, 2.0 * (double)g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * real));
-                r.tiles_m = 0;           // few tiles: linear order
-                hipLaunchKernelGGL((gemm_f32_kernel<EPI_RAW>), dim3((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)real), dim3(G_THREADS), 0, c->stream, r);
-                HIP_TRY(c, hipGetLastError());
-            }
-            return launch_splitk_epilogue<EPI>(c, g, r.C, real);
-        }
-    }
-    const double flops = 2.0 * (double)g.M * g.N * g.K;
-    const double a_rows = (double)g.M;
-    const double bytes = 4.0 * (a_rows * g.K + (double)g.N * g.K + (double)g.M * g.N * splits);
-    ProfScope ps(c, kid, flops, bytes);
-    // 256-row tiles (fewer LDS-DMA instructions per MFMA) once they fill the 512 resident slots
-    const int tiles_m256 = (g.M + G2_BM - 1) / G2_BM;
-    const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n * splits >= 512);
-    const int tm_used = big ? tiles_m256 : tiles_m;
-    // measured: traffic -50..60 %, time neutral for 8 column tiles and for the 256-row kernel,
-    // -10 % for the 128-row kernel with 2 column tiles (not used there)
-    const bool xcd_order = c->xcd_order >= 0 ? c->xcd_order != 0
-                                             : (g.tiles_n >= 8 || big) && tile_map_pays(tm_used, g.tiles_n, splits);
-    g.tiles_m = xcd_order ? tm_used : 0;
-    const dim3 grid(xcd_order ? tile_map_grid(tm_used, g.tiles_n) : (unsigned)(tm_used * g.tiles_n), 1, (unsigned)splits);
-    if (big) hipLaunchKernelGGL((gemm256_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(G_THREADS), 0, c->stream, g);
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
-}
-
-// first per-pair layer (fragment-time h1 kernels, 4 <= nt <= 128)
-template <int EPI>
-int launch_pair(csi_ctx* c, int kid, GemmArgs g) {
-    if (g.nt < 4 || g.nt > 128)
-        return fail(c, CSI_ERR_INVALID_ARG, "the per-pair layer supports 4 <= nt <= 128 (got %d)", g.nt);
-    if (g.M <= 0) return CSI_OK;
-    if ((g.K & 3) || (g.lda & 3) || (g.ldb % G_BK))
-        return fail(c, CSI_ERR_INVALID_ARG, "pair gemm: K/lda must be multiples of 4 and ldb of 32 (K=%d lda=%d ldb=%d)",
-                    g.K, g.lda, g.ldb);
-    g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    const int tiles_m = (g.M + G_BM - 1) / G_BM;
-    const int tiles_m256 = (g.M + P2_BM - 1) / P2_BM;
-    const double flops = 2.0 * (double)g.M * g.N * g.K;
-    const double bytes = 4.0 * ((double)g.M / g.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
-
-    // small batch: split K over the chip, combine + epilogue in a second (tiny) kernel
-    const int S = c->force_pair_tile ? 1 : small_batch_splits((long)tiles_m * g.tiles_n, g.K);
-    if (S > 1) {
-        int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)S * g.M * g.N * sizeof(float));
-        if (rc) return rc;
-        GemmArgs r = g;
-        r.C = reinterpret_cast<float*>(c->skbuf);
-        r.ldc = g.N;
-        r.k_per_split = ((g.K + G_BK - 1) / G_BK + S - 1) / S * G_BK;
-        const int real = (g.K + r.k_per_split - 1) / r.k_per_split;
-        {
-            ProfScope ps(c, kid, flops, bytes);
-            const dim3 grid((unsigned)(tiles_m * g.tiles_n), 1, (unsigned)real);
-            if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI_RAW, 1>), grid, dim3(G_THREADS), 0, c->stream, r);
-            else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI_RAW, 2>), grid, dim3(G_THREADS), 0, c->stream, r);
-            HIP_TRY(c, hipGetLastError());
-        }
-        return launch_splitk_epilogue<EPI>(c, g, r.C, real);
-    }
-
-    ProfScope ps(c, kid, flops, bytes);
-    // 256-row tiles halve the LDS-DMA instructions per MFMA; use them once they fill the 512
-    // resident workgroup slots, 128-row tiles (more workgroups) below that.
-    const bool big = c->force_pair_tile == 256 || (c->force_pair_tile != 128 && (long)tiles_m256 * g.tiles_n >= 512);
-    if (big) {
-        const dim3 grid((unsigned)(tiles_m256 * g.tiles_n));
-        if (g.nt < 8) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
-        else if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
-        else hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 2, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
-    } else {
-        const dim3 grid((unsigned)(tiles_m * g.tiles_n));
-        g.k_per_split = (g.K + G_BK - 1) / G_BK * G_BK;
-        if (g.nt <= 64) hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 1>), grid, dim3(G_THREADS), 0, c->stream, g);
-        else hipLaunchKernelGGL((pair_gemm_f32_kernel<EPI, 2>), grid, dim3(G_THREADS), 0, c->stream, g);
-    }
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
-}
-
-// Split-K factor of layer 0.  The grid should fill whole rounds of the 512 resident workgroups
-// (256 CUs x 2): pick the smallest factor whose last round is >= 90 % full, else the fullest.
-int choose_splits(int M, int N, int K, int* k_per_split) {
-    const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-    const int ktiles = (K + G_BK - 1) / G_BK;
-    static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32, 40};
-    int best = 1;
-    double best_eff = -1.0;
-    for (int s : cand) {
-        if (s > 1 && ktiles / s < 8) break;           // keep >= 8 k-tiles (of 32) per block
-        const int kps = (ktiles + s - 1) / s;
-        const int real = (ktiles + kps - 1) / kps;
-        const double rounds = (double)tiles * real / 512.0;
-        const double eff = rounds / std::ceil(rounds);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
-        if (eff >= 0.9) { best = s; break; }
-    }
-    const int kps = (ktiles + best - 1) / best * G_BK;
-    *k_per_split = kps;
-    return (K + kps - 1) / kps;
-}
-
-int build_pilot_table(csi_ctx* c, Model& m) {
-    if (!m.loaded || !c->pilot_ok || c->cfg.nt == 0) return CSI_OK;
-    const int nt = c->cfg.nt, h1 = c->cfg.hidden[0];
-    if (!m.T) {
-        const size_t bytes = ((size_t)nt * h1 + G_SLACK_FLOATS) * sizeof(float);
-        if (hipMalloc((void**)&m.T, bytes) != hipSuccess)
-            return fail(c, CSI_ERR_NOMEM, "pilot table allocation failed");
-        HIP_TRY(c, hipMemsetAsync(m.T, 0, bytes, c->stream));
-    }
-    ProfScope ps(c, K_PILOT_TABLE, 2.0 * nt * nt * h1, 4.0 * (nt * nt + 2.0 * nt * h1));
-    hipLaunchKernelGGL(pilot_table_kernel, dim3((h1 + 255) / 256, nt), dim3(256), 0, c->stream,
-                       c->P, m.W0p, m.layers[0].bias, m.T, nt, h1);
-    HIP_TRY(c, hipGetLastError());
-    m.table_ok = true;
-    return CSI_OK;
-}
-
-// ---------------------------------------------------------------- DNN, shared layer 0
-// d_ltf: [npkt][nr][len_ltf] one component plane; d_out: [npkt][nr][nt][n_out]
-int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float* d_out) {
-    const csi_config& cf = c->cfg;
-    const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
-    int maxh = 0;
-    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
-    // Packet chunks: as few as the workspace allows, all of (nearly) the same size so that every
-    // chunk fills the machine equally well.  Per packet: layer-0 slabs (+ their sum when split-K
-    // is on - the factor depends on the chunk size, hence the loop) and the ping-pong buffers of
-    // the hidden activations.
-    const size_t hid_pkt = (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);   // 1.5 GiB
-    const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
-    int64_t nchunks = 1, chunk = npkt;
-    int splits_max = 1;
-    for (;;) {
-        chunk = (npkt + nchunks - 1) / nchunks;
-        int kps_tmp;
-        splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
-        const size_t need = ((size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt) * (size_t)chunk;
-        if ((need <= budget && chunk <= max_rows) || chunk == 1) break;
-        nchunks = std::max(nchunks + 1, (int64_t)((double)nchunks * (double)need / (double)budget));
-    }
-    {   // the last chunk can be shorter and may want a different split factor
-        int kps_tmp;
-        const int64_t tail = npkt - (nchunks - 1) * chunk;
-        if (tail > 0 && tail != chunk)
-            splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
-    }
-    const size_t slab_floats = (size_t)chunk * nr * h1;
-    const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk;
-    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_chunk);
-    if (rc) return rc;
-
-    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
-        const int64_t np = std::min(chunk, npkt - p0);
-        const int M1 = (int)(np * nr);
-        const int M2 = (int)(np * nr * nt);
-        float* slabs = reinterpret_cast<float*>(c->ws);
-        float* l0sum = slabs + slab_floats * splits_max;              // unused when splits_max == 1
-        float* hbuf[2];
-        hbuf[0] = slabs + slab_floats * (splits_max > 1 ? splits_max + 1 : 1);
-        hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh;
-
-        // layer 0, LTF part: L0[M1][h1] = ltf[M1][len_ltf] * W0[0:len_ltf, :]
-        const float* l0 = nullptr;
-        if (M1 <= 8 && m.W0rm && !c->force_pair_tile) {
-            // a handful of preambles: stream W0 once (HBM-bound) instead of running a GEMM
-            const int S = (cf.len_ltf + 4 * SK_KS - 1) / (4 * SK_KS);
-            rc = ensure_bytes(c, &c->l0skinny, &c->l0skinny_bytes, (size_t)(S + 1) * 8 * h1 * sizeof(float));
-            if (rc) return rc;
-            float* sl = reinterpret_cast<float*>(c->l0skinny);
-            float* sum = sl + (size_t)S * M1 * h1;
-            {
-                ProfScope ps(c, K_LAYER0_LTF, 2.0 * M1 * h1 * cf.len_ltf, 4.0 * ((double)cf.len_ltf * h1 + (double)M1 * cf.len_ltf + (double)S * M1 * h1));
-                hipLaunchKernelGGL((layer0_skinny_kernel<8>), dim3((unsigned)S, (unsigned)((h1 + 255) / 256)), dim3(256), 0, c->stream,
-                                   d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, m.W0rm, h1, cf.len_ltf, sl);
-                HIP_TRY(c, hipGetLastError());
-            }
-            {
-                const size_t n4 = (size_t)M1 * h1 / 4;
-                ProfScope ps(c, K_SPLITK_REDUCE, (double)(S - 1) * M1 * h1, 4.0 * (S + 1) * M1 * h1);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64), 0, c->stream, sl, sum, n4, S);
-                HIP_TRY(c, hipGetLastError());
-            }
-            l0 = sum;
-        }
-        int kps = 0;
-        const int splits = l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps);
-        GemmArgs g{};
-        g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
-        g.lda = cf.len_ltf;
-        g.Bt = m.layers[0].Wt;
-        g.ldb = m.layers[0].ldw;
-        g.C = slabs;
-        g.ldc = h1;
-        g.M = M1; g.N = h1; g.K = cf.len_ltf;
-        g.k_per_split = kps;
-        if (!l0) {
-            rc = launch_gemm<EPI_RAW>(c, K_LAYER0_LTF, g, splits);
-            if (rc) return rc;
-            l0 = slabs;
-        }
-        if (splits > 1) {
-            const size_t n4 = (size_t)M1 * h1 / 4;
-            ProfScope ps(c, K_SPLITK_REDUCE, (double)(splits - 1) * M1 * h1, 4.0 * (splits + 1) * M1 * h1);
-            const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, slabs, l0sum, n4, splits);
-            HIP_TRY(c, hipGetLastError());
-            l0 = l0sum;
-        }
-
-        // first per-pair layer: h1 generated in the prologue from L0 + T
-        float* out_chunk = d_out + (size_t)p0 * nr * nt * cf.n_out;
-        GemmArgs p{};
-        p.A = l0; p.lda = h1;
-        p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = m.layers[0].shift; p.nt = nt;
-        p.M = M2; p.K = h1;
-        const Layer& l1 = m.layers[1];
-        p.Bt = l1.Wt; p.ldb = l1.ldw; p.N = l1.out;
-        p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
-        p.k_per_split = ((h1 + G_BK - 1) / G_BK) * G_BK;
-        if (nh == 1) {
-            p.C = out_chunk; p.ldc = cf.n_out;
-            rc = launch_pair<EPI_BIAS>(c, K_REGRESSOR, p);
-            if (rc) return rc;
-            continue;
-        }
-        p.C = hbuf[0]; p.ldc = l1.out;
-        rc = launch_pair<EPI_BIAS_RELU_AFFINE>(c, K_PAIR_DENSE, p);
-        if (rc) return rc;
-        int cur = 0;
-        for (int li = 2; li <= nh; ++li) {
-            const Layer& l = m.layers[li];
-            GemmArgs q{};
-            q.A = hbuf[cur]; q.lda = l.in;
-            q.Bt = l.Wt; q.ldb = l.ldw;
-            q.M = M2; q.N = l.out; q.K = l.in;
-            q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
-            q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
-            if (li == nh) {
-                q.C = out_chunk; q.ldc = cf.n_out;
-                rc = launch_gemm<EPI_BIAS>(c, K_REGRESSOR, q, 1);
-            } else {
-                q.C = hbuf[cur ^ 1]; q.ldc = l.out;
-                rc = launch_gemm<EPI_BIAS_RELU_AFFINE>(c, K_DENSE_HIDDEN, q, 1);
-                cur ^= 1;
-            }
-            if (rc) return rc;
-        }
-    }
-    return CSI_OK;
-}
-
-// ---------------------------------------------------------------- bf16 mode
-template <int EPI, bool OUT_BF16>
-int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
-    if (g.M <= 0) return CSI_OK;
-    if ((g.lda & 7) || (g.ldb % B_BK))
-        return fail(c, CSI_ERR_INVALID_ARG, "bf16 gemm: lda must be a multiple of 8 and ldb of 64 (lda=%d ldb=%d)", g.lda, g.ldb);
-    const double flops = 2.0 * (double)g.M * g.N * g.K;
-    const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (OUT_BF16 ? 2.0 : 4.0) * (double)g.M * g.N * splits;
-    ProfScope ps(c, kid, flops, bytes);
-    // 256x256 tiles (8 waves) once they fill the 256 CUs, 128x128 tiles (4 waves, 2 per CU) below
-    const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splits;
-    if (big_tiles >= 256) {
-        g.tiles_n = (g.N + 255) / 256;
-        dim3 grid((unsigned)(((g.M + 255) / 256) * g.tiles_n), 1, (unsigned)splits);
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 4, 4, 2, 2>), grid, dim3(512), 0, c->stream, g);
-    } else {
-        g.tiles_n = (g.N + 127) / 128;
-        dim3 grid((unsigned)(((g.M + 127) / 128) * g.tiles_n), 1, (unsigned)splits);
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, c->stream, g);
-    }
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
-}
-
-int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
-    ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * n);
-    const size_t n8 = n / 8;
-    const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 8192);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, src, dst, n8);
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
-}
-
-// hidden layers 1.. and the regressor on a bf16 activation matrix hin [M][l.in]; writes d_out fp32
-int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_t* hb1, float* d_out, int first_layer) {
-    const csi_config& cf = c->cfg;
-    bf16_t* hb[2] = {hb0, hb1};
-    const bf16_t* cur = hin;
-    int w = 0;
-    for (int li = first_layer; li <= cf.n_hidden; ++li) {
-        const Layer& l = m.layers[li];
-        GemmBf16Args q{};
-        q.A = cur; q.lda = l.in;
-        q.Bt = l.Wb; q.ldb = l.ldwb;
-        q.M = M; q.N = l.out; q.K = l.in;
-        q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
-        q.k_per_split = l.ldwb;
-        int rc;
-        if (li == cf.n_hidden) {
-            q.C = d_out; q.ldc = cf.n_out;
-            rc = launch_gemm_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, 1);
-        } else {
-            q.C = hb[w]; q.ldc = l.out;
-            rc = launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN, q, 1);
-            cur = hb[w];
-            w ^= 1;
-        }
-        if (rc) return rc;
-    }
-    return CSI_OK;
-}
-
-int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float* d_out) {
-    const csi_config& cf = c->cfg;
-    const int nt = cf.nt, nr = cf.nr, h1 = cf.hidden[0], nh = cf.n_hidden;
-    int maxh = 0;
-    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
-    // per packet: bf16 preamble copy, fp32 layer-0 product, bf16 h1, bf16 ping-pong hidden buffers
-    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 + (size_t)nr * nt * h1 * 2 +
-                           (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);
-    int64_t cap = std::max<int64_t>(1, (int64_t)(budget / per_pkt));
-    cap = std::min(cap, (int64_t)0x7fffffff / ((int64_t)nr * nt * 2));
-    const int64_t nchunks = (npkt + cap - 1) / cap;
-    const int64_t chunk = (npkt + nchunks - 1) / nchunks;
-    int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_pkt * (size_t)chunk + 1024);
-    if (rc) return rc;
-    char* base = c->ws;
-    bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
-    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4;
-    bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
-    bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
-    bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
-    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
-        const int64_t np = std::min(chunk, npkt - p0);
-        const int M1 = (int)(np * nr), M2 = (int)(np * nr * nt);
-        rc = cast_bf16(c, d_ltf + (size_t)p0 * nr * cf.len_ltf, xb, (size_t)M1 * cf.len_ltf);
-        if (rc) return rc;
-        GemmBf16Args g{};
-        g.A = xb; g.lda = cf.len_ltf;
-        g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
-        g.C = l0; g.ldc = h1;
-        g.M = M1; g.N = h1; g.K = cf.len_ltf;
-        g.k_per_split = cf.len_ltf;
-        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, 1);
-        if (rc) return rc;
-        {
-            ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
-            const size_t total = (size_t)M2 * (h1 / 8);
-            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
-            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, l0, 1, (size_t)0, m.T,
-                               m.layers[0].scale, m.layers[0].shift, h1b, M2, nt, h1);
-            HIP_TRY(c, hipGetLastError());
-        }
-        rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);
-        if (rc) return rc;
-    }
-    return CSI_OK;
-}
 
 int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     if (!c) return CSI_ERR_INVALID_ARG;

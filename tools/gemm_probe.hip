@@ -158,6 +158,10 @@ int main(int argc, char** argv) {
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 2, 3>("hidden 1024x1024", g, 1, 7);
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 2, 2>("hidden 1024x1024", g, 1, 7);
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 4, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 4, 2, 2, 4, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 2, 2, 3>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 1, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 1, 3>("hidden 1024x1024", g, 1, 7);
         }
         return 0;
     }
