@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
     ap.add_argument('--no-ls', action='store_true', help='time the DNN only')
+    ap.add_argument('--workspace-gb', type=float, default=0.0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32 = the headline fp32 path; bf16 = BASELINE config 3 (use with --nt 64 --packets 5000)')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
@@ -64,7 +65,8 @@ def main():
     nt, nr, npkt, hidden = args.nt, args.nr, args.packets, tuple(args.hidden)
     import torch
     ndev = max(torch.cuda.device_count(), 1)
-    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev, dtype=args.dtype)
+    eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev, dtype=args.dtype,
+                        workspace_bytes=int(args.workspace_gb * 2**30))
 
     # weights: created on rank 0, broadcast as one flat buffer (RCCL over xGMI when world > 1)
     wts = None

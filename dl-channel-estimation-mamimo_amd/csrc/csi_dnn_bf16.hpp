@@ -13,9 +13,17 @@ int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (OUT_BF16 ? 2.0 : 4.0) * (double)g.M * g.N * splits;
     ProfScope ps(c, kid, flops, bytes);
-    // 256x256 tiles (8 waves) once they fill the 256 CUs, 128x128 tiles (4 waves, 2 per CU) below
-    const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splits;
-    if (big_tiles >= 256) {
+    // 256x256 ping-pong tiles (8 waves, 1 workgroup per CU) once they fill the 256 CUs, 128x128
+    // tiles (4 waves, 2 per CU) below
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    const long big_tiles = (long)tiles_m * ((g.N + PP_BN - 1) / PP_BN) * splits;
+    const bool wide_ok = !OUT_BF16 || ((g.N & 7) == 0 && (g.ldc & 7) == 0);
+    const int force = c->force_pair_tile;      // "force_tile" option: 256 -> ping-pong kernel, 128 -> 128x128 lock-step kernel
+    if (wide_ok && (force == 256 || (force == 0 && big_tiles >= 256))) {
+        g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+        dim3 grid(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits);
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OUT_BF16, 5>), grid, dim3(PP_THREADS), 0, c->stream, g);
+    } else if (big_tiles >= 256 && force != 128) {
         g.tiles_n = (g.N + 255) / 256;
         dim3 grid((unsigned)(((g.M + 255) / 256) * g.tiles_n), 1, (unsigned)splits);
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OUT_BF16, 2, 4, 4, 2, 2>), grid, dim3(512), 0, c->stream, g);
@@ -26,6 +34,24 @@ int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
     }
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
+}
+
+// Split-K of the bf16 layer-0 product ([M1 x len_ltf] x [len_ltf x h1], M1 = packets x rx): with one
+// 256x256 workgroup per CU the row tiles alone rarely fill whole rounds of 256 CUs (config 3:
+// 79 x 4 tiles = 1.23 rounds); choose the split count whose last round is fullest.
+constexpr int BF16_L0_MAX_SPLITS = 6;
+int bf16_layer0_splits(int M1, int h1, int K) {
+    const long tiles = (long)((M1 + PP_BM - 1) / PP_BM + 7) / 8 * 8 * ((h1 + PP_BN - 1) / PP_BN);      // as launched (pp_grid)
+    if (tiles < 256) return 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= BF16_L0_MAX_SPLITS; ++s) {
+        if (K / s < 1024) break;
+        const long blocks = tiles * s;
+        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256) - 0.01 * (s - 1);     // slab traffic
+        if (eff > best_eff) { best_eff = eff; best = s; }
+    }
+    return best;
 }
 
 int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
@@ -72,9 +98,10 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     int maxh = 0;
     for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
     // per packet: bf16 preamble copy, fp32 layer-0 product, bf16 h1, bf16 ping-pong hidden buffers
-    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 + (size_t)nr * nt * h1 * 2 +
+    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 * BF16_L0_MAX_SPLITS + (size_t)nr * nt * h1 * 2 +
                            (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)3 << 29);
+    // default 8 GiB: a whole config-3 step (5000 packets) in one chunk, so that layer 0 sees M1 = 20000 rows
+    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)8 << 30);
     int64_t cap = std::max<int64_t>(1, (int64_t)(budget / per_pkt));
     cap = std::min(cap, (int64_t)0x7fffffff / ((int64_t)nr * nt * 2));
     const int64_t nchunks = (npkt + cap - 1) / cap;
@@ -83,7 +110,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     if (rc) return rc;
     char* base = c->ws;
     bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
-    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4;
+    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4 * BF16_L0_MAX_SPLITS;
     bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
     bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
     bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
@@ -97,15 +124,14 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
         g.C = l0; g.ldc = h1;
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
-        g.k_per_split = cf.len_ltf;
-        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, 1);
+        const int S = bf16_layer0_splits(M1, h1, cf.len_ltf);
+        g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
+        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, S);
         if (rc) return rc;
         {
             ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
-            const size_t total = (size_t)M2 * (h1 / 8);
-            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
-            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, l0, 1, (size_t)0, m.T,
-                               m.layers[0].scale, m.layers[0].shift, h1b, M2, nt, h1);
+            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3((unsigned)std::min(M1, 65536)), dim3(256), 0, c->stream, l0, S, (size_t)M1 * h1, m.T,
+                               m.layers[0].scale, m.layers[0].shift, h1b, M1, nt, h1);
             HIP_TRY(c, hipGetLastError());
         }
         rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);

@@ -23,6 +23,8 @@
 namespace csi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t bf16_t;
 
 constexpr int B_BK = 64;                      // bf16 k-columns per stage (128-byte rows)
@@ -195,6 +197,291 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bf1
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256 "ping-pong" kernel for the large bf16 grids.
+//
+// At bf16 rates the lock-step kernel above loses the matrix pipe whenever its waves issue LDS-DMA
+// pieces (60-185 cycles each, 8 per wave and 64-column k-tile) or wait at the one barrier per
+// k-tile.  Here the 8 waves form two groups of four (wm = 0 / 1, one wave of each group on every
+// SIMD) that run the SAME instruction stream half a phase apart:
+//
+//     group 0:  load | MFMA | load | MFMA | ...         a phase = 16 k-columns of the wave's
+//     group 1:       | load | MFMA | load | MFMA ...     128x64 output (6 ds_read_b128, 8 MFMAs)
+//
+// Every segment ends in an s_barrier, group 1 executes one extra barrier up front (and skips its
+// last one), so a wave's fragment reads and DMA issue always run beside the other group's 8
+// MFMAs (256 pipe cycles) on the same SIMD.
+//
+// LDS: ring of NSUB sub-tiles of 32 k-columns ((256 + 256) rows x 64 B = 32 KiB each, XOR chunk
+// swizzle (row>>2)&3 on the DMA source and the read address).  Sub-tile u + NSUB - 1 is issued
+// while sub-tile u is read (2 pieces per wave and phase).  Ordering (local step = segment index
+// of the wave, group 1 one step behind group 0):
+//   RAW  every wave counts its own pieces with vmcnt in the SECOND load segment of sub-tile u
+//        (sub-tile u + 1 complete, the 4 (NSUB - 2) younger pieces stay in flight) and two
+//        barriers lie between that wait and the first read by either group;
+//   WAR  slot (u - 1) % NSUB is re-filled from the first load segment of sub-tile u; its last
+//        reads (second load segment of sub-tile u - 1) were retired by the lgkmcnt(0) in front
+//        of that segment's barrier, one (group 0) or two (group 1) barriers earlier.
+constexpr int PP_BM = 256, PP_BN = 256;
+constexpr int PP_BK = 32;                            // bf16 k-columns per sub-tile
+constexpr int PP_ROWF = 16;                          // floats per image row (64 B)
+constexpr int PP_SUBF = (PP_BM + PP_BN) * PP_ROWF;   // floats per sub-tile
+constexpr int PP_PW = 4;                             // 1-KiB DMA pieces per wave and sub-tile
+constexpr int PP_THREADS = 512;
+
+// s_waitcnt through the builtin (gfx9 encoding: vmcnt = [15:14|3:0], expcnt = [6:4], lgkmcnt = [11:8]) so
+// that the compiler's own wait-count bookkeeping sees it; an asm statement is opaque to it and it
+// then re-waits for every fragment read in front of the MFMAs that were meant to cover them
+template <int N>
+__device__ __forceinline__ void pp_wait_vm_lgkm() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pp_wait_lgkm() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pp_wait_vm_lgkm_rt(int n) {
+    if (n >= 12) pp_wait_vm_lgkm<12>();
+    else if (n >= 8) pp_wait_vm_lgkm<8>();
+    else if (n >= 4) pp_wait_vm_lgkm<4>();
+    else pp_wait_vm_lgkm<0>();
+}
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// grid: 8 * tiles_n * ceil(tiles_m / 8) workgroups; workgroup b runs on XCD b % 8, and the tiles_n
+// column tiles of a row tile are consecutive on ONE XCD (A rows enter that L2 once)
+__host__ __forceinline__ unsigned pp_grid(int tiles_m, int tiles_n) { return 8u * tiles_n * ((tiles_m + 7) / 8); }
+
+template <int EPI, bool OUT_BF16, int NSUB, int DBG = 0>
+__global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmBf16Args g) {
+    static_assert(NSUB == 4 || NSUB == 5, "ring depth");
+    constexpr int D = NSUB - 1;
+    __shared__ __attribute__((aligned(16))) float lds[NSUB * PP_SUBF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    if (tm * PP_BM >= g.M) return;
+    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nsub = (kend - kbeg + PP_BK - 1) / PP_BK;
+
+    // DMA piece = 16 image rows; lane -> row 16*piece + lane/4, physical chunk lane%4.  Waves 0-3
+    // carry the A rows, waves 4-7 the B rows: one buffer descriptor per wave (tile base, SGPRs),
+    // a 32-bit byte offset per lane and piece, the k advance in the scalar offset - an issue is
+    // s_mov m0 + buffer_load ... lds, no vector address arithmetic in the loop.
+    const bool a_side = wave < 4;
+    const bf16_t* tile_base = a_side ? g.A + (size_t)m0 * g.lda + kbeg : g.Bt + (size_t)n0 * g.ldb + kbeg;
+    const int ld = a_side ? g.lda : g.ldb;
+    const int rmax = a_side ? g.M - 1 - m0 : g.N - 1 - n0;          // last valid row of this tile
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tile_base, 0, 0x7fffffff, 0x00020000);
+    int voff[PP_PW];
+#pragma unroll
+    for (int u = 0; u < PP_PW; ++u) {
+        const int row = 16 * ((wave & 3) * PP_PW + u) + (lane >> 2);
+        const int clog = (lane & 3) ^ ((row >> 2) & 3);
+        voff[u] = (min(row, rmax) * ld + clog * 8) * 2;
+    }
+    auto issue = [&](int sub, int slot, int u) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (wave * PP_PW + u) * 256),
+                                                 16, voff[u], sub * (PP_BK * 2), 0, 0);
+    };
+
+    const int fswz = (l31 >> 2) & 3;
+    int xo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;            // floats
+    const int abase = (wm * 128 + l31) * PP_ROWF;
+    const int bbase = (PP_BM + wn * 64 + l31) * PP_ROWF;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragments of the phase being multiplied / of the next phase (read during the MFMAs)
+    bf16x8 fa[2][4], fb[2][2];
+    auto read_frags = [&](int slot, int c, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+        const float* st = lds + slot * PP_SUBF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(st + abase + i * 32 * PP_ROWF + xo[c]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(st + bbase + j * 32 * PP_ROWF + xo[c]));
+    };
+
+    const int npro = min(nsub, D);
+    for (int t = 0; t < npro; ++t)
+#pragma unroll
+        for (int u = 0; u < PP_PW; ++u) issue(t, t, u);
+    pp_wait_vm_lgkm_rt(PP_PW * (npro - 1));
+    pp_barrier();                       // sub-tile 0 visible to every wave
+    read_frags(0, 0, fa[0], fb[0]);
+    pp_wait_lgkm();
+    if (wm == 1) pp_barrier();          // group 1 runs one segment behind
+
+    // MFMA segment: 8 MFMAs on the current fragments with the 6 fragment reads of the next phase
+    // issued in their shadow; the reads are retired before the closing barrier (WAR rule above)
+    auto mfma_seg = [&](int cur, bool more, int nslot, int nc, bool closing_barrier) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (more && !(DBG & 2)) read_frags(nslot, nc, fa[cur ^ 1], fb[cur ^ 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        if (more && !(DBG & 2)) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        pp_wait_lgkm();
+        __builtin_amdgcn_sched_barrier(0);
+        if (closing_barrier) pp_barrier();
+    };
+
+    int slot = 0, fill = D % NSUB;       // slot read now / slot that sub-tile u + D goes to
+    int u = 0;
+    for (; u < nsub - D; ++u) {
+        const int nslot = slot + 1 == NSUB ? 0 : slot + 1;
+        // phase (u, 0): sub-tile u + 1 must have landed before any wave reads it in the next MFMA segment but one
+        if (!(DBG & 1)) { issue(u + D, fill, 0); issue(u + D, fill, 1); }
+        if (!(DBG & 4)) pp_wait_vm_lgkm<(DBG & 1) ? 0 : PP_PW * (D - 2) + 2>();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_seg(0, true, slot, 1, true);
+        // phase (u, 1)
+        if (!(DBG & 1)) { issue(u + D, fill, 2); issue(u + D, fill, 3); }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_seg(1, true, nslot, 0, true);
+        slot = nslot;
+        fill = fill + 1 == NSUB ? 0 : fill + 1;
+    }
+    for (; u < nsub; ++u) {
+        const int r = nsub - 1 - u;      // sub-tiles still to come after this one
+        const int nslot = slot + 1 == NSUB ? 0 : slot + 1;
+        if (r >= 1) pp_wait_vm_lgkm_rt(PP_PW * (r - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_seg(0, true, slot, 1, true);
+        pp_barrier();
+        mfma_seg(1, r >= 1, nslot, 0, !(wm == 1 && r == 0));
+        slot = nslot;
+    }
+
+    if ((DBG & 8) && g.M > 0) return;
+    const bool full_rows = (m0 + PP_BM) <= g.M;
+    if constexpr (OUT_BF16) {
+        // bf16 output through a wave-private LDS image so that every lane stores 16 contiguous
+        // bytes (2-byte stores of the C/D layout cost 8x the store instructions and ~20 % of the
+        // kernel).  The ring is idle here: every DMA has landed and every fragment read was retired
+        // in front of a barrier this wave has passed.  Image: [64 row pairs][64 columns] words,
+        // word = (row 2P | row 2P+1 << 16) of one column - the C/D layout holds rows 2P, 2P+1 of a
+        // column in adjacent accumulator registers, so packing needs no cross-lane traffic.
+        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            auto fin = [&](float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                return v;
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const f32x2 v = {fin(acc[mi][nj][2 * r2]), fin(acc[mi][nj][2 * r2 + 1])};
+                    const int P = mi * 16 + 4 * (r2 >> 1) + 2 * hi + (r2 & 1);
+                    ep[P * 64 + nj * 32 + l31] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cg = lane & 7;
+        const int col8 = n0 + wn * 64 + cg * 8;
+        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + col8;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int P = pass * 8 + (lane >> 3);
+            const uint4 w0 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8 + 4);
+            uint4 e, o;
+            e.x = (w0.x & 0xffffu) | (w0.y << 16);  o.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
+            e.y = (w0.z & 0xffffu) | (w0.w << 16);  o.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
+            e.z = (w1.x & 0xffffu) | (w1.y << 16);  o.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
+            e.w = (w1.z & 0xffffu) | (w1.w << 16);  o.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
+            const int row = m0 + wm * 128 + 2 * P;
+            if (full_rows) {
+                if (col8 < g.N) {
+                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                    *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+                }
+            } else {
+                if (col8 < g.N && row < g.M) *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                if (col8 < g.N && row + 1 < g.M) *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+            }
+        }
+    } else {
+        // fp32 output straight from the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+        // 32 lanes x 4 B = one 128-byte line per row
+        const int wrow = m0 + wm * 128 + 4 * hi;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int col = n0 + wn * 64 + nj * 32 + l31;
+            const bool cok = col < g.N;
+            const int colc = min(col, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) +
+                        (size_t)wrow * g.ldc + col;
+            auto put = [&](int rr, float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                cf[(size_t)rr * g.ldc] = v;
+            };
+            if (full_rows) {
+                if (cok) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
+                    }
+            }
+        }
+    }
+}
+
 // dst[i] = bf16(src[i]); n8 = number of 8-element groups
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -221,33 +508,48 @@ __global__ void f32_to_bf16_rows_kernel(const float* __restrict__ src, bf16_t* _
     }
 }
 
-// h1[(pr,t)][k] = bf16( bn0( relu( L0[pr][k] + T[t][k] ) ) ), 8 columns per thread.
-// L0 fp32 [M1][h1] (sum of S slabs), T fp32 [nt][h1], out bf16 [M1*nt][h1]
-__global__ void pair_h1_bf16_kernel(const float* __restrict__ L0, int S, size_t slab, const float* __restrict__ T,
-                                    const float* __restrict__ s0, const float* __restrict__ t0,
-                                    bf16_t* __restrict__ out, int M2, int nt, int h1) {
-    const int c8 = h1 >> 3;
-    const size_t total = (size_t)M2 * c8;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int m = (int)(i / c8);
-        const int k = (int)(i - (size_t)m * c8) * 8;
-        const int pr = m / nt, t = m - pr * nt;
-        uint32_t o[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 l = *reinterpret_cast<const f32x4*>(L0 + (size_t)pr * h1 + k + 4 * h);
-            for (int z = 1; z < S; ++z) l += *reinterpret_cast<const f32x4*>(L0 + z * slab + (size_t)pr * h1 + k + 4 * h);
-            const f32x4 tt = *reinterpret_cast<const f32x4*>(T + (size_t)t * h1 + k + 4 * h);
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(s0 + k + 4 * h);
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(t0 + k + 4 * h);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(l[e] + tt[e], 0.f), sv[e], hv[e]);
-            o[2 * h] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o[2 * h + 1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+// h1[(pr,t)][k] = bf16( bn0( relu( L0[pr][k] + T[t][k] ) ) ).
+// L0 fp32 [S slabs][M1][h1] (split-K partial sums of layer 0), T fp32 [nt][h1], out bf16 [M1*nt][h1].
+// One workgroup = one (packet, rx) row of L0 and 2048 columns at most: a thread owns 8 columns, sums
+// the slabs and keeps scale/shift in registers, then walks the nt pilot rows - per output row one
+// 32-byte read of T (L2-resident) and one 16-byte store, both fully coalesced.  HBM-write-bound.
+__global__ __launch_bounds__(256) void pair_h1_bf16_kernel(const float* __restrict__ L0, int S, size_t slab, const float* __restrict__ T,
+                                                           const float* __restrict__ s0, const float* __restrict__ t0,
+                                                           bf16_t* __restrict__ out, int M1, int nt, int h1) {
+    const int c8 = h1 >> 3;                                   // 8-column groups per row
+    const int gpb = min(c8, 256);                             // groups per workgroup pass
+    const int tsplit = 256 / gpb;                             // pilot rows handled side by side
+    const int g = threadIdx.x % gpb, tl = threadIdx.x / gpb;
+    for (int pr = blockIdx.x; pr < M1; pr += gridDim.x) {
+        for (int g0 = 0; g0 < c8; g0 += gpb) {
+            const int k = (g0 + g) * 8;
+            if (g0 + g >= c8 || tl >= tsplit) continue;
+            f32x4 la = *reinterpret_cast<const f32x4*>(L0 + (size_t)pr * h1 + k);
+            f32x4 lb = *reinterpret_cast<const f32x4*>(L0 + (size_t)pr * h1 + k + 4);
+            for (int z = 1; z < S; ++z) {
+                la += *reinterpret_cast<const f32x4*>(L0 + z * slab + (size_t)pr * h1 + k);
+                lb += *reinterpret_cast<const f32x4*>(L0 + z * slab + (size_t)pr * h1 + k + 4);
+            }
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(s0 + k), sb = *reinterpret_cast<const f32x4*>(s0 + k + 4);
+            const f32x4 ha = *reinterpret_cast<const f32x4*>(t0 + k), hb = *reinterpret_cast<const f32x4*>(t0 + k + 4);
+            bf16_t* orow = out + (size_t)pr * nt * h1 + k;
+#pragma unroll 4
+            for (int t = tl; t < nt; t += tsplit) {
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(T + (size_t)t * h1 + k);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(T + (size_t)t * h1 + k + 4);
+                uint4 o;
+                f32x2 v;
+                v = f32x2{fmaf(fmaxf(la[0] + ta[0], 0.f), sa[0], ha[0]), fmaf(fmaxf(la[1] + ta[1], 0.f), sa[1], ha[1])};
+                o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                v = f32x2{fmaf(fmaxf(la[2] + ta[2], 0.f), sa[2], ha[2]), fmaf(fmaxf(la[3] + ta[3], 0.f), sa[3], ha[3])};
+                o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                v = f32x2{fmaf(fmaxf(lb[0] + tb[0], 0.f), sb[0], hb[0]), fmaf(fmaxf(lb[1] + tb[1], 0.f), sb[1], hb[1])};
+                o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                v = f32x2{fmaf(fmaxf(lb[2] + tb[2], 0.f), sb[2], hb[2]), fmaf(fmaxf(lb[3] + tb[3], 0.f), sb[3], hb[3])};
+                o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                *reinterpret_cast<uint4*>(orow + (size_t)t * h1) = o;
+            }
         }
-        *reinterpret_cast<uint4*>(out + (size_t)m * h1 + k) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 

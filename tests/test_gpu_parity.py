@@ -356,6 +356,28 @@ def test_bf16_mode_matches_bf16_emulation(pkg, oracle, nt, nr, npkt, hidden):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
 
 
+@pytest.mark.parametrize('tile', [128, 256])
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(8, 2, 37, (64, 64)), (64, 2, 5, (128, 72)), (4, 2, 70, (72, 40, 24))])
+def test_bf16_both_tile_kernels(pkg, oracle, tile, nt, nr, npkt, hidden):
+    """The 256x256 ping-pong kernel (force_tile=256) and the 128x128 lock-step kernel (128) against the
+    bf16 emulation on ragged shapes: row counts that are no multiple of 256, widths below one tile,
+    k-extents that end inside a 32-column sub-tile, split-K slabs of layer 0."""
+    rng = np.random.default_rng(7 * nt + npkt)
+    w_re, w_im = _weights(oracle, 900 + nt, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=8.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    e.set_option('force_tile', tile)
+    o_re, o_im = e.predict(ltf)
+    b_re, b_im = oracle.predict_packets_bf16(ltf, P, w_re, w_im)
+    assert rel_rows(o_re, b_re) < BF16_TOL_IMPL and rel_rows(o_im, b_im) < BF16_TOL_IMPL
+    x = oracle.samples_from_packets(ltf[:3], P.astype(np.float32), 'imag')
+    y = e.predict_samples('imag', x)
+    assert rel_rows(y, oracle.fc_forward_bf16(x, w_im)) < BF16_TOL_IMPL
+    o2_re, o2_im = e.predict(ltf)
+    assert np.array_equal(o_re, o2_re) and np.array_equal(o_im, o2_im)
+
+
 def test_bf16_mode_shipped_model_slice(pkg, oracle):
     """Nt=64, Nr=4 (config 3 shape), shipped 1024x1024 model, a few packets: exercises the 256x256
     tile kernel through the layer sizes of the real model."""

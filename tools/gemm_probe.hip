@@ -142,6 +142,37 @@ static bf16_t* dalloc_bf16(size_t n, float scale) {
     return d;
 }
 
+
+// checksum of a bf16 output sample (first 64 rows x 1024 cols) for cross-kernel comparison
+static double bf16_checksum(const void* C, int ldc) {
+    std::vector<bf16_t> h((size_t)64 * ldc);
+    CK(hipMemcpy(h.data(), C, h.size() * 2, hipMemcpyDeviceToHost));
+    double s = 0; for (size_t i = 0; i < h.size(); ++i) { uint32_t u = (uint32_t)h[i] << 16; float f; memcpy(&f, &u, 4); s += f * (double)((i % 7) + 1); }
+    return s;
+}
+
+template <int EPI, bool OB, int NSUB, int DBG = 0>
+double run_bf16_pp(const char* name, GemmBf16Args g, int splits, int iters) {
+    g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    dim3 grid(pp_grid(tiles_m, g.tiles_n), 1, splits);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OB, NSUB, DBG>), grid, dim3(PP_THREADS), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, OB, NSUB, DBG>), grid, dim3(PP_THREADS), 0, 0, g);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], fl = 2.0 * g.M * g.N * g.K;
+    printf("bf16 %-22s ping-pong 256x256 NSUB=%d DBG=%d  med %.3f ms  %.0f TF (best %.0f)  checksum %.6g\n", name, NSUB, DBG, med, fl / med / 1e9, fl / ts[0] / 1e9, OB ? bf16_checksum(g.C, g.ldc) : 0.0);
+    return med;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "bf16") {
         const int M = 262144, H = 1024;
@@ -153,15 +184,24 @@ int main(int argc, char** argv) {
         g.bias = bias; g.scale = sc; g.shift = sh;
         for (int rep = 0; rep < 2; ++rep) {
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 2, 2, 2>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 2, 2, 4>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 2, 2>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 2, 3>("hidden 1024x1024", g, 1, 7);
+            printf("   checksum lock-step %.6g\n", bf16_checksum(g.C, g.ldc));
+            CK(hipMemset(C, 0, (size_t)M * H * 2));
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 4>("hidden 1024x1024", g, 1, 7);
+            CK(hipMemset(C, 0, (size_t)M * H * 2));
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 1>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 2>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 4>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 12>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 14>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 10>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 9>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 8>("hidden 1024x1024", g, 1, 7);
+            run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5, 11>("hidden 1024x1024", g, 1, 7);
+            { GemmBf16Args g4 = g; g4.K = 4096; g4.k_per_split = 4096; g4.lda = 1024; g4.ldb = 1024; g4.M = 65536;   // K-loop 4x longer over the same memory (rows wrap inside the buffers)
+              run_bf16_pp<EPI_BIAS_RELU_AFFINE, true, 5>("K=4096 M=65536 (aliased)", g4, 1, 7); }
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 2, 2>("hidden 1024x1024", g, 1, 7);
             run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 2, 4, 4, 2>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 4, 2, 2, 4, 2>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 2, 2, 3>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 1, 2>("hidden 1024x1024", g, 1, 7);
-            run_bf16<EPI_BIAS_RELU_AFFINE, true, 2, 4, 4, 1, 3>("hidden 1024x1024", g, 1, 7);
         }
         return 0;
     }
