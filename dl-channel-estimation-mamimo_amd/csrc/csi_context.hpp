@@ -83,6 +83,7 @@ struct csi_ctx {
     std::string err;
     Model model[2];
     float* P = nullptr;          // device [nt][nt]
+    float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)
     bool pilot_ok = false;
     // LS constants
     float* tw = nullptr;         // [2][256]
@@ -103,6 +104,8 @@ struct csi_ctx {
     int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
     bool use_graph = false;
     std::vector<GraphEntry> graphs;
+    int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
+    int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first (tests)
     int ls_fft_first_max = 32;   // FFT-first LS kernel up to this Nt (measured: faster at 32, slower at 64); debug knob CSI_LS_FFT_FIRST_MAX
     int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
     // profiling

@@ -14,6 +14,53 @@
 
 namespace {
 
+// Which LS kernel serves this context.  FFT-first (all Nt spectra in LDS) up to ls_fft_first_max
+// antennas, the chunked FFT-first kernel (accumulators persist over 16/32-symbol chunks) up to
+// Nt = 128, the despread-first kernel beyond (or when forced through the "ls_kernel" option).
+enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3 };
+struct LsPlan {
+    int mode;
+    const void* fn;
+    size_t lds;
+    int threads;
+    int per_cu;           // resident workgroups per CU (persistent grids)
+};
+LsPlan ls_plan(const csi_ctx* c) {
+    const int nt = c->cfg.nt;
+    int mode = c->ls_kernel;
+    if (mode == LS_AUTO) mode = nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST);
+    if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
+    if (mode == LS_CHUNKED && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
+    LsPlan p{};
+    p.mode = mode;
+    if (mode == LS_FFT_FIRST) {
+        p.fn = nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>;
+        p.lds = (size_t)(nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+        p.threads = LS_THREADS;
+        p.per_cu = std::max(1, std::min(8, (int)((160 * 1024) / p.lds)));
+    } else if (mode == LS_CHUNKED) {
+        const int jt = (nt + 31) / 32;
+        p.fn = jt == 1 ? (const void*)ls_estimate_chunked_kernel<1, 4, 16>
+               : jt == 2 ? (const void*)ls_estimate_chunked_kernel<2, 4, 16>
+                       : (jt == 3 ? (const void*)ls_estimate_chunked_kernel<3, 8, 32> : (const void*)ls_estimate_chunked_kernel<4, 8, 32>);
+        p.lds = (size_t)((jt <= 2 ? 16 : 32) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+        p.threads = jt <= 2 ? 256 : 512;
+        p.per_cu = jt == 1 ? 3 : (jt == 2 ? 2 : 1);       // register-limited: 3 / 2 / 2 waves per SIMD
+    } else {
+        p.fn = (const void*)ls_despread_first_kernel;
+        p.lds = (size_t)(LSD_ROWS * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+        p.threads = LS_THREADS;
+        p.per_cu = 2;
+    }
+    return p;
+}
+int ls_prepare(csi_ctx* c) {
+    if (c->cfg.nt == 0) return CSI_OK;
+    const LsPlan p = ls_plan(c);
+    HIP_TRY(c, hipFuncSetAttribute(p.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    return CSI_OK;
+}
+
 int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): only csi_predict_samples is available");
@@ -84,6 +131,8 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     c->d_in = cfg->len_ltf + cfg->nt;
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
+    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(3, std::max(0, std::atoi(e)));
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);
@@ -132,17 +181,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
         c->err = "bin table upload failed";
         return bail(CSI_ERR_HIP);
     }
-    const size_t ls_lds = (size_t)(cfg->nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-    if (cfg->nt > 0) {
-        const bool fft_first = cfg->nt <= c->ls_fft_first_max;
-        const size_t bytes = fft_first ? ls_lds : (size_t)(LSD_ROWS * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-        const void* fn = !fft_first ? (const void*)ls_despread_first_kernel
-                         : (cfg->nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-            c->err = "hipFuncSetAttribute(LS kernel) failed";
-            return bail(CSI_ERR_HIP);
-        }
-    }
+    if (ls_prepare(c) != CSI_OK) return bail(CSI_ERR_HIP);
     *out = c;
     return CSI_OK;
 }
@@ -157,6 +196,7 @@ void csi_destroy(csi_ctx* c) {
     free_model(c->model[0]);
     free_model(c->model[1]);
     if (c->P) hipFree(c->P);
+    if (c->Ppad) hipFree(c->Ppad);
     if (c->tw) hipFree(c->tw);
     if (c->bin_pos) hipFree(c->bin_pos);
     if (c->denom) hipFree(c->denom);
@@ -276,6 +316,13 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
     drop_graphs(c);
     int rc = upload(c, &c->P, P, (size_t)c->cfg.nt * c->cfg.nt);
     if (rc) return rc;
+    {   // zero-padded copy for the chunked LS kernel (rows / columns up to the next multiple of 32)
+        const int nt = c->cfg.nt, ldp = (nt + 31) / 32 * 32;
+        std::vector<float> pad((size_t)ldp * ldp, 0.f);
+        for (int j = 0; j < nt; ++j) std::memcpy(&pad[(size_t)j * ldp], P + (size_t)j * nt, sizeof(float) * nt);
+        rc = upload(c, &c->Ppad, pad.data(), pad.size());
+        if (rc) return rc;
+    }
     c->pilot_ok = true;
     for (int d = 0; d < 2; ++d) {
         c->model[d].table_ok = false;
@@ -345,13 +392,13 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         return fail(c, CSI_ERR_INVALID_ARG, "csi_ls_estimate_device: bad argument");
     if (npkt == 0) return CSI_OK;
     const csi_config& cf = c->cfg;
-    const bool fft_first = cf.nt <= c->ls_fft_first_max;   // spectra of all Nt symbols in LDS, else despread first
-    const size_t lds = (size_t)((fft_first ? cf.nt : LSD_ROWS) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+    const LsPlan plan = ls_plan(c);
     const int n_jc = (cf.nt + LSD_ROWS - 1) / LSD_ROWS;
     HIP_TRY(c, hipSetDevice(cf.device));
     const int64_t nblk = npkt * cf.nr;
     LsArgs a{};
-    a.P = c->P; a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
+    a.P = c->P; a.Ppad = c->Ppad; a.ldp = (cf.nt + 31) / 32 * 32; a.dbg = c->ls_debug;
+    a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
     a.nt = cf.nt; a.len_ltf = cf.len_ltf;
     const int64_t max_grid = ((int64_t)1 << 30) / n_jc;      // also keeps nb inside an int
     for (int64_t b0 = 0; b0 < nblk; b0 += max_grid) {
@@ -361,15 +408,16 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
         a.h_re = d_h_re + (size_t)b0 * cf.nt * LS_NDATA;
         a.h_im = d_h_im + (size_t)b0 * cf.nt * LS_NDATA;
         const double pairs = (double)nb * cf.nt;
+        int nb32 = (int)nb;
         ProfScope ps(c, K_LS_ESTIMATE, pairs * (10240.0 + 8.0 * LS_NDATA * cf.nt), pairs * (2560.0 + 1872.0));
-        if (fft_first) {
-            // persistent grid: as many workgroups as the LDS lets reside (x256 CUs)
-            const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
-            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)256 * per_cu);
-            if (cf.nt <= 32) hipLaunchKernelGGL((ls_estimate_kernel<8>), dim3(grid), dim3(LS_THREADS), lds, c->stream, a, (int)nb);
-            else hipLaunchKernelGGL((ls_estimate_kernel<16>), dim3(grid), dim3(LS_THREADS), lds, c->stream, a, (int)nb);
-        } else
-            hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), lds, c->stream, a, n_jc);
+        if (plan.mode == LS_DESPREAD_FIRST) {
+            hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), plan.lds, c->stream, a, n_jc);
+        } else {
+            // persistent grid: as many workgroups as can reside (x256 CUs)
+            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)256 * plan.per_cu);
+            void* kargs[] = {(void*)&a, (void*)&nb32};
+            HIP_TRY(c, hipLaunchKernel(plan.fn, dim3(grid), dim3(plan.threads), kargs, plan.lds, c->stream));
+        }
         HIP_TRY(c, hipGetLastError());
     }
     return CSI_OK;
@@ -458,13 +506,13 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "ls_fft_first_max") {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;
-        if (c->cfg.nt > 0) {
-            const bool fft_first = c->cfg.nt <= c->ls_fft_first_max;
-            const size_t bytes = (size_t)((fft_first ? c->cfg.nt : LSD_ROWS) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
-            const void* fn = !fft_first ? (const void*)ls_despread_first_kernel
-                             : (c->cfg.nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>);
-            HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        }
+        return ls_prepare(c);
+    } else if (n == "ls_debug") {
+        c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
+    } else if (n == "ls_kernel") {
+        if (value < 0 || value > 3) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked) or 3 (despread first)");
+        c->ls_kernel = (int)value;
+        return ls_prepare(c);
     } else {
         return fail(c, CSI_ERR_INVALID_ARG, "csi_set_option: unknown option '%s'", name);
     }

@@ -34,6 +34,9 @@ struct LsArgs {
     const float* ltf_re;     // [nblk][len_ltf]
     const float* ltf_im;
     const float* P;          // [nt][nt] row j = pilot sequence of tx j
+    const float* Ppad;       // [ceil32(nt)][ldp] zero-padded copy of P (chunked kernel)
+    int ldp;                 // ceil32(nt)
+    int dbg;                 // timing experiments only ("ls_debug" option): 1 skip FFT, 2 skip despread, 4 skip stores, 8 skip scatter
     const float* tw;         // [2][256] cos / -sin table, exp(-2 pi i u / 256)
     const int* bin_pos;      // [234] natural-order FFT index f(q) of data bin q
     const float* denom;      // [234] nt * ltf[q]
@@ -115,11 +118,12 @@ __device__ __forceinline__ void ls_fft256_wave(float* const (&fr)[NS], const flo
     }
 }
 
-// FFT of rows first, first+4, ... < n of an image [n][2][LS_PLANE] by this wave, two at a time
-__device__ __forceinline__ void ls_fft_rows(float* F, int first, int n, const float* tw_re, const float* tw_im, int lane) {
+// FFT of rows first, first+step, ... < n of an image [n][2][LS_PLANE] by this wave, two at a time
+__device__ __forceinline__ void ls_fft_rows(float* F, int first, int n, const float* tw_re, const float* tw_im, int lane,
+                                            int step = 4) {
     int s = first;
-    for (; s + 4 < n; s += 8) {
-        float* const pr[2] = {F + (size_t)s * 2 * LS_PLANE, F + (size_t)(s + 4) * 2 * LS_PLANE};
+    for (; s + step < n; s += 2 * step) {
+        float* const pr[2] = {F + (size_t)s * 2 * LS_PLANE, F + (size_t)(s + step) * 2 * LS_PLANE};
         ls_fft256_wave<2>(pr, tw_re, tw_im, lane);
     }
     if (s < n) {
@@ -236,6 +240,171 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a,
             }
         }
         __syncthreads();          // spectra consumed; LDS may be overwritten by the next item
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunked FFT-first kernel for 32 < Nt <= 32*JT: the same data flow, but the LTF symbols pass
+// through LDS in chunks of CH (16: 36.9 KiB, 32: 73.7 KiB, so two workgroups still share a CU) and the despread
+// products D[j][q] += sum_{s in chunk} P[j][s] F[s][q] stay in the MFMA accumulators across
+// the chunks (NW waves x QW bin tiles x JT antenna tiles x {re, im} x 16 registers).  The input
+// is read exactly once; the next chunk's samples are requested as soon as the transforms are
+// done and stream in beside the MFMAs.
+template <int JT, int NW, int CH>
+__global__ __launch_bounds__(64 * NW, (JT == 1 ? 3 : 2)) void ls_estimate_chunked_kernel(const LsArgs a, int nblk) {
+    constexpr int SPW = CH / NW;               // symbols per wave and chunk
+    constexpr int QW = 8 / NW;                 // bin tiles (32 bins) per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw_re = smem;
+    float* tw_im = smem + LS_FFT;
+    float* F = smem + 2 * LS_FFT;              // [CH][2][LS_PLANE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = a.nt;
+    const int nchunk = (nt + CH - 1) / CH;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+
+    for (int i = tid; i < LS_FFT; i += 64 * NW) {
+        tw_re[i] = a.tw[i];
+        tw_im[i] = a.tw[LS_FFT + i];
+    }
+
+    f32x4 vr[SPW], vi[SPW];
+    auto fetch = [&](size_t blk, int ch) {
+        const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
+        const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            const int s = min(ch * CH + wave + NW * u, nt - 1);      // clamp: surplus slots re-read a valid symbol
+            vr[u] = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
+            vi[u] = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
+        }
+    };
+
+    // bin positions / scale of this wave's bin tiles
+    int pos[QW];
+    float rden[QW];
+    bool qok[QW];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        const int q = (wave + NW * qi) * 32 + l31;
+        qok[qi] = q < LS_NDATA;
+        pos[qi] = ls_phys(a.bin_pos[qok[qi] ? q : 0]);
+        rden[qi] = a.denom[qok[qi] ? q : 0];
+    }
+
+    size_t blk = blockIdx.x;
+    if (blk < (size_t)nblk) fetch(blk, 0);
+    for (; blk < (size_t)nblk; blk += gridDim.x) {
+        f32x16 acc[QW][JT][2];
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[qi][jt][0][e] = 0.f; acc[qi][jt][1][e] = 0.f; }
+
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int ns = min(CH, nt - ch * CH);                 // symbols in this chunk
+            // ---- registers -> LDS rows wave, wave+NW, ... at base-4 digit-reversed positions
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) {
+                const int r = wave + NW * u;
+                if (r < ns && !(a.dbg & 8)) {
+                    float* fr = F + (size_t)r * 2 * LS_PLANE;
+                    float* fi = fr + LS_PLANE;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int p = ls_phys(c * 64 + rev3);
+                        fr[p] = vr[u][c];
+                        fi[p] = vi[u][c];
+                    }
+                }
+            }
+            __syncthreads();
+            // one transform at a time: the accumulators leave no room for two interleaved ones
+            for (int r = wave; r < ns && !(a.dbg & 1); r += NW) {
+                float* const pr[1] = {F + (size_t)r * 2 * LS_PLANE};
+                ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
+            }
+            __syncthreads();
+            // ---- the next chunk (or the next item's first chunk) starts streaming now
+            if (ch + 1 < nchunk) fetch(blk, ch + 1);
+            else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+
+            // ---- despread on the matrix core: D[j][q] += sum_s P[j][s] * F[s][f(q)].  Branch-free: the
+            // pilot entries come from the zero-padded copy Ppad (rows / columns >= nt are 0), so rows
+            // of F beyond this chunk's symbols only ever meet a zero (they hold finite spectra of
+            // the previous chunk: chunk 0 is always full when nt > 32).  Operands of step ks + 1
+            // are requested before the MFMAs of step ks.
+            const int ksteps = (a.dbg & 2) ? 0 : (ns + 1) >> 1;
+            const float* prow = a.Ppad + (size_t)l31 * a.ldp + ch * CH + hi;
+            const float* frow = F + (size_t)hi * 2 * LS_PLANE;
+            float pvn[JT], bren[QW], bimn[QW];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) pvn[jt] = prow[(size_t)jt * 32 * a.ldp];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) { bren[qi] = frow[pos[qi]]; bimn[qi] = frow[LS_PLANE + pos[qi]]; }
+            for (int ks = 0; ks < ksteps; ++ks) {
+                float pv[JT], bre[QW], bim[QW];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) pv[jt] = pvn[jt];
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) { bre[qi] = bren[qi]; bim[qi] = bimn[qi]; }
+                const int kn = min(ks + 1, CH / 2 - 1);
+                const float* fn = frow + (size_t)kn * 4 * LS_PLANE;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) pvn[jt] = prow[(size_t)jt * 32 * a.ldp + 2 * kn];
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) { bren[qi] = fn[pos[qi]]; bimn[qi] = fn[LS_PLANE + pos[qi]]; }
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        acc[qi][jt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bre[qi], acc[qi][jt][0], 0, 0, 0);
+                        acc[qi][jt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bim[qi], acc[qi][jt][1], 0, 0, 0);
+                    }
+            }
+            __syncthreads();          // spectra consumed; LDS may be overwritten by the next chunk
+        }
+        // ---- scale and store: rows j = jt*32 + (r&3) + 8*(r>>2) + 4*hi, bins q coalesced over the lanes.
+        // One base pointer per plane and compile-time row offsets; full antenna tiles store without
+        // per-row tests (a branch per store splits the epilogue into ~128 blocks whose hoisted
+        // addresses spill).
+        const bool full = (nt & 31) == 0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            if (!qok[qi] || (a.dbg & 4)) continue;
+            const size_t o = (blk * nt + 4 * hi) * LS_NDATA + (size_t)((wave + NW * qi) * 32 + l31);
+            float* pre = a.h_re + o;
+            float* pim = a.h_im + o;
+            const float inv = rden[qi];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if (jt * 32 >= nt) break;
+                if (full || (jt + 1) * 32 <= nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        pre[jo * LS_NDATA] = acc[qi][jt][0][r] / inv;
+                        pim[jo * LS_NDATA] = acc[qi][jt][1][r] / inv;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        if (jo + 4 * hi < nt) {
+                            pre[jo * LS_NDATA] = acc[qi][jt][0][r] / inv;
+                            pim[jo * LS_NDATA] = acc[qi][jt][1][r] / inv;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 

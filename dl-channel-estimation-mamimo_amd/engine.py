@@ -109,7 +109,7 @@ class CsiEngine:
         self._check(self._lib.csi_synchronize(self._ctx))
 
     def set_option(self, name, value):
-        """Tuning knobs of csi_set_option: 'use_graph', 'force_tile', 'xcd_order', 'ls_fft_first_max'."""
+        """Tuning knobs of csi_set_option: 'use_graph', 'force_tile', 'xcd_order', 'ls_fft_first_max', 'ls_kernel'."""
         self._check(self._lib.csi_set_option(self._ctx, name.encode(), int(value)))
 
     def empty(self, shape):

@@ -84,19 +84,31 @@ def test_ls_non_power_of_two_nt_generic_pilot(pkg, oracle, nt):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
 
 
-@pytest.mark.parametrize('thr', ['0', '64'])
-def test_ls_both_kernels_agree(pkg, oracle, monkeypatch, thr):
-    """The FFT-first and the despread-first LS kernels are interchangeable for Nt <= 64 (the
-    default switches at Nt = 32 on measured speed); force each one."""
-    monkeypatch.setenv('CSI_LS_FFT_FIRST_MAX', thr)
-    rng = np.random.default_rng(int(thr) + 3)
-    for nt, nr in ((8, 2), (32, 3), (64, 2)):
-        P = _pilot(rng, nt)
-        ltf, H = oracle.make_structured_packets(rng, 3, nr, P, snr_db=None)
+@pytest.mark.parametrize('kernel', [1, 2, 3])
+def test_ls_all_kernels_agree(pkg, oracle, kernel):
+    """The three LS kernels (1 FFT-first, 2 chunked FFT-first, 3 despread-first) against the oracle on
+    every Nt each of them serves, incl. partial MFMA tiles and partial symbol chunks (Nt = 40, 72, 100)
+    and many more items than resident workgroups (persistent loops)."""
+    rng = np.random.default_rng(kernel + 3)
+    cases = {1: ((8, 2, 3), (32, 3, 3), (64, 2, 3), (40, 1, 2)),
+             2: ((40, 2, 3), (64, 2, 3), (72, 1, 2), (96, 2, 2), (100, 1, 2), (128, 2, 2), (64, 4, 300)),
+             3: ((8, 2, 3), (64, 2, 3), (72, 1, 2), (128, 2, 2), (160, 1, 1))}[kernel]
+    for nt, nr, npkt in cases:
+        P = _pilot(rng, nt) if nt & (nt - 1) == 0 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+        if npkt > 10:
+            ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+        else:
+            ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
         e = pkg.CsiEngine(nt, nr, hidden=(8,))
+        e.set_option('ls_kernel', kernel)
         e.set_pilot(P)
         h = e.ls_estimate(ltf)
-        assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([H.real, H.imag], -1)) < TOL
+        sel = slice(None) if npkt <= 10 else np.r_[0:2, npkt - 2:npkt]
+        ref = oracle.ls_estimate(np.asarray(ltf)[sel].astype(np.complex64), P)
+        assert rel_rows(np.concatenate([h[sel].real, h[sel].imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL, (nt, nr, npkt)
+        if npkt > 10:       # persistent walk: every item written, and identical on a second run
+            assert np.isfinite(h.view(np.float32)).all() and np.abs(h).sum(axis=(1, 2, 3)).min() > 0
+            assert np.array_equal(h, e.ls_estimate(ltf))
 
 
 @pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 2), (32, 2, 1), (40, 1, 1)])
