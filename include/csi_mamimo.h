@@ -132,7 +132,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "force_tile"       128 | 256: row-tile height of every GEMM (0 = chosen by grid size)
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
- *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 32, max 64)
+ *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
  *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt); a choice the
  *                         kernel cannot serve falls back to the automatic one */
