@@ -173,6 +173,7 @@ double run_bf16_pp(const char* name, GemmBf16Args g, int splits, int iters) {
     return med;
 }
 
+
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "bf16") {
         const int M = 262144, H = 1024;
