@@ -9,7 +9,7 @@ from ._lib import CsiError, build_library, library_path, load_library   # noqa: 
 from .engine import CsiEngine, DeviceArray                              # noqa: F401
 from .model import CSIModel, load_weight_file, save_weight_file         # noqa: F401
 from .inference import CSIPredictor                                     # noqa: F401
-from . import synth, dist, dataset                                      # noqa: F401
+from . import synth, dist, dataset, trainer                             # noqa: F401
 
 __all__ = ['CsiEngine', 'DeviceArray', 'CSIModel', 'CSIPredictor', 'CsiError', 'build_library',
-           'library_path', 'load_library', 'load_weight_file', 'save_weight_file', 'synth', 'dist', 'dataset']
+           'library_path', 'load_library', 'load_weight_file', 'save_weight_file', 'synth', 'dist', 'dataset', 'trainer']

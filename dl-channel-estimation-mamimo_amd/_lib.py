@@ -39,6 +39,11 @@ class CsiTensor(ctypes.Structure):
                 ('rows', ctypes.c_int64), ('cols', ctypes.c_int64)]
 
 
+class CsiTrainConfig(ctypes.Structure):
+    _fields_ = [('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float),
+                ('bn_momentum', ctypes.c_float), ('dropout', ctypes.c_float), ('seed', ctypes.c_uint64)]
+
+
 _fp = ctypes.POINTER(ctypes.c_float)
 _vp = ctypes.c_void_p
 _ctx = ctypes.c_void_p
@@ -58,6 +63,12 @@ SYMBOLS = {
     'csi_ls_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     'csi_lmmse_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, ctypes.c_int, _fp, _fp, _fp]),
     'csi_lmmse_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    'csi_train_begin': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(CsiTrainConfig), ctypes.POINTER(CsiTensor), ctypes.c_int]),
+    'csi_train_step': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, ctypes.c_float, _fp]),
+    'csi_train_eval': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, _fp]),
+    'csi_train_set_lr': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_float]),
+    'csi_train_get': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_char_p, _fp, ctypes.c_int64]),
+    'csi_train_end': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int]),
     'csi_synchronize': (ctypes.c_int, [_ctx]),
     'csi_set_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
     'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),

@@ -34,11 +34,14 @@ enum KernelId {
     K_CAST_BF16,         // fp32 -> bf16 of the preambles (bf16 mode)
     K_PAIR_H1_BF16,      // materialise h1 in bf16 (bf16 mode)
     K_LMMSE,             // Levinson solve of the LMMSE smoother
+    K_TRAIN_GEMM,        // forward / dgrad / wgrad products of csi_train_step
+    K_TRAIN_ELEMWISE,    // BatchNormalization, dropout, loss, Adam of csi_train_step
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
-    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson"};
+    "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson",
+    "train_gemm", "train_elementwise"};
 
 thread_local std::string g_create_error;
 
@@ -76,12 +79,15 @@ struct ProfSpan {
 
 }  // namespace
 
+struct csi_trainer;          // csi_train.hpp
+
 struct csi_ctx {
     csi_config cfg;
     int d_in = 0;
     hipStream_t stream = nullptr;
     std::string err;
     Model model[2];
+    csi_trainer* trainer[2] = {nullptr, nullptr};   // on-box fine-tuning state per component model
     float* P = nullptr;          // device [nt][nt]
     float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)
     bool pilot_ok = false;

@@ -11,6 +11,7 @@
 #include "csi_context.hpp"
 #include "csi_dnn_f32.hpp"
 #include "csi_dnn_bf16.hpp"
+#include "csi_train.hpp"
 
 namespace {
 
@@ -195,6 +196,7 @@ void csi_destroy(csi_ctx* c) {
     drop_graphs(c);
     free_model(c->model[0]);
     free_model(c->model[1]);
+    for (int d = 0; d < 2; ++d) tr_free(c->trainer[d]);
     if (c->P) hipFree(c->P);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->tw) hipFree(c->tw);
@@ -517,6 +519,98 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         return fail(c, CSI_ERR_INVALID_ARG, "csi_set_option: unknown option '%s'", name);
     }
     return CSI_OK;
+}
+
+
+// ---------------------------------------------------------------- on-box fine-tuning
+static int trainer_of(csi_ctx* c, int model, const char* fn, csi_trainer** t) {
+    if (model < 0 || model > 1) return fail(c, CSI_ERR_INVALID_ARG, "%s: model must be 0 or 1", fn);
+    if (!c->trainer[model]) return fail(c, CSI_ERR_NOT_READY, "%s: csi_train_begin was not called for model %d", fn, model);
+    *t = c->trainer[model];
+    return CSI_OK;
+}
+
+int csi_train_begin(csi_ctx* c, int model, const csi_train_config* tc, const csi_tensor* tensors, int n) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (model < 0 || model > 1 || !tc || n < 0 || (n > 0 && !tensors)) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_begin: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int rc = tr_begin(c, model, tc, tensors, n);
+    if (rc && c->trainer[model]) { tr_free(c->trainer[model]); c->trainer[model] = nullptr; }
+    return rc;
+}
+
+int csi_train_step(csi_ctx* c, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_step", &t)) return rc0;
+    if (!x || !y || B < 2 || B > (1 << 20) || noise_std < 0.f) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_step: bad argument (2 <= B <= 2^20)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_step(c, t, x, y, (int)B, noise_std, loss);
+}
+
+int csi_train_eval(csi_ctx* c, int model, const float* x, const float* y, int64_t B, float* loss) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_eval", &t)) return rc0;
+    if (!x || !y || !loss || B < 1 || B > (1 << 20)) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_eval: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_eval(c, t, x, y, (int)B, loss);
+}
+
+int csi_train_set_lr(csi_ctx* c, int model, float lr) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_set_lr", &t)) return rc0;
+    if (!(lr > 0.f)) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_set_lr: lr must be positive");
+    t->tc.lr = lr;
+    return CSI_OK;
+}
+
+int csi_train_get(csi_ctx* c, int model, const char* name, float* out, int64_t count) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_get", &t)) return rc0;
+    if (!name || !out || count <= 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_get: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_get(c, t, name, out, count);
+}
+
+int csi_train_end(csi_ctx* c, int model, int commit) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_end", &t)) return rc0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = CSI_OK;
+    if (commit) {
+        // hand the trained tensors to the inference model exactly as a caller of csi_load_weights would
+        const csi_config& cf = c->cfg;
+        std::vector<std::string> names;
+        std::vector<std::vector<float>> data;
+        std::vector<std::pair<int64_t, int64_t>> shape;
+        auto add = [&](const std::string& nm, int64_t r, int64_t q) {
+            names.push_back(nm);
+            shape.push_back({r, q});
+            data.emplace_back((size_t)(r * q));
+        };
+        for (int li = 0; li <= cf.n_hidden; ++li) {
+            const auto& l = t->layers[li];
+            const std::string base = li == cf.n_hidden ? std::string("fc_regressor") : "fc_dense" + std::to_string(li);
+            add(base + ".kernel", l.in, l.out);
+            add(base + ".bias", 1, l.out);
+            if (li < cf.n_hidden && cf.use_bn)
+                for (const char* sfx : {".gamma", ".beta", ".moving_mean", ".moving_variance"}) add("bn" + std::to_string(li) + sfx, 1, l.out);
+        }
+        std::vector<csi_tensor> ts(names.size());
+        for (size_t i = 0; i < names.size() && !rc; ++i) {
+            rc = tr_get(c, t, names[i].c_str(), data[i].data(), (int64_t)data[i].size());
+            ts[i] = csi_tensor{names[i].c_str(), data[i].data(), shape[i].first, shape[i].second};
+        }
+        if (!rc) rc = csi_load_weights(c, model, ts.data(), (int)ts.size());
+    }
+    hipStreamSynchronize(c->stream);
+    tr_free(t);
+    c->trainer[model] = nullptr;
+    return rc;
 }
 
 int csi_synchronize(csi_ctx* c) {

@@ -139,6 +139,89 @@ class CsiEngine:
             n += 1
         self._check(self._lib.csi_load_weights(self._ctx, int(idx), arr, n))
 
+    # ------------------------------------------------------------------ on-box fine-tuning (csi_train_*)
+    def _tensor_array(self, weights):
+        keep, arr = [], (_lib.CsiTensor * max(1, len(weights)))()
+        n = 0
+        for name, val in weights.items():
+            if not isinstance(val, np.ndarray):
+                continue
+            a = _f32c(val)
+            keep.append(a)
+            arr[n].name = name.encode()
+            arr[n].data = _fp(a)
+            arr[n].rows = a.shape[0] if a.ndim == 2 else 1
+            arr[n].cols = a.shape[1] if a.ndim == 2 else a.size
+            n += 1
+        return keep, arr, n
+
+    def train_begin(self, model, weights=None, lr=1e-4, dropout=0.15, seed=0, beta1=0.9, beta2=0.999, eps=1e-7,
+                    bn_momentum=0.99):
+        """Trainer of one component model (reference: Adam(lr), --dropout, keras defaults elsewhere;
+        massiveMIMO_CSI_prediction_DNN.py:16,19,272).  weights=None: Glorot-uniform initialisation."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        tc = _lib.CsiTrainConfig(lr=lr, beta1=beta1, beta2=beta2, eps=eps, bn_momentum=bn_momentum, dropout=dropout, seed=seed)
+        keep, arr, n = self._tensor_array(weights or {})
+        self._check(self._lib.csi_train_begin(self._ctx, int(idx), ctypes.byref(tc), arr if n else None, n))
+
+    def train_step(self, model, x, y, noise_std=0.0):
+        """One optimiser step on the rows x [B, len_ltf+nt], labels y [B, n_out]; returns the batch loss."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        x, y = _f32c(x), _f32c(y)
+        if x.ndim != 2 or x.shape[1] != self.d_in or y.shape != (x.shape[0], self.n_out):
+            raise CsiError(-1, f'x must be [B,{self.d_in}] and y [B,{self.n_out}], got {x.shape} / {y.shape}')
+        loss = ctypes.c_float()
+        self._check(self._lib.csi_train_step(self._ctx, int(idx), _fp(x), _fp(y), x.shape[0], float(noise_std), ctypes.byref(loss)))
+        return float(loss.value)
+
+    def train_eval(self, model, x, y):
+        """mse of the current trainer parameters in inference mode (the reference's val_loss)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        x, y = _f32c(x), _f32c(y)
+        if x.ndim != 2 or x.shape[1] != self.d_in or y.shape != (x.shape[0], self.n_out):
+            raise CsiError(-1, f'x must be [B,{self.d_in}] and y [B,{self.n_out}], got {x.shape} / {y.shape}')
+        loss = ctypes.c_float()
+        self._check(self._lib.csi_train_eval(self._ctx, int(idx), _fp(x), _fp(y), x.shape[0], ctypes.byref(loss)))
+        return float(loss.value)
+
+    def train_set_lr(self, model, lr):
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        self._check(self._lib.csi_train_set_lr(self._ctx, int(idx), float(lr)))
+
+    def train_tensor_names(self):
+        names = []
+        for i, _ in enumerate(self.hidden):
+            names += [f'fc_dense{i}.kernel', f'fc_dense{i}.bias']
+            if self.use_bn:
+                names += [f'bn{i}.gamma', f'bn{i}.beta', f'bn{i}.moving_mean', f'bn{i}.moving_variance']
+        return names + ['fc_regressor.kernel', 'fc_regressor.bias']
+
+    def _train_shape(self, name):
+        base = name[5:] if name.startswith('grad:') else name
+        widths = (self.d_in,) + self.hidden
+        if base.startswith('fc_regressor'):
+            fan_in, out = self.hidden[-1], self.n_out
+        else:
+            i = int(''.join(ch for ch in base.split('.')[0] if ch.isdigit()))
+            fan_in, out = widths[i], self.hidden[i]
+        return (fan_in, out) if base.endswith('.kernel') else (out,)
+
+    def train_get(self, model, name):
+        """One trainer tensor by keras name ('grad:<name>': gradient of the last step)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        if (name[5:] if name.startswith('grad:') else name) not in self.train_tensor_names():
+            raise CsiError(-1, f"train_get: unknown tensor '{name}'")
+        out = np.empty(self._train_shape(name), np.float32)
+        self._check(self._lib.csi_train_get(self._ctx, int(idx), name.encode(), _fp(out), out.size))
+        return out
+
+    def train_weights(self, model):
+        return {n: self.train_get(model, n) for n in self.train_tensor_names()}
+
+    def train_end(self, model, commit=True):
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        self._check(self._lib.csi_train_end(self._ctx, int(idx), int(bool(commit))))
+
     def set_pilot(self, P):
         """P [nt, nt], row j = pilot sequence of tx j (= dataset['P'][:, j],
         massiveMIMO_dataGenerator.py:311)."""

@@ -19,6 +19,7 @@
  *                                                                   csi_ls_estimate[_device]
  *   LMMSE_ce per link   helperMIMOChannelEstimate.m:37-39, LMMSE_ce.m  csi_lmmse_estimate[_device]
  *   --execTime profiler loop                       DNN.py:441-475   csi_profile_*
+ *   Model.fit step (noise, BN, dropout, Adam)       DNN.py:272-316   csi_train_*
  *
  * Conventions: every function returns 0 on success or a negative csi_status; it never calls
  * exit().  All buffers are caller-owned, row-major, contiguous float32.  A context is bound
@@ -122,6 +123,38 @@ int  csi_lmmse_estimate(csi_ctx* ctx, const float* h_re, const float* h_im, int6
                         const float* snr_db, float* out_re, float* out_im);
 int  csi_lmmse_estimate_device(csi_ctx* ctx, const float* d_h_re, const float* d_h_im, int64_t npkt, const float* d_hvec,
                                int L, const float* d_snr_db, float* d_out_re, float* d_out_im);
+
+/* ---- On-box fine-tuning: one optimiser step of the reference's fit(),
+ * massiveMIMO_CSI_prediction_DNN.py:272-316, for one component model (fp32 contexts only).
+ *   GaussianNoise on the LTF columns of x only (DNN.py:191-193; stddev per batch from the caller,
+ *   changeNoisePower DNN.py:92-100) -> Dense(relu) -> BatchNormalization(batch statistics) ->
+ *   Dropout after every hidden layer but the last (DNN.py:211-226) -> Dense(linear), loss 'mse',
+ *   Adam (DNN.py:272-273).  Keras defaults: beta1 0.9, beta2 0.999, eps 1e-7, BN momentum 0.99. */
+typedef struct {
+    float    lr;            /* --lr (1e-4)                                                  */
+    float    beta1, beta2, eps;
+    float    bn_momentum;
+    float    dropout;       /* --dropout (0.15)                                             */
+    uint64_t seed;          /* noise / dropout / initialisation streams                     */
+} csi_train_config;
+
+/* Creates the trainer of model 0 (real) / 1 (imag) from the named tensors of csi_load_weights
+ * (n > 0), or with Glorot-uniform kernels, zero biases and identity BatchNormalization (n == 0,
+ * DNN.py:213,227).  The inference model of the context is untouched until csi_train_end(commit). */
+int  csi_train_begin(csi_ctx* ctx, int model, const csi_train_config* cfg, const csi_tensor* tensors, int n);
+/* x [B][len_ltf+nt] rows as Model.fit receives them (dataGenerator.py:299-316), y [B][n_out];
+ * host buffers, synchronous when loss != NULL.  noise_std = 0 disables the AWGN layer. */
+int  csi_train_step(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss);
+/* mse of the current parameters in inference mode (running statistics, no noise, no dropout):
+ * the val_loss that EarlyStopping / ReduceLROnPlateau monitor (DNN.py:285-286). */
+int  csi_train_eval(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float* loss);
+int  csi_train_set_lr(csi_ctx* ctx, int model, float lr);
+/* Reads one tensor by its keras name (kernels as [in][out]); "grad:<name>" reads the gradient of
+ * the last step (tests). */
+int  csi_train_get(csi_ctx* ctx, int model, const char* name, float* out, int64_t count);
+/* commit != 0: loads the trained tensors into the inference model (as csi_load_weights would,
+ * pilot table included); then releases the trainer. */
+int  csi_train_end(csi_ctx* ctx, int model, int commit);
 
 int  csi_synchronize(csi_ctx* ctx);
 

@@ -442,3 +442,97 @@ def make_structured_packets(rng, npkt, nr, P, snr_db=None, n_taps=8):
         ltf = ltf + noise
     h_true = hfull[..., data_carrier_indices() - 1]                           # [p,r,j,234]
     return ltf, h_true
+
+
+# ------------------------------------------------------------------------------------------------
+# Training step.  Restates, in fp64 numpy, what keras does for the reference's
+# fit() (massiveMIMO_CSI_prediction_DNN.py:191-193 AWGN on the LTF input, :211-227 the layer stack,
+# :272-273 Adam + mse).  Keras is not available here: BatchNormalization (training: biased batch
+# variance, eps 1e-3, running statistics moved with momentum 0.99), Dropout (kept units scaled by
+# 1/(1-rate)), mse (mean over all elements) and Adam (lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+# p -= lr_t*m/(sqrt(v)+1e-7)) follow the published keras definitions - parity unpinned.
+def train_forward_backward(w, x, y, use_bn=True, bn_eps=1e-3, noise=None, masks=None, dropout=0.0):
+    """One forward/backward pass.  w: dict of keras-named tensors; x [B, d_in], y [B, n_out];
+    noise: array added to x (already scaled) or None; masks: list of keep masks (bool [B, width])
+    per hidden layer or None.  Returns (loss, grads dict, batch statistics [(mean, var), ...])."""
+    w = {k: np.asarray(v, np.float64) for k, v in w.items() if k != 'bn_eps'}
+    n_hidden = sum(1 for k in w if k.startswith('fc_dense') and k.endswith('.kernel'))
+    h = np.asarray(x, np.float64) + (0.0 if noise is None else np.asarray(noise, np.float64))
+    B = h.shape[0]
+    cache = []
+    stats = []
+    for i in range(n_hidden):
+        inp = h
+        a = np.maximum(inp @ w[f'fc_dense{i}.kernel'] + w[f'fc_dense{i}.bias'], 0.0)
+        if use_bn:
+            mu, var = a.mean(0), a.var(0)
+            istd = 1.0 / np.sqrt(var + bn_eps)
+            xhat = (a - mu) * istd
+            o = xhat * w[f'bn{i}.gamma'] + w[f'bn{i}.beta']
+            stats.append((mu, var))
+        else:
+            xhat, istd, o = None, None, a
+        keep = None
+        if masks is not None and i < n_hidden - 1 and dropout > 0.0:
+            keep = np.asarray(masks[i], bool)
+            o = np.where(keep, o / (1.0 - dropout), 0.0)
+        cache.append((inp, a, xhat, istd, keep))
+        h = o
+    out = h @ w['fc_regressor.kernel'] + w['fc_regressor.bias']
+    diff = out - np.asarray(y, np.float64)
+    loss = float(np.mean(diff ** 2))
+    g = {}
+    dout = 2.0 * diff / diff.size
+    g['fc_regressor.kernel'] = h.T @ dout
+    g['fc_regressor.bias'] = dout.sum(0)
+    dh = dout @ w['fc_regressor.kernel'].T
+    for i in range(n_hidden - 1, -1, -1):
+        inp, a, xhat, istd, keep = cache[i]
+        if keep is not None:
+            dh = np.where(keep, dh / (1.0 - dropout), 0.0)
+        if use_bn:
+            g[f'bn{i}.gamma'] = (dh * xhat).sum(0)
+            g[f'bn{i}.beta'] = dh.sum(0)
+            da = w[f'bn{i}.gamma'] * istd / B * (B * dh - g[f'bn{i}.beta'] - xhat * g[f'bn{i}.gamma'])
+        else:
+            da = dh
+        dz = da * (a > 0)
+        g[f'fc_dense{i}.kernel'] = inp.T @ dz
+        g[f'fc_dense{i}.bias'] = dz.sum(0)
+        if i > 0:
+            dh = dz @ w[f'fc_dense{i}.kernel'].T
+    return loss, g, stats
+
+
+def adam_init(w):
+    keys = [k for k in w if 'moving' not in k and k != 'bn_eps']
+    return {'t': 0, 'm': {k: np.zeros_like(np.asarray(w[k], np.float64)) for k in keys},
+            'v': {k: np.zeros_like(np.asarray(w[k], np.float64)) for k in keys}}
+
+
+def train_step_reference(w, state, x, y, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, use_bn=True, bn_eps=1e-3,
+                         bn_momentum=0.99, noise=None, masks=None, dropout=0.0):
+    """One optimiser step in fp64; returns (loss, new weights, grads).  state from adam_init (updated in place)."""
+    loss, g, stats = train_forward_backward(w, x, y, use_bn, bn_eps, noise, masks, dropout)
+    state['t'] += 1
+    t = state['t']
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    new = {k: np.asarray(v, np.float64).copy() for k, v in w.items() if k != 'bn_eps'}
+    for k, gk in g.items():
+        state['m'][k] = beta1 * state['m'][k] + (1.0 - beta1) * gk
+        state['v'][k] = beta2 * state['v'][k] + (1.0 - beta2) * gk * gk
+        new[k] = new[k] - lr_t * state['m'][k] / (np.sqrt(state['v'][k]) + eps)
+    for i, (mu, var) in enumerate(stats):
+        new[f'bn{i}.moving_mean'] = new[f'bn{i}.moving_mean'] * bn_momentum + mu * (1.0 - bn_momentum)
+        new[f'bn{i}.moving_variance'] = new[f'bn{i}.moving_variance'] * bn_momentum + var * (1.0 - bn_momentum)
+    return loss, new, g
+
+
+def eval_loss_reference(w, x, y, use_bn=True, bn_eps=1e-3):
+    """Inference-mode mse (val_loss)."""
+    ww = dict(w)
+    ww['bn_eps'] = bn_eps
+    if not use_bn:
+        ww = {k: v for k, v in ww.items() if not k.startswith('bn') or k == 'bn_eps'}
+    out = fc_forward(np.asarray(x, np.float64), ww, np.float64)
+    return float(np.mean((out - np.asarray(y, np.float64)) ** 2))
