@@ -1,6 +1,8 @@
 """Command-line twin of the reference's test run
 (``massiveMIMO_CSI_prediction_DNN.py --test``, lines 330-411, driven by
-full_pipeline_maMIMO_DNNEst.sh:47):
+full_pipeline_maMIMO_DNNEst.sh:47) and, with ``--train``, of its training run (lines 272-319,
+pipe.sh:40: ``--train -x dataset.b --nn 1024 1024 -d MODEL --bs 256 --epochs 1000 --method default_SNR --useBN``),
+which writes ``<d>_weights-improvement.safetensors`` into the work directory:
 
     python -m dl_channel_estimation_mamimo_amd.cli --test -x testDataset.b --modeldir MODEL \\
            -d OUT --nn 1024 1024 --useBN --datasource matlab_maMimo
@@ -20,7 +22,18 @@ import numpy as np
 
 def build_parser():
     p = argparse.ArgumentParser(description='Test CSI prediction network on MI355X')
-    p.add_argument('--test', action='store_true', help='(kept for command-line compatibility; this tool only tests)')
+    p.add_argument('--test', action='store_true', help='test run (default)')
+    p.add_argument('--train', action='store_true', help='train both component models on the dataset (on-box fine-tuning)')
+    p.add_argument('--epochs', default=500, type=int)
+    p.add_argument('--lr', default=0.0001, type=float)
+    p.add_argument('--bs', default=256, type=int)
+    p.add_argument('--method', default='default', help="'default_SNR': AWGN on the LTF input at a random SNR per batch")
+    p.add_argument('--valTrainRatio', default=0.15, type=float)
+    p.add_argument('--valSameTrain', action='store_true')
+    p.add_argument('--onlyReal', action='store_true')
+    p.add_argument('--onlyImag', action='store_true')
+    p.add_argument('--init', default='', help='folder with weights to start from (default: Glorot-uniform initialisation)')
+    p.add_argument('--seed', default=0, type=int)
     p.add_argument('--model', default='FC', help='DNN model type; only FC is on this path')
     p.add_argument('-x', required=True, help='dataset pickle written by create_massiveMIMO_CSIest_dnn_dataset.py')
     p.add_argument('--datasource', default='matlab_maMimo')
@@ -28,7 +41,7 @@ def build_parser():
     p.add_argument('--modeldir', default='', help='folder holding {real,imag}_keras_model/ or <d>_weights-improvement.safetensors')
     p.add_argument('--nn', default=[256, 128], type=int, nargs='+', help='neurons per hidden layer')
     p.add_argument('--useBN', action='store_true')
-    p.add_argument('--dropout', default=0.15, type=float, help='ignored at inference (identity)')
+    p.add_argument('--dropout', default=0.15, type=float, help='training only; identity at inference')
     p.add_argument('--execTime', action='store_true', help='print per-kernel HIP-event times')
     p.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     p.add_argument('--device', default=0, type=int)
@@ -46,12 +59,49 @@ def _find_weights(modeldir, d):
     sys.exit(0)
 
 
+def train_main(args):
+    """--train: DNN.py:104-111 (work directory), :124-151 (split + generators), :272-319 (fit, save)."""
+    from . import dataset as ds
+    from . import trainer
+    from .engine import CsiEngine
+    from .model import load_weight_file, save_weight_file
+    os.makedirs(args.workdir, exist_ok=True)
+    data = ds.load_dataset(args.x)
+    sim = data['simParams']
+    nt, nr = int(sim['nTX']), int(sim['nRX'])
+    n_out = int(np.asarray(data['y']['real']).shape[1])
+    if args.valSameTrain:
+        print('WARNING! Validation SAME AS Training!')
+        train_ids = val_ids = list(range(int(np.asarray(data['X']).shape[0])))
+    else:
+        print('Validation separate from Training')
+        train_ids, val_ids = ds.split_train_val(data, args.valTrainRatio)
+    eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=args.device)
+    dims = ['real'] if args.onlyReal else (['imag'] if args.onlyImag else ['real', 'imag'])
+    for d in dims:
+        print('Working on *', d, '* model')
+        tr = ds.SampleGenerator(train_ids, data, d, batch_size=args.bs, shuffle=True, seed=args.seed)
+        va = ds.SampleGenerator(val_ids, data, d, batch_size=args.bs, shuffle=True, seed=args.seed + 1)
+        if len(tr) == 0 or len(va) == 0:
+            print('Not enough samples for one batch of %d in the training / validation split. Aborting...' % args.bs)
+            sys.exit(0)
+        init = load_weight_file(_find_weights(args.init, d)) if args.init else None
+        hist = trainer.fit(eng, d, tr, va, epochs=args.epochs, lr=args.lr, dropout=args.dropout, weights=init,
+                           method=args.method, seed=args.seed)
+        path = os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.safetensors')
+        save_weight_file(path, hist['weights'])
+        print('%s model: best val_loss %.6e after %d epochs; weights saved to %s' % (d, hist['best_val_loss'], len(hist['loss']), path))
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.model != 'FC' or args.datasource != 'matlab_maMimo':
         print('Only --model FC --datasource matlab_maMimo is on the MI355X path. Aborting...')
         sys.exit(0)
     modeldir = args.modeldir or args.workdir
+    if args.train:
+        return train_main(args)
     if not os.path.isdir(args.workdir):
         print('Given directory does not exists. Aborting...')          # DNN.py:113-115
         sys.exit(0)

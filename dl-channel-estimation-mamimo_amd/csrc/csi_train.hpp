@@ -136,7 +136,7 @@ int tr_forward(csi_ctx* c, csi_trainer* t, int B, bool training) {
             if (rc) return rc;
             const float p = li < nh - 1 ? t->tc.dropout : 0.f;
             ProfScope ps(c, K_TRAIN_ELEMWISE, 8.0 * B * l.out, 12.0 * B * l.out);
-            hipLaunchKernelGGL(bn_dropout_forward_kernel, dim3((l.out + 63) / 64), dim3(64), 0, c->stream, l.a, l.h, B, l.out, l.ldo,
+            hipLaunchKernelGGL(bn_dropout_forward_kernel, dim3((l.out + TRC - 1) / TRC), dim3(TRC, TRC), 0, c->stream, l.a, l.h, B, l.out, l.ldo,
                                cf.use_bn, l.gamma, l.beta, l.mmean, l.mvar, l.mu, l.istd, cf.bn_eps, t->tc.bn_momentum, p, tr_stream(t, li));
             HIP_TRY(c, hipGetLastError());
         } else {
@@ -159,10 +159,10 @@ int tr_forward(csi_ctx* c, csi_trainer* t, int B, bool training) {
 
 int tr_loss(csi_ctx* c, csi_trainer* t, int B, bool want_grad, float* h_loss) {
     auto& r = t->layers.back();
-    const int nblk = (r.out + 63) / 64;
+    const int nblk = (r.out + TRC - 1) / TRC;
     {
         ProfScope ps(c, K_TRAIN_ELEMWISE, 4.0 * B * r.out, 16.0 * B * r.out);
-        hipLaunchKernelGGL(mse_grad_kernel, dim3(nblk), dim3(64), 0, c->stream, t->out, t->y, t->dout, t->doutt, r.gb, t->partial, B, r.out,
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(nblk), dim3(TRC, TRC), 0, c->stream, t->out, t->y, t->dout, t->doutt, r.gb, t->partial, B, r.out,
                            r.ldo, t->ldb, want_grad ? 1 : 0);
         hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, t->partial, nblk, 1.0f / ((float)B * (float)r.out), t->loss);
         HIP_TRY(c, hipGetLastError());
@@ -241,7 +241,7 @@ int tr_step(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, f
         const float p = li < nh - 1 ? t->tc.dropout : 0.f;
         {
             ProfScope ps(c, K_TRAIN_ELEMWISE, 12.0 * B * l.out, 20.0 * B * l.out);
-            hipLaunchKernelGGL(bn_dropout_backward_kernel, dim3((l.out + 63) / 64), dim3(64), 0, c->stream, t->dh[cur], l.a, t->dz, t->dzt, B,
+            hipLaunchKernelGGL(bn_dropout_backward_kernel, dim3((l.out + TRC - 1) / TRC), dim3(TRC, TRC), 0, c->stream, t->dh[cur], l.a, t->dz, t->dzt, B,
                                l.out, l.ldo, t->ldb, cf.use_bn, l.gamma, l.mu, l.istd, l.ggamma, l.gbeta, l.gb, p, tr_stream(t, li));
             HIP_TRY(c, hipGetLastError());
         }
@@ -388,10 +388,10 @@ int tr_begin(csi_ctx* c, int model, const csi_train_config* tc, const csi_tensor
         fan_in = l.out;
     }
     t->maxw = maxw;
-    if ((cf.n_out + 63) / 64 > 64) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_begin: n_out above 4096 is not supported");
+    if ((cf.n_out + TRC - 1) / TRC > 128) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_begin: n_out above 4096 is not supported");
     rc |= tr_alloc(c, t, &t->ones, maxw);
     rc |= tr_alloc(c, t, &t->zeros, maxw);
-    rc |= tr_alloc(c, t, &t->partial, 64);
+    rc |= tr_alloc(c, t, &t->partial, 128);
     rc |= tr_alloc(c, t, &t->loss, 4);
     if (rc) return CSI_ERR_NOMEM;
     rc = tr_fill(c, t->ones, maxw, 1.f);

@@ -75,34 +75,63 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
-// BatchNormalization (training) + Dropout over a [B][F] post-relu activation a.
+// Column kernels: a workgroup of 32 x 32 threads owns 32 feature columns; thread (tx, ty) walks the
+// rows ty, ty+32, ... (a wave reads two 128-byte row segments per step) and column sums are
+// combined through LDS in a fixed order (deterministic).
+constexpr int TRC = 32;
+
+__device__ __forceinline__ float tr_col_sum(float v, float (*red)[TRC + 1], int tx, int ty) {
+    red[ty][tx] = v;
+    __syncthreads();
+    if (ty == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TRC; ++i) s += red[i][tx];
+        red[0][tx] = s;
+    }
+    __syncthreads();
+    const float r = red[0][tx];
+    __syncthreads();
+    return r;
+}
+
+// BatchNormalization (training) + Dropout over a [B][F] post-relu activation a (row pitch ld).
 //   mu = mean_b a, var = mean_b (a-mu)^2, xhat = (a-mu)*rsqrt(var+eps), h = keep*(gamma*xhat+beta)/(1-p)
-// One thread per feature; saves mu / inv_std for the backward pass, moves the running statistics
-// (keras: moving = moving*momentum + batch*(1-momentum); the variance moved is the biased one).
+// Saves mu / inv_std for the backward pass, moves the running statistics (keras:
+// moving = moving*momentum + batch*(1-momentum); the variance moved is the biased one).
 // use_bn == 0: h = keep*a/(1-p).   p == 0: no dropout.
-__global__ void bn_dropout_forward_kernel(const float* __restrict__ a, float* __restrict__ h, int B, int F, int ld, int use_bn,
-                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          float* __restrict__ mmean, float* __restrict__ mvar, float* __restrict__ mu_out,
-                                          float* __restrict__ istd_out, float eps, float momentum, float p, uint64_t stream) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= F) return;
+__global__ __launch_bounds__(TRC * TRC) void bn_dropout_forward_kernel(const float* __restrict__ a, float* __restrict__ h, int B, int F, int ld,
+                                                                        int use_bn, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, float* __restrict__ mmean,
+                                                                        float* __restrict__ mvar, float* __restrict__ mu_out,
+                                                                        float* __restrict__ istd_out, float eps, float momentum, float p,
+                                                                        uint64_t stream) {
+    __shared__ float red[TRC][TRC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int j = blockIdx.x * TRC + tx;
+    const bool ok = j < F;
     float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
     if (use_bn) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += a[(size_t)b * ld + j];
-        mu = s / (float)B;
+        if (ok) for (int b = ty; b < B; b += TRC) s += a[(size_t)b * ld + j];
+        mu = tr_col_sum(s, red, tx, ty) / (float)B;
         float q = 0.f;
-        for (int b = 0; b < B; ++b) { const float d = a[(size_t)b * ld + j] - mu; q = fmaf(d, d, q); }
-        const float var = q / (float)B;
+        if (ok) for (int b = ty; b < B; b += TRC) { const float d = a[(size_t)b * ld + j] - mu; q = fmaf(d, d, q); }
+        const float var = tr_col_sum(q, red, tx, ty) / (float)B;
         is = 1.0f / sqrtf(var + eps);
-        ga = gamma[j]; be = beta[j];
-        mmean[j] = mmean[j] * momentum + mu * (1.f - momentum);
-        mvar[j] = mvar[j] * momentum + var * (1.f - momentum);
-        mu_out[j] = mu;
-        istd_out[j] = is;
+        if (ok) {
+            ga = gamma[j]; be = beta[j];
+            if (ty == 0) {
+                mmean[j] = mmean[j] * momentum + mu * (1.f - momentum);
+                mvar[j] = mvar[j] * momentum + var * (1.f - momentum);
+                mu_out[j] = mu;
+                istd_out[j] = is;
+            }
+        }
     }
+    if (!ok) return;
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = ty; b < B; b += TRC) {
         float v = a[(size_t)b * ld + j];
         if (use_bn) v = fmaf((v - mu) * is, ga, be);
         if (p > 0.f) v = tr_uniform(stream, (uint64_t)b * F + j) >= p ? v * keep_scale : 0.f;
@@ -113,71 +142,107 @@ __global__ void bn_dropout_forward_kernel(const float* __restrict__ a, float* __
 // Backward of Dropout -> BatchNormalization(training) -> relu for one hidden layer.
 //   dy = dh*keep/(1-p);  dgamma = sum dy*xhat, dbeta = sum dy
 //   da = gamma*istd/B * (B*dy - dbeta - xhat*dgamma);  dz = da * (a > 0);  dbias = sum dz
-// Writes dz [B][F] and its transpose dzt [F][ldt] (wgrad operand).
-__global__ void bn_dropout_backward_kernel(const float* __restrict__ dh, const float* __restrict__ a, float* __restrict__ dz,
-                                           float* __restrict__ dzt, int B, int F, int ld, int ldt, int use_bn,
-                                           const float* __restrict__ gamma, const float* __restrict__ mu_in,
-                                           const float* __restrict__ istd_in, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                           float* __restrict__ dbias, float p, uint64_t stream) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= F) return;
+// Writes dz [B][F] and its transpose dzt [F][ldt] (wgrad operand; through an LDS tile so that both
+// stores are coalesced).
+__global__ __launch_bounds__(TRC * TRC) void bn_dropout_backward_kernel(const float* __restrict__ dh, const float* __restrict__ a,
+                                                                         float* __restrict__ dz, float* __restrict__ dzt, int B, int F, int ld,
+                                                                         int ldt, int use_bn, const float* __restrict__ gamma,
+                                                                         const float* __restrict__ mu_in, const float* __restrict__ istd_in,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                         float* __restrict__ dbias, float p, uint64_t stream) {
+    __shared__ float red[TRC][TRC + 1];
+    __shared__ float tile[TRC][TRC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int f0 = blockIdx.x * TRC;
+    const int j = f0 + tx;
+    const bool ok = j < F;
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    auto dy_at = [&](int b) {
+        float dy = dh[(size_t)b * ld + j];
+        if (p > 0.f) dy = tr_uniform(stream, (uint64_t)b * F + j) >= p ? dy * keep_scale : 0.f;
+        return dy;
+    };
     float mu = 0.f, is = 1.f, ga = 1.f, sdy = 0.f, sdyx = 0.f;
     if (use_bn) {
-        mu = mu_in[j]; is = istd_in[j]; ga = gamma[j];
-        for (int b = 0; b < B; ++b) {
-            float dy = dh[(size_t)b * ld + j];
-            if (p > 0.f) dy = tr_uniform(stream, (uint64_t)b * F + j) >= p ? dy * keep_scale : 0.f;
-            const float xh = (a[(size_t)b * ld + j] - mu) * is;
-            sdy += dy;
-            sdyx = fmaf(dy, xh, sdyx);
-        }
-        dgamma[j] = sdyx;
-        dbeta[j] = sdy;
+        if (ok) { mu = mu_in[j]; is = istd_in[j]; ga = gamma[j]; }
+        float s0 = 0.f, s1 = 0.f;
+        if (ok)
+            for (int b = ty; b < B; b += TRC) {
+                const float dy = dy_at(b);
+                s0 += dy;
+                s1 = fmaf(dy, (a[(size_t)b * ld + j] - mu) * is, s1);
+            }
+        sdy = tr_col_sum(s0, red, tx, ty);
+        sdyx = tr_col_sum(s1, red, tx, ty);
+        if (ok && ty == 0) { dgamma[j] = sdyx; dbeta[j] = sdy; }
     }
     float sb = 0.f;
     const float invB = 1.f / (float)B;
-    for (int b = 0; b < B; ++b) {
-        float dy = dh[(size_t)b * ld + j];
-        if (p > 0.f) dy = tr_uniform(stream, (uint64_t)b * F + j) >= p ? dy * keep_scale : 0.f;
-        const float av = a[(size_t)b * ld + j];
-        float da = dy;
-        if (use_bn) {
-            const float xh = (av - mu) * is;
-            da = ga * is * (dy - invB * sdy - invB * xh * sdyx);
+    for (int b0 = 0; b0 < B; b0 += TRC) {
+        const int b = b0 + ty;
+        float g = 0.f;
+        if (ok && b < B) {
+            const float dy = dy_at(b);
+            const float av = a[(size_t)b * ld + j];
+            float da = dy;
+            if (use_bn) da = ga * is * (dy - invB * sdy - invB * ((av - mu) * is) * sdyx);
+            g = av > 0.f ? da : 0.f;
+            dz[(size_t)b * ld + j] = g;
+            sb += g;
         }
-        const float g = av > 0.f ? da : 0.f;
-        dz[(size_t)b * ld + j] = g;
-        dzt[(size_t)j * ldt + b] = g;
-        sb += g;
+        tile[ty][tx] = g;                        // [row][feature]
+        __syncthreads();
+        const int fo = f0 + ty, bo = b0 + tx;    // transposed store: feature = ty, row = tx
+        if (fo < F && bo < B) dzt[(size_t)fo * ldt + bo] = tile[tx][ty];
+        __syncthreads();
     }
-    dbias[j] = sb;
+    const float tot = tr_col_sum(sb, red, tx, ty);
+    if (ok && ty == 0) dbias[j] = tot;
 }
 
 // mse loss and its gradient for the regressor output: loss = mean (out-y)^2 over B*N elements,
-// dout = 2 (out-y)/(B*N); also dout^T [N][ldt] and dbias[n] = sum_b dout.  One workgroup per
-// 64 output columns; partial losses per workgroup are combined by loss_finish_kernel (fixed order).
-__global__ __launch_bounds__(64) void mse_grad_kernel(const float* __restrict__ out, const float* __restrict__ y, float* __restrict__ dout,
-                                                      float* __restrict__ doutt, float* __restrict__ dbias, float* __restrict__ partial,
-                                                      int B, int N, int ldo, int ldt, int want_grad) {
-    const int n = blockIdx.x * 64 + threadIdx.x;
-    float acc = 0.f, sb = 0.f;
+// dout = 2 (out-y)/(B*N); also dout^T [N][ldt] and dbias[n] = sum_b dout.  One workgroup per 32
+// output columns; the per-workgroup partial losses are combined by loss_finish_kernel (fixed order).
+__global__ __launch_bounds__(TRC * TRC) void mse_grad_kernel(const float* __restrict__ out, const float* __restrict__ y, float* __restrict__ dout,
+                                                              float* __restrict__ doutt, float* __restrict__ dbias, float* __restrict__ partial,
+                                                              int B, int N, int ldo, int ldt, int want_grad) {
+    __shared__ float red[TRC][TRC + 1];
+    __shared__ float tile[TRC][TRC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int n0 = blockIdx.x * TRC;
+    const int n = n0 + tx;
+    const bool ok = n < N;
     const float sc = 2.0f / ((float)B * (float)N);
-    if (n < N) {
-        for (int b = 0; b < B; ++b) {
+    float acc = 0.f, sb = 0.f;
+    for (int b0 = 0; b0 < B; b0 += TRC) {
+        const int b = b0 + ty;
+        float g = 0.f;
+        if (ok && b < B) {
             const float d = out[(size_t)b * ldo + n] - y[(size_t)b * N + n];
             acc = fmaf(d, d, acc);
-            if (want_grad) {
-                const float g = sc * d;
-                dout[(size_t)b * ldo + n] = g;
-                doutt[(size_t)n * ldt + b] = g;
-                sb += g;
-            }
+            g = sc * d;
+            if (want_grad) dout[(size_t)b * ldo + n] = g;
+            sb += g;
         }
-        if (want_grad) dbias[n] = sb;
+        if (want_grad) {
+            tile[ty][tx] = g;
+            __syncthreads();
+            const int no = n0 + ty, bo = b0 + tx;
+            if (no < N && bo < B) doutt[(size_t)no * ldt + bo] = tile[tx][ty];
+            __syncthreads();
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+    const float col = tr_col_sum(acc, red, tx, ty);
+    const float colb = tr_col_sum(sb, red, tx, ty);
+    if (want_grad && ok && ty == 0) dbias[n] = colb;
+    // sum of the 32 column totals of this workgroup
+    red[0][tx] = ok ? col : 0.f;
+    __syncthreads();
+    if (tx == 0 && ty == 0) {
+        float s = 0.f;
+        for (int i = 0; i < TRC; ++i) s += red[0][i];
+        partial[blockIdx.x] = s;
+    }
 }
 __global__ void loss_finish_kernel(const float* __restrict__ partial, int n, float inv_count, float* __restrict__ loss) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {

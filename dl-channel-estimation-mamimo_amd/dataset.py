@@ -98,3 +98,66 @@ def export_predictions(workdir, packed, out_real, out_imag):
         files[d] = export_packet_mats(workdir, d, x_rows, np.asarray(out).reshape(npkt * nr * nt, -1),
                                       lab.reshape(npkt * nr * nt, -1), nt, nr)
     return files
+
+
+# ------------------------------------------------------------------------------------------------
+# Training-side twins: the sample split of loadDataset and the batch generator
+# the reference hands to Model.fit.
+def split_train_val(ds, val_train_ratio=0.15):
+    """(train_ids, val_ids) as massiveMIMO_dataGenerator.py:46-55 + DNN.py:124-127 build them: the
+    last floor(Npkt * ratio) PACKETS (whole packets, nTX*nRX samples each) are the validation set."""
+    sim = ds['simParams']
+    per_pkt = int(sim['nTX']) * int(sim['nRX'])
+    n = int(np.asarray(ds['X']).shape[0])
+    if n % per_pkt:
+        print('Num. of packets is not an integer. Please double check --nTX and --nRX arguments to match the provided dataset. Aborting...')
+        raise SystemExit(-1)                                                   # gen.py:47-50
+    n_val = int(np.floor((n // per_pkt) * val_train_ratio)) * per_pkt
+    return list(range(n - n_val)), list(range(n - n_val, n))
+
+
+class SampleGenerator:
+    """Twin of the reference's DataGenerator for datasource 'matlab_maMimo', method 'default' /
+    'default_SNR' (massiveMIMO_dataGenerator.py:213-316): ``gen[b] -> ([Xsig [bs,lenLTF,1], Xp [bs,nTX]], y [bs,nSubCarr], None)``
+    with Xsig = the rx preamble of the sample's LTF key (component ``d``), Xp = dataset['P'][:, iTx];
+    floor(len(ids)/bs) batches per epoch; indexes reshuffled by on_epoch_end() when shuffle is set."""
+
+    def __init__(self, list_ids, ds, d, batch_size=256, shuffle=True, seed=None):
+        self.list_IDs = list(list_ids)
+        self.dataset = ds
+        self.d = d
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self._rng = np.random.default_rng(seed)
+        self._X = np.asarray(ds['X'])
+        self._P = np.asarray(ds['P'], dtype=np.float32)
+        self._y = np.asarray(ds['y'][d], dtype=np.float32)
+        self.on_epoch_end()
+
+    def __len__(self):
+        return int(np.floor(len(self.list_IDs) / self.batch_size))
+
+    def __getitem__(self, index):
+        idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
+        ids = [self.list_IDs[k] for k in idx]
+        len_ltf = int(np.asarray(self.dataset['LTF'][int(self._X[ids[0], 0])][self.d]).shape[0])
+        xsig = np.empty((len(ids), len_ltf, 1), np.float32)
+        xp = np.empty((len(ids), self._P.shape[0]), np.float32)
+        for i, s in enumerate(ids):
+            xsig[i, :, 0] = self.dataset['LTF'][int(self._X[s, 0])][self.d]
+            xp[i] = self._P[:, int(self._X[s, 1])]
+        return [xsig, xp], self._y[ids], None
+
+    def reorder_indexes(self):
+        self.indexes = np.arange(len(self.list_IDs))
+
+    def set_batchsize(self, bs):
+        self.batch_size = int(bs)
+
+    def get_batchsize(self):
+        return self.batch_size
+
+    def on_epoch_end(self):
+        self.indexes = np.arange(len(self.list_IDs))
+        if self.shuffle:
+            self._rng.shuffle(self.indexes)

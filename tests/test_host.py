@@ -208,3 +208,30 @@ def test_two_rank_weight_broadcast_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert 'rank 0 ok 0 6' in outs[0] and 'rank 1 ok 6 11' in outs[1]
+
+
+def test_sample_generator_matches_reference_generator(pkg, golden_dir):
+    """The training-side batch generator against the batches recorded from the reference's own
+    DataGenerator (ordered mode, batch = nTX*nRX; and its epoch length at batch size 5)."""
+    g, ds = _golden_dataset(golden_dir)
+    n = int(g['npkt']) * int(g['nr']) * int(g['nt'])
+    for d in ('real', 'imag'):
+        gen = pkg.dataset.SampleGenerator(list(range(n)), ds, d, batch_size=5, shuffle=True, seed=3)
+        assert len(gen) == int(g[f'{d}_len_bs5'])
+        first = gen[0]
+        assert first[0][0].shape == (5, 1280, 1) and first[0][1].shape == (5, 4) and first[1].shape == (5, 234) and first[2] is None
+        gen.reorder_indexes()
+        gen.set_batchsize(int(g['nt']) * int(g['nr']))
+        assert len(gen) == int(g[f'{d}_len']) and gen.get_batchsize() == 8
+        for b in range(len(gen)):
+            X, y, _ = gen[b]
+            np.testing.assert_array_equal(X[0], g[f'{d}_Xsig'][b].astype(np.float32))
+            np.testing.assert_array_equal(X[1], g[f'{d}_Xp'][b].astype(np.float32))
+            np.testing.assert_array_equal(y, g[f'{d}_y'][b].astype(np.float32))
+        # shuffling permutes the samples of an epoch, nothing else
+        gen.on_epoch_end()
+        assert sorted(gen.indexes.tolist()) == list(range(n)) and gen.indexes.tolist() != list(range(n))
+    tr, va = pkg.dataset.split_train_val(ds, 0.34)          # floor(3 * 0.34) = 1 packet of 8 samples
+    assert tr == list(range(16)) and va == list(range(16, 24))
+    tr, va = pkg.dataset.split_train_val(ds, 0.15)          # floor(0.45) = 0 packets: as in the reference
+    assert len(tr) == 24 and va == []
