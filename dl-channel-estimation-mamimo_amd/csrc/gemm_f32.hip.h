@@ -551,7 +551,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm_f32_kernel(const GemmA
 // =============================================================================================
 constexpr int P2_BM = 256;
 
-template <int EPI, int TPW, int LPW>
+template <int EPI, int TPW, int LPW, int DBG = 0>     // DBG: timing ablations of tools/gemm_probe only (1 no in-loop DMA, 2 no h1 generation, 4 no setprio, 8 no stores)
 __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const GemmArgs g) {
     constexpr int TROWS = 64 * TPW, LROWS = 64 * LPW;
     constexpr int STAGE = (128 + TROWS + LROWS) * R_BK;             // floats
@@ -663,10 +663,10 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const Ge
                 const f32x4 l = *reinterpret_cast<const f32x4*>(st + loff[mi][c]);
                 const f32x4 t = *reinterpret_cast<const f32x4*>(st + toff[mi][c]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[mi][e] = fmaf(fmaxf(l[e] + t[e], 0.f), sv[e], hv[e]);
+                for (int e = 0; e < 4; ++e) a[mi][e] = (DBG & 2) ? l[e] : fmaf(fmaxf(l[e] + t[e], 0.f), sv[e], hv[e]);
             }
-            if (MORE) issue(kt + D, c);
-            __builtin_amdgcn_s_setprio(1);      // the MFMA cluster outranks the other workgroup's loads/VALU (+4 %)
+            if (MORE && !(DBG & 1)) issue(kt + D, c);
+            if (!(DBG & 4)) __builtin_amdgcn_s_setprio(1);      // the MFMA cluster outranks the other workgroup's loads/VALU (+4 %)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -675,18 +675,19 @@ __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const Ge
                     acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b1[s], acc[mi][1], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (!(DBG & 4)) __builtin_amdgcn_s_setprio(0);
         }
     };
     int kt = 0;
     for (; kt < nkt - D; ++kt) {
-        handover(D - 1);
+        handover((DBG & 1) ? 0 : D - 1);
         ktile(kt, std::true_type{});
     }
     for (; kt < nkt; ++kt) {
-        handover(nkt - 1 - kt);
+        handover((DBG & 1) ? 0 : nkt - 1 - kt);
         ktile(kt, std::false_type{});
     }
+    if ((DBG & 8) && g.M > 0) return;
     gemm_epilogue<EPI, 4, P2_BM>(acc, g, m0, n0, wm, wn, l31, hi);
 }
 

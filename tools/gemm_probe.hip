@@ -90,17 +90,17 @@ double run_pair(const char* name, GemmArgs g, int iters, std::vector<float>* out
     return med;
 }
 
-template <int EPI>
+template <int EPI, int DBG = 0>
 double run_pair256(const char* name, GemmArgs g, int iters, std::vector<float>* out = nullptr) {
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     dim3 grid(((g.M + P2_BM - 1) / P2_BM) * g.tiles_n);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(256), 0, 0, g);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1, DBG>), grid, dim3(256), 0, 0, g);
     CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < iters; ++i) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1>), grid, dim3(256), 0, 0, g);
+        hipLaunchKernelGGL((pair_gemm256_f32_kernel<EPI, 1, 1, DBG>), grid, dim3(256), 0, 0, g);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
     }
@@ -225,6 +225,12 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         run_pair<EPI_BIAS_RELU_AFFINE, 1>("pair_dense tpw1", p, 7, &o1);
         run_pair256<EPI_BIAS_RELU_AFFINE>("pair_dense 256x128", p, 7, &o2);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 1>("pair_dense 256x128 no DMA", p, 7);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 2>("pair_dense 256x128 no h1 gen", p, 7);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 3>("pair_dense 256x128 no DMA/h1", p, 7);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 4>("pair_dense 256x128 no setprio", p, 7);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 8>("pair_dense 256x128 no stores", p, 7);
+        run_pair256<EPI_BIAS_RELU_AFFINE, 11>("pair_dense 256x128 MFMA skeleton", p, 7);
         { double d = 0; for (int i = 0; i < 256; ++i) d = std::max(d, (double)std::fabs(o1[i] - o2[i])); printf("   max |diff| 128 vs 256 tile: %g (value %g)\n", d, o1[7]); }
         run<EPI_RAW>("layer0 (split 2)", l, 2, 7);
         run256<EPI_RAW>("layer0 (split 2) 256x128", l, 2, 7);
