@@ -73,6 +73,8 @@ SYMBOLS = {
     'csi_set_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
     'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),
     'csi_device_free': (ctypes.c_int, [_ctx, _vp]),
+    'csi_host_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),
+    'csi_host_free': (ctypes.c_int, [_ctx, _vp]),
     'csi_memcpy_h2d': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64]),
     'csi_memcpy_d2h': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64]),
     'csi_synth_white': (ctypes.c_int, [_ctx, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, _vp, _vp]),

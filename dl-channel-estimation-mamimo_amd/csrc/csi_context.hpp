@@ -80,6 +80,7 @@ struct ProfSpan {
 }  // namespace
 
 struct csi_trainer;          // csi_train.hpp
+struct csi_hostpipe;         // csi_hostpipe.hpp
 
 struct csi_ctx {
     csi_config cfg;
@@ -88,6 +89,8 @@ struct csi_ctx {
     std::string err;
     Model model[2];
     csi_trainer* trainer[2] = {nullptr, nullptr};   // on-box fine-tuning state per component model
+    csi_hostpipe* hostpipe = nullptr;               // streams / pinned slots / host threads of the host-buffer entry points
+    int host_threads = 0;                           // "host_threads" option: threads of the user <-> pinned copies (0 = automatic)
     float* P = nullptr;          // device [nt][nt]
     float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)
     bool pilot_ok = false;

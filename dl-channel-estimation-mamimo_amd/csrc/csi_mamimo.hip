@@ -12,6 +12,7 @@
 #include "csi_dnn_f32.hpp"
 #include "csi_dnn_bf16.hpp"
 #include "csi_train.hpp"
+#include "csi_hostpipe.hpp"
 
 namespace {
 
@@ -197,6 +198,7 @@ void csi_destroy(csi_ctx* c) {
     free_model(c->model[0]);
     free_model(c->model[1]);
     for (int d = 0; d < 2; ++d) tr_free(c->trainer[d]);
+    delete c->hostpipe;
     if (c->P) hipFree(c->P);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->tw) hipFree(c->tw);
@@ -509,6 +511,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;
         return ls_prepare(c);
+    } else if (n == "host_threads") {
+        if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 64");
+        if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
+        c->host_threads = (int)value;
     } else if (n == "ls_debug") {
         c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
     } else if (n == "ls_kernel") {
@@ -619,31 +625,13 @@ int csi_synchronize(csi_ctx* c) {
     return CSI_OK;
 }
 
-// ---- host-buffer entry points: stage through device memory in packet chunks
+// ---- host-buffer entry points: two-slot pipeline of csi_hostpipe.hpp
 static int host_packets(csi_ctx* c, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im,
                         int n_out, bool ls) {
-    const csi_config& cf = c->cfg;
-    const size_t in_pkt = (size_t)cf.nr * cf.len_ltf * sizeof(float);
-    const size_t out_pkt = (size_t)cf.nr * cf.nt * n_out * sizeof(float);
-    int64_t chunk = std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)(2 * (in_pkt + out_pkt)));
-    chunk = std::min(chunk, npkt);
-    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, 2 * (in_pkt + out_pkt) * (size_t)chunk);
-    if (rc) return rc;
-    float* d_re = reinterpret_cast<float*>(c->stage);
-    float* d_im = reinterpret_cast<float*>(c->stage + in_pkt * chunk);
-    float* d_ore = reinterpret_cast<float*>(c->stage + 2 * in_pkt * chunk);
-    float* d_oim = reinterpret_cast<float*>(c->stage + 2 * in_pkt * chunk + out_pkt * chunk);
-    for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
-        const int64_t np = std::min(chunk, npkt - p0);
-        HIP_TRY(c, hipMemcpyAsync(d_re, re + (size_t)p0 * cf.nr * cf.len_ltf, in_pkt * np, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(d_im, im + (size_t)p0 * cf.nr * cf.len_ltf, in_pkt * np, hipMemcpyHostToDevice, c->stream));
-        rc = ls ? csi_ls_estimate_device(c, d_re, d_im, np, d_ore, d_oim) : csi_predict_device(c, d_re, d_im, np, d_ore, d_oim);
-        if (rc) return rc;
-        HIP_TRY(c, hipMemcpyAsync(o_re + (size_t)p0 * cf.nr * cf.nt * n_out, d_ore, out_pkt * np, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(o_im + (size_t)p0 * cf.nr * cf.nt * n_out, d_oim, out_pkt * np, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return CSI_OK;
+    return hp_packets(c, re, im, npkt, o_re, o_im, n_out,
+                      [c, ls](const float* d_re, const float* d_im, int64_t np, float* d_ore, float* d_oim) {
+                          return ls ? csi_ls_estimate_device(c, d_re, d_im, np, d_ore, d_oim) : csi_predict_device(c, d_re, d_im, np, d_ore, d_oim);
+                      });
 }
 
 int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* out_re, float* out_im) {
@@ -775,6 +763,23 @@ int csi_device_free(csi_ctx* c, void* dptr) {
     if (!dptr) return CSI_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipFree(dptr));
+    return CSI_OK;
+}
+
+int csi_host_malloc(csi_ctx* c, void** ptr, int64_t bytes) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!ptr || bytes <= 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_host_malloc: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, CSI_ERR_NOMEM, "csi_host_malloc: %lld bytes of pinned host memory are not available", (long long)bytes);
+    }
+    return CSI_OK;
+}
+
+int csi_host_free(csi_ctx* c, void* ptr) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (ptr) HIP_TRY(c, hipHostFree(ptr));
     return CSI_OK;
 }
 

@@ -241,24 +241,51 @@ class CsiEngine:
             raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {re.shape}')
         return re, im
 
-    def predict(self, ltf, ltf_im=None):
+    def _out_planes(self, out, npkt, width):
+        shape = (npkt, self.nr, self.nt, width)
+        if out is None:
+            return np.empty(shape, dtype=np.float32), np.empty(shape, dtype=np.float32)
+        o_re, o_im = out
+        for o in (o_re, o_im):
+            if o.dtype != np.float32 or o.shape != shape or not o.flags['C_CONTIGUOUS']:
+                raise CsiError(-1, f'out planes must be C-contiguous float32 {shape}')
+        return o_re, o_im
+
+    def predict(self, ltf, ltf_im=None, out=None):
         """DNN estimate.  ltf complex [npkt,nr,len_ltf] (or two float planes).
-        Returns (out_real, out_imag) float32 [npkt,nr,nt,n_out]."""
+        Returns (out_real, out_imag) float32 [npkt,nr,nt,n_out]; ``out=(o_re, o_im)`` reuses caller
+        buffers (pinned ones from ``pinned_empty`` are DMA'd directly)."""
         re, im = self._split(ltf, ltf_im)
         npkt = re.shape[0]
-        o_re = np.empty((npkt, self.nr, self.nt, self.n_out), dtype=np.float32)
-        o_im = np.empty_like(o_re)
+        o_re, o_im = self._out_planes(out, npkt, self.n_out)
         self._check(self._lib.csi_predict(self._ctx, _fp(re), _fp(im), npkt, _fp(o_re), _fp(o_im)))
         return o_re, o_im
 
-    def ls_estimate(self, ltf, ltf_im=None):
-        """LS estimate, complex64 [npkt,nr,nt,234]."""
+    def ls_estimate(self, ltf, ltf_im=None, out=None):
+        """LS estimate, complex64 [npkt,nr,nt,234]; with ``out=(h_re, h_im)`` the two float32 planes
+        are returned instead (no complex assembly on the host)."""
         re, im = self._split(ltf, ltf_im)
         npkt = re.shape[0]
-        h_re = np.empty((npkt, self.nr, self.nt, N_DATA), dtype=np.float32)
-        h_im = np.empty_like(h_re)
+        h_re, h_im = self._out_planes(out, npkt, N_DATA)
         self._check(self._lib.csi_ls_estimate(self._ctx, _fp(re), _fp(im), npkt, _fp(h_re), _fp(h_im)))
-        return h_re + 1j * h_im
+        if out is not None:
+            return h_re, h_im
+        h = np.empty(h_re.shape, dtype=np.complex64)
+        h.real = h_re
+        h.imag = h_im
+        return h
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """numpy array in pinned host memory (csi_host_malloc); freed with the array."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self._check(self._lib.csi_host_malloc(self._ctx, ctypes.byref(p), max(n, 1)))
+        buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        lib, ctx, addr = self._lib, self._ctx, p.value
+        import weakref
+        weakref.finalize(buf, lambda: lib.csi_host_free(ctx, ctypes.c_void_p(addr)))
+        return arr
 
     def lmmse_estimate(self, h_ls, hvec, snr_db):
         """LMMSE smoothing (LMMSE_ce.m) of an LS estimate.  h_ls complex [npkt,nr,nt,234]; hvec

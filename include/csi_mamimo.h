@@ -24,7 +24,9 @@
  * Conventions: every function returns 0 on success or a negative csi_status; it never calls
  * exit().  All buffers are caller-owned, row-major, contiguous float32.  A context is bound
  * to one GPU and one HIP stream and is not thread-safe; use one context per GPU.  Host-buffer
- * entry points are synchronous.  *_device entry points take device pointers, enqueue on the
+ * entry points are synchronous; internally they pipeline upload, kernels and download over packet
+ * chunks (pinned staging slots, a few host threads) and DMA directly from / to buffers the caller
+ * has pinned (hipHostMalloc / hipHostRegister).  *_device entry points take device pointers, enqueue on the
  * context's stream and return without waiting; call csi_synchronize before reading results.
  *
  * Sample / output order everywhere: s = p*Nr*Nt + iRx*Nt + iTx
@@ -166,6 +168,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
+ *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
+ *                         slots of the host-buffer entry points (0 = automatic, up to 8)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
  *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt); a choice the
  *                         kernel cannot serve falls back to the automatic one */
@@ -174,6 +178,10 @@ int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
 /* Device-memory plumbing so that a host program needs no other GPU runtime. */
 int  csi_device_malloc(csi_ctx* ctx, void** dptr, int64_t bytes);
 int  csi_device_free(csi_ctx* ctx, void* dptr);
+/* Pinned (page-locked) host memory: buffers from here are DMA'd directly by the host-buffer entry
+ * points instead of being staged through the library's own pinned slots. */
+int  csi_host_malloc(csi_ctx* ctx, void** ptr, int64_t bytes);
+int  csi_host_free(csi_ctx* ctx, void* ptr);
 int  csi_memcpy_h2d(csi_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 int  csi_memcpy_d2h(csi_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 /* i.i.d. CN(0,1) preambles generated on the device by a counter-based RNG (element index

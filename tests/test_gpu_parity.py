@@ -520,6 +520,40 @@ def test_cli_test_run_end_to_end(pkg, oracle, tmp_path, capsys):
         np.testing.assert_array_equal(m['true_y'], y.imag.reshape(npkt, nr * nt, 234)[n])
 
 
+def test_host_pipeline_many_chunks_pinned_and_pageable(pkg, oracle):
+    """The host-buffer entry points pipeline upload / kernels / download over packet chunks through two
+    slots: many chunks (Nt=4, Nr=2: 8192-packet chunks -> use 20000 packets), caller buffers pageable
+    or pinned (csi_host_malloc), one or several copy threads - all bit-identical, and right on
+    sampled packets."""
+    rng = np.random.default_rng(123)
+    nt, nr, npkt, hidden = 4, 2, 20000, (32, 16)
+    w_re, w_im = _weights(oracle, 77, nt, hidden)
+    P = oracle.hadamard(nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    re = rng.standard_normal((npkt, nr, 320 * nt), dtype=np.float32)
+    im = rng.standard_normal((npkt, nr, 320 * nt), dtype=np.float32)
+    o_re, o_im = e.predict(re, im)
+    h = e.ls_estimate(re, im)
+    sel = np.r_[0:2, 8191:8194, npkt - 2:npkt]
+    ltf = (re[sel] + 1j * im[sel]).astype(np.complex64)
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL
+    ref = oracle.ls_estimate(ltf, P)
+    assert rel_rows(np.concatenate([h[sel].real, h[sel].imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    # pinned caller buffers, and a different number of copy threads
+    p_re, p_im = e.pinned_empty(re.shape), e.pinned_empty(im.shape)
+    p_re[...] = re
+    p_im[...] = im
+    out = (e.pinned_empty(o_re.shape), e.pinned_empty(o_im.shape))
+    q_re, q_im = e.predict(p_re, p_im, out=out)
+    assert q_re is out[0] and np.array_equal(q_re, o_re) and np.array_equal(q_im, o_im)
+    e.set_option('host_threads', 1)
+    s_re, s_im = e.predict(re, im)
+    assert np.array_equal(s_re, o_re) and np.array_equal(s_im, o_im)
+    hp = e.ls_estimate(re, im, out=(np.empty(o_re.shape, np.float32), np.empty(o_re.shape, np.float32)))
+    assert np.array_equal(hp[0], h.real) and np.array_equal(hp[1], h.imag)
+
+
 # ------------------------------------------------------------------------------------ device path
 def test_device_resident_path_and_profile(pkg, oracle):
     rng = np.random.default_rng(41)

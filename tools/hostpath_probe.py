@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry points (csi_ls_estimate + csi_predict) with
+pre-allocated, pre-touched caller buffers: pageable numpy arrays, and pinned ones
+(csi_host_malloc -> detected by the library, DMA'd directly).  GPU box:
+    python tools/hostpath_probe.py [--packets 4000] [--threads 0]"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dl_channel_estimation_mamimo_amd as pkg   # noqa: E402
+from oracle import csi_oracle as o               # noqa: E402  (weights only; nothing is checked here)
+
+
+def fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--packets', type=int, default=4000)
+    ap.add_argument('--nt', type=int, default=32)
+    ap.add_argument('--nr', type=int, default=4)
+    ap.add_argument('--threads', type=int, default=0)
+    ap.add_argument('--reps', type=int, default=3)
+    a = ap.parse_args()
+    nt, nr, npkt = a.nt, a.nr, a.packets
+    rng = np.random.default_rng(0)
+    e = pkg.CsiEngine(nt, nr, hidden=(1024, 1024))
+    w = o.make_weights(rng, 321 * nt, (1024, 1024), 234)
+    e.load_weights('real', w)
+    e.load_weights('imag', w)
+    e.set_pilot(o.hadamard(nt))
+    if a.threads:
+        e.set_option('host_threads', a.threads)
+    lib, ctx = e._lib, e._ctx
+
+    def buffers(pinned):
+        shp_i, shp_o = (npkt, nr, 320 * nt), (npkt, nr, nt, 234)
+        if pinned:
+            mk = lambda s: e.pinned_empty(s)
+        else:
+            mk = lambda s: np.empty(s, np.float32)
+        re, im, ore, oim = mk(shp_i), mk(shp_i), mk(shp_o), mk(shp_o)
+        re[...] = rng.standard_normal(shp_i[1:], dtype=np.float32)
+        im[...] = re
+        ore[...] = 0
+        oim[...] = 0
+        return re, im, ore, oim
+
+    for pinned in (False, True):
+        re, im, ore, oim = buffers(pinned)
+        gb = (re.nbytes + im.nbytes) * 2 + (ore.nbytes + oim.nbytes) * 2
+        for name, fn in (('csi_predict', lib.csi_predict), ('csi_ls_estimate', lib.csi_ls_estimate)):
+            fn(ctx, fp(re), fp(im), npkt, fp(ore), fp(oim))
+            ts = []
+            for _ in range(a.reps):
+                t0 = time.perf_counter()
+                rc = fn(ctx, fp(re), fp(im), npkt, fp(ore), fp(oim))
+                ts.append(time.perf_counter() - t0)
+                assert rc == 0
+            t = min(ts)
+            moved = re.nbytes + im.nbytes + ore.nbytes + oim.nbytes
+            print(f'{"pinned  " if pinned else "pageable"} {name:16s} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
+                  f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions)')
+
+
+if __name__ == '__main__':
+    main()
