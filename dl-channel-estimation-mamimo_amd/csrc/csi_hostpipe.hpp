@@ -145,6 +145,9 @@ int hp_get(csi_ctx* c, csi_hostpipe** out) {
 }
 
 int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, bool need_pin_in, bool need_pin_out) {
+    if ((!need_pin_in || h->pin_in_bytes >= in_bytes) && (!need_pin_out || h->pin_out_bytes >= out_bytes) &&
+        h->dev_bytes >= in_bytes + out_bytes)
+        return CSI_OK;                                    // every call ends drained: nothing in flight uses the slots
     HIP_TRY(c, hipStreamSynchronize(h->s_in));
     HIP_TRY(c, hipStreamSynchronize(h->s_out));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
