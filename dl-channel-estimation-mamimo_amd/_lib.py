@@ -122,6 +122,12 @@ def load_library():
     if not os.path.exists(_SO):
         raise CsiError(-4, f'{_SO} not found: build it with __graft_entry__.build() '
                            f'(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the library
+    # links /opt/rocm's.  Whichever is loaded first serves both (same soname).  Measured on the GPU
+    # box: torch first -> both work; library first -> torch.cuda reports no device, which would break
+    # the RCCL weight broadcast of a multi-rank run.  So in a multi-rank job torch goes first.
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch                      # noqa: F401
     lib = ctypes.CDLL(_SO)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it

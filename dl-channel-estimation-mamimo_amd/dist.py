@@ -3,7 +3,11 @@
 The path has no steady-state exchange: every packet is independent and the weights are
 read-only.  The only collective is the load-time broadcast of the weight blob
 and the pilot matrix from rank 0 - ``torch.distributed`` with the ``nccl`` backend, which is
-RCCL over xGMI on ROCm (``gloo`` on CPU-only hosts, used by the tests)."""
+RCCL over xGMI on ROCm (``gloo`` on CPU-only hosts, used by the tests).
+
+Process order matters on ROCm: call ``init_process_group`` (which imports torch and selects the GPU)
+BEFORE the first ``CsiEngine`` is created - see ``_lib.load_library`` for why; with WORLD_SIZE > 1
+in the environment ``load_library`` enforces it."""
 import os
 import numpy as np
 
