@@ -47,7 +47,7 @@ LsPlan ls_plan(const csi_ctx* c) {
                        : (jt == 3 ? (const void*)ls_estimate_chunked_kernel<3, 8, 32> : (const void*)ls_estimate_chunked_kernel<4, 8, 32>);
         p.lds = (size_t)((jt <= 2 ? 16 : 32) * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
         p.threads = jt <= 2 ? 256 : 512;
-        p.per_cu = jt == 1 ? 3 : (jt == 2 ? 2 : 1);       // register-limited: 3 / 2 / 2 waves per SIMD
+        p.per_cu = jt <= 2 ? 2 : 1;                       // register-limited: 2 waves per SIMD
     } else {
         p.fn = (const void*)ls_despread_first_kernel;
         p.lds = (size_t)(LSD_ROWS * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a,
 // is read exactly once; the next chunk's samples are requested as soon as the transforms are
 // done and stream in beside the MFMAs.
 template <int JT, int NW, int CH>
-__global__ __launch_bounds__(64 * NW, (JT == 1 ? 3 : 2)) void ls_estimate_chunked_kernel(const LsArgs a, int nblk) {
+__global__ __launch_bounds__(64 * NW, 2) void ls_estimate_chunked_kernel(const LsArgs a, int nblk) {
     constexpr int SPW = CH / NW;               // symbols per wave and chunk
     constexpr int QW = 8 / NW;                 // bin tiles (32 bins) per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -325,15 +325,22 @@ __global__ __launch_bounds__(64 * NW, (JT == 1 ? 3 : 2)) void ls_estimate_chunke
                 }
             }
             __syncthreads();
+            // ---- the next chunk (or the next item's first chunk) starts streaming: before the
+            // transforms where the registers allow it (JT == 1), behind them otherwise
+            if (JT == 1) {
+                if (ch + 1 < nchunk) fetch(blk, ch + 1);
+                else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+            }
             // one transform at a time: the accumulators leave no room for two interleaved ones
             for (int r = wave; r < ns && !(a.dbg & 1); r += NW) {
                 float* const pr[1] = {F + (size_t)r * 2 * LS_PLANE};
                 ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
             }
             __syncthreads();
-            // ---- the next chunk (or the next item's first chunk) starts streaming now
-            if (ch + 1 < nchunk) fetch(blk, ch + 1);
-            else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+            if (JT != 1) {
+                if (ch + 1 < nchunk) fetch(blk, ch + 1);
+                else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+            }
 
             // ---- despread on the matrix core: D[j][q] += sum_s P[j][s] * F[s][f(q)].  Branch-free: the
             // pilot entries come from the zero-padded copy Ppad (rows / columns >= nt are 0), so rows
