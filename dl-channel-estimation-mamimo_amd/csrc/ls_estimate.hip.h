@@ -331,10 +331,14 @@ __global__ __launch_bounds__(64 * NW, 2) void ls_estimate_chunked_kernel(const L
                 if (ch + 1 < nchunk) fetch(blk, ch + 1);
                 else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
             }
-            // one transform at a time: the accumulators leave no room for two interleaved ones
-            for (int r = wave; r < ns && !(a.dbg & 1); r += NW) {
-                float* const pr[1] = {F + (size_t)r * 2 * LS_PLANE};
-                ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
+            // two interleaved transforms per wave where the registers allow it (JT == 1), else one
+            if (JT == 1) {
+                if (!(a.dbg & 1)) ls_fft_rows(F, wave, ns, tw_re, tw_im, lane, NW);
+            } else {
+                for (int r = wave; r < ns && !(a.dbg & 1); r += NW) {
+                    float* const pr[1] = {F + (size_t)r * 2 * LS_PLANE};
+                    ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
+                }
             }
             __syncthreads();
             if (JT != 1) {
