@@ -250,8 +250,9 @@ __global__ __launch_bounds__(LS_THREADS) void ls_estimate_kernel(const LsArgs a,
 // the chunks (NW waves x QW bin tiles x JT antenna tiles x {re, im} x 16 registers).  The input
 // is read exactly once; the next chunk's samples are requested as soon as the transforms are
 // done and stream in beside the MFMAs.
-template <int JT, int NW, int CH>
-__global__ __launch_bounds__(64 * NW, 2) void ls_estimate_chunked_kernel(const LsArgs a, int nblk) {
+template <int JT, int NW, int CH, int MINW = 2>
+__global__ __launch_bounds__(64 * NW, MINW) void ls_estimate_chunked_kernel(const LsArgs a, int nblk) {
+    constexpr bool EARLY = JT == 1 || (JT == 2 && NW == 8);      // accumulators small enough to hold the prefetch across the transforms
     constexpr int SPW = CH / NW;               // symbols per wave and chunk
     constexpr int QW = 8 / NW;                 // bin tiles (32 bins) per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ls_estimate_chunked_kernel(const L
             __syncthreads();
             // ---- the next chunk (or the next item's first chunk) starts streaming: before the
             // transforms where the registers allow it (JT == 1), behind them otherwise
-            if (JT == 1) {
+            if (EARLY) {
                 if (ch + 1 < nchunk) fetch(blk, ch + 1);
                 else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
             }
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ls_estimate_chunked_kernel(const L
                 }
             }
             __syncthreads();
-            if (JT != 1) {
+            if (!EARLY) {
                 if (ch + 1 < nchunk) fetch(blk, ch + 1);
                 else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
             }
