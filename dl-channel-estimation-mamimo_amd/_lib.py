@@ -65,6 +65,9 @@ SYMBOLS = {
     'csi_lmmse_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'csi_train_begin': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(CsiTrainConfig), ctypes.POINTER(CsiTensor), ctypes.c_int]),
     'csi_train_step': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, ctypes.c_float, _fp]),
+    'csi_train_backward': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, ctypes.c_float, _fp]),
+    'csi_train_grads': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(_fp), ctypes.POINTER(ctypes.c_int64)]),
+    'csi_train_apply': (ctypes.c_int, [_ctx, ctypes.c_int]),
     'csi_train_eval': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, _fp]),
     'csi_train_set_lr': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_float]),
     'csi_train_get': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_char_p, _fp, ctypes.c_int64]),

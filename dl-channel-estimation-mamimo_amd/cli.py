@@ -76,7 +76,15 @@ def train_main(args):
     else:
         print('Validation separate from Training')
         train_ids, val_ids = ds.split_train_val(data, args.valTrainRatio)
-    eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=args.device)
+    # under torchrun: one process per GPU, samples sharded by rank, gradients all-reduced over RCCL
+    from . import dist
+    rank, world, local = dist.env_rank_world()
+    if world > 1:
+        dist.init_process_group(os.environ.get('CSI_DIST_BACKEND', 'nccl'))       # before the engine: see _lib.load_library
+        train_ids, val_ids = train_ids[rank::world], val_ids[rank::world]
+        n = min(dist.all_reduce_min(len(train_ids) // args.bs), len(train_ids) // args.bs)
+        train_ids = train_ids[:n * args.bs]                                       # same number of steps on every rank
+    eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=(local if world > 1 else args.device))
     dims = ['real'] if args.onlyReal else (['imag'] if args.onlyImag else ['real', 'imag'])
     for d in dims:
         print('Working on *', d, '* model')
@@ -86,11 +94,19 @@ def train_main(args):
             print('Not enough samples for one batch of %d in the training / validation split. Aborting...' % args.bs)
             sys.exit(0)
         init = load_weight_file(_find_weights(args.init, d)) if args.init else None
+        if world > 1 and init is None:
+            # identical initial tensors on every rank: rank 0 draws them (Glorot through a scratch trainer), all receive
+            if rank == 0:
+                eng.train_begin(d, lr=args.lr, dropout=args.dropout, seed=args.seed)
+                init = eng.train_weights(d)
+                eng.train_end(d, commit=False)
+            init = dist.broadcast_weights(init, src=0)
         hist = trainer.fit(eng, d, tr, va, epochs=args.epochs, lr=args.lr, dropout=args.dropout, weights=init,
-                           method=args.method, seed=args.seed)
-        path = os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.safetensors')
-        save_weight_file(path, hist['weights'])
-        print('%s model: best val_loss %.6e after %d epochs; weights saved to %s' % (d, hist['best_val_loss'], len(hist['loss']), path))
+                           method=args.method, seed=args.seed, verbose=(rank == 0), data_parallel=(world > 1))
+        if rank == 0:
+            path = os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.safetensors')
+            save_weight_file(path, hist['weights'])
+            print('%s model: best val_loss %.6e after %d epochs; weights saved to %s' % (d, hist['best_val_loss'], len(hist['loss']), path))
     return 0
 
 

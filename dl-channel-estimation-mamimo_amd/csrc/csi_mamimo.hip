@@ -551,7 +551,42 @@ int csi_train_step(csi_ctx* c, int model, const float* x, const float* y, int64_
     if (int rc0 = trainer_of(c, model, "csi_train_step", &t)) return rc0;
     if (!x || !y || B < 2 || B > (1 << 20) || noise_std < 0.f) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_step: bad argument (2 <= B <= 2^20)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return tr_step(c, t, x, y, (int)B, noise_std, loss);
+    const int rc = tr_backward(c, t, x, y, (int)B, noise_std, nullptr);
+    if (rc) return rc;
+    const int rc2 = tr_apply(c, t);
+    if (rc2) return rc2;
+    if (loss) {
+        HIP_TRY(c, hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CSI_OK;
+}
+
+int csi_train_backward(csi_ctx* c, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_backward", &t)) return rc0;
+    if (!x || !y || B < 2 || B > (1 << 20) || noise_std < 0.f) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_backward: bad argument (2 <= B <= 2^20)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_backward(c, t, x, y, (int)B, noise_std, loss);
+}
+
+int csi_train_grads(csi_ctx* c, int model, float** d_grads, int64_t* count) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_grads", &t)) return rc0;
+    if (!d_grads || !count) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_grads: bad argument");
+    *d_grads = t->gflat;
+    *count = t->gcount;
+    return CSI_OK;
+}
+
+int csi_train_apply(csi_ctx* c, int model) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_apply", &t)) return rc0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_apply(c, t);
 }
 
 int csi_train_eval(csi_ctx* c, int model, const float* x, const float* y, int64_t B, float* loss) {

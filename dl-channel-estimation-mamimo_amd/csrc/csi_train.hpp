@@ -38,6 +38,9 @@ struct csi_trainer {
     float *dz = nullptr, *dzt = nullptr, *dh[2] = {nullptr, nullptr};
     float *out = nullptr, *dout = nullptr, *doutt = nullptr, *partial = nullptr, *loss = nullptr;
     float *ones = nullptr, *zeros = nullptr, *tmp = nullptr;
+    float* gflat = nullptr;           // all gradients, one allocation (data-parallel all-reduce operand)
+    int64_t gcount = 0;
+    bool grads_pending = false;       // csi_train_backward ran, csi_train_apply has not
     size_t tmp_floats = 0;
 };
 
@@ -202,7 +205,8 @@ int tr_clear_batch_padding(csi_ctx* c, csi_trainer* t, int B) {
     return rc;
 }
 
-int tr_step(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, float noise_std, float* h_loss) {
+// forward + backward of one batch: loss and all gradients (no parameter update)
+int tr_backward(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, float noise_std, float* h_loss) {
     const csi_config& cf = c->cfg;
     const int nh = cf.n_hidden;
     int rc = tr_reserve(c, t, B);
@@ -263,28 +267,35 @@ int tr_step(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, f
         }
     }
 
-    // ---- Adam (keras: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t))
-    const double tt = (double)t->step;
-    const float lr_t = (float)((double)t->tc.lr * std::sqrt(1.0 - std::pow((double)t->tc.beta2, tt)) / (1.0 - std::pow((double)t->tc.beta1, tt)));
-    {
-        double elems = 0.0;
-        for (auto& l : t->layers) elems += (double)l.out * l.ldw;
-        ProfScope ps(c, K_TRAIN_ELEMWISE, 10.0 * elems, 28.0 * elems);
-        for (int li = 0; li <= nh; ++li) {
-            auto& l = t->layers[li];
-            rc = tr_adam(c, t, l.Wt, l.gWt, l.mWt, l.vWt, (size_t)l.out * l.ldw, lr_t);
-            if (!rc) rc = tr_adam(c, t, l.b, l.gb, l.mb, l.vb, l.out, lr_t);
-            if (!rc && li < nh && cf.use_bn) {
-                rc = tr_adam(c, t, l.gamma, l.ggamma, l.mgamma, l.vgamma, l.out, lr_t);
-                if (!rc) rc = tr_adam(c, t, l.beta, l.gbeta, l.mbeta, l.vbeta, l.out, lr_t);
-            }
-            if (rc) return rc;
-        }
-    }
+    t->grads_pending = true;
     if (h_loss) {
         HIP_TRY(c, hipMemcpyAsync(h_loss, t->loss, sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return CSI_OK;
+}
+
+// Adam on the gradients of the last backward pass (keras: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t))
+int tr_apply(csi_ctx* c, csi_trainer* t) {
+    const csi_config& cf = c->cfg;
+    const int nh = cf.n_hidden;
+    if (!t->grads_pending) return fail(c, CSI_ERR_NOT_READY, "csi_train_apply: no gradients pending (call csi_train_backward first)");
+    const double tt = (double)t->step;
+    const float lr_t = (float)((double)t->tc.lr * std::sqrt(1.0 - std::pow((double)t->tc.beta2, tt)) / (1.0 - std::pow((double)t->tc.beta1, tt)));
+    double elems = 0.0;
+    for (auto& l : t->layers) elems += (double)l.out * l.ldw;
+    ProfScope ps(c, K_TRAIN_ELEMWISE, 10.0 * elems, 28.0 * elems);
+    for (int li = 0; li <= nh; ++li) {
+        auto& l = t->layers[li];
+        int rc = tr_adam(c, t, l.Wt, l.gWt, l.mWt, l.vWt, (size_t)l.out * l.ldw, lr_t);
+        if (!rc) rc = tr_adam(c, t, l.b, l.gb, l.mb, l.vb, l.out, lr_t);
+        if (!rc && li < nh && cf.use_bn) {
+            rc = tr_adam(c, t, l.gamma, l.ggamma, l.mgamma, l.vgamma, l.out, lr_t);
+            if (!rc) rc = tr_adam(c, t, l.beta, l.gbeta, l.mbeta, l.vbeta, l.out, lr_t);
+        }
+        if (rc) return rc;
+    }
+    t->grads_pending = false;
     return CSI_OK;
 }
 
@@ -366,6 +377,9 @@ int tr_begin(csi_ctx* c, int model, const csi_train_config* tc, const csi_tensor
     t->layers.resize(nh + 1);
     int fan_in = c->d_in, maxw = 0;
     int rc = 0;
+    // every gradient lives in ONE flat buffer (regressor first, layer 0 last = the order the backward
+    // pass produces them): a data-parallel caller all-reduces it with a single collective
+    size_t gtotal = 0;
     for (int li = 0; li <= nh; ++li) {
         auto& l = t->layers[li];
         l.in = fan_in;
@@ -373,19 +387,35 @@ int tr_begin(csi_ctx* c, int model, const csi_train_config* tc, const csi_tensor
         l.ldw = r32(li == 0 ? fan_in : t->layers[li - 1].ldo);      // = the padded K the forward GEMM walks
         l.ldo = r32(l.out);
         maxw = std::max(maxw, l.ldo);
+        gtotal += (size_t)l.out * l.ldw + r32(l.out) * (size_t)(li < nh && cf.use_bn ? 3 : 1);
+        fan_in = l.out;
+    }
+    rc = tr_alloc(c, t, &t->gflat, gtotal);
+    if (rc) return rc;
+    t->gcount = (int64_t)gtotal;
+    size_t goff = 0;
+    auto carve = [&](float** p, size_t n) { *p = t->gflat + goff; goff += n; };
+    for (int li = nh; li >= 0; --li) {
+        auto& l = t->layers[li];
+        carve(&l.gWt, (size_t)l.out * l.ldw);
+        carve(&l.gb, r32(l.out));
+        if (li < nh && cf.use_bn) { carve(&l.ggamma, r32(l.out)); carve(&l.gbeta, r32(l.out)); }
+    }
+    for (int li = 0; li <= nh; ++li) {
+        auto& l = t->layers[li];
         const size_t nw = (size_t)l.out * l.ldw;
-        rc |= tr_alloc(c, t, &l.Wt, nw);  rc |= tr_alloc(c, t, &l.gWt, nw);
+        rc |= tr_alloc(c, t, &l.Wt, nw);
         rc |= tr_alloc(c, t, &l.mWt, nw); rc |= tr_alloc(c, t, &l.vWt, nw);
-        rc |= tr_alloc(c, t, &l.b, l.out);  rc |= tr_alloc(c, t, &l.gb, l.out);
+        rc |= tr_alloc(c, t, &l.b, l.out);
         rc |= tr_alloc(c, t, &l.mb, l.out); rc |= tr_alloc(c, t, &l.vb, l.out);
         if (li > 0) rc |= tr_alloc(c, t, &l.Wk, (size_t)l.in * l.ldo);
         if (li < nh) {
-            for (float** p : {&l.gamma, &l.beta, &l.mmean, &l.mvar, &l.ggamma, &l.gbeta, &l.mgamma, &l.vgamma, &l.mbeta, &l.vbeta, &l.mu,
-                              &l.istd, &l.scale, &l.shift})
+            for (float** p : {&l.gamma, &l.beta, &l.mmean, &l.mvar, &l.mgamma, &l.vgamma, &l.mbeta, &l.vbeta, &l.mu, &l.istd, &l.scale,
+                              &l.shift})
                 rc |= tr_alloc(c, t, p, l.out);
+            if (!cf.use_bn) { rc |= tr_alloc(c, t, &l.ggamma, l.out); rc |= tr_alloc(c, t, &l.gbeta, l.out); }
         }
         if (rc) return CSI_ERR_NOMEM;
-        fan_in = l.out;
     }
     t->maxw = maxw;
     if ((cf.n_out + TRC - 1) / TRC > 128) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_begin: n_out above 4096 is not supported");

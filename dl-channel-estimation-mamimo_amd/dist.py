@@ -73,6 +73,11 @@ def broadcast_weights(weights, src=0, device=None):
     return out
 
 
+def world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -92,6 +97,11 @@ def all_reduce_max(value, device=None):
     return float(t.item())
 
 
+def all_reduce_min(value, device=None):
+    """min over ranks of a python number."""
+    return -all_reduce_max(-float(value), device)
+
+
 def all_reduce_sum(value, device=None):
     import torch
     import torch.distributed as dist
@@ -102,3 +112,47 @@ def all_reduce_sum(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class _DevView:
+    """Zero-copy view of library-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def all_reduce_device(ptr, count, average=True):
+    """In-place sum (or mean) all-reduce over the ranks of ``count`` float32 values at device address
+    ``ptr`` - the flat gradient buffer of ``csi_train_grads``.  One collective for the whole model:
+    over RCCL the xGMI rings are per-link bound, so one large bucket beats many small ones; the layer-0
+    gradient (83 % of the bytes) is produced last by the backward pass, so there is little to overlap.
+    The caller has to synchronise the library's stream first (``engine.synchronize()``)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    t = torch.as_tensor(_DevView(ptr, count), device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if average:
+        t.mul_(1.0 / dist.get_world_size())
+    torch.cuda.synchronize()
+
+
+def all_reduce_mean_arrays(arrays):
+    """Mean over the ranks of a dict of small host arrays (running BatchNormalization statistics at the
+    end of a data-parallel fit)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return arrays
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    names = sorted(arrays)
+    flat = torch.from_numpy(np.concatenate([np.asarray(arrays[k], np.float32).ravel() for k in names])).to(dev)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    host = (flat / dist.get_world_size()).cpu().numpy()
+    out, off = {}, 0
+    for k in names:
+        n = int(np.asarray(arrays[k]).size)
+        out[k] = host[off:off + n].reshape(np.asarray(arrays[k]).shape).copy()
+        off += n
+    return out

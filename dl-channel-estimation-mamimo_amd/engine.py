@@ -174,6 +174,28 @@ class CsiEngine:
         self._check(self._lib.csi_train_step(self._ctx, int(idx), _fp(x), _fp(y), x.shape[0], float(noise_std), ctypes.byref(loss)))
         return float(loss.value)
 
+    def train_backward(self, model, x, y, noise_std=0.0):
+        """Loss and gradients of one batch without the parameter update (data-parallel step, part 1)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        x, y = _f32c(x), _f32c(y)
+        if x.ndim != 2 or x.shape[1] != self.d_in or y.shape != (x.shape[0], self.n_out):
+            raise CsiError(-1, f'x must be [B,{self.d_in}] and y [B,{self.n_out}], got {x.shape} / {y.shape}')
+        loss = ctypes.c_float()
+        self._check(self._lib.csi_train_backward(self._ctx, int(idx), _fp(x), _fp(y), x.shape[0], float(noise_std), ctypes.byref(loss)))
+        return float(loss.value)
+
+    def train_grads(self, model):
+        """(device pointer, element count) of the flat gradient buffer (the all-reduce operand)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        p, n = ctypes.POINTER(ctypes.c_float)(), ctypes.c_int64()
+        self._check(self._lib.csi_train_grads(self._ctx, int(idx), ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.cast(p, ctypes.c_void_p).value, int(n.value)
+
+    def train_apply(self, model):
+        """Adam on the (all-reduced) gradients (data-parallel step, part 2)."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        self._check(self._lib.csi_train_apply(self._ctx, int(idx)))
+
     def train_eval(self, model, x, y):
         """mse of the current trainer parameters in inference mode (the reference's val_loss)."""
         idx = {'real': 0, 'imag': 1}.get(model, model)

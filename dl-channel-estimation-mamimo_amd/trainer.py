@@ -9,6 +9,8 @@ plain ``[bs, d_in]`` array; ``len(gen)`` is the number of batches; ``on_epoch_en
 present (massiveMIMO_dataGenerator.py:264-316)."""
 import numpy as np
 
+from . import dist
+
 SNR_LEVELS_MAMIMO = (30, 20, 10, 0, -10, -20)       # DNN.py:303
 
 
@@ -48,10 +50,15 @@ def evaluate(engine, model, gen):
 
 def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, weights=None, method='default_SNR',
         snr_levels=SNR_LEVELS_MAMIMO, es_patience=25, rlr_patience=20, rlr_factor=0.1, min_lr=None, seed=0,
-        verbose=True, commit=True):
+        verbose=True, commit=True, data_parallel=False):
     """Trains one component model ('real' / 'imag') and returns the history dict
     {'loss': [...], 'val_loss': [...], 'lr': [...]}.  With commit the best weights (lowest val_loss,
-    EarlyStopping restore_best_weights) become the engine's inference model."""
+    EarlyStopping restore_best_weights) become the engine's inference model.
+
+    data_parallel (torch.distributed initialised, one process per GPU, every rank calling fit with its
+    own shard of batches and the same seed / initial weights): each step is backward -> one flat
+    gradient all-reduce (RCCL) -> Adam, so all ranks hold identical parameters; the validation loss is
+    averaged over the ranks; BatchNormalization running statistics are averaged at the end."""
     rng = np.random.default_rng(seed)
     min_lr = lr * 0.01 if min_lr is None else min_lr
     engine.train_begin(model, weights=weights, lr=lr, dropout=dropout, seed=seed)
@@ -64,11 +71,20 @@ def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, we
             X, y, _ = train_gen[b]
             rows = rows_from_batch(X)
             std = noise_std_for(avg_pow, rng.choice(snr_levels)) if method == 'default_SNR' else 0.0
-            tot += engine.train_step(model, rows, np.asarray(y, np.float32), noise_std=std) * rows.shape[0]
+            if data_parallel:
+                loss = engine.train_backward(model, rows, np.asarray(y, np.float32), noise_std=std)
+                engine.synchronize()
+                dist.all_reduce_device(*engine.train_grads(model), average=True)
+                engine.train_apply(model)
+            else:
+                loss = engine.train_step(model, rows, np.asarray(y, np.float32), noise_std=std)
+            tot += loss * rows.shape[0]
             cnt += rows.shape[0]
         if hasattr(train_gen, 'on_epoch_end'):
             train_gen.on_epoch_end()
         val = evaluate(engine, model, val_gen)
+        if data_parallel:
+            val = dist.all_reduce_sum(val) / dist.world_size()
         hist['loss'].append(tot / max(cnt, 1))
         hist['val_loss'].append(val)
         hist['lr'].append(cur_lr)
@@ -76,6 +92,9 @@ def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, we
             print(f'Epoch {ep + 1}/{epochs} - loss: {hist["loss"][-1]:.6g} - val_loss: {val:.6g} - lr: {cur_lr:.3g}')
         if val < best:
             best, best_w, es_wait = val, engine.train_weights(model), 0
+            if data_parallel:
+                bn = {k: v for k, v in best_w.items() if 'moving_' in k}
+                best_w.update(dist.all_reduce_mean_arrays(bn))
         else:
             es_wait += 1
             if es_wait >= es_patience:

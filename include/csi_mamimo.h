@@ -147,6 +147,15 @@ int  csi_train_begin(csi_ctx* ctx, int model, const csi_train_config* cfg, const
 /* x [B][len_ltf+nt] rows as Model.fit receives them (dataGenerator.py:299-316), y [B][n_out];
  * host buffers, synchronous when loss != NULL.  noise_std = 0 disables the AWGN layer. */
 int  csi_train_step(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss);
+/* Data-parallel form of a step: csi_train_backward computes the loss and every gradient of the
+ * rank's batch without touching the parameters; csi_train_grads exposes all gradients as ONE
+ * flat device buffer (regressor first, layer 0 last) for a single sum all-reduce (RCCL) that the
+ * caller scales by 1/world; csi_train_apply runs Adam on whatever the buffer then holds.
+ * csi_train_step == backward + apply.  BatchNormalization statistics stay per rank (keras
+ * MirroredStrategy default). */
+int  csi_train_backward(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss);
+int  csi_train_grads(csi_ctx* ctx, int model, float** d_grads, int64_t* count);
+int  csi_train_apply(csi_ctx* ctx, int model);
 /* mse of the current parameters in inference mode (running statistics, no noise, no dropout):
  * the val_loss that EarlyStopping / ReduceLROnPlateau monitor (DNN.py:285-286). */
 int  csi_train_eval(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float* loss);

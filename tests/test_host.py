@@ -189,6 +189,8 @@ lo, hi = m.dist.shard_range(11, rank, d.get_world_size())
 tot = m.dist.all_reduce_sum(hi - lo)
 mx = m.dist.all_reduce_max(float(rank + 1))
 assert tot == 11 and mx == 2.0, (tot, mx)
+mean = m.dist.all_reduce_mean_arrays({'mv': np.full((2, 3), float(rank), np.float32), 'mm': np.array([1.0 + rank], np.float32)})
+assert m.dist.world_size() == 2 and np.allclose(mean['mv'], 0.5) and mean['mv'].shape == (2, 3) and np.allclose(mean['mm'], 1.5)
 m.dist.barrier()
 print('rank', rank, 'ok', lo, hi)
 '''

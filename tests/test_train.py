@@ -236,3 +236,52 @@ def test_cli_train_then_test(pkg, oracle, tmp_path, capsys):
     rc = cli.main(['--test', '-x', str(tmp_path / 'train.b'), '--modeldir', str(work), '-d', str(outdir), '--nn', '32', '16',
                    '--useBN', '--datasource', 'matlab_maMimo'])
     assert rc == 0 and 'loss (mse vs labels)' in capsys.readouterr().out
+
+
+def _dp_worker(rank, world, port, tmp, repo):
+    """One rank of the data-parallel check (2 processes sharing GPU 0, gloo carrying the CUDA all-reduce)."""
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, repo)
+    import numpy as np
+    import dl_channel_estimation_mamimo_amd as pkg
+    pkg.dist.init_process_group('gloo')
+    z = np.load(os.path.join(tmp, 'problem.npz'))
+    w = {k: z[k] for k in z.files if k not in ('x', 'y')}
+    x, y = z['x'], z['y']
+    e = pkg.CsiEngine(4, 2, hidden=(48, 32), use_bn=False)
+    e.train_begin('real', weights=w, lr=1e-3, dropout=0.0, seed=5)
+    for step in range(2):
+        xs = (x + 0.05 * step).astype(np.float32)
+        e.train_backward('real', xs[rank::world], y[rank::world])
+        e.synchronize()
+        pkg.dist.all_reduce_device(*e.train_grads('real'), average=True)
+        e.train_apply('real')
+    out = e.train_weights('real')
+    m = pkg.dist.all_reduce_mean_arrays({'a': np.full(3, float(rank), np.float32)})
+    np.savez(os.path.join(tmp, f'rank{rank}.npz'), mean_probe=m['a'], **out)
+    e.train_end('real', commit=False)
+
+
+@pytest.mark.gpu
+def test_data_parallel_step_equals_full_batch_step(pkg, oracle, tmp_path):
+    """Two ranks, each on half of a batch: backward -> flat gradient all-reduce (mean) -> Adam gives every
+    rank the parameters of the single-process step on the whole batch (model without BatchNormalization,
+    whose statistics are per rank by design)."""
+    import os
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(8)
+    w, x, y = _problem(oracle, rng, 4, (48, 32), 64, use_bn=False)
+    np.savez(tmp_path / 'problem.npz', x=x, y=y, **{k: v for k, v in w.items() if k != 'bn_eps'})
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_dp_worker, args=(2, 29533, str(tmp_path), repo), nprocs=2, join=True)
+    ref = {k: np.asarray(v, np.float64) for k, v in w.items() if k != 'bn_eps'}
+    state = oracle.adam_init(ref)
+    for step in range(2):
+        _, ref, _ = oracle.train_step_reference(ref, state, (x + 0.05 * step).astype(np.float32), y, lr=1e-3, use_bn=False)
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    assert np.allclose(r0['mean_probe'], 0.5)
+    for k in ref:
+        np.testing.assert_array_equal(r0[k], r1[k])            # identical parameters on both ranks
+        assert np.max(np.abs(r0[k] - ref[k])) < 0.05 * 1e-3 * 2 + 1e-6 and _rel(r0[k], ref[k]) < 1e-4, k
