@@ -82,9 +82,9 @@ def train_main(args):
     if world > 1:
         dist.init_process_group(os.environ.get('CSI_DIST_BACKEND', 'nccl'))       # before the engine: see _lib.load_library
         train_ids, val_ids = train_ids[rank::world], val_ids[rank::world]
-        n = min(dist.all_reduce_min(len(train_ids) // args.bs), len(train_ids) // args.bs)
+        n = int(dist.all_reduce_min(len(train_ids) // args.bs))
         train_ids = train_ids[:n * args.bs]                                       # same number of steps on every rank
-    eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=(local if world > 1 else args.device))
+    eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=(local % dist.local_device_count() if world > 1 else args.device))
     dims = ['real'] if args.onlyReal else (['imag'] if args.onlyImag else ['real', 'imag'])
     for d in dims:
         print('Working on *', d, '* model')

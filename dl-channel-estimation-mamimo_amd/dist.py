@@ -73,6 +73,12 @@ def broadcast_weights(weights, src=0, device=None):
     return out
 
 
+def local_device_count():
+    """GPUs visible to this process (ranks are mapped onto them round-robin)."""
+    import torch
+    return max(torch.cuda.device_count(), 1)
+
+
 def world_size():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_initialized() else 1
