@@ -555,7 +555,7 @@ template <int EPI, int TPW, int LPW, int DBG = 0>     // DBG: timing ablations o
 __global__ __launch_bounds__(G_THREADS, 2) void pair_gemm256_f32_kernel(const GemmArgs g) {
     constexpr int TROWS = 64 * TPW, LROWS = 64 * LPW;
     constexpr int STAGE = (128 + TROWS + LROWS) * R_BK;             // floats
-    constexpr int NS = (TPW + LPW == 2) ? 4 : 3;                    // 64 KiB / 60 KiB of LDS
+    constexpr int NS = 4;                                           // 64 KiB / 80 KiB of LDS: two workgroups per CU either way
     constexpr int D = NS - 1;
     constexpr int P = 2 + TPW + LPW;
     constexpr int TOFF = 128 * R_BK, LOFF = (128 + TROWS) * R_BK;
