@@ -37,6 +37,44 @@ def test_oracle_gradients_match_finite_differences(oracle):
         assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, fd, g[name][idx])
 
 
+def test_oracle_forward_backward_match_torch_autograd(oracle):
+    """Independent cross-check of the oracle's hand-derived forward / backward (Dense, relu,
+    BatchNormalization with batch statistics, dropout mask, mse) against PyTorch autograd in float64,
+    and of its inference forward against torch's batch_norm in eval mode.  (PyTorch is a third
+    implementation of the published layer definitions, not the reference - the Keras rows stay
+    'parity unpinned'.)"""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(17)
+    w, x, y = _problem(oracle, rng, 4, (24, 16), 32, n_out=10)
+    w = {k: (np.asarray(v, np.float64) if k != 'bn_eps' else v) for k, v in w.items()}
+    masks = [rng.random((32, 24)) >= 0.3, None]
+    loss, g, stats = oracle.train_forward_backward(w, x, y, masks=masks, dropout=0.3)
+    tw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items() if k != 'bn_eps'}
+    h = torch.tensor(x, dtype=torch.float64)
+    for i in range(2):
+        a = torch.relu(h @ tw[f'fc_dense{i}.kernel'] + tw[f'fc_dense{i}.bias'])
+        h = F.batch_norm(a, None, None, tw[f'bn{i}.gamma'], tw[f'bn{i}.beta'], training=True, eps=1e-3)
+        if i == 0:
+            h = torch.where(torch.tensor(masks[0]), h / (1.0 - 0.3), torch.zeros_like(h))
+    out = h @ tw['fc_regressor.kernel'] + tw['fc_regressor.bias']
+    tl = torch.mean((out - torch.tensor(y, dtype=torch.float64)) ** 2)
+    tl.backward()
+    assert abs(float(tl) - loss) < 1e-12 * max(1.0, loss)
+    for k, gk in g.items():
+        assert _rel(gk, tw[k].grad.numpy()) < 1e-10, k
+    # inference mode
+    ref = oracle.fc_forward(x.astype(np.float64), w, np.float64)
+    h = torch.tensor(x, dtype=torch.float64)
+    with torch.no_grad():
+        for i in range(2):
+            a = torch.relu(h @ tw[f'fc_dense{i}.kernel'] + tw[f'fc_dense{i}.bias'])
+            h = F.batch_norm(a, torch.tensor(w[f'bn{i}.moving_mean']), torch.tensor(w[f'bn{i}.moving_variance']),
+                             tw[f'bn{i}.gamma'], tw[f'bn{i}.beta'], training=False, eps=1e-3)
+        out = h @ tw['fc_regressor.kernel'] + tw['fc_regressor.bias']
+    assert _rel(ref, out.numpy()) < 1e-12
+
+
 def test_trainer_schedule_logic(pkg):
     """noise schedule and batch assembly of the python loop (no GPU): DNN.py:97-100, dataGenerator.py:314."""
     tr = pkg.trainer
