@@ -52,7 +52,8 @@ def _find_weights(modeldir, d):
     from .model import WEIGHT_FILE
     for cand in (os.path.join(modeldir, d + '_keras_model', WEIGHT_FILE),
                  os.path.join(modeldir, d + '_weights-improvement.safetensors'),
-                 os.path.join(modeldir, d + '_weights-improvement.pt')):
+                 os.path.join(modeldir, d + '_weights-improvement.pt'),
+                 os.path.join(modeldir, d + '_weights-improvement.npz')):
         if os.path.exists(cand):
             return cand
     print('Given model directory holds no weights for the %s model. Aborting...' % d)

@@ -20,9 +20,11 @@ CONFIG_FILE = 'config.json'
 
 
 def save_weight_file(path, weights):
-    """weights: dict name -> float32 ndarray.  Format by extension (.safetensors | .pt)."""
+    """weights: dict name -> float32 ndarray.  Format by extension (.safetensors | .pt | .npz)."""
     tensors = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items() if isinstance(v, np.ndarray)}
-    if path.endswith('.pt'):
+    if path.endswith('.npz'):
+        np.savez(path, **tensors)
+    elif path.endswith('.pt'):
         import torch
         torch.save({k: torch.from_numpy(v) for k, v in tensors.items()}, path)
     else:
@@ -30,7 +32,43 @@ def save_weight_file(path, weights):
         save_file(tensors, path)
 
 
+def normalize_keras_names(tensors):
+    """Accept the variable names Keras itself uses and map them to the container's names:
+        'fc_dense0/kernel:0', 'fc_regressor/bias:0'                       (model.weights[i].name)
+        'fc_dense0/fc_dense0/kernel:0'                                    (HDF5 group/dataset paths)
+        'batch_normalization_7/moving_mean:0'                             (auto-numbered BatchNormalization)
+    BatchNormalization layers are matched by ORDER (their numeric suffixes sorted), which is how the
+    reference itself pairs them (load_weights by topology, DNN.py:334): the n-th one becomes bn{n}.
+    Names already in container form pass through."""
+    import re
+    out, bn = {}, {}
+    for name, val in tensors.items():
+        n = name.split(':')[0]
+        parts = n.split('/')
+        if len(parts) >= 2:
+            layer, var = parts[-2], parts[-1]
+        elif '.' in n:
+            layer, var = n.rsplit('.', 1)
+        else:
+            out[name] = val
+            continue
+        m = re.fullmatch(r'batch_normalization(?:_(\d+))?', layer)
+        if m:
+            bn.setdefault(int(m.group(1) or 0), {})[var] = val
+        else:
+            out[f'{layer}.{var}'] = val
+    for i, key in enumerate(sorted(bn)):
+        for var, val in bn[key].items():
+            out[f'bn{i}.{var}'] = val
+    return out
+
+
 def load_weight_file(path):
+    """.safetensors | .pt | .npz (np.savez(path, **{v.name: v.numpy() for v in keras_model.weights}) on a
+    Keras host needs nothing but numpy); Keras variable names are normalised."""
+    if path.endswith('.npz'):
+        with np.load(path) as z:
+            return normalize_keras_names({k: np.asarray(z[k], dtype=np.float32) for k in z.files})
     if path.endswith('.pt'):
         import torch
         return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in torch.load(path, map_location='cpu').items()}

@@ -237,3 +237,33 @@ def test_sample_generator_matches_reference_generator(pkg, golden_dir):
     assert tr == list(range(16)) and va == list(range(16, 24))
     tr, va = pkg.dataset.split_train_val(ds, 0.15)          # floor(0.45) = 0 packets: as in the reference
     assert len(tr) == 24 and va == []
+
+
+def test_keras_variable_names_and_npz_container(pkg, tmp_path):
+    """A Keras host can export with numpy alone: np.savez(path, **{v.name: v.numpy() for v in model.weights}).
+    The loader maps Keras' own variable names (incl. HDF5-style paths and auto-numbered
+    BatchNormalization layers, matched by order like the reference's load_weights) to the container names."""
+    rng = np.random.default_rng(3)
+    raw = {
+        'fc_dense0/kernel:0': rng.standard_normal((1284, 16)).astype(np.float32), 'fc_dense0/bias:0': np.zeros(16, np.float32),
+        'batch_normalization_6/gamma:0': np.full(16, 6.0, np.float32), 'batch_normalization_6/beta:0': np.zeros(16, np.float32),
+        'batch_normalization_6/moving_mean:0': np.zeros(16, np.float32), 'batch_normalization_6/moving_variance:0': np.ones(16, np.float32),
+        'fc_dense1/fc_dense1/kernel:0': rng.standard_normal((16, 8)).astype(np.float32), 'fc_dense1/fc_dense1/bias:0': np.zeros(8, np.float32),
+        'batch_normalization_7/gamma:0': np.full(8, 7.0, np.float32), 'batch_normalization_7/beta:0': np.zeros(8, np.float32),
+        'batch_normalization_7/moving_mean:0': np.zeros(8, np.float32), 'batch_normalization_7/moving_variance:0': np.ones(8, np.float32),
+        'fc_regressor/kernel:0': rng.standard_normal((8, 234)).astype(np.float32), 'fc_regressor/bias:0': np.zeros(234, np.float32),
+    }
+    f = tmp_path / 'real_weights-improvement.npz'
+    np.savez(f, **raw)
+    w = pkg.load_weight_file(str(f))
+    assert set(w) == {'fc_dense0.kernel', 'fc_dense0.bias', 'fc_dense1.kernel', 'fc_dense1.bias', 'fc_regressor.kernel', 'fc_regressor.bias'} | {
+        f'bn{i}.{v}' for i in (0, 1) for v in ('gamma', 'beta', 'moving_mean', 'moving_variance')}
+    assert w['bn0.gamma'][0] == 6.0 and w['bn1.gamma'][0] == 7.0 and w['bn1.gamma'].shape == (8,)
+    np.testing.assert_array_equal(w['fc_dense1.kernel'], raw['fc_dense1/fc_dense1/kernel:0'])
+    from dl_channel_estimation_mamimo_amd.model import config_from_weights, normalize_keras_names
+    assert config_from_weights(w, 4) == dict(hidden=[16, 8], n_out=234, use_bn=True)
+    assert normalize_keras_names(w) == w                       # container names pass through
+    g = tmp_path / 'round.npz'
+    pkg.save_weight_file(str(g), w)
+    w2 = pkg.load_weight_file(str(g))
+    assert set(w2) == set(w) and all(np.array_equal(w[k], w2[k]) for k in w)
