@@ -54,6 +54,36 @@ int bf16_layer0_splits(int M1, int h1, int K) {
     return best;
 }
 
+// first per-pair layer with h1 generated inside the GEMM (gemm_bf16_pp_pair_kernel); usable when the
+// grid is large, the reduction length fits the LDS copy of the bn0 vectors and rows are 16-byte aligned
+bool pair_fused_ok(const csi_ctx* c, int M, int N, int K, bool out_bf16, int ldc) {
+    if (c->force_pair_tile == 128 || c->bf16_fused_h1 == 0) return false;
+    const long tiles = (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN);
+    if (tiles < 256 && c->force_pair_tile != 256) return false;
+    if (K > 4096 || (K % PP_BK) != 0) return false;
+    return !out_bf16 || ((N & 7) == 0 && (ldc & 7) == 0);
+}
+
+template <int EPI, bool OUT_BF16>
+int launch_pair_bf16(csi_ctx* c, int kid, GemmBf16Args g, const PairSrc& ps) {
+    if (g.M <= 0) return CSI_OK;
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 4.0 * ((double)g.M / ps.nt * g.K + (double)ps.nt * g.K) + 2.0 * (double)g.N * g.K + (OUT_BF16 ? 2.0 : 4.0) * (double)g.M * g.N;
+    ProfScope psc(c, kid, flops, bytes);
+    g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    const size_t lds = (size_t)(PPP_RING_FLOATS + 2 * g.K) * sizeof(float);
+    auto kern = gemm_bf16_pp_pair_kernel<EPI, OUT_BF16>;
+    static thread_local size_t attr_set = 0;       // per instantiation
+    if (attr_set < lds) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, ps);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
 int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
     ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * n);
     const size_t n8 = n / 8;
@@ -64,7 +94,9 @@ int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
 }
 
 // hidden layers 1.. and the regressor on a bf16 activation matrix hin [M][l.in]; writes d_out fp32
-int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_t* hb1, float* d_out, int first_layer) {
+// fused: the first layer of the tail generates its A operand from (L0, T) - hin is then unused
+int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_t* hb1, float* d_out, int first_layer,
+              const PairSrc* fused = nullptr) {
     const csi_config& cf = c->cfg;
     bf16_t* hb[2] = {hb0, hb1};
     const bf16_t* cur = hin;
@@ -77,13 +109,16 @@ int bf16_tail(csi_ctx* c, Model& m, const bf16_t* hin, int M, bf16_t* hb0, bf16_
         q.M = M; q.N = l.out; q.K = l.in;
         q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
         q.k_per_split = l.ldwb;
+        const bool fuse = fused && li == first_layer;
         int rc;
         if (li == cf.n_hidden) {
             q.C = d_out; q.ldc = cf.n_out;
-            rc = launch_gemm_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, 1);
+            rc = fuse ? launch_pair_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, *fused) : launch_gemm_bf16<EPI_BIAS, false>(c, K_REGRESSOR, q, 1);
         } else {
             q.C = hb[w]; q.ldc = l.out;
-            rc = launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN, q, 1);
+            const int kid = li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN;
+            rc = fuse ? launch_pair_bf16<EPI_BIAS_RELU_AFFINE, true>(c, kid, q, *fused)
+                      : launch_gemm_bf16<EPI_BIAS_RELU_AFFINE, true>(c, kid, q, 1);
             cur = hb[w];
             w ^= 1;
         }
@@ -98,7 +133,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     int maxh = 0;
     for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
     // per packet: bf16 preamble copy, fp32 layer-0 product, bf16 h1, bf16 ping-pong hidden buffers
-    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 * BF16_L0_MAX_SPLITS + (size_t)nr * nt * h1 * 2 +
+    const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 * (BF16_L0_MAX_SPLITS + 1) + (size_t)nr * nt * h1 * 2 +
                            (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
     // default 8 GiB: a whole config-3 step (5000 packets) in one chunk, so that layer 0 sees M1 = 20000 rows
     const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)8 << 30);
@@ -110,7 +145,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     if (rc) return rc;
     char* base = c->ws;
     bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
-    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4 * BF16_L0_MAX_SPLITS;
+    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4 * (BF16_L0_MAX_SPLITS + 1);
     bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
     bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
     bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
@@ -128,13 +163,29 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
         rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, S);
         if (rc) return rc;
-        {
-            ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
-            hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3((unsigned)std::min(M1, 65536)), dim3(256), 0, c->stream, l0, S, (size_t)M1 * h1, m.T,
-                               m.layers[0].scale, m.layers[0].shift, h1b, M1, nt, h1);
-            HIP_TRY(c, hipGetLastError());
+        const Layer& l1 = m.layers[1];
+        const bool regressor_first = cf.n_hidden == 1;
+        if (pair_fused_ok(c, M2, l1.out, h1, !regressor_first, l1.out)) {
+            // h1 is generated inside the first per-pair GEMM from the (slab-summed) layer-0 product
+            float* l0sum = l0;
+            if (S > 1) {
+                l0sum = l0 + (size_t)S * M1 * h1;
+                ProfScope ps(c, K_SPLITK_REDUCE, (double)S * M1 * h1, 4.0 * (S + 1) * (double)M1 * h1);
+                const size_t n4 = (size_t)M1 * h1 / 4;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, c->stream, l0, l0sum, n4, S);
+                HIP_TRY(c, hipGetLastError());
+            }
+            PairSrc src{l0sum, m.T, m.layers[0].scale, m.layers[0].shift, h1, nt};
+            rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
+        } else {
+            {
+                ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
+                hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3((unsigned)std::min(M1, 65536)), dim3(256), 0, c->stream, l0, S, (size_t)M1 * h1, m.T,
+                                   m.layers[0].scale, m.layers[0].shift, h1b, M1, nt, h1);
+                HIP_TRY(c, hipGetLastError());
+            }
+            rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);
         }
-        rc = bf16_tail(c, m, h1b, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1);
         if (rc) return rc;
     }
     return CSI_OK;

@@ -511,6 +511,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;
         return ls_prepare(c);
+    } else if (n == "bf16_fused_h1") {
+        drop_graphs(c);
+        c->bf16_fused_h1 = value != 0;
     } else if (n == "host_threads") {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 64");
         if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }

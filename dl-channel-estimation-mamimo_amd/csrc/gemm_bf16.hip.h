@@ -482,6 +482,278 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmB
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong kernel of the FIRST per-pair layer with the A operand generated in the kernel:
+//     A[(pr,t)][k] = bf16( bn0( relu( L0[pr][k] + T[t][k] ) ) )        (fp32 in, rounded once)
+// so h1 never exists in HBM (pair_h1_bf16_kernel wrote 2.6 GB per launch at config 3 and this
+// kernel read it back).  Same phase structure as gemm_bf16_pp_kernel; differences:
+//   * every wave owns two A pieces and two B pieces of a sub-tile.  B pieces are LDS-DMA'd 3
+//     sub-tiles ahead (one per phase).  For the A pieces the wave loads the L0 / T values of
+//     sub-tile u+2 into registers in the first load segment of sub-tile u (8 x 16 B, L2-resident
+//     operands) and, in the second, turns them into 2 x 16 B of bf16 and writes them into the A
+//     image with ds_write_b128 (lane-linear, i.e. the layout the DMA would have produced).
+//   * one vmcnt per sub-tile: vmcnt(1) in front of the generation (the loads it needs are older
+//     than the single DMA issued behind them).  Memory operations retire in order, so that wait
+//     also retires every older B piece - which is what the hand-over of B sub-tile u+1 needs.
+//   * bn0 scale / shift live in LDS (8 * K bytes behind the ring).
+// RAW: the A image of sub-tile u+2 is written (lgkmcnt(0), barrier) in load segment (u,1) and first
+// read in MFMA segment (u+1,1) - four barriers later for either group.  WAR: its slot last held
+// sub-tile u-2, whose final reads were retired two sub-tiles ago.
+constexpr int PPP_RING_FLOATS = 4 * PP_SUBF;           // LDS ring of the fused kernel (4 sub-tiles)
+
+struct PairSrc {
+    const float* L0;       // [M / nt][ldl] fp32 (single slab)
+    const float* T;        // [nt][ldl] fp32 pilot table incl. bias
+    const float* s0;       // [K] bn0 scale (1 without BN)
+    const float* t0;       // [K] bn0 shift
+    int ldl, nt;
+};
+
+template <int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const GemmBf16Args g, const PairSrc ps) {
+    constexpr int NSUB = 4, D = 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring + 2 * K floats (s0 | t0)
+    float* sv_l = lds + NSUB * PP_SUBF;
+    float* hv_l = sv_l + g.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    if (tm * PP_BM >= g.M) return;
+    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+    const int nsub = (g.K + PP_BK - 1) / PP_BK;
+
+    for (int i = tid; i < g.K; i += PP_THREADS) {
+        sv_l[i] = ps.s0[i];
+        hv_l[i] = ps.t0[i];
+    }
+
+    // ---- B side: pieces 2w, 2w+1 of the 16 B pieces of a sub-tile
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb), 0, 0x7fffffff, 0x00020000);
+    int voff[2];
+    // ---- A side: pieces 2w, 2w+1 of the 16 A pieces; this lane's row and 8-column group
+    const float* lrow[2];
+    const float* trow[2];
+    const int clog = (lane & 3) ^ ((lane >> 4) & 3);          // (row >> 2) & 3 == (lane >> 4) & 3 for every piece
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = 16 * (2 * wave + u) + (lane >> 2);
+        voff[u] = (min(row, g.N - 1 - n0) * g.ldb + clog * 8) * 2;
+        const int m = min(m0 + row, g.M - 1);
+        const int pr = m / ps.nt, t = m - pr * ps.nt;
+        lrow[u] = ps.L0 + (size_t)pr * ps.ldl + clog * 8;
+        trow[u] = ps.T + (size_t)t * ps.ldl + clog * 8;
+    }
+    auto issue_b = [&](int sub, int slot, int u) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
+                                                 16, voff[u], sub * (PP_BK * 2), 0, 0);
+    };
+    f32x4 lv[2][2], tv[2][2];
+    auto load_a = [&](int sub, int u) {                 // L0 / T values of A piece u of sub-tile sub
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            lv[u][h] = *reinterpret_cast<const f32x4*>(lrow[u] + sub * PP_BK + 4 * h);
+            tv[u][h] = *reinterpret_cast<const f32x4*>(trow[u] + sub * PP_BK + 4 * h);
+        }
+    };
+    auto gen_a = [&](int sub, int slot, int u) {        // -> 16 B of bf16 per lane, lane-linear in the A image
+        const int k = sub * PP_BK + clog * 8;
+        const f32x4 s_lo = *reinterpret_cast<const f32x4*>(sv_l + k), s_hi = *reinterpret_cast<const f32x4*>(sv_l + k + 4);
+        const f32x4 h_lo = *reinterpret_cast<const f32x4*>(hv_l + k), h_hi = *reinterpret_cast<const f32x4*>(hv_l + k + 4);
+        uint4 o;
+        f32x2 v;
+        v = f32x2{fmaf(fmaxf(lv[u][0][0] + tv[u][0][0], 0.f), s_lo[0], h_lo[0]), fmaf(fmaxf(lv[u][0][1] + tv[u][0][1], 0.f), s_lo[1], h_lo[1])};
+        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        v = f32x2{fmaf(fmaxf(lv[u][0][2] + tv[u][0][2], 0.f), s_lo[2], h_lo[2]), fmaf(fmaxf(lv[u][0][3] + tv[u][0][3], 0.f), s_lo[3], h_lo[3])};
+        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        v = f32x2{fmaf(fmaxf(lv[u][1][0] + tv[u][1][0], 0.f), s_hi[0], h_hi[0]), fmaf(fmaxf(lv[u][1][1] + tv[u][1][1], 0.f), s_hi[1], h_hi[1])};
+        o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        v = f32x2{fmaf(fmaxf(lv[u][1][2] + tv[u][1][2], 0.f), s_hi[2], h_hi[2]), fmaf(fmaxf(lv[u][1][3] + tv[u][1][3], 0.f), s_hi[3], h_hi[3])};
+        o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + (2 * wave + u) * 256 + lane * 4) = o;
+    };
+
+    const int fswz = (l31 >> 2) & 3;
+    int xo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;
+    const int abase = (wm * 128 + l31) * PP_ROWF;
+    const int bbase = (PP_BM + wn * 64 + l31) * PP_ROWF;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    bf16x8 fa[2][4], fb[2][2];
+    auto read_frags = [&](int slot, int c, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+        const float* st = lds + slot * PP_SUBF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(st + abase + i * 32 * PP_ROWF + xo[c]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(st + bbase + j * 32 * PP_ROWF + xo[c]));
+    };
+    auto mfma_seg = [&](int cur, bool more, int nslot, int nc, bool closing_barrier) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (more) read_frags(nslot, nc, fa[cur ^ 1], fb[cur ^ 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        pp_wait_lgkm();
+        __builtin_amdgcn_sched_barrier(0);
+        if (closing_barrier) pp_barrier();
+    };
+
+    // ---- prologue: B sub-tiles 0..2 in flight, A sub-tiles 0 and 1 generated synchronously
+    __syncthreads();                    // s0 / t0 staged
+    const int npro = min(nsub, D);
+    for (int t = 0; t < npro; ++t) { issue_b(t, t, 0); issue_b(t, t, 1); }
+    for (int t = 0; t < min(nsub, 2); ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            load_a(t, p);
+            gen_a(t, t, p);             // the compiler waits for the loads it just issued
+        }
+    pp_wait_vm_lgkm<0>();
+    if (nsub > 2) { load_a(2, 0); load_a(2, 1); }      // consumed in the two load segments of sub-tile 0
+    pp_barrier();
+    read_frags(0, 0, fa[0], fb[0]);
+    pp_wait_lgkm();
+    if (wm == 1) pp_barrier();          // group 1 runs one segment behind
+
+    int slot = 0;
+    // one sub-tile (two phases).  STEADY: sub-tiles u+2 and u+3 exist and u is not the last one -
+    // straight-line code, so that the MFMA / fragment-read interleave pattern applies
+    auto subtile = [&](int u, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int nslot = (slot + 1) & 3;
+        const bool has_a = STEADY || u + 2 < nsub, has_b = STEADY || u + D < nsub, last = !STEADY && u == nsub - 1;
+        // Each phase p (0, 1): turn the values requested one sub-tile ago into A piece p of sub-tile u+2
+        // and store it, request piece p of sub-tile u+3 into the same registers, issue B piece p of
+        // sub-tile u+3.  The values waited for are older than 4 loads + 2 DMAs -> vmcnt(6).
+        const bool nxt_a = STEADY || u + 3 < nsub;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (has_a) {
+                if (STEADY) pp_wait_vm_lgkm<6>(); else pp_wait_vm_lgkm<0>();
+                gen_a(u + 2, (slot + 2) & 3, p);
+                if (nxt_a) load_a(u + 3, p);
+            } else if (p == 1) {
+                pp_wait_vm_lgkm<0>();   // tail: every outstanding B piece has landed
+            }
+            if (has_b) issue_b(u + D, (slot + D) & 3, p);
+            pp_wait_lgkm();             // the A image is written before the barrier publishes it
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            if (p == 0) mfma_seg(0, true, slot, 1, true);
+        }
+        mfma_seg(1, !last, nslot, 0, !(wm == 1 && last));
+        slot = nslot;
+    };
+    int u = 0;
+    for (; u + D < nsub; ++u) subtile(u, std::true_type{});
+    for (; u < nsub; ++u) subtile(u, std::false_type{});
+
+    // ---- epilogue: as gemm_bf16_pp_kernel
+    const bool full_rows = (m0 + PP_BM) <= g.M;
+    if constexpr (OUT_BF16) {
+        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            auto fin = [&](float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                return v;
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const f32x2 v = {fin(acc[mi][nj][2 * r2]), fin(acc[mi][nj][2 * r2 + 1])};
+                    const int P = mi * 16 + 4 * (r2 >> 1) + 2 * hi + (r2 & 1);
+                    ep[P * 64 + nj * 32 + l31] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cg = lane & 7;
+        const int col8 = n0 + wn * 64 + cg * 8;
+        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + col8;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int P = pass * 8 + (lane >> 3);
+            const uint4 w0 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8 + 4);
+            uint4 e, o;
+            e.x = (w0.x & 0xffffu) | (w0.y << 16);  o.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
+            e.y = (w0.z & 0xffffu) | (w0.w << 16);  o.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
+            e.z = (w1.x & 0xffffu) | (w1.y << 16);  o.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
+            e.w = (w1.z & 0xffffu) | (w1.w << 16);  o.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
+            const int row = m0 + wm * 128 + 2 * P;
+            if (full_rows) {
+                if (col8 < g.N) {
+                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                    *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+                }
+            } else {
+                if (col8 < g.N && row < g.M) *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                if (col8 < g.N && row + 1 < g.M) *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+            }
+        }
+    } else {
+        const int wrow = m0 + wm * 128 + 4 * hi;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int col = n0 + wn * 64 + nj * 32 + l31;
+            const bool cok = col < g.N;
+            const int colc = min(col, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            float* cf = reinterpret_cast<float*>(g.C) + (size_t)wrow * g.ldc + col;
+            auto put = [&](int rr, float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                cf[(size_t)rr * g.ldc] = v;
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                    if (cok && (full_rows || (wrow + rr) < g.M)) put(rr, acc[mi][nj][r]);
+                }
+        }
+    }
+}
+
 // dst[i] = bf16(src[i]); n8 = number of 8-element groups
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

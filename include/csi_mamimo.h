@@ -177,6 +177,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
+ *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
+ *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
  *                         slots of the host-buffer entry points (0 = automatic, up to 8)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked

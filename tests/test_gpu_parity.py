@@ -368,11 +368,11 @@ def test_bf16_mode_matches_bf16_emulation(pkg, oracle, nt, nr, npkt, hidden):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
 
 
-@pytest.mark.parametrize('tile', [128, 256])
-@pytest.mark.parametrize('nt,nr,npkt,hidden', [(8, 2, 37, (64, 64)), (64, 2, 5, (128, 72)), (4, 2, 70, (72, 40, 24))])
-def test_bf16_both_tile_kernels(pkg, oracle, tile, nt, nr, npkt, hidden):
-    """The 256x256 ping-pong kernel (force_tile=256) and the 128x128 lock-step kernel (128) against the
-    bf16 emulation on ragged shapes: row counts that are no multiple of 256, widths below one tile,
+@pytest.mark.parametrize('tile,fused', [(128, 0), (256, 0), (256, 1)])
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(8, 2, 37, (64, 64)), (64, 2, 5, (128, 72)), (4, 2, 70, (96, 40, 24)), (16, 2, 21, (64,))])
+def test_bf16_both_tile_kernels(pkg, oracle, tile, fused, nt, nr, npkt, hidden):
+    """The 256x256 ping-pong kernel (force_tile=256; with h1 materialised or generated in the kernel) and
+    the 128x128 lock-step kernel (128) against the bf16 emulation on ragged shapes: row counts that are no multiple of 256, widths below one tile,
     k-extents that end inside a 32-column sub-tile, split-K slabs of layer 0."""
     rng = np.random.default_rng(7 * nt + npkt)
     w_re, w_im = _weights(oracle, 900 + nt, nt, hidden)
@@ -380,6 +380,7 @@ def test_bf16_both_tile_kernels(pkg, oracle, tile, nt, nr, npkt, hidden):
     ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=8.0)[0].astype(np.complex64)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
     e.set_option('force_tile', tile)
+    e.set_option('bf16_fused_h1', fused)      # 1: h1 generated inside the first per-pair GEMM (incl. a regressor-only model)
     o_re, o_im = e.predict(ltf)
     b_re, b_im = oracle.predict_packets_bf16(ltf, P, w_re, w_im)
     assert rel_rows(o_re, b_re) < BF16_TOL_IMPL and rel_rows(o_im, b_im) < BF16_TOL_IMPL
