@@ -84,6 +84,26 @@ int launch_pair_bf16(csi_ctx* c, int kid, GemmBf16Args g, const PairSrc& ps) {
     return CSI_OK;
 }
 
+// layer 0 straight from the fp32 preambles (the bf16 conversion happens while the A image is built)
+int launch_layer0_cast_bf16(csi_ctx* c, GemmBf16Args g, const float* x, int ldx, int splits) {
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 4.0 * (double)g.M * g.K + 2.0 * (double)g.N * g.K + 4.0 * (double)g.M * g.N * splits;
+    ProfScope psc(c, K_LAYER0_LTF, flops, bytes);
+    g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
+    auto kern = gemm_bf16_pp_pair_kernel<EPI_RAW, false, true>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
 int cast_bf16(csi_ctx* c, const float* src, bf16_t* dst, size_t n) {
     ProfScope ps(c, K_CAST_BF16, 0.0, 6.0 * n);
     const size_t n8 = n / 8;
@@ -152,8 +172,6 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     for (int64_t p0 = 0; p0 < npkt; p0 += chunk) {
         const int64_t np = std::min(chunk, npkt - p0);
         const int M1 = (int)(np * nr), M2 = (int)(np * nr * nt);
-        rc = cast_bf16(c, d_ltf + (size_t)p0 * nr * cf.len_ltf, xb, (size_t)M1 * cf.len_ltf);
-        if (rc) return rc;
         GemmBf16Args g{};
         g.A = xb; g.lda = cf.len_ltf;
         g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
@@ -161,7 +179,17 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
         const int S = bf16_layer0_splits(M1, h1, cf.len_ltf);
         g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
-        rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, S);
+        const long l0_tiles = (long)((M1 + PP_BM - 1) / PP_BM) * ((h1 + PP_BN - 1) / PP_BN) * S;
+        const bool l0_fused = c->bf16_fused_h1 != 0 && c->force_pair_tile != 128 && (l0_tiles >= 256 || c->force_pair_tile == 256) &&
+                              g.k_per_split / PP_BK >= 3 && (cf.len_ltf & 3) == 0;
+        if (l0_fused) {
+            // the conversion happens inside the GEMM: no separate pass over the preambles
+            rc = launch_layer0_cast_bf16(c, g, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, S);
+        } else {
+            rc = cast_bf16(c, d_ltf + (size_t)p0 * nr * cf.len_ltf, xb, (size_t)M1 * cf.len_ltf);
+            if (rc) return rc;
+            rc = launch_gemm_bf16<EPI_RAW, false>(c, K_LAYER0_LTF, g, S);
+        }
         if (rc) return rc;
         const Layer& l1 = m.layers[1];
         const bool regressor_first = cf.n_hidden == 1;

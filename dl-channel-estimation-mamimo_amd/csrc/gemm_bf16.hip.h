@@ -509,7 +509,10 @@ struct PairSrc {
     int ldl, nt;
 };
 
-template <int EPI, bool OUT_BF16>
+// CAST = true: the plain variant of the same machinery for layer 0 - A[m][k] = bf16(X[m][k]) from the
+// fp32 preambles (ps.L0 = X, ps.ldl = its row pitch; no T / bn0), split-K over blockIdx.z - which
+// removes the separate cast pass over the inputs.
+template <int EPI, bool OUT_BF16, bool CAST = false>
 __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const GemmBf16Args g, const PairSrc ps) {
     constexpr int NSUB = 4, D = 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring + 2 * K floats (s0 | t0)
@@ -526,15 +529,18 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
     if (tm * PP_BM >= g.M) return;
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
-    const int nsub = (g.K + PP_BK - 1) / PP_BK;
+    const int kbeg = CAST ? blockIdx.z * g.k_per_split : 0;
+    const int kend = CAST ? min(g.K, kbeg + g.k_per_split) : g.K;
+    const int nsub = (kend - kbeg + PP_BK - 1) / PP_BK;
 
-    for (int i = tid; i < g.K; i += PP_THREADS) {
-        sv_l[i] = ps.s0[i];
-        hv_l[i] = ps.t0[i];
-    }
+    if (!CAST)
+        for (int i = tid; i < g.K; i += PP_THREADS) {
+            sv_l[i] = ps.s0[i];
+            hv_l[i] = ps.t0[i];
+        }
 
     // ---- B side: pieces 2w, 2w+1 of the 16 B pieces of a sub-tile
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb + kbeg), 0, 0x7fffffff, 0x00020000);
     int voff[2];
     // ---- A side: pieces 2w, 2w+1 of the 16 A pieces; this lane's row and 8-column group
     const float* lrow[2];
@@ -545,9 +551,14 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
         const int row = 16 * (2 * wave + u) + (lane >> 2);
         voff[u] = (min(row, g.N - 1 - n0) * g.ldb + clog * 8) * 2;
         const int m = min(m0 + row, g.M - 1);
-        const int pr = m / ps.nt, t = m - pr * ps.nt;
-        lrow[u] = ps.L0 + (size_t)pr * ps.ldl + clog * 8;
-        trow[u] = ps.T + (size_t)t * ps.ldl + clog * 8;
+        if (CAST) {
+            lrow[u] = ps.L0 + (size_t)m * ps.ldl + kbeg + clog * 8;
+            trow[u] = lrow[u];
+        } else {
+            const int pr = m / ps.nt, t = m - pr * ps.nt;
+            lrow[u] = ps.L0 + (size_t)pr * ps.ldl + clog * 8;
+            trow[u] = ps.T + (size_t)t * ps.ldl + clog * 8;
+        }
     }
     auto issue_b = [&](int sub, int slot, int u) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
@@ -558,10 +569,19 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             lv[u][h] = *reinterpret_cast<const f32x4*>(lrow[u] + sub * PP_BK + 4 * h);
-            tv[u][h] = *reinterpret_cast<const f32x4*>(trow[u] + sub * PP_BK + 4 * h);
+            if (!CAST) tv[u][h] = *reinterpret_cast<const f32x4*>(trow[u] + sub * PP_BK + 4 * h);
         }
     };
     auto gen_a = [&](int sub, int slot, int u) {        // -> 16 B of bf16 per lane, lane-linear in the A image
+        if (CAST) {
+            uint4 o;
+            o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{lv[u][0][0], lv[u][0][1]}), bf16x2));
+            o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{lv[u][0][2], lv[u][0][3]}), bf16x2));
+            o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{lv[u][1][0], lv[u][1][1]}), bf16x2));
+            o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{lv[u][1][2], lv[u][1][3]}), bf16x2));
+            *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + (2 * wave + u) * 256 + lane * 4) = o;
+            return;
+        }
         const int k = sub * PP_BK + clog * 8;
         const f32x4 s_lo = *reinterpret_cast<const f32x4*>(sv_l + k), s_hi = *reinterpret_cast<const f32x4*>(sv_l + k + 4);
         const f32x4 h_lo = *reinterpret_cast<const f32x4*>(hv_l + k), h_hi = *reinterpret_cast<const f32x4*>(hv_l + k + 4);
@@ -657,7 +677,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (has_a) {
-                if (STEADY) pp_wait_vm_lgkm<6>(); else pp_wait_vm_lgkm<0>();
+                if (STEADY) pp_wait_vm_lgkm<(CAST ? 4 : 6)>(); else pp_wait_vm_lgkm<0>();
                 gen_a(u + 2, (slot + 2) & 3, p);
                 if (nxt_a) load_a(u + 3, p);
             } else if (p == 1) {
@@ -737,19 +757,28 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
             float bias = 0.f, sc = 1.f, sh = 0.f;
             if (EPI != EPI_RAW) bias = g.bias[colc];
             if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-            float* cf = reinterpret_cast<float*>(g.C) + (size_t)wrow * g.ldc + col;
+            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) + (size_t)wrow * g.ldc + col;
             auto put = [&](int rr, float v) {
                 if (EPI == EPI_BIAS) v += bias;
                 if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
                 cf[(size_t)rr * g.ldc] = v;
             };
+            if (full_rows) {
+                if (cok) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
-                    if (cok && (full_rows || (wrow + rr) < g.M)) put(rr, acc[mi][nj][r]);
+                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
                 }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
+                    }
+            }
         }
     }
 }
