@@ -253,6 +253,108 @@ __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "mem
 // column tiles of a row tile are consecutive on ONE XCD (A rows enter that L2 once)
 __host__ __forceinline__ unsigned pp_grid(int tiles_m, int tiles_n) { return 8u * tiles_n * ((tiles_m + 7) / 8); }
 
+// Epilogue of the 256x256 ping-pong kernels: 8 waves as 2 (rows) x 4 (columns), 128x64 per wave.
+// bf16 output goes through a wave-private LDS image so that every lane stores 16 contiguous bytes
+// (2-byte stores of the C/D layout cost 8x the store instructions).  The ring is idle by then: every
+// DMA has landed and every fragment read was retired in front of a barrier the wave has passed.
+// Image: [64 row pairs][64 columns] words, word = (row 2P | row 2P+1 << 16) of one column - the C/D
+// layout holds rows 2P, 2P+1 of a column in adjacent accumulator registers, so packing needs no
+// cross-lane traffic.  fp32 output is stored straight from the C/D layout (col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)): 32 lanes x 4 B = one 128-byte line per row; EPI_RAW writes
+// split-K slab blockIdx.z.
+template <int EPI, bool OUT_BF16>
+__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmBf16Args& g, float* lds, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool full_rows = (m0 + PP_BM) <= g.M;
+    if constexpr (OUT_BF16) {
+        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            auto fin = [&](float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                return v;
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const f32x2 v = {fin(acc[mi][nj][2 * r2]), fin(acc[mi][nj][2 * r2 + 1])};
+                    const int P = mi * 16 + 4 * (r2 >> 1) + 2 * hi + (r2 & 1);
+                    ep[P * 64 + nj * 32 + l31] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cg = lane & 7;
+        const int col8 = n0 + wn * 64 + cg * 8;
+        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + col8;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int P = pass * 8 + (lane >> 3);
+            const uint4 w0 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8 + 4);
+            uint4 e, o;
+            e.x = (w0.x & 0xffffu) | (w0.y << 16);  o.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
+            e.y = (w0.z & 0xffffu) | (w0.w << 16);  o.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
+            e.z = (w1.x & 0xffffu) | (w1.y << 16);  o.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
+            e.w = (w1.z & 0xffffu) | (w1.w << 16);  o.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
+            const int row = m0 + wm * 128 + 2 * P;
+            if (full_rows) {
+                if (col8 < g.N) {
+                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                    *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+                }
+            } else {
+                if (col8 < g.N && row < g.M) *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
+                if (col8 < g.N && row + 1 < g.M) *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
+            }
+        }
+    } else {
+        // fp32 output straight from the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+        // 32 lanes x 4 B = one 128-byte line per row
+        const int wrow = m0 + wm * 128 + 4 * hi;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int col = n0 + wn * 64 + nj * 32 + l31;
+            const bool cok = col < g.N;
+            const int colc = min(col, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) +
+                        (size_t)wrow * g.ldc + col;
+            auto put = [&](int rr, float v) {
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                cf[(size_t)rr * g.ldc] = v;
+            };
+            if (full_rows) {
+                if (cok) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
+                    }
+            }
+        }
+    }
+}
+
 template <int EPI, bool OUT_BF16, int NSUB, int DBG = 0>
 __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmBf16Args g) {
     static_assert(NSUB == 4 || NSUB == 5, "ring depth");
@@ -387,99 +489,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmB
     }
 
     if ((DBG & 8) && g.M > 0) return;
-    const bool full_rows = (m0 + PP_BM) <= g.M;
-    if constexpr (OUT_BF16) {
-        // bf16 output through a wave-private LDS image so that every lane stores 16 contiguous
-        // bytes (2-byte stores of the C/D layout cost 8x the store instructions and ~20 % of the
-        // kernel).  The ring is idle here: every DMA has landed and every fragment read was retired
-        // in front of a barrier this wave has passed.  Image: [64 row pairs][64 columns] words,
-        // word = (row 2P | row 2P+1 << 16) of one column - the C/D layout holds rows 2P, 2P+1 of a
-        // column in adjacent accumulator registers, so packing needs no cross-lane traffic.
-        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
-            float bias = 0.f, sc = 1.f, sh = 0.f;
-            if (EPI != EPI_RAW) bias = g.bias[colc];
-            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-            auto fin = [&](float v) {
-                if (EPI == EPI_BIAS) v += bias;
-                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
-                return v;
-            };
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    const f32x2 v = {fin(acc[mi][nj][2 * r2]), fin(acc[mi][nj][2 * r2 + 1])};
-                    const int P = mi * 16 + 4 * (r2 >> 1) + 2 * hi + (r2 & 1);
-                    ep[P * 64 + nj * 32 + l31] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-                }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int cg = lane & 7;
-        const int col8 = n0 + wn * 64 + cg * 8;
-        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + col8;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int P = pass * 8 + (lane >> 3);
-            const uint4 w0 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8 + 4);
-            uint4 e, o;
-            e.x = (w0.x & 0xffffu) | (w0.y << 16);  o.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
-            e.y = (w0.z & 0xffffu) | (w0.w << 16);  o.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
-            e.z = (w1.x & 0xffffu) | (w1.y << 16);  o.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
-            e.w = (w1.z & 0xffffu) | (w1.w << 16);  o.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
-            const int row = m0 + wm * 128 + 2 * P;
-            if (full_rows) {
-                if (col8 < g.N) {
-                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
-                    *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
-                }
-            } else {
-                if (col8 < g.N && row < g.M) *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
-                if (col8 < g.N && row + 1 < g.M) *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
-            }
-        }
-    } else {
-        // fp32 output straight from the C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
-        // 32 lanes x 4 B = one 128-byte line per row
-        const int wrow = m0 + wm * 128 + 4 * hi;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int col = n0 + wn * 64 + nj * 32 + l31;
-            const bool cok = col < g.N;
-            const int colc = min(col, g.N - 1);
-            float bias = 0.f, sc = 1.f, sh = 0.f;
-            if (EPI != EPI_RAW) bias = g.bias[colc];
-            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) +
-                        (size_t)wrow * g.ldc + col;
-            auto put = [&](int rr, float v) {
-                if (EPI == EPI_BIAS) v += bias;
-                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
-                cf[(size_t)rr * g.ldc] = v;
-            };
-            if (full_rows) {
-                if (cok) {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
-                }
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
-                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
-                    }
-            }
-        }
-    }
+    pp_epilogue<EPI, OUT_BF16>(acc, g, lds, m0, n0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -696,91 +706,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     for (; u + D < nsub; ++u) subtile(u, std::true_type{});
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
-    // ---- epilogue: as gemm_bf16_pp_kernel
-    const bool full_rows = (m0 + PP_BM) <= g.M;
-    if constexpr (OUT_BF16) {
-        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
-            float bias = 0.f, sc = 1.f, sh = 0.f;
-            if (EPI != EPI_RAW) bias = g.bias[colc];
-            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-            auto fin = [&](float v) {
-                if (EPI == EPI_BIAS) v += bias;
-                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
-                return v;
-            };
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    const f32x2 v = {fin(acc[mi][nj][2 * r2]), fin(acc[mi][nj][2 * r2 + 1])};
-                    const int P = mi * 16 + 4 * (r2 >> 1) + 2 * hi + (r2 & 1);
-                    ep[P * 64 + nj * 32 + l31] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-                }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int cg = lane & 7;
-        const int col8 = n0 + wn * 64 + cg * 8;
-        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + col8;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int P = pass * 8 + (lane >> 3);
-            const uint4 w0 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(ep + P * 64 + cg * 8 + 4);
-            uint4 e, o;
-            e.x = (w0.x & 0xffffu) | (w0.y << 16);  o.x = (w0.x >> 16) | (w0.y & 0xffff0000u);
-            e.y = (w0.z & 0xffffu) | (w0.w << 16);  o.y = (w0.z >> 16) | (w0.w & 0xffff0000u);
-            e.z = (w1.x & 0xffffu) | (w1.y << 16);  o.z = (w1.x >> 16) | (w1.y & 0xffff0000u);
-            e.w = (w1.z & 0xffffu) | (w1.w << 16);  o.w = (w1.z >> 16) | (w1.w & 0xffff0000u);
-            const int row = m0 + wm * 128 + 2 * P;
-            if (full_rows) {
-                if (col8 < g.N) {
-                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
-                    *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
-                }
-            } else {
-                if (col8 < g.N && row < g.M) *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = e;
-                if (col8 < g.N && row + 1 < g.M) *reinterpret_cast<uint4*>(cb + (size_t)(row + 1) * g.ldc) = o;
-            }
-        }
-    } else {
-        const int wrow = m0 + wm * 128 + 4 * hi;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int col = n0 + wn * 64 + nj * 32 + l31;
-            const bool cok = col < g.N;
-            const int colc = min(col, g.N - 1);
-            float bias = 0.f, sc = 1.f, sh = 0.f;
-            if (EPI != EPI_RAW) bias = g.bias[colc];
-            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
-            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) + (size_t)wrow * g.ldc + col;
-            auto put = [&](int rr, float v) {
-                if (EPI == EPI_BIAS) v += bias;
-                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
-                cf[(size_t)rr * g.ldc] = v;
-            };
-            if (full_rows) {
-                if (cok) {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
-                }
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
-                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
-                    }
-            }
-        }
-    }
+    pp_epilogue<EPI, OUT_BF16>(acc, g, lds, m0, n0, wave, lane);
 }
 
 // dst[i] = bf16(src[i]); n8 = number of 8-element groups
