@@ -68,6 +68,8 @@ SYMBOLS = {
     'csi_train_backward': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, ctypes.c_float, _fp]),
     'csi_train_grads': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(_fp), ctypes.POINTER(ctypes.c_int64)]),
     'csi_train_apply': (ctypes.c_int, [_ctx, ctypes.c_int]),
+    'csi_train_set_dataset': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _fp, ctypes.c_int64]),
+    'csi_train_indexed': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, ctypes.c_float, _fp]),
     'csi_train_eval': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp, ctypes.c_int64, _fp]),
     'csi_train_set_lr': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_float]),
     'csi_train_get': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_char_p, _fp, ctypes.c_int64]),

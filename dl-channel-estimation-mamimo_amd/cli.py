@@ -86,6 +86,7 @@ def train_main(args):
         n = int(dist.all_reduce_min(len(train_ids) // args.bs))
         train_ids = train_ids[:n * args.bs]                                       # same number of steps on every rank
     eng = CsiEngine(nt, nr, hidden=args.nn, n_out=n_out, use_bn=args.useBN, device=(local % dist.local_device_count() if world > 1 else args.device))
+    eng.set_pilot(np.asarray(data['P'], dtype=np.float64).T)          # the pilot columns of a sample are rows of P (resident dataset)
     dims = ['real'] if args.onlyReal else (['imag'] if args.onlyImag else ['real', 'imag'])
     for d in dims:
         print('Working on *', d, '* model')
@@ -103,7 +104,7 @@ def train_main(args):
                 eng.train_end(d, commit=False)
             init = dist.broadcast_weights(init, src=0)
         hist = trainer.fit(eng, d, tr, va, epochs=args.epochs, lr=args.lr, dropout=args.dropout, weights=init,
-                           method=args.method, seed=args.seed, verbose=(rank == 0), data_parallel=(world > 1))
+                           method=args.method, seed=args.seed, verbose=(rank == 0), data_parallel=(world > 1), resident=data)
         if rank == 0:
             path = os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.safetensors')
             save_weight_file(path, hist['weights'])

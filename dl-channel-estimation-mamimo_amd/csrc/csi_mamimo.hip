@@ -554,7 +554,7 @@ int csi_train_step(csi_ctx* c, int model, const float* x, const float* y, int64_
     if (int rc0 = trainer_of(c, model, "csi_train_step", &t)) return rc0;
     if (!x || !y || B < 2 || B > (1 << 20) || noise_std < 0.f) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_step: bad argument (2 <= B <= 2^20)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const int rc = tr_backward(c, t, x, y, (int)B, noise_std, nullptr);
+    const int rc = tr_backward(c, t, x, y, nullptr, (int)B, noise_std, nullptr);
     if (rc) return rc;
     const int rc2 = tr_apply(c, t);
     if (rc2) return rc2;
@@ -571,7 +571,7 @@ int csi_train_backward(csi_ctx* c, int model, const float* x, const float* y, in
     if (int rc0 = trainer_of(c, model, "csi_train_backward", &t)) return rc0;
     if (!x || !y || B < 2 || B > (1 << 20) || noise_std < 0.f) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_backward: bad argument (2 <= B <= 2^20)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return tr_backward(c, t, x, y, (int)B, noise_std, loss);
+    return tr_backward(c, t, x, y, nullptr, (int)B, noise_std, loss);
 }
 
 int csi_train_grads(csi_ctx* c, int model, float** d_grads, int64_t* count) {
@@ -598,7 +598,38 @@ int csi_train_eval(csi_ctx* c, int model, const float* x, const float* y, int64_
     if (int rc0 = trainer_of(c, model, "csi_train_eval", &t)) return rc0;
     if (!x || !y || !loss || B < 1 || B > (1 << 20)) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_eval: bad argument");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return tr_eval(c, t, x, y, (int)B, loss);
+    return tr_eval(c, t, x, y, nullptr, (int)B, loss);
+}
+
+int csi_train_set_dataset(csi_ctx* c, int model, const float* ltf_table, int64_t n_rows, const int32_t* ltf_row, const int32_t* itx,
+                          const float* y, int64_t N) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_set_dataset", &t)) return rc0;
+    if (!ltf_table || !ltf_row || !y || n_rows <= 0 || N <= 0 || N > 0x7fffffff || (c->cfg.nt > 0 && !itx))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_train_set_dataset: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return tr_set_dataset(c, t, ltf_table, n_rows, ltf_row, itx, y, N);
+}
+
+// mode 0: step (backward + Adam), 1: backward only, 2: inference-mode loss
+int csi_train_indexed(csi_ctx* c, int model, int mode, const int32_t* ids, int64_t B, float noise_std, float* loss) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    csi_trainer* t = nullptr;
+    if (int rc0 = trainer_of(c, model, "csi_train_indexed", &t)) return rc0;
+    if (!ids || mode < 0 || mode > 2 || B < (mode == 2 ? 1 : 2) || B > (1 << 20) || noise_std < 0.f || (mode == 2 && !loss))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_train_indexed: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (mode == 2) return tr_eval(c, t, nullptr, nullptr, ids, (int)B, loss);
+    int rc = tr_backward(c, t, nullptr, nullptr, ids, (int)B, noise_std, mode == 1 ? loss : nullptr);
+    if (rc || mode == 1) return rc;
+    rc = tr_apply(c, t);
+    if (rc) return rc;
+    if (loss) {
+        HIP_TRY(c, hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CSI_OK;
 }
 
 int csi_train_set_lr(csi_ctx* c, int model, float lr) {

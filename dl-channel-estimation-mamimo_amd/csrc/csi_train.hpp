@@ -38,6 +38,11 @@ struct csi_trainer {
     float *dz = nullptr, *dzt = nullptr, *dh[2] = {nullptr, nullptr};
     float *out = nullptr, *dout = nullptr, *doutt = nullptr, *partial = nullptr, *loss = nullptr;
     float *ones = nullptr, *zeros = nullptr, *tmp = nullptr;
+    // resident dataset (csi_train_set_dataset): preamble table, per-sample table row / tx index, labels
+    float *ds_table = nullptr, *ds_y = nullptr;
+    int *ds_row = nullptr, *ds_itx = nullptr, *ids = nullptr;
+    int64_t ds_n = 0, ds_rows = 0;
+    int ids_cap = 0;
     float* gflat = nullptr;           // all gradients, one allocation (data-parallel all-reduce operand)
     int64_t gcount = 0;
     bool grads_pending = false;       // csi_train_backward ran, csi_train_apply has not
@@ -205,23 +210,47 @@ int tr_clear_batch_padding(csi_ctx* c, csi_trainer* t, int B) {
     return rc;
 }
 
-// forward + backward of one batch: loss and all gradients (no parameter update)
-int tr_backward(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, float noise_std, float* h_loss) {
+// stage a batch: from host rows (ids == nullptr) or from the resident dataset by sample index
+int tr_stage(csi_ctx* c, csi_trainer* t, const float* x, const float* y, const int* ids, int B, float noise_std, uint64_t stream) {
     const csi_config& cf = c->cfg;
-    const int nh = cf.n_hidden;
     int rc = tr_reserve(c, t, B);
-    if (rc) return rc;
-    rc = tr_upload_batch(c, t, x, y, B);
     if (rc) return rc;
     rc = tr_clear_batch_padding(c, t, B);
     if (rc) return rc;
-    t->step += 1;
-    {
-        ProfScope ps(c, K_TRAIN_ELEMWISE, 0.0, 12.0 * B * t->k0);
+    const int n_noisy = cf.nt > 0 ? cf.len_ltf : t->k0;
+    ProfScope ps(c, K_TRAIN_ELEMWISE, 0.0, 12.0 * B * t->k0);
+    if (!ids) {
+        rc = tr_upload_batch(c, t, x, y, B);
+        if (rc) return rc;
         hipLaunchKernelGGL(train_input_kernel, dim3((t->k0 + 31) / 32, (B + 31) / 32), dim3(256), 0, c->stream, t->x, t->xn, t->xt, B, t->k0,
-                           t->ldx, t->ldb, cf.nt > 0 ? cf.len_ltf : t->k0, noise_std, tr_stream(t, 60));
-        HIP_TRY(c, hipGetLastError());
+                           t->ldx, t->ldb, n_noisy, noise_std, stream);
+    } else {
+        if (!t->ds_table) return fail(c, CSI_ERR_NOT_READY, "no resident dataset: call csi_train_set_dataset first");
+        if (B > t->ids_cap) {
+            const int cap = std::max(B, 256);
+            float* p = nullptr;
+            rc = tr_alloc(c, t, &p, (size_t)cap);
+            if (rc) return rc;
+            t->ids = reinterpret_cast<int*>(p);
+            t->ids_cap = cap;
+        }
+        for (int b = 0; b < B; ++b)
+            if (ids[b] < 0 || ids[b] >= t->ds_n) return fail(c, CSI_ERR_INVALID_ARG, "sample index %d outside the resident dataset (%lld samples)", ids[b], (long long)t->ds_n);
+        HIP_TRY(c, hipMemcpyAsync(t->ids, ids, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(train_gather_kernel, dim3((t->k0 + 31) / 32, (B + 31) / 32), dim3(256), 0, c->stream, t->ds_table, t->ds_row, t->ds_itx,
+                           c->P, t->ds_y, t->ids, t->xn, t->xt, t->y, B, t->k0, n_noisy, cf.nt, t->layers.back().out, t->ldx, t->ldb, noise_std, stream);
     }
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// forward + backward of one batch: loss and all gradients (no parameter update)
+int tr_backward(csi_ctx* c, csi_trainer* t, const float* x, const float* y, const int* ids, int B, float noise_std, float* h_loss) {
+    const csi_config& cf = c->cfg;
+    const int nh = cf.n_hidden;
+    t->step += 1;
+    int rc = tr_stage(c, t, x, y, ids, B, noise_std, tr_stream(t, 60));
+    if (rc) return rc;
     rc = tr_forward(c, t, B, true);
     if (rc) return rc;
     rc = tr_loss(c, t, B, true, nullptr);
@@ -299,17 +328,39 @@ int tr_apply(csi_ctx* c, csi_trainer* t) {
     return CSI_OK;
 }
 
-int tr_eval(csi_ctx* c, csi_trainer* t, const float* x, const float* y, int B, float* h_loss) {
-    int rc = tr_reserve(c, t, B);
+int tr_eval(csi_ctx* c, csi_trainer* t, const float* x, const float* y, const int* ids, int B, float* h_loss) {
+    int rc = tr_stage(c, t, x, y, ids, B, 0.f, (uint64_t)0);
     if (rc) return rc;
-    rc = tr_upload_batch(c, t, x, y, B);
-    if (rc) return rc;
-    hipLaunchKernelGGL(train_input_kernel, dim3((t->k0 + 31) / 32, (B + 31) / 32), dim3(256), 0, c->stream, t->x, t->xn, t->xt, B, t->k0, t->ldx,
-                       t->ldb, 0, 0.f, (uint64_t)0);
-    HIP_TRY(c, hipGetLastError());
     rc = tr_forward(c, t, B, false);
     if (rc) return rc;
     return tr_loss(c, t, B, false, h_loss);
+}
+
+// upload the training set once: it stays in HBM for the whole fit (491 MB + 359 MB at the shipped size)
+int tr_set_dataset(csi_ctx* c, csi_trainer* t, const float* table, int64_t n_rows, const int* ltf_row, const int* itx, const float* y, int64_t N) {
+    const csi_config& cf = c->cfg;
+    if (cf.nt > 0 && !c->pilot_ok) return fail(c, CSI_ERR_NOT_READY, "csi_train_set_dataset: csi_set_pilot first (the pilot columns of a sample are rows of P)");
+    const int len = cf.nt > 0 ? cf.len_ltf : t->k0;
+    for (int64_t i = 0; i < N; ++i) {
+        if (ltf_row[i] < 0 || ltf_row[i] >= n_rows) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_set_dataset: ltf_row[%lld] out of range", (long long)i);
+        if (cf.nt > 0 && (itx[i] < 0 || itx[i] >= cf.nt)) return fail(c, CSI_ERR_INVALID_ARG, "csi_train_set_dataset: itx[%lld] out of range", (long long)i);
+    }
+    float *p_row = nullptr, *p_itx = nullptr;
+    int rc = tr_alloc(c, t, &t->ds_table, (size_t)n_rows * len);
+    if (!rc) rc = tr_alloc(c, t, &t->ds_y, (size_t)N * t->layers.back().out);
+    if (!rc) rc = tr_alloc(c, t, &p_row, (size_t)N);
+    if (!rc) rc = tr_alloc(c, t, &p_itx, (size_t)N);
+    if (rc) return rc;
+    t->ds_row = reinterpret_cast<int*>(p_row);
+    t->ds_itx = reinterpret_cast<int*>(p_itx);
+    HIP_TRY(c, hipMemcpyAsync(t->ds_table, table, (size_t)n_rows * len * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(t->ds_y, y, (size_t)N * t->layers.back().out * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(t->ds_row, ltf_row, (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (cf.nt > 0) HIP_TRY(c, hipMemcpyAsync(t->ds_itx, itx, (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    t->ds_n = N;
+    t->ds_rows = n_rows;
+    return CSI_OK;
 }
 
 // name -> device pointer / shape of a trainer tensor.  Kernels are exposed in the keras layout

@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void train_input_kernel(const float* __restric
     }
 }
 
+// Resident-dataset form of train_input_kernel: row b of the batch is sample ids[b] of a dataset that
+// lives in HBM - its LTF part is row ltf_row[s] of the preamble table (every rx preamble stored once,
+// create_massiveMIMO_CSIest_dnn_dataset.py:50-63), its pilot part row itx[s] of P
+// (massiveMIMO_dataGenerator.py:309-311).  Also gathers the labels: yb[b] = y[ids[b]].
+__global__ __launch_bounds__(256) void train_gather_kernel(const float* __restrict__ table, const int* __restrict__ ltf_row,
+                                                           const int* __restrict__ itx, const float* __restrict__ P,
+                                                           const float* __restrict__ yall, const int* __restrict__ ids,
+                                                           float* __restrict__ xn, float* __restrict__ xt, float* __restrict__ yb, int B, int K,
+                                                           int len_ltf, int nt, int n_out, int ldx, int ldt, float noise_std, uint64_t stream) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, k = k0 + tx;
+        float v = 0.f;
+        if (b < B && k < K) {
+            const int s = ids[b];
+            if (k < len_ltf) {
+                v = table[(size_t)ltf_row[s] * len_ltf + k];
+                if (noise_std != 0.f) v += noise_std * tr_normal(stream, (uint64_t)b * K + k);
+            } else {
+                v = P[(size_t)itx[s] * nt + (k - len_ltf)];
+            }
+            xn[(size_t)b * ldx + k] = v;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, b = b0 + tx;
+        if (k < K && b < B) xt[(size_t)k * ldt + b] = tile[tx][r];
+    }
+    // labels: the first column-blocks of the grid copy them (n_out <= K always holds: 234 vs 321*nt)
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, n = k0 + tx;
+        if (b < B && n < n_out) yb[(size_t)b * n_out + n] = yall[(size_t)ids[b] * n_out + n];
+    }
+}
+
 // dst[c][r] = src[r][c]   (src [R][lds_], dst [C][ldd], ldd >= R, padding untouched)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int lds_, int ldd) {
     __shared__ float tile[32][33];

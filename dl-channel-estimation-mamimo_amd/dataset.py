@@ -123,15 +123,24 @@ class SampleGenerator:
     floor(len(ids)/bs) batches per epoch; indexes reshuffled by on_epoch_end() when shuffle is set."""
 
     def __init__(self, list_ids, ds, d, batch_size=256, shuffle=True, seed=None):
-        self.list_IDs = list(list_ids)
+        self.list_IDs = np.asarray(list(list_ids), dtype=np.int64)
         self.dataset = ds
         self.d = d
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
         self._rng = np.random.default_rng(seed)
-        self._X = np.asarray(ds['X'])
-        self._P = np.asarray(ds['P'], dtype=np.float32)
+        X = np.asarray(ds['X'])
+        self._P = np.ascontiguousarray(np.asarray(ds['P'], dtype=np.float32).T)      # row t = ds['P'][:, t]
         self._y = np.asarray(ds['y'][d], dtype=np.float32)
+        self._itx = X[:, 1].astype(np.int64)
+        # every rx preamble once, as one float32 table: a batch is then two fancy-indexing gathers instead
+        # of bs dictionary look-ups and row copies (the reference's loop, massiveMIMO_dataGenerator.py:299-312)
+        keys = sorted({int(k) for k in X[self.list_IDs, 0]}) if len(self.list_IDs) else []
+        self._ltf = (np.stack([np.asarray(ds['LTF'][k][d], dtype=np.float32) for k in keys]) if keys
+                     else np.zeros((0, 0), np.float32))
+        row_of_key = {k: i for i, k in enumerate(keys)}
+        self._ltf_row = np.full(X.shape[0], -1, dtype=np.int64)
+        self._ltf_row[self.list_IDs] = [row_of_key[int(k)] for k in X[self.list_IDs, 0]]
         self.on_epoch_end()
 
     def __len__(self):
@@ -139,14 +148,14 @@ class SampleGenerator:
 
     def __getitem__(self, index):
         idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
-        ids = [self.list_IDs[k] for k in idx]
-        len_ltf = int(np.asarray(self.dataset['LTF'][int(self._X[ids[0], 0])][self.d]).shape[0])
-        xsig = np.empty((len(ids), len_ltf, 1), np.float32)
-        xp = np.empty((len(ids), self._P.shape[0]), np.float32)
-        for i, s in enumerate(ids):
-            xsig[i, :, 0] = self.dataset['LTF'][int(self._X[s, 0])][self.d]
-            xp[i] = self._P[:, int(self._X[s, 1])]
+        ids = self.list_IDs[idx]
+        xsig = self._ltf[self._ltf_row[ids]][:, :, None]
+        xp = self._P[self._itx[ids]]
         return [xsig, xp], self._y[ids], None
+
+    def batch_ids(self, index):
+        """Dataset sample indices of batch ``index`` (the resident-dataset training path sends only these)."""
+        return self.list_IDs[self.indexes[index * self.batch_size:(index + 1) * self.batch_size]]
 
     def reorder_indexes(self):
         self.indexes = np.arange(len(self.list_IDs))
@@ -161,3 +170,15 @@ class SampleGenerator:
         self.indexes = np.arange(len(self.list_IDs))
         if self.shuffle:
             self._rng.shuffle(self.indexes)
+
+
+def resident_arrays(ds, d):
+    """The dataset in the form csi_train_set_dataset takes: (ltf_table [n_keys, lenLTF] float32 - every rx
+    preamble of component ``d`` once, ltf_row [N], itx [N], y [N, nSubCarr]) for ALL samples of the pickle,
+    so that training and validation generators can both address it by sample index."""
+    X = np.asarray(ds['X'])
+    keys = sorted({int(k) for k in X[:, 0]})
+    row_of_key = {k: i for i, k in enumerate(keys)}
+    table = np.stack([np.asarray(ds['LTF'][k][d], dtype=np.float32) for k in keys])
+    ltf_row = np.array([row_of_key[int(k)] for k in X[:, 0]], dtype=np.int32)
+    return table, ltf_row, X[:, 1].astype(np.int32), np.asarray(ds['y'][d], dtype=np.float32)

@@ -196,6 +196,37 @@ class CsiEngine:
         idx = {'real': 0, 'imag': 1}.get(model, model)
         self._check(self._lib.csi_train_apply(self._ctx, int(idx)))
 
+    def train_set_dataset(self, model, ltf_table, ltf_row, itx, y):
+        """Upload a training set once (csi_train_set_dataset): ltf_table [n_rows, len_ltf] every rx preamble
+        of this component once, per sample its table row, tx index and labels [N, n_out]."""
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        table, y = _f32c(ltf_table), _f32c(y)
+        row = np.ascontiguousarray(ltf_row, dtype=np.int32)
+        itx = np.ascontiguousarray(itx, dtype=np.int32)
+        if table.ndim != 2 or table.shape[1] != self.len_ltf or y.shape != (row.size, self.n_out) or itx.shape != row.shape:
+            raise CsiError(-1, f'dataset shapes: table [n,{self.len_ltf}], ltf_row/itx [N], y [N,{self.n_out}]')
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._check(self._lib.csi_train_set_dataset(self._ctx, int(idx), _fp(table), table.shape[0], row.ctypes.data_as(ip),
+                                                    itx.ctypes.data_as(ip), _fp(y), row.size))
+
+    def _train_indexed(self, model, mode, ids, noise_std):
+        idx = {'real': 0, 'imag': 1}.get(model, model)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        loss = ctypes.c_float()
+        self._check(self._lib.csi_train_indexed(self._ctx, int(idx), mode, ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ids.size,
+                                                float(noise_std), ctypes.byref(loss)))
+        return float(loss.value)
+
+    def train_step_indexed(self, model, ids, noise_std=0.0):
+        """One optimiser step on the samples ``ids`` of the resident dataset."""
+        return self._train_indexed(model, 0, ids, noise_std)
+
+    def train_backward_indexed(self, model, ids, noise_std=0.0):
+        return self._train_indexed(model, 1, ids, noise_std)
+
+    def train_eval_indexed(self, model, ids):
+        return self._train_indexed(model, 2, ids, 0.0)
+
     def train_eval(self, model, x, y):
         """mse of the current trainer parameters in inference mode (the reference's val_loss)."""
         idx = {'real': 0, 'imag': 1}.get(model, model)

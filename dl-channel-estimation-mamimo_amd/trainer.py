@@ -37,10 +37,15 @@ def noise_std_for(avg_sig_pow, snr_db):
     return float(np.sqrt(avg_sig_pow / 10.0 ** (snr_db / 10.0)) / np.sqrt(2.0))
 
 
-def evaluate(engine, model, gen):
+def evaluate(engine, model, gen, resident=False):
     """keras Model.evaluate: batch losses averaged with the batch sizes as weights."""
     tot, cnt = 0.0, 0
     for b in range(len(gen)):
+        if resident:
+            ids = gen.batch_ids(b)
+            tot += engine.train_eval_indexed(model, ids) * len(ids)
+            cnt += len(ids)
+            continue
         X, y, _ = gen[b]
         rows = rows_from_batch(X)
         tot += engine.train_eval(model, rows, np.asarray(y, np.float32)) * rows.shape[0]
@@ -50,7 +55,7 @@ def evaluate(engine, model, gen):
 
 def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, weights=None, method='default_SNR',
         snr_levels=SNR_LEVELS_MAMIMO, es_patience=25, rlr_patience=20, rlr_factor=0.1, min_lr=None, seed=0,
-        verbose=True, commit=True, data_parallel=False):
+        verbose=True, commit=True, data_parallel=False, resident=None):
     """Trains one component model ('real' / 'imag') and returns the history dict
     {'loss': [...], 'val_loss': [...], 'lr': [...]}.  With commit the best weights (lowest val_loss,
     EarlyStopping restore_best_weights) become the engine's inference model.
@@ -58,19 +63,38 @@ def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, we
     data_parallel (torch.distributed initialised, one process per GPU, every rank calling fit with its
     own shard of batches and the same seed / initial weights): each step is backward -> one flat
     gradient all-reduce (RCCL) -> Adam, so all ranks hold identical parameters; the validation loss is
-    averaged over the ranks; BatchNormalization running statistics are averaged at the end."""
+    averaged over the ranks; BatchNormalization running statistics are averaged at the end.
+
+    resident = the dataset dict (dataset.load_dataset): the training set is uploaded once
+    (csi_train_set_dataset, engine.set_pilot must have been called) and every step sends only the batch's
+    sample indices (``gen.batch_ids(b)``, dataset.SampleGenerator) - no per-step batch assembly or upload."""
     rng = np.random.default_rng(seed)
     min_lr = lr * 0.01 if min_lr is None else min_lr
     engine.train_begin(model, weights=weights, lr=lr, dropout=dropout, seed=seed)
+    if resident is not None:
+        from . import dataset as _ds
+        engine.train_set_dataset(model, *_ds.resident_arrays(resident, model if isinstance(model, str) else ('real', 'imag')[model]))
     avg_pow = average_signal_power(train_gen) if method == 'default_SNR' else 0.0
     hist = {'loss': [], 'val_loss': [], 'lr': []}
     best, best_w, es_wait, rlr_best, rlr_wait, cur_lr = np.inf, None, 0, np.inf, 0, lr
     for ep in range(epochs):
         tot, cnt = 0.0, 0
         for b in range(len(train_gen)):
+            std = noise_std_for(avg_pow, rng.choice(snr_levels)) if method == 'default_SNR' else 0.0
+            if resident is not None:
+                ids = train_gen.batch_ids(b)
+                if data_parallel:
+                    loss = engine.train_backward_indexed(model, ids, noise_std=std)
+                    engine.synchronize()
+                    dist.all_reduce_device(*engine.train_grads(model), average=True)
+                    engine.train_apply(model)
+                else:
+                    loss = engine.train_step_indexed(model, ids, noise_std=std)
+                tot += loss * len(ids)
+                cnt += len(ids)
+                continue
             X, y, _ = train_gen[b]
             rows = rows_from_batch(X)
-            std = noise_std_for(avg_pow, rng.choice(snr_levels)) if method == 'default_SNR' else 0.0
             if data_parallel:
                 loss = engine.train_backward(model, rows, np.asarray(y, np.float32), noise_std=std)
                 engine.synchronize()
@@ -82,7 +106,7 @@ def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, we
             cnt += rows.shape[0]
         if hasattr(train_gen, 'on_epoch_end'):
             train_gen.on_epoch_end()
-        val = evaluate(engine, model, val_gen)
+        val = evaluate(engine, model, val_gen, resident=resident is not None)
         if data_parallel:
             val = dist.all_reduce_sum(val) / dist.world_size()
         hist['loss'].append(tot / max(cnt, 1))

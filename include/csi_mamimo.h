@@ -156,6 +156,16 @@ int  csi_train_step(csi_ctx* ctx, int model, const float* x, const float* y, int
 int  csi_train_backward(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float noise_std, float* loss);
 int  csi_train_grads(csi_ctx* ctx, int model, float** d_grads, int64_t* count);
 int  csi_train_apply(csi_ctx* ctx, int model);
+/* Resident training set (288 GB of HBM: the data stays on the device for the whole fit).  The
+ * dataset is handed over once in the reference's own de-duplicated form
+ * (create_massiveMIMO_CSIest_dnn_dataset.py:50-63): ltf_table [n_rows][len_ltf] = every rx preamble
+ * of this component once, and per sample s its table row ltf_row[s], its tx index itx[s] (the
+ * pilot columns are row itx[s] of csi_set_pilot's P) and its labels y[s][n_out].  A batch is then
+ * B sample indices: csi_train_indexed(mode 0 = step, 1 = backward only, 2 = inference-mode loss)
+ * gathers the rows on the device (AWGN applied on the fly) - no per-step host assembly or upload. */
+int  csi_train_set_dataset(csi_ctx* ctx, int model, const float* ltf_table, int64_t n_rows, const int32_t* ltf_row,
+                           const int32_t* itx, const float* y, int64_t N);
+int  csi_train_indexed(csi_ctx* ctx, int model, int mode, const int32_t* ids, int64_t B, float noise_std, float* loss);
 /* mse of the current parameters in inference mode (running statistics, no noise, no dropout):
  * the val_loss that EarlyStopping / ReduceLROnPlateau monitor (DNN.py:285-286). */
 int  csi_train_eval(csi_ctx* ctx, int model, const float* x, const float* y, int64_t B, float* loss);

@@ -361,3 +361,52 @@ def test_cli_train_under_torchrun_two_ranks(pkg, oracle, tmp_path):
     assert 'Epoch 2/2' in res.stdout and 'weights saved to' in res.stdout
     w = pkg.load_weight_file(str(tmp_path / 'model' / 'real_weights-improvement.safetensors'))
     assert np.isfinite(w['fc_dense0.kernel']).all()
+
+
+@pytest.mark.gpu
+def test_resident_dataset_steps_equal_host_row_steps(pkg, oracle):
+    """The training set uploaded once + batches addressed by sample index (csi_train_set_dataset /
+    csi_train_indexed) give bit-identical steps to batches assembled on the host by the generator twin -
+    with AWGN and dropout on (the counter-based streams depend only on seed, step and position)."""
+    rng = np.random.default_rng(40)
+    nt, nr, npkt, hidden = 4, 2, 12, (32, 16)
+    P_rows = rng.integers(-2, 3, (nt, nt)).astype(np.float64)           # generic pilot matrix, not symmetric
+    n = npkt * nr * nt
+    X = np.zeros((n, 2), dtype=int)
+    LTF = {}
+    for p in range(npkt):
+        for r in range(nr):
+            key = 7000 + 13 * (p * nr + r)
+            LTF[key] = {'real': rng.standard_normal(320 * nt), 'imag': rng.standard_normal(320 * nt)}
+            for t in range(nt):
+                X[p * nr * nt + r * nt + t] = [key, t]
+    ds = {'X': X, 'y': {'real': rng.standard_normal((n, 234)), 'imag': rng.standard_normal((n, 234))}, 'LTF': LTF,
+          'P': P_rows.T.copy(), 'simParams': {'nTX': nt, 'nRX': nr}}
+    w = oracle.make_weights(rng, 321 * nt, hidden, 234)
+    results = []
+    for resident in (False, True):
+        e = pkg.CsiEngine(nt, nr, hidden=hidden)
+        e.set_pilot(P_rows)
+        gen = pkg.dataset.SampleGenerator(list(range(n)), ds, 'imag', batch_size=32, shuffle=True, seed=9)
+        e.train_begin('imag', weights=w, lr=1e-3, dropout=0.2, seed=11)
+        if resident:
+            e.train_set_dataset('imag', *pkg.dataset.resident_arrays(ds, 'imag'))
+        losses = []
+        for b in range(len(gen)):
+            if resident:
+                losses.append(e.train_step_indexed('imag', gen.batch_ids(b), noise_std=0.3))
+            else:
+                Xb, yb, _ = gen[b]
+                losses.append(e.train_step('imag', pkg.trainer.rows_from_batch(Xb), yb, noise_std=0.3))
+        ev = e.train_eval_indexed('imag', gen.batch_ids(0)) if resident else e.train_eval('imag', pkg.trainer.rows_from_batch(gen[0][0]), gen[0][1])
+        results.append((losses, ev, e.train_weights('imag')))
+        e.train_end('imag', commit=False)
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    for k in results[0][2]:
+        np.testing.assert_array_equal(results[0][2][k], results[1][2][k])
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.train_begin('real', lr=1e-3)
+    with pytest.raises(pkg.CsiError):
+        e.train_step_indexed('real', [0, 1, 2])                  # no dataset uploaded
+    with pytest.raises(pkg.CsiError):
+        e.train_set_dataset('real', *pkg.dataset.resident_arrays(ds, 'real'))      # pilot not set

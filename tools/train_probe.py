@@ -38,6 +38,22 @@ def main():
     for k, v in e.profile().items():
         if v['launches']:
             print('  %-20s %5d launches  %9.3f ms/step  %8.1f TFLOP/s' % (k, v['launches'] // 5, v['ms'] / 5, v['flops'] / max(v['ms'], 1e-9) / 1e9))
+    # resident dataset: 512 rx preambles x nt tx = the samples of 128 packets, batches addressed by index
+    e.set_pilot(np.eye(a.nt) * 2.0 - 1.0)
+    n_rows = 512
+    table = rng.standard_normal((n_rows, 320 * a.nt)).astype(np.float32)
+    N = n_rows * a.nt
+    e.train_set_dataset('real', table, np.repeat(np.arange(n_rows), a.nt), np.tile(np.arange(a.nt), n_rows),
+                        rng.standard_normal((N, 234)).astype(np.float32))
+    ids = [rng.permutation(N)[:a.bs] for _ in range(a.steps)]
+    e.profile_enable(False)
+    for i in range(3):
+        e.train_step_indexed('real', ids[i], noise_std=0.1)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        e.train_step_indexed('real', ids[i], noise_std=0.1)
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f'train_step_indexed (resident dataset): {dt * 1e3:.3f} ms/step ({a.bs / dt:.0f} samples/s)')
     t0 = time.perf_counter()
     for _ in range(5):
         e.train_eval('real', x, y)
