@@ -55,27 +55,37 @@ def time_reference_loop(ltf, P, w_re, w_im, budget_s=12.0, min_packets=8):
         # intra-op thread count that is fastest on this machine before timing
         max_thr = torch.get_num_threads()
         cands = sorted({t for t in (4, 8, 16, 32, 64, max_thr) if t <= max_thr})
-        best_thr, best_t = max_thr, float('inf')
+        scores = []
         for thr in cands:
             torch.set_num_threads(thr)
             f_re(xs[0][0]); f_im(xs[0][1])              # warm-up at this setting
             ts = []
-            for p in range(min(4, n)):
+            for p in range(6):
+                q = p % n
                 t0 = time.perf_counter()
-                f_re(xs[p][0]); f_im(xs[p][1])
+                f_re(xs[q][0]); f_im(xs[q][1])
                 ts.append(time.perf_counter() - t0)
-            if min(ts) < best_t:
-                best_t, best_thr = min(ts), thr
+            scores.append((float(np.median(ts)), thr))
+        # the two best settings each get half of the budget; the faster one is reported (a single lucky
+        # sample once selected 128 threads on a busy host and under-reported the CPU 16x)
+        finalists = [thr for _, thr in sorted(scores)[:2]]
+        best = None
+        for thr in finalists:
+            torch.set_num_threads(thr)
+            for p in range(min(3, n)):                  # warm-up
+                f_re(xs[p][0]); f_im(xs[p][1])
+            done, t_dnn, per_pkt = 0, 0.0, []
+            while done < n and (done < min_packets or t_dnn < budget_s / len(finalists)):
+                t0 = time.perf_counter()
+                f_re(xs[done][0]); f_im(xs[done][1])
+                per_pkt.append(time.perf_counter() - t0)
+                t_dnn += per_pkt[-1]
+                done += 1
+            cand = (float(np.median(per_pkt)), thr, done, t_dnn, per_pkt)
+            if best is None or cand[0] < best[0]:
+                best = cand
+        _, best_thr, done, t_dnn, per_pkt = best
         torch.set_num_threads(best_thr)
-        for p in range(min(3, n)):                      # warm-up
-            f_re(xs[p][0]); f_im(xs[p][1])
-        done, t_dnn, per_pkt = 0, 0.0, []
-        while done < n and (done < min_packets or t_dnn < budget_s):
-            t0 = time.perf_counter()
-            f_re(xs[done][0]); f_im(xs[done][1])
-            per_pkt.append(time.perf_counter() - t0)
-            t_dnn += per_pkt[-1]
-            done += 1
     ls_t = []
     for p in range(min(done, 16)):
         t0 = time.perf_counter()
