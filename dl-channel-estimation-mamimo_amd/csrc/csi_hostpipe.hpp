@@ -176,12 +176,32 @@ int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, b
 }
 
 // run(d_re, d_im, np, d_ore, d_oim) enqueues the kernels of np packets on c->stream
+int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
+                    const std::function<int(const float*, const float*, int64_t, float*, float*)>& run);
+
 int hp_packets(csi_ctx* c, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
                const std::function<int(const float*, const float*, int64_t, float*, float*)>& run) {
-    const csi_config& cf = c->cfg;
     csi_hostpipe* h = nullptr;
     int rc = hp_get(c, &h);
     if (rc) return rc;
+    rc = hp_packets_impl(c, h, re, im, npkt, o_re, o_im, n_out, run);
+    if (rc) {
+        // an error left copies / kernels in flight that still reference the caller's buffers and the
+        // slots: drain everything before handing control back (the error text of the failure is kept)
+        const std::string keep = c->err;
+        hipStreamSynchronize(h->s_in);
+        hipStreamSynchronize(c->stream);
+        hipStreamSynchronize(h->s_out);
+        (void)hipGetLastError();
+        c->err = keep;
+    }
+    return rc;
+}
+
+int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
+                    const std::function<int(const float*, const float*, int64_t, float*, float*)>& run) {
+    const csi_config& cf = c->cfg;
+    int rc = CSI_OK;
     const size_t in_pkt = (size_t)cf.nr * cf.len_ltf * sizeof(float);            // one plane
     const size_t out_pkt = (size_t)cf.nr * cf.nt * n_out * sizeof(float);        // one plane
     // chunk: large enough for full-size GEMM tiles (>= 64k pair rows), small enough to pipeline
