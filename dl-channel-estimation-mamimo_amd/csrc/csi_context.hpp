@@ -114,6 +114,7 @@ struct csi_ctx {
     bool use_graph = false;
     std::vector<GraphEntry> graphs;
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
+    bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
     int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first (tests)
     int ls_fft_first_max = 31;   // FFT-first LS kernel up to this Nt; from 32 on the chunked kernel is faster (0.64 vs 0.67 ms at 32, 2.1 vs 3.9 ms at 64); debug knob CSI_LS_FFT_FIRST_MAX

@@ -19,7 +19,7 @@ namespace {
 // Which LS kernel serves this context.  FFT-first (all Nt spectra in LDS) up to ls_fft_first_max
 // antennas, the chunked FFT-first kernel (accumulators persist over 16/32-symbol chunks) up to
 // Nt = 128, the despread-first kernel beyond (or when forced through the "ls_kernel" option).
-enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3 };
+enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4 };
 struct LsPlan {
     int mode;
     const void* fn;
@@ -30,12 +30,20 @@ struct LsPlan {
 LsPlan ls_plan(const csi_ctx* c) {
     const int nt = c->cfg.nt;
     int mode = c->ls_kernel;
-    if (mode == LS_AUTO) mode = nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST);
+    const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
+    if (mode == LS_FWHT && !fwht_ok) mode = LS_AUTO;
+    if (mode == LS_AUTO) mode = fwht_ok ? LS_FWHT : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST));
     if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
     if (mode == LS_CHUNKED && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
     LsPlan p{};
     p.mode = mode;
-    if (mode == LS_FFT_FIRST) {
+    if (mode == LS_FWHT) {
+        p.fn = nt == 16 ? (const void*)ls_estimate_fwht_kernel<16> : nt == 32 ? (const void*)ls_estimate_fwht_kernel<32>
+               : nt == 64 ? (const void*)ls_estimate_fwht_kernel<64> : (const void*)ls_estimate_fwht_kernel<128, 2>;
+        p.lds = (size_t)(16 * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
+        p.threads = nt == 128 ? 512 : 256;
+        p.per_cu = nt == 16 ? 3 : (nt == 128 ? 1 : 2);
+    } else if (mode == LS_FFT_FIRST) {
         p.fn = nt <= 32 ? (const void*)ls_estimate_kernel<8> : (const void*)ls_estimate_kernel<16>;
         p.lds = (size_t)(nt * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
         p.threads = LS_THREADS;
@@ -134,7 +142,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
-    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(3, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(4, std::max(0, std::atoi(e)));
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);
@@ -320,6 +328,14 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
     drop_graphs(c);
     int rc = upload(c, &c->P, P, (size_t)c->cfg.nt * c->cfg.nt);
     if (rc) return rc;
+    {   // Sylvester Hadamard?  P[j][s] == (-1)^popcount(j & s) exactly -> the Walsh-Hadamard despread applies
+        const int nt = c->cfg.nt;
+        bool syl = nt >= 2 && (nt & (nt - 1)) == 0;
+        for (int j = 0; syl && j < nt; ++j)
+            for (int q = 0; q < nt; ++q)
+                if (P[(size_t)j * nt + q] != ((__builtin_popcount(j & q) & 1) ? -1.0f : 1.0f)) { syl = false; break; }
+        c->p_sylvester = syl;
+    }
     {   // zero-padded copy for the chunked LS kernel (rows / columns up to the next multiple of 32)
         const int nt = c->cfg.nt, ldp = (nt + 31) / 32 * 32;
         std::vector<float> pad((size_t)ldp * ldp, 0.f);
@@ -327,6 +343,8 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
         rc = upload(c, &c->Ppad, pad.data(), pad.size());
         if (rc) return rc;
     }
+    rc = ls_prepare(c);
+    if (rc) return rc;
     c->pilot_ok = true;
     for (int d = 0; d < 2; ++d) {
         c->model[d].table_ok = false;
@@ -521,7 +539,7 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "ls_debug") {
         c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
     } else if (n == "ls_kernel") {
-        if (value < 0 || value > 3) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked) or 3 (despread first)");
+        if (value < 0 || value > 4) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first) or 4 (Walsh-Hadamard)");
         c->ls_kernel = (int)value;
         return ls_prepare(c);
     } else {

@@ -421,6 +421,134 @@ __global__ __launch_bounds__(64 * NW, MINW) void ls_estimate_chunked_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Walsh-Hadamard despread for the pilot matrix the 802.11-style sounding actually uses beyond 8
+// streams: the Sylvester Hadamard matrix P[j][s] = (-1)^popcount(j & s)  (Nt a power of two).
+// The despread  H[j] = sum_s P[j][s] F[s]  is then a fast Walsh-Hadamard transform over the symbol
+// index: Nt log2 Nt additions per bin instead of Nt^2 multiply-adds on the matrix pipe (which at
+// Nt = 64 is 0.5 ms of pure MFMA time per config-3 launch).  Same chunked data flow as
+// ls_estimate_chunked_kernel (16 symbols per chunk, one thread per bin):
+//   per chunk c   w[0..15] = FWHT16 of this bin's 16 spectra (registers, 64 additions per plane)
+//                 acc[16 a + j'] += (-1)^popcount(a & c) * w[j']      (the cross-chunk stages:
+//                 H_N = H_{N/16} (x) H_16 in the Sylvester order)
+// The host selects this kernel only when csi_set_pilot saw exactly that matrix; any other P takes
+// the MFMA despread.  Results differ from it only in summation order.
+// SPLIT = 2 (Nt = 128): 512 threads, two threads per bin, each owning half of the output blocks (64
+// antennas = 128 accumulator registers); both run the same FWHT16 of the chunk.
+template <int NT, int SPLIT = 1>
+__global__ __launch_bounds__(256 * SPLIT, 2) void ls_estimate_fwht_kernel(const LsArgs a, int nblk) {
+    static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
+    static_assert(NT / SPLIT <= 64, "at most 64 antennas (128 accumulators) per thread");
+    constexpr int CH = 16, NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, NOWN = NCH / SPLIT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw_re = smem;
+    float* tw_im = smem + LS_FFT;
+    float* F = smem + 2 * LS_FFT;              // [CH][2][LS_PLANE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+    if (tid < LS_FFT) {
+        tw_re[tid] = a.tw[tid];
+        tw_im[tid] = a.tw[LS_FFT + tid];
+    }
+
+    f32x4 vr[SPW], vi[SPW];
+    auto fetch = [&](size_t blk, int ch) {
+        const float* gre = a.ltf_re + blk * a.len_ltf + LS_CP + 4 * lane;
+        const float* gim = a.ltf_im + blk * a.len_ltf + LS_CP + 4 * lane;
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            const int s = ch * CH + wave + NW * u;
+            vr[u] = *reinterpret_cast<const f32x4*>(gre + (size_t)s * LS_SYM);
+            vi[u] = *reinterpret_cast<const f32x4*>(gim + (size_t)s * LS_SYM);
+        }
+    };
+
+    const int q = tid & 255;                    // this thread's data bin
+    const int own = (tid >> 8) * NOWN;          // first output block (of 16 antennas) this thread accumulates
+    const bool qok = q < LS_NDATA;
+    const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
+    const float den = a.denom[qok ? q : 0];
+
+    size_t blk = blockIdx.x;
+    if (blk < (size_t)nblk) fetch(blk, 0);
+    for (; blk < (size_t)nblk; blk += gridDim.x) {
+        float hre[NOWN * CH], him[NOWN * CH];
+#pragma unroll
+        for (int j = 0; j < NOWN * CH; ++j) { hre[j] = 0.f; him[j] = 0.f; }
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) {
+                float* fr = F + (size_t)(wave + NW * u) * 2 * LS_PLANE;
+                float* fi = fr + LS_PLANE;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int p = ls_phys(c * 64 + rev3);
+                    fr[p] = vr[u][c];
+                    fi[p] = vi[u][c];
+                }
+            }
+            __syncthreads();
+            // next samples requested before the transforms (two interleaved per wave) while the
+            // registers allow it, behind single transforms at NT = 64 (128 accumulators)
+            if (NT / SPLIT <= 32) {
+                if (ch + 1 < NCH) fetch(blk, ch + 1);
+                else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+                ls_fft_rows(F, wave, CH, tw_re, tw_im, lane, NW);
+            } else {
+                for (int r = wave; r < CH; r += NW) {
+                    float* const pr[1] = {F + (size_t)r * 2 * LS_PLANE};
+                    ls_fft256_wave<1>(pr, tw_re, tw_im, lane);
+                }
+            }
+            __syncthreads();
+            if (NT / SPLIT > 32) {
+                if (ch + 1 < NCH) fetch(blk, ch + 1);
+                else if (blk + gridDim.x < (size_t)nblk) fetch(blk + gridDim.x, 0);
+            }
+            // ---- this bin's 16 spectra -> registers, FWHT16 per plane
+            float wr[CH], wi[CH];
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                wr[r] = F[(size_t)r * 2 * LS_PLANE + pos];
+                wi[r] = F[(size_t)r * 2 * LS_PLANE + LS_PLANE + pos];
+            }
+#pragma unroll
+            for (int h = 1; h < CH; h <<= 1)
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if (!(i & h)) {
+                        const float xr = wr[i], yr = wr[i + h], xi = wi[i], yi = wi[i + h];
+                        wr[i] = xr + yr; wr[i + h] = xr - yr;
+                        wi[i] = xi + yi; wi[i + h] = xi - yi;
+                    }
+            // ---- cross-chunk stages: block a of the output takes +-w by the sign of H_{NT/16}[a][ch]
+#pragma unroll
+            for (int ab = 0; ab < NOWN; ++ab) {
+                const float sgn = (__builtin_popcount((own + ab) & ch) & 1) ? -1.f : 1.f;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    hre[ab * CH + j] = fmaf(sgn, wr[j], hre[ab * CH + j]);
+                    him[ab * CH + j] = fmaf(sgn, wi[j], him[ab * CH + j]);
+                }
+            }
+            __syncthreads();          // spectra consumed
+        }
+        if (qok) {
+            float* pre = a.h_re + (blk * NT + own * CH) * LS_NDATA + q;
+            float* pim = a.h_im + (blk * NT + own * CH) * LS_NDATA + q;
+#pragma unroll
+            for (int j = 0; j < NOWN * CH; ++j) {
+                pre[j * LS_NDATA] = hre[j] / den;
+                pim[j * LS_NDATA] = him[j] / den;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Large-Nt variant (Nt > 64, where Nt spectra no longer fit the 160 KiB LDS): by linearity the
 // despread is done FIRST, in the time domain, and only the despread rows are transformed:
 //   Y[j][n] = sum_s P[j][s] x[s][64+n]          H[j][q] = FFT(Y[j])[f(q)] / (Nt ltf[q])

@@ -192,8 +192,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
  *                         slots of the host-buffer entry points (0 = automatic, up to 8)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
- *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt); a choice the
- *                         kernel cannot serve falls back to the automatic one */
+ *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
+ *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix - chosen
+ *                         automatically then); a choice the kernel cannot serve falls back */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
 
 /* Device-memory plumbing so that a host program needs no other GPU runtime. */

@@ -111,6 +111,37 @@ def test_ls_all_kernels_agree(pkg, oracle, kernel):
             assert np.array_equal(h, e.ls_estimate(ltf))
 
 
+@pytest.mark.parametrize('nt,nr,npkt', [(16, 2, 5), (32, 3, 300), (64, 2, 7), (128, 2, 3)])
+def test_ls_walsh_hadamard_despread(pkg, oracle, nt, nr, npkt):
+    """With the Sylvester Hadamard pilot matrix the LS despread is a fast Walsh-Hadamard transform
+    (chosen automatically): same answer as the oracle and as the MFMA despread (ls_kernel 2) up to the
+    summation order; a P that is not exactly that matrix must not take it."""
+    rng = np.random.default_rng(nt + npkt)
+    P = oracle.hadamard(nt)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    e.set_pilot(P)
+    h = e.ls_estimate(ltf)                       # automatic -> Walsh-Hadamard kernel
+    sel = slice(None) if npkt <= 10 else np.r_[0:2, npkt - 2:npkt]
+    ref = oracle.ls_estimate(ltf[sel], P)
+    assert rel_rows(np.concatenate([h[sel].real, h[sel].imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    e.set_option('ls_kernel', 2)
+    h2 = e.ls_estimate(ltf)                      # MFMA despread
+    assert not np.array_equal(h, h2)             # really another kernel (summation order differs) ...
+    assert rel_rows(np.concatenate([h.real, h.imag], -1).reshape(-1, 468), np.concatenate([h2.real, h2.imag], -1).reshape(-1, 468)) < 2e-6
+    e.set_option('ls_kernel', 0)
+    assert np.array_equal(h, e.ls_estimate(ltf))                 # deterministic
+    # a pilot matrix that differs from the Sylvester matrix in one sign: generic path, still right
+    P2 = P.copy()
+    P2[3, 5] = -P2[3, 5]
+    e2 = pkg.CsiEngine(nt, nr, hidden=(8,))
+    e2.set_pilot(P2)
+    e2.set_option('ls_kernel', 4)                # forcing it is refused silently (falls back)
+    g = e2.ls_estimate(ltf[:2])
+    ref2 = oracle.ls_estimate(ltf[:2], P2)
+    assert rel_rows(np.concatenate([g.real, g.imag], -1), np.concatenate([ref2.real, ref2.imag], -1)) < TOL
+
+
 @pytest.mark.parametrize('nt,nr,npkt', [(4, 2, 2), (32, 2, 1), (40, 1, 1)])
 def test_lmmse_matches_reference_formula(pkg, oracle, nt, nr, npkt):
     """LMMSE smoothing (LMMSE_ce.m, one 234x234 inverse per link in the reference; one Levinson solve
