@@ -225,7 +225,7 @@ def main():
         p = prof['ls_estimate']
         gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
         out['roofline_ls'] = {'bound': 'hbm', 'kernel': 'ls_estimate', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': gbs / HBM_PEAK_GBS, 'traffic': hbm_per_launch('ls_estimate_kernel'),
+                              'frac': gbs / HBM_PEAK_GBS, 'traffic': hbm_per_launch('ls_estimate_'),
                               'algorithmic_bytes_per_launch': p['bytes'] / max(p['launches'], 1)}
 
     if cpu_baseline:
