@@ -60,7 +60,7 @@ def test_oracle_forward_backward_match_torch_autograd(oracle):
     out = h @ tw['fc_regressor.kernel'] + tw['fc_regressor.bias']
     tl = torch.mean((out - torch.tensor(y, dtype=torch.float64)) ** 2)
     tl.backward()
-    assert abs(float(tl) - loss) < 1e-12 * max(1.0, loss)
+    assert abs(tl.item() - loss) < 1e-12 * max(1.0, loss)
     for k, gk in g.items():
         assert _rel(gk, tw[k].grad.numpy()) < 1e-10, k
     # inference mode
