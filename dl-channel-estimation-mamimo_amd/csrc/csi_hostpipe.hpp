@@ -214,6 +214,36 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
     if (rc) return rc;
 
     const int64_t nchunks = (npkt + chunk - 1) / chunk;
+    if (nchunks == 1 && 2 * (in_pkt + out_pkt) * (size_t)npkt <= ((size_t)8 << 20)) {
+        // small call (the reference's per-packet loop): nothing to pipeline - one stream, no events, no
+        // thread hand-over; the staging copies are a few hundred KB
+        float* d_re = reinterpret_cast<float*>(h->dev[0]);
+        float* d_im = reinterpret_cast<float*>(h->dev[0] + in_pkt * chunk);
+        float* d_ore = reinterpret_cast<float*>(h->dev[0] + 2 * in_pkt * chunk);
+        float* d_oim = reinterpret_cast<float*>(h->dev[0] + 2 * in_pkt * chunk + out_pkt * chunk);
+        const float* s_re = re;
+        const float* s_im = im;
+        if (!in_pinned) {
+            std::memcpy(h->pin_in[0], re, in_pkt * npkt);
+            std::memcpy(h->pin_in[0] + in_pkt * chunk, im, in_pkt * npkt);
+            s_re = reinterpret_cast<const float*>(h->pin_in[0]);
+            s_im = reinterpret_cast<const float*>(h->pin_in[0] + in_pkt * chunk);
+        }
+        HIP_TRY(c, hipMemcpyAsync(d_re, s_re, in_pkt * npkt, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_im, s_im, in_pkt * npkt, hipMemcpyHostToDevice, c->stream));
+        rc = run(d_re, d_im, npkt, d_ore, d_oim);
+        if (rc) return rc;
+        float* t_re = out_pinned ? o_re : reinterpret_cast<float*>(h->pin_out[0]);
+        float* t_im = out_pinned ? o_im : reinterpret_cast<float*>(h->pin_out[0] + out_pkt * chunk);
+        HIP_TRY(c, hipMemcpyAsync(t_re, d_ore, out_pkt * npkt, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(t_im, d_oim, out_pkt * npkt, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!out_pinned) {
+            std::memcpy(o_re, t_re, out_pkt * npkt);
+            std::memcpy(o_im, t_im, out_pkt * npkt);
+        }
+        return CSI_OK;
+    }
     auto np_of = [&](int64_t i) { return std::min(chunk, npkt - i * chunk); };
     auto drain = [&](int64_t i) -> int {                 // pinned[slot] -> user, after the D2H of chunk i
         const int s = (int)(i & 1);
