@@ -107,6 +107,13 @@ struct csi_ctx {
     // split-K slabs of the small-batch path
     char* skbuf = nullptr;
     size_t skbuf_bytes = 0;
+    // second stream + scratch set so that the real and the imag model of a SMALL call run side by side
+    // (a one-packet call is launch-latency bound: 12 short kernels in a row; see csi_predict_device)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    char *aux_ws = nullptr, *aux_l0skinny = nullptr, *aux_skbuf = nullptr;
+    size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0;
+    int small_call_overlap = 1;  // "small_call_overlap" option
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;

@@ -214,6 +214,12 @@ void csi_destroy(csi_ctx* c) {
     if (c->denom) hipFree(c->denom);
     if (c->ws) hipFree(c->ws);
     if (c->stage) hipFree(c->stage);
+    if (c->aux_ws) hipFree(c->aux_ws);
+    if (c->aux_l0skinny) hipFree(c->aux_l0skinny);
+    if (c->aux_skbuf) hipFree(c->aux_skbuf);
+    if (c->aux_fork) hipEventDestroy(c->aux_fork);
+    if (c->aux_join) hipEventDestroy(c->aux_join);
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->skbuf) hipFree(c->skbuf);
     if (c->l0skinny) hipFree(c->l0skinny);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -368,9 +374,37 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
             if (r) return r;
             return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
         }
-        int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        // small call: the two component models are independent and each is a chain of short,
+        // launch-latency-bound kernels - run the imag model on a second stream with its own scratch
+        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && npkt * c->cfg.nr <= 64;
+        if (!overlap) {
+            int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+            if (r) return r;
+            return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+        }
+        if (!c->aux_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->aux_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+        auto swap_scratch = [&]() {
+            std::swap(c->stream, c->aux_stream);
+            std::swap(c->ws, c->aux_ws); std::swap(c->ws_bytes, c->aux_ws_bytes);
+            std::swap(c->l0skinny, c->aux_l0skinny); std::swap(c->l0skinny_bytes, c->aux_l0skinny_bytes);
+            std::swap(c->skbuf, c->aux_skbuf); std::swap(c->skbuf_bytes, c->aux_skbuf_bytes);
+        };
+        swap_scratch();                                   // imag model: aux stream, aux scratch
+        int r = predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+        hipError_t e = r ? hipSuccess : hipEventRecord(c->aux_join, c->stream);
+        swap_scratch();
         if (r) return r;
-        return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+        HIP_TRY(c, e);
+        r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        if (r) return r;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->aux_join, 0));
+        return CSI_OK;
     };
     if (!c->use_graph || c->prof_on) return run();
 
@@ -529,6 +563,8 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;
         return ls_prepare(c);
+    } else if (n == "small_call_overlap") {
+        c->small_call_overlap = value != 0;
     } else if (n == "bf16_fused_h1") {
         drop_graphs(c);
         c->bf16_fused_h1 = value != 0;

@@ -187,6 +187,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
+ *   "small_call_overlap" 1 (default): calls of at most 64 rx preambles run the real and the imag model on
+ *                         two streams side by side (they are launch-latency bound); 0: one after the other
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
