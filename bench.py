@@ -147,6 +147,20 @@ def main():
             'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'],
             'gpu_over_cpu': value / r['pairs_per_s']}
 
+    # one-packet latency (the reference's literal per-packet call, DNN.py:346), device-resident, outside the timed region
+    latency = None
+    if rank == 0 and world == 1:
+        ts = []
+        for i in range(40):
+            eng.synchronize()
+            t1 = time.perf_counter()
+            if not args.no_ls:
+                eng.ls_estimate_device(d_re, d_im, 1, d_hre, d_him)
+            eng.predict_device(d_re, d_im, 1, d_ore, d_oim)
+            eng.synchronize()
+            ts.append(time.perf_counter() - t1)
+        latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6), 'what': 'LS + DNN(real) + DNN(imag) of one packet, device-resident, median of 30 calls'}
+
     host_path = None
     if rank == 0 and args.host_path > 0:
         k = min(args.host_path, npkt)
@@ -218,6 +232,7 @@ def main():
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,
         'parity_check': check,
+        'latency': latency,
     }
     if host_path:
         out['host_path_pcie_inclusive'] = host_path
