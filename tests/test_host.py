@@ -267,3 +267,28 @@ def test_keras_variable_names_and_npz_container(pkg, tmp_path):
     pkg.save_weight_file(str(g), w)
     w2 = pkg.load_weight_file(str(g))
     assert set(w2) == set(w) and all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def _build_c_smoke(pkg, tmp_path):
+    pkg.build_library()
+    exe = str(tmp_path / 'c_api_smoke')
+    so_dir = os.path.dirname(pkg.library_path())
+    cmd = ['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', os.path.join(REPO, 'tests', 'c_api_smoke.c'), '-I', os.path.join(REPO, 'include'),
+           '-L', so_dir, '-lcsi_mamimo', '-lm', '-Wl,-rpath,' + so_dir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links(pkg, tmp_path):
+    """The drop-in boundary is a C-ABI: include/csi_mamimo.h compiles as C99 with -Wall -Wextra -Werror and a
+    plain-C program links against the shared object (no C++, Python or torch types in the interface)."""
+    _build_c_smoke(pkg, tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_program_runs_through_the_abi(pkg, tmp_path):
+    exe = _build_c_smoke(pkg, tmp_path)
+    res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert res.returncode == 0, res.stdout
+    assert 'c_api_smoke: abi 1' in res.stdout
