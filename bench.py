@@ -144,7 +144,8 @@ def main():
             'sample': '%d packets one by one (batch = Nt*Nr rows, naive un-shared fp32 network, torch-CPU sgemm, '
                       'real then imag model) + numpy LS; median per-packet latency; host cpu_count=%d'
                       % (r['packets'], os.cpu_count()),
-            'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'],
+            'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'], 'cpu_model': r['cpu_model'],
+            'dnn_one_large_batch': {'value': r['batched_dnn_pairs_per_s'], 'packets': r['batched_packets']},
             'gpu_over_cpu': value / r['pairs_per_s']}
 
     # one-packet latency (the reference's literal per-packet call, DNN.py:346), device-resident, outside the timed region

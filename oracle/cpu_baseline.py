@@ -12,6 +12,17 @@ import numpy as np
 from . import csi_oracle as o
 
 
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def _torch_model(w):
     import torch
     t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in w.items() if isinstance(v, np.ndarray)}
@@ -86,6 +97,17 @@ def time_reference_loop(ltf, P, w_re, w_im, budget_s=12.0, min_packets=8):
                 best = cand
         _, best_thr, done, t_dnn, per_pkt = best
         torch.set_num_threads(best_thr)
+        # second figure: the same naive network fed ONE large batch (what a batched CPU user would get)
+        nb = min(n, 32)
+        xb_re = torch.cat([xs[p][0] for p in range(nb)])
+        xb_im = torch.cat([xs[p][1] for p in range(nb)])
+        f_re(xb_re); f_im(xb_im)
+        tb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f_re(xb_re); f_im(xb_im)
+            tb.append(time.perf_counter() - t0)
+        batched_pairs_per_s = nb * nr * nt / float(np.median(tb))
     ls_t = []
     for p in range(min(done, 16)):
         t0 = time.perf_counter()
@@ -95,6 +117,7 @@ def time_reference_loop(ltf, P, w_re, w_im, budget_s=12.0, min_packets=8):
     # favours the CPU (the baseline is never under-reported)
     med_dnn, med_ls = float(np.median(per_pkt)), float(np.median(ls_t))
     ppp = nr * nt
-    return dict(packets=done, pairs=done * ppp, threads=torch.get_num_threads(), dnn_s=t_dnn,
+    return dict(packets=done, pairs=done * ppp, threads=torch.get_num_threads(), dnn_s=t_dnn, batched_dnn_pairs_per_s=batched_pairs_per_s,
+                batched_packets=nb, cpu_model=_cpu_model(),
                 dnn_ms_per_packet=med_dnn * 1e3, ls_ms_per_packet=med_ls * 1e3,
                 dnn_pairs_per_s=ppp / med_dnn, ls_pairs_per_s=ppp / med_ls, pairs_per_s=ppp / (med_dnn + med_ls))

@@ -368,6 +368,21 @@ def test_empty_and_error_paths(pkg, oracle):
         e.predict(np.zeros((1, nr, 7), dtype=np.complex64))
 
 
+def test_hip_path_matches_committed_oracle_fixture(pkg, golden_dir):
+    """LS and DNN of the committed Nt=4 fixture (tests/golden/oracle_nt4.npz) without running the oracle."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'oracle_nt4.npz'))
+    w = {tag: {k.split('.', 1)[1]: g[k] for k in g.files if k.startswith(f'w_{tag}.')} for tag in ('re', 'im')}
+    e = pkg.CsiEngine(int(g['nt']), int(g['nr']), hidden=(64, 64))
+    e.load_weights('real', w['re'])
+    e.load_weights('imag', w['im'])
+    e.set_pilot(g['P'])
+    o_re, o_im = e.predict(g['ltf'])
+    assert rel_rows(o_re, g['dnn_real']) < TOL and rel_rows(o_im, g['dnn_imag']) < TOL
+    h = e.ls_estimate(g['ltf'])
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([g['ls'].real, g['ls'].imag], -1)) < TOL
+
+
 # ------------------------------------------------------------------------------------ bf16 mode
 BF16_TOL_IMPL = 4e-3     # vs the bf16-operand emulation: only accumulation-order induced bf16 re-roundings
 BF16_TOL_FMT = 3e-2      # vs the fp64 oracle: the format error of 8-bit-mantissa operands (NOT the fp32 contract)

@@ -177,3 +177,21 @@ def test_nmse(oracle):
     h = rng.standard_normal((2, 2, 4, 234)) + 1j * rng.standard_normal((2, 2, 4, 234))
     assert oracle.nmse_subk(h, h) == 0.0
     assert abs(oracle.nmse_subk(h, 0.9 * h) - 0.01) < 1e-12
+
+
+def _oracle_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'oracle_nt4.npz'))
+    w = {tag: {k.split('.', 1)[1]: g[k] for k in g.files if k.startswith(f'w_{tag}.')} for tag in ('re', 'im')}
+    return g, w['re'], w['im']
+
+
+def test_oracle_reproduces_its_committed_fixture(oracle, golden_dir):
+    """The oracle's own outputs for a seeded Nt=4 problem are committed (tests/golden/oracle_nt4.npz,
+    written by make_oracle_fixture.py): an edit that changes what the oracle computes shows up here."""
+    g, w_re, w_im = _oracle_fixture(golden_dir)
+    ls = oracle.ls_estimate(g['ltf'], g['P'])
+    np.testing.assert_allclose(ls, g['ls'], rtol=0, atol=1e-12 * np.abs(g['ls']).max())
+    o_re, o_im = oracle.predict_packets(g['ltf'], g['P'], w_re, w_im, np.float64, pkt_batch=3)
+    np.testing.assert_allclose(o_re, g['dnn_real'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(o_im, g['dnn_imag'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(oracle.recombine(o_re, o_im), g['csi'])
