@@ -14,6 +14,7 @@
 #include "../../include/csi_mamimo.h"
 #include "gemm_f32.hip.h"
 #include "gemm_bf16.hip.h"
+#include "gemm_hs.hip.h"
 #include "ls_estimate.hip.h"
 #include "lmmse.hip.h"
 
@@ -50,6 +51,9 @@ struct Layer {
     int ldw = 0;
     bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
     int ldwb = 0;
+    uint16_t* Wh = nullptr;   // [out][ldwh] split-f16 ("hs", gemm_hs.hip.h) copy of Wt * 2^wshift; layer 0: LTF columns only
+    int ldwh = 0;             // halves per row = 2 * (in rounded up to 16)
+    int wshift = 0;
     float* bias = nullptr;    // [out]
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
     float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
@@ -120,6 +124,10 @@ struct csi_ctx {
     int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
     bool use_graph = false;
     std::vector<GraphEntry> graphs;
+    int f32_engine = -1;         // "f32_engine" option: fp32 contexts, 0 = native fp32 MFMA kernels, 1 = split-f16 kernels (gemm_hs.hip.h)
+                                 // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)
+    int hs_act_shift = 4;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
+    int hs_in_shift = 4;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
@@ -240,6 +248,7 @@ int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
 void free_layer(Layer& l) {
     if (l.Wt) hipFree(l.Wt);
     if (l.Wb) hipFree(l.Wb);
+    if (l.Wh) hipFree(l.Wh);
     if (l.bias) hipFree(l.bias);
     if (l.scale) hipFree(l.scale);
     if (l.shift) hipFree(l.shift);

@@ -182,10 +182,12 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
     int64_t nchunks = 1, chunk = npkt;
     int splits_max = 1;
+    const bool hs_ok = hs_static_ok(c, m);          // split-f16 engine available for this model (csi_dnn_hs.hpp)
     for (;;) {
         chunk = (npkt + nchunks - 1) / nchunks;
         int kps_tmp;
         splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
+        if (hs_ok) splits_max = std::max(splits_max, hs_layer0_splits(c, (int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp));
         const size_t need = ((size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt) * (size_t)chunk;
         if ((need <= budget && chunk <= max_rows) || chunk == 1) break;
         nchunks = std::max(nchunks + 1, (int64_t)((double)nchunks * (double)need / (double)budget));
@@ -193,8 +195,10 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     {   // the last chunk can be shorter and may want a different split factor
         int kps_tmp;
         const int64_t tail = npkt - (nchunks - 1) * chunk;
-        if (tail > 0 && tail != chunk)
+        if (tail > 0 && tail != chunk) {
             splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
+            if (hs_ok) splits_max = std::max(splits_max, hs_layer0_splits(c, (int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
+        }
     }
     const size_t slab_floats = (size_t)chunk * nr * h1;
     const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk;
@@ -235,7 +239,13 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
             l0 = sum;
         }
         int kps = 0;
-        const int splits = l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps);
+        const int hs_splits = (hs_ok && !l0) ? hs_layer0_splits(c, M1, h1, cf.len_ltf, &kps) : 0;
+        if (hs_splits) {
+            rc = hs_launch_layer0(c, m.layers[0], d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps, hs_splits, slabs);
+            if (rc) return rc;
+            l0 = slabs;
+        }
+        const int splits = hs_splits ? hs_splits : (l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps));
         GemmArgs g{};
         g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
         g.lda = cf.len_ltf;
@@ -261,6 +271,11 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
 
         // first per-pair layer: h1 generated in the prologue from L0 + T
         float* out_chunk = d_out + (size_t)p0 * nr * nt * cf.n_out;
+        if (hs_ok && hs_tail_wanted(c, M2, m.layers[1].out)) {
+            rc = hs_tail(c, m, l0, M2, hbuf[0], hbuf[1], out_chunk);
+            if (rc) return rc;
+            continue;
+        }
         GemmArgs p{};
         p.A = l0; p.lda = h1;
         p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = m.layers[0].shift; p.nt = nt;

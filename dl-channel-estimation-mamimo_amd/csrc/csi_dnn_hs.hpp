@@ -1,0 +1,166 @@
+// csi_dnn_hs.hpp - host side of the split-f16 engine of fp32 contexts (gemm_hs.hip.h): which GEMMs
+// of a packet chunk run on it and how they are launched.  The engine serves the throughput regime
+// (256x256 tiles, one workgroup per CU); small calls stay on the native fp32 MFMA kernels, and since
+// the layer-0 product L0 is plain fp32 either way the two engines mix freely per layer.
+#pragma once
+#include "csi_context.hpp"
+
+namespace {
+
+constexpr int HS_L0_MAX_SPLITS = 8;
+constexpr long HS_MIN_BLOCKS = 128;             // automatic mode: at least half a round of 256 CUs
+
+// shapes the kernels can serve: every hidden width a multiple of 16 (hs groups), bn0 vectors of the
+// first per-pair layer in LDS behind the ring, split weights present
+bool hs_static_ok(const csi_ctx* c, const Model& m) {
+    const csi_config& cf = c->cfg;
+    if (c->f32_engine == 0 || cf.dtype != CSI_DTYPE_F32 || cf.nt <= 0 || (cf.len_ltf % HS_G) != 0) return false;
+    if (cf.hidden[0] > 4096) return false;
+    for (int i = 0; i < cf.n_hidden; ++i)
+        if (cf.hidden[i] % HS_G) return false;
+    for (const Layer& l : m.layers)
+        if (!l.Wh) return false;
+    return true;
+}
+
+long hs_tiles(int M, int N) { return (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN); }
+
+// per-pair layers of a chunk of M2 rows on the split engine?
+bool hs_tail_wanted(const csi_ctx* c, int M2, int n1) {
+    if (c->force_pair_tile == 128) return false;
+    return c->f32_engine == 1 || c->force_pair_tile == 256 || hs_tiles(M2, n1) >= HS_MIN_BLOCKS;
+}
+
+// Split-K of the layer-0 product on the split engine: the count (<= 8, >= 512 k-columns each) whose
+// last round of 256 workgroups is fullest; 0 = leave layer 0 to the native kernels.
+int hs_layer0_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) {
+    if (M1 <= 8 || c->force_pair_tile == 128) return 0;
+    const long tiles = (long)((M1 + PP_BM - 1) / PP_BM + 7) / 8 * 8 * ((h1 + PP_BN - 1) / PP_BN);       // as launched (pp_grid)
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= HS_L0_MAX_SPLITS; ++s) {
+        if (s > 1 && K / s < 512) break;
+        const long blocks = tiles * s;
+        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256) - 0.01 * (s - 1);
+        if (eff > best_eff) { best_eff = eff; best = s; }
+    }
+    const int kps = ((K + best - 1) / best + 63) / 64 * 64;
+    const int real = (K + kps - 1) / kps;
+    if (kps / HS_G < 3) return 0;
+    if (!(c->f32_engine == 1 || c->force_pair_tile == 256) && hs_tiles(M1, h1) * real < HS_MIN_BLOCKS) return 0;
+    *k_per_split = kps;
+    return real;
+}
+
+template <typename Kern>
+int hs_dynamic_lds(csi_ctx* c, Kern kern, size_t bytes, size_t* have) {
+    if (*have < bytes) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        *have = bytes;
+    }
+    return CSI_OK;
+}
+
+// layer 0: slabs[z][M1][h1] = (X[M1][K] * W0[0:K, :]) over k range z, X converted inside the kernel
+int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
+    GemmHsArgs g{};
+    g.Bt = l0.Wh; g.ldb = l0.ldwh;
+    g.C = slabs; g.ldc = h1;
+    g.M = M1; g.N = h1; g.K = K;
+    g.k_per_split = kps;
+    g.tiles_n = (h1 + PP_BN - 1) / PP_BN;
+    g.acc_scale = std::ldexp(1.f, -(c->hs_in_shift + l0.wshift));
+    const double flops = 2.0 * (double)M1 * h1 * K;
+    const double bytes = 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits);
+    ProfScope ps(c, K_LAYER0_LTF, flops, bytes);
+    auto kern = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
+    static thread_local size_t have = 0;
+    const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
+    int rc = hs_dynamic_lds(c, kern, lds, &have);
+    if (rc) return rc;
+    PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
+    const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
+                       std::ldexp(1.f, c->hs_in_shift));
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// first per-pair layer: A generated from (L0, T, bn0); hs output (a hidden layer follows) or fp32
+// output with bias only (the regressor follows layer 0 directly)
+template <int EPI, bool OUT_HS>
+int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
+    g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 4.0 * ((double)g.M / src.nt * g.K + (double)src.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    ProfScope ps(c, kid, flops, bytes);
+    auto kern = gemm_hs_pp_pair_kernel<EPI, OUT_HS, false>;
+    static thread_local size_t have = 0;
+    const size_t lds = (size_t)(PPP_RING_FLOATS + 2 * g.K) * sizeof(float);
+    int rc = hs_dynamic_lds(c, kern, lds, &have);
+    if (rc) return rc;
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, c->hs_act_shift));
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+template <int EPI, bool OUT_HS>
+int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
+    g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    g.k_per_split = (g.K + HS_G - 1) / HS_G * HS_G;
+    const double flops = 2.0 * (double)g.M * g.N * g.K;
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    ProfScope ps(c, kid, flops, bytes);
+    const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
+    hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI, OUT_HS>), dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), 0, c->stream, g);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+// the per-pair layers of one chunk: l0sum [M1][h1] fp32 -> out [M2][n_out] fp32; hbuf0 / hbuf1 are the
+// ping-pong activation buffers of the fp32 path re-used as hs matrices (same 4 bytes per element)
+int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, float* hbuf1, float* out) {
+    const csi_config& cf = c->cfg;
+    const int nh = cf.n_hidden, h1 = cf.hidden[0];
+    const float sa = std::ldexp(1.f, c->hs_act_shift);
+    const Layer& l1 = m.layers[1];
+    PairSrc src{l0sum, m.T, m.layers[0].scale, m.layers[0].shift, h1, cf.nt};
+    GemmHsArgs p{};
+    p.Bt = l1.Wh; p.ldb = l1.ldwh;
+    p.M = M2; p.N = l1.out; p.K = h1;
+    p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
+    p.acc_scale = std::ldexp(1.f, -(c->hs_act_shift + l1.wshift));
+    p.out_scale = sa;
+    if (nh == 1) {
+        p.C = out; p.ldc = cf.n_out;
+        return hs_launch_pair<EPI_BIAS, false>(c, K_REGRESSOR, p, src);
+    }
+    uint16_t* hb[2] = {reinterpret_cast<uint16_t*>(hbuf0), reinterpret_cast<uint16_t*>(hbuf1)};
+    p.C = hb[0]; p.ldc = 2 * l1.out;
+    int rc = hs_launch_pair<EPI_BIAS_RELU_AFFINE, true>(c, K_PAIR_DENSE, p, src);
+    if (rc) return rc;
+    int cur = 0;
+    for (int li = 2; li <= nh; ++li) {
+        const Layer& l = m.layers[li];
+        GemmHsArgs q{};
+        q.A = hb[cur]; q.lda = 2 * l.in;
+        q.Bt = l.Wh; q.ldb = l.ldwh;
+        q.M = M2; q.N = l.out; q.K = l.in;
+        q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+        q.acc_scale = std::ldexp(1.f, -(c->hs_act_shift + l.wshift));
+        q.out_scale = sa;
+        if (li == nh) {
+            q.C = out; q.ldc = cf.n_out;
+            rc = hs_launch_gemm<EPI_BIAS, false>(c, K_REGRESSOR, q);
+        } else {
+            q.C = hb[cur ^ 1]; q.ldc = 2 * l.out;
+            rc = hs_launch_gemm<EPI_BIAS_RELU_AFFINE, true>(c, K_DENSE_HIDDEN, q);
+            cur ^= 1;
+        }
+        if (rc) return rc;
+    }
+    return CSI_OK;
+}
+
+}  // namespace

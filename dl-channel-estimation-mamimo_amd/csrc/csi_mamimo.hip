@@ -9,6 +9,7 @@
 //   csi_predict_samples literal un-shared network      -> gemm_f32_kernel
 //   csi_ls_estimate*    FFT + despread                 -> ls_estimate_kernel
 #include "csi_context.hpp"
+#include "csi_dnn_hs.hpp"
 #include "csi_dnn_f32.hpp"
 #include "csi_dnn_bf16.hpp"
 #include "csi_train.hpp"
@@ -279,6 +280,32 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
         } else {
             rc = upload(c, &L.Wt, wt.data(), wt.size());
             if (rc) return rc;
+            // split-f16 copy for gemm_hs.hip.h: W * 2^wshift (largest magnitude in [2^12, 2^13)) as
+            // hi + lo halves in groups of 16 k-columns; layer 0 keeps its LTF columns only (the pilot
+            // rows live in the table T)
+            const int kh = (li == 0 && cf.nt > 0) ? cf.len_ltf : fan_in;
+            float wmax = 0.f;
+            for (int o = 0; o < out; ++o)
+                for (int i = 0; i < kh; ++i) wmax = std::max(wmax, std::fabs(wt[(size_t)o * L.ldw + i]));
+            int e = 0;
+            if (wmax > 0.f && std::isfinite(wmax)) std::frexp(wmax, &e);
+            L.wshift = std::max(-40, std::min(40, 13 - e));
+            const float ws = std::ldexp(1.f, L.wshift);
+            L.ldwh = 2 * ((kh + HS_G - 1) / HS_G * HS_G);
+            std::vector<uint16_t> wh((size_t)out * L.ldwh, 0);
+            for (int o = 0; o < out; ++o)
+                for (int i = 0; i < kh; ++i) {
+                    const float x = wt[(size_t)o * L.ldw + i] * ws;
+                    const _Float16 hi = (_Float16)x;
+                    const _Float16 lo = (_Float16)(x - (float)hi);
+                    uint16_t* d = &wh[(size_t)o * L.ldwh + (i >> 4) * 32 + (i & 15)];
+                    std::memcpy(d, &hi, 2);
+                    std::memcpy(d + 16, &lo, 2);
+                }
+            const size_t hbytes = wh.size() * 2 + 4096;
+            if (hipMalloc((void**)&L.Wh, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
+            HIP_TRY(c, hipMemset(L.Wh, 0, hbytes));
+            HIP_TRY(c, hipMemcpy(L.Wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
         }
         rc = upload(c, &L.bias, b->data, out);
         if (rc) return rc;
@@ -565,6 +592,14 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         return ls_prepare(c);
     } else if (n == "small_call_overlap") {
         c->small_call_overlap = value != 0;
+    } else if (n == "f32_engine") {
+        if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
+        drop_graphs(c);
+        c->f32_engine = (int)value;
+    } else if (n == "hs_act_shift" || n == "hs_in_shift") {
+        if (value < -8 || value > 14) return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14", name);
+        drop_graphs(c);
+        (n == "hs_act_shift" ? c->hs_act_shift : c->hs_in_shift) = (int)value;
     } else if (n == "bf16_fused_h1") {
         drop_graphs(c);
         c->bf16_fused_h1 = value != 0;

@@ -1,0 +1,539 @@
+// gemm_hs.hip.h - the fp32 dense layers (massiveMIMO_CSI_prediction_DNN.py:211-227) on the f16
+// matrix cores with SPLIT operands: fp32-grade results at a multiple of the fp32 MFMA rate.
+//
+// Arithmetic.  Every fp32 operand x (times a power of two s chosen per matrix, exact) is carried as
+//     hi = f16(s*x)   (round to nearest even),      lo = f16(s*x - hi)
+// so that s*x = hi + lo + e with |e| <= 2^-23 |s*x| (two 11-bit significands; below the f16 normal
+// range the absolute error is 2^-25).  A product of two such operands is evaluated as
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (the dropped a_lo*b_lo is <= 2^-22 |a*b|)
+// = three v_mfma_f32_32x32x16_f16 per 16 k-columns.  f16 x f16 products are exact in fp32 and the
+// accumulation is fp32, exactly as in the native fp32 MFMA path; the per-term operand error
+// (~2^-22) is below the fp32 accumulation error of a K = 1024 reduction, so the result meets the
+// same 1e-5 norm-relative contract as gemm_f32.hip.h (measured: DESIGN.md 4.6).  The accumulator is
+// multiplied by 2^-(sa+sw) in the epilogue (exact) before bias / relu / BatchNormalization.
+// Range: |s*x| must stay below 65504 - operands are scaled so that the weights' maximum sits at
+// 2^12..2^13 and activations are multiplied by 2^hs_act_shift (default 2^4: |activation| < 4094).
+//
+// Storage ("hs" matrices, 4 bytes per element like fp32).  Row-major, K contiguous, in groups of 16
+// k-columns: 16 hi halves (32 B) followed by the 16 lo halves (32 B).  One 64-byte group of a row is
+// one image row of a ping-pong sub-tile, i.e. byte for byte the layout gemm_bf16_pp_kernel stages
+// (its "k-columns 0-15" are the hi plane, "16-31" the lo plane), so the LDS-DMA addressing, the
+// XOR swizzle and the fragment reads are shared with that kernel.
+//
+// Kernels: gemm_hs_pp_kernel (both operands hs in HBM), gemm_hs_pp_pair_kernel (A generated in the
+// kernel from L0 + T - the first per-pair layer - or converted from fp32 rows - layer 0), both on
+// the 256x256 / 8-wave ping-pong schedule of gemm_bf16.hip.h with THREE 8-MFMA phases per
+// sub-tile:    P0: a_hi x b_lo    P1: a_hi x b_hi    P2: a_lo x b_hi
+// so that each phase prefetches into fragment registers the previous phase has released (b_hi in
+// P0, a_lo in P1, next a_hi + b_lo in P2) - 48 fragment registers, no double buffering.
+#pragma once
+#include "gemm_bf16.hip.h"
+
+namespace csi {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HS_G = 16;                       // k-columns per group (= per ping-pong sub-tile)
+
+struct GemmHsArgs {
+    const uint16_t* A;     // hs [M][lda]   (lda in halves = 2 * K rounded up to 16)
+    const uint16_t* Bt;    // hs [N][ldb]   weights, K-major
+    void* C;               // fp32 [M][ldc] (EPI_RAW slabs / EPI_BIAS) or hs [M][ldc halves]
+    int M, N, K;           // K = reduction length actually walked (multiple of 16 as stored)
+    int lda, ldb, ldc;
+    int k_per_split;       // real k-columns per blockIdx.z, multiple of 16
+    int tiles_n;
+    float acc_scale;       // 2^-(sa + sw): undoes the operand scaling (exact)
+    float out_scale;       // hs output: 2^sa of the layer that reads it
+    const float* bias;
+    const float* scale;    // BN scale / shift
+    const float* shift;
+};
+
+// (a, b) -> packed hi halves, packed lo halves
+__device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 x = {a, b};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// Epilogue of the hs ping-pong kernels (8 waves as 2 x 4, 128 x 64 per wave).  fp32 output straight
+// from the C/D layout.  hs output: per half of the wave's rows, (hi | lo << 16) words go through a
+// wave-private LDS image [64 rows][64 columns]; a lane then owns 8 columns of a row, separates the
+// planes with two v_perm_b32 per word pair and stores 16 B of hi and 16 B of lo (the 8 lanes of a
+// row write 256 contiguous bytes).  The ring is idle by then (see pp_epilogue).
+template <int EPI, bool OUT_HS>
+__device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArgs& g, float* lds, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool full_rows = (m0 + PP_BM) <= g.M;
+    const float as = g.acc_scale;
+    if constexpr (OUT_HS) {
+        const float os = g.out_scale;
+        uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
+        const int cg = lane & 7;
+        const int col8 = n0 + wn * 64 + cg * 8;
+        // halves offset of this lane's 8 columns inside a row: group (col8 / 16), hi part
+        uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (col8 >> 4) * 32 + (col8 & 8);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
+                float bias = 0.f, sc = 1.f, sh = 0.f;
+                if (EPI != EPI_RAW) bias = g.bias[colc];
+                if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float v0 = acc[2 * half + m2][nj][r] * as, v1 = acc[2 * half + m2][nj][r + 1] * as;
+                        if (EPI == EPI_BIAS) { v0 += bias; v1 += bias; }
+                        if (EPI == EPI_BIAS_RELU_AFFINE) { v0 = fmaf(fmaxf(v0 + bias, 0.f), sc, sh); v1 = fmaf(fmaxf(v1 + bias, 0.f), sc, sh); }
+                        uint32_t h, l;
+                        hs_split2(v0 * os, v1 * os, h, l);
+                        const int row = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // rows row, row + 1
+                        ep[row * 64 + nj * 32 + l31] = (h & 0xffffu) | (l << 16);
+                        ep[(row + 1) * 64 + nj * 32 + l31] = (h >> 16) | (l & 0xffff0000u);
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int rl = pass * 8 + (lane >> 3);
+                const uint4 w0 = *reinterpret_cast<const uint4*>(ep + rl * 64 + cg * 8);
+                const uint4 w1 = *reinterpret_cast<const uint4*>(ep + rl * 64 + cg * 8 + 4);
+                uint4 vh, vl;
+                vh.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x05040100u);  vl.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x07060302u);
+                vh.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u);  vl.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x07060302u);
+                vh.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u);  vl.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x07060302u);
+                vh.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u);  vl.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u);
+                const int row = m0 + wm * 128 + half * 64 + rl;
+                if (col8 < g.N && (full_rows || row < g.M)) {
+                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = vh;
+                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc + 16) = vl;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        const int wrow = m0 + wm * 128 + 4 * hi;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int col = n0 + wn * 64 + nj * 32 + l31;
+            const bool cok = col < g.N;
+            const int colc = min(col, g.N - 1);
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if (EPI != EPI_RAW) bias = g.bias[colc];
+            if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+            float* cf = reinterpret_cast<float*>(g.C) + (EPI == EPI_RAW ? (size_t)blockIdx.z * g.M * g.ldc : (size_t)0) +
+                        (size_t)wrow * g.ldc + col;
+            auto put = [&](int rr, float v) {
+                v *= as;
+                if (EPI == EPI_BIAS) v += bias;
+                if (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v + bias, 0.f), sc, sh);
+                cf[(size_t)rr * g.ldc] = v;
+            };
+            if (full_rows) {
+                if (cok) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) put(mi * 32 + (r & 3) + 8 * (r >> 2), acc[mi][nj][r]);
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (cok && (wrow + rr) < g.M) put(rr, acc[mi][nj][r]);
+                    }
+            }
+        }
+    }
+}
+
+// The three MFMA phases of a sub-tile, shared by both kernels.  Fragment registers: a_hi, a_lo (4
+// row tiles each), b_hi, b_lo (2 column tiles each).  rd(slot, c, ...) reads chunk pair c (0 = hi
+// plane, 1 = lo plane) of a sub-tile.
+struct HsFrags {
+    f16x8 a_hi[4], a_lo[4], b_hi[2], b_lo[2];
+};
+
+template <int PH, typename RdA, typename RdB>
+__device__ __forceinline__ void hs_mfma_seg(f32x16 (&acc)[4][2], HsFrags& f, RdA&& read_a, RdB&& read_b, bool more, int slot, int nslot,
+                                            bool closing_barrier) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (PH == 0) read_b(slot, 0, f.b_hi);
+    if (PH == 1) read_a(slot, 1, f.a_lo);
+    if (PH == 2 && more) {
+        read_a(nslot, 0, f.a_hi);
+        read_b(nslot, 1, f.b_lo);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16x8 a = PH == 2 ? f.a_lo[i] : f.a_hi[i];
+            const f16x8 b = PH == 0 ? f.b_lo[j] : f.b_hi[j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+        }
+    constexpr int NRD = PH == 0 ? 2 : (PH == 1 ? 4 : 6);
+    if (PH != 2 || more) {
+#pragma unroll
+        for (int q = 0; q < NRD; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 - NRD, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    pp_wait_lgkm();
+    __builtin_amdgcn_sched_barrier(0);
+    if (closing_barrier) pp_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Both operands hs in HBM.  Ring of NSUB sub-tiles of 16 k-columns (32 KiB each: 256 A rows + 256 B
+// rows x 64 B), each wave DMAs 4 one-KiB pieces per sub-tile (2 + 1 + 1 over the three phases), D =
+// NSUB - 1 sub-tiles ahead.  Sub-tile u+1 is first read by the prefetch in P2(u); its pieces are
+// waited for in the load segment of P1(u) (vmcnt leaves the 4(D-2)+3 younger pieces in flight) - a
+// full phase earlier, so that the barrier pair in between publishes the other group's pieces too.
+// Slot of sub-tile u+D = slot of u-1, whose last fragment read (a_lo, P1(u-1)) was retired two
+// barriers before either group issues into it.
+template <int EPI, bool OUT_HS, int NSUB = 5, int DBG = 0>
+__global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsArgs g) {
+    constexpr int D = NSUB - 1;
+    __shared__ __attribute__((aligned(16))) float lds[NSUB * PP_SUBF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    if (tm * PP_BM >= g.M) return;
+    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nsub = (kend - kbeg + HS_G - 1) / HS_G;
+
+    const bool a_side = wave < 4;
+    const uint16_t* tile_base = a_side ? g.A + (size_t)m0 * g.lda + 2 * kbeg : g.Bt + (size_t)n0 * g.ldb + 2 * kbeg;
+    const int ld = a_side ? g.lda : g.ldb;
+    const int rmax = a_side ? g.M - 1 - m0 : g.N - 1 - n0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tile_base, 0, 0x7fffffff, 0x00020000);
+    int voff[PP_PW];
+#pragma unroll
+    for (int u = 0; u < PP_PW; ++u) {
+        const int row = 16 * ((wave & 3) * PP_PW + u) + (lane >> 2);
+        const int clog = (lane & 3) ^ ((row >> 2) & 3);
+        voff[u] = (min(row, rmax) * ld + clog * 8) * 2;
+    }
+    auto issue = [&](int sub, int slot, int u) {
+        if (DBG & 1) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (wave * PP_PW + u) * 256),
+                                                 16, voff[u], sub * 64, 0, 0);
+    };
+
+    const int fswz = (l31 >> 2) & 3;
+    int xo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;            // floats
+    const int abase = (wm * 128 + l31) * PP_ROWF;
+    const int bbase = (PP_BM + wn * 64 + l31) * PP_ROWF;
+    auto read_a = [&](int slot, int c, f16x8 (&a)[4]) {
+        const float* st = lds + slot * PP_SUBF + abase + xo[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + i * 32 * PP_ROWF));
+    };
+    auto read_b = [&](int slot, int c, f16x8 (&b)[2]) {
+        const float* st = lds + slot * PP_SUBF + bbase + xo[c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + j * 32 * PP_ROWF));
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    HsFrags f;
+
+    const int npro = min(nsub, D);
+    for (int t = 0; t < npro; ++t)
+#pragma unroll
+        for (int u = 0; u < PP_PW; ++u) issue(t, t, u);
+    pp_wait_vm_lgkm_rt(PP_PW * (npro - 1));
+    pp_barrier();                       // sub-tile 0 visible to every wave
+    read_a(0, 0, f.a_hi);
+    read_b(0, 1, f.b_lo);
+    pp_wait_lgkm();
+    if (wm == 1) pp_barrier();          // group 1 runs one segment behind
+
+    int slot = 0, fill = D % NSUB;
+    int u = 0;
+    for (; u < nsub - D; ++u) {
+        const int nslot = slot + 1 == NSUB ? 0 : slot + 1;
+        issue(u + D, fill, 0);
+        issue(u + D, fill, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        issue(u + D, fill, 2);
+        pp_wait_vm_lgkm<(DBG & 1) ? 0 : PP_PW * (D - 2) + 3>();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
+        issue(u + D, fill, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<2>(acc, f, read_a, read_b, true, slot, nslot, true);
+        slot = nslot;
+        fill = fill + 1 == NSUB ? 0 : fill + 1;
+    }
+    for (; u < nsub; ++u) {
+        const int r = nsub - 1 - u;      // sub-tiles still to come after this one
+        const int nslot = slot + 1 == NSUB ? 0 : slot + 1;
+        pp_barrier();
+        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        if (r >= 1) pp_wait_vm_lgkm_rt(PP_PW * (r - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
+        pp_barrier();
+        hs_mfma_seg<2>(acc, f, read_a, read_b, r >= 1, slot, nslot, !(wm == 1 && r == 0));
+        slot = nslot;
+    }
+
+    if ((DBG & 8) && g.M > 0) return;
+    hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A operand produced in the kernel (PairSrc as in gemm_bf16.hip.h):
+//   pair mode:  A[(pr,t)][k] = split( in_scale * bn0( relu( L0[pr][k] + T[t][k] ) ) )   - the scale is
+//               folded into the LDS copy of s0 / t0, so it costs no multiply in the loop;
+//   CAST mode:  A[m][k] = split( in_scale * X[m][k] )  from fp32 rows (layer 0), split-K over z.
+// Every wave owns 32 A rows (lane -> row, 8-column half of the 16-column sub-tile): per sub-tile it
+// turns the 8 (+8) values it requested one sub-tile earlier into 16 B of hi and 16 B of lo, writes
+// both chunks at their swizzled places (rows are permuted over the lanes so that each 16-lane
+// ds_write_b128 group covers all 64 banks), requests the next values, and issues its two B pieces
+// (one in P0, one in P1) D = 3 sub-tiles ahead.  One vmcnt(2) per sub-tile: the values are older
+// than the two B pieces issued behind them, and the wait retires every older B piece as well -
+// including sub-tile u+1, which P2(u) prefetches two barriers later.
+template <int EPI, bool OUT_HS, bool CAST = false>
+__global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const GemmHsArgs g, const PairSrc ps, const float in_scale) {
+    constexpr int NSUB = 4, D = 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring + 2 * K floats (s0 | t0)
+    float* sv_l = lds + NSUB * PP_SUBF;
+    float* hv_l = sv_l + g.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    if (tm * PP_BM >= g.M) return;
+    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+    const int kbeg = CAST ? blockIdx.z * g.k_per_split : 0;
+    const int kend = CAST ? min(g.K, kbeg + g.k_per_split) : g.K;
+    const int nsub = (kend - kbeg + HS_G - 1) / HS_G;
+
+    if (!CAST)
+        for (int i = tid; i < g.K; i += PP_THREADS) {
+            sv_l[i] = ps.s0[i] * in_scale;
+            hv_l[i] = ps.t0[i] * in_scale;
+        }
+
+    // ---- B side: pieces 2w, 2w+1 of the 16 B pieces of a sub-tile
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb + 2 * kbeg), 0, 0x7fffffff, 0x00020000);
+    int voff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = 16 * (2 * wave + u) + (lane >> 2);
+        const int clog = (lane & 3) ^ ((row >> 2) & 3);
+        voff[u] = (min(row, g.N - 1 - n0) * g.ldb + clog * 8) * 2;
+    }
+    auto issue_b = [&](int sub, int slot, int u) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
+                                                 16, voff[u], sub * 64, 0, 0);
+    };
+    // ---- A side: row 32w + perm(lane >> 1) (bits 2 and 3 swapped), k half lane & 1
+    const int ridx = lane >> 1, kh = lane & 1;
+    const int arow = 32 * wave + ((ridx & 3) | ((ridx & 4) << 1) | ((ridx & 8) >> 1) | (ridx & 16));
+    const int aswz = (arow >> 2) & 3;
+    const int a_hi_off = arow * PP_ROWF + ((kh ^ aswz) << 2);            // floats inside a sub-tile
+    const int a_lo_off = arow * PP_ROWF + (((2 + kh) ^ aswz) << 2);
+    const float* lrow;
+    const float* trow;
+    {
+        const int m = min(m0 + arow, g.M - 1);
+        if (CAST) {
+            lrow = ps.L0 + (size_t)m * ps.ldl + kbeg + 8 * kh;
+            trow = lrow;
+        } else {
+            const int pr = m / ps.nt, t = m - pr * ps.nt;
+            lrow = ps.L0 + (size_t)pr * ps.ldl + 8 * kh;
+            trow = ps.T + (size_t)t * ps.ldl + 8 * kh;
+        }
+    }
+    f32x4 lv[2], tv[2];
+    auto load_a = [&](int sub) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            lv[h] = *reinterpret_cast<const f32x4*>(lrow + sub * HS_G + 4 * h);
+            if (!CAST) tv[h] = *reinterpret_cast<const f32x4*>(trow + sub * HS_G + 4 * h);
+        }
+    };
+    auto gen_a = [&](int sub, int slot) {
+        f32x4 v[2];
+        if (CAST) {
+            v[0] = lv[0] * in_scale;
+            v[1] = lv[1] * in_scale;
+        } else {
+            const int k = sub * HS_G + 8 * kh;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 s = *reinterpret_cast<const f32x4*>(sv_l + k + 4 * h);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(hv_l + k + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[h][e] = fmaf(fmaxf(lv[h][e] + tv[h][e], 0.f), s[e], b[e]);
+            }
+        }
+        uint4 oh, ol;
+        hs_split2(v[0][0], v[0][1], oh.x, ol.x);
+        hs_split2(v[0][2], v[0][3], oh.y, ol.y);
+        hs_split2(v[1][0], v[1][1], oh.z, ol.z);
+        hs_split2(v[1][2], v[1][3], oh.w, ol.w);
+        float* st = lds + slot * PP_SUBF;
+        *reinterpret_cast<uint4*>(st + a_hi_off) = oh;
+        *reinterpret_cast<uint4*>(st + a_lo_off) = ol;
+    };
+
+    const int fswz = (l31 >> 2) & 3;
+    int xo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;
+    const int abase = (wm * 128 + l31) * PP_ROWF;
+    const int bbase = (PP_BM + wn * 64 + l31) * PP_ROWF;
+    auto read_a = [&](int slot, int c, f16x8 (&a)[4]) {
+        const float* st = lds + slot * PP_SUBF + abase + xo[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + i * 32 * PP_ROWF));
+    };
+    auto read_b = [&](int slot, int c, f16x8 (&b)[2]) {
+        const float* st = lds + slot * PP_SUBF + bbase + xo[c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + j * 32 * PP_ROWF));
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    HsFrags f;
+
+    // ---- prologue: B sub-tiles 0..2 in flight, A sub-tiles 0 and 1 generated synchronously
+    __syncthreads();                    // s0 / t0 staged
+    const int npro = min(nsub, D);
+    for (int t = 0; t < npro; ++t) { issue_b(t, t, 0); issue_b(t, t, 1); }
+    for (int t = 0; t < min(nsub, 2); ++t) {
+        load_a(t);
+        gen_a(t, t);                    // the compiler waits for the loads it just issued
+    }
+    pp_wait_vm_lgkm<0>();
+    if (nsub > 2) load_a(2);            // consumed in P0 of sub-tile 0
+    pp_barrier();
+    read_a(0, 0, f.a_hi);
+    read_b(0, 1, f.b_lo);
+    pp_wait_lgkm();
+    if (wm == 1) pp_barrier();          // group 1 runs one segment behind
+
+    int slot = 0;
+    auto subtile = [&](int u, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int nslot = (slot + 1) & 3;
+        const bool has_a = STEADY || u + 2 < nsub, nxt_a = STEADY || u + 3 < nsub, has_b = STEADY || u + D < nsub;
+        const bool last = !STEADY && u == nsub - 1;
+        // P0
+        if (has_a) {
+            if (STEADY) pp_wait_vm_lgkm<2>(); else pp_wait_vm_lgkm<0>();
+            gen_a(u + 2, (slot + 2) & 3);
+            if (nxt_a) load_a(u + 3);
+        } else {
+            pp_wait_vm_lgkm<0>();       // tail: every outstanding B piece has landed
+        }
+        if (has_b) issue_b(u + D, (slot + D) & 3, 0);
+        pp_wait_lgkm();                 // the A image is written before the barrier publishes it
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        // P1
+        if (has_b) issue_b(u + D, (slot + D) & 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
+        // P2
+        pp_barrier();
+        hs_mfma_seg<2>(acc, f, read_a, read_b, !last, slot, nslot, !(wm == 1 && last));
+        slot = nslot;
+    };
+    int u = 0;
+    for (; u + D < nsub; ++u) subtile(u, std::true_type{});
+    for (; u < nsub; ++u) subtile(u, std::false_type{});
+
+    hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
+}
+
+// dst (hs [rows][ldh]) = split(scale * src[rows][cols]) with zero padding up to ldh / 2 columns.
+// One thread = 8 columns of a row: 32 B in, 16 B of hi + 16 B of lo out.
+__global__ void f32_to_hs_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, uint16_t* __restrict__ dst, int ldh, float scale) {
+    const int c8 = ldh >> 4;                                  // 8-column groups per row
+    const size_t total = (size_t)rows * c8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool vec = (ld_src & 3) == 0 && (((uintptr_t)src) & 15) == 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int r = (int)(i / c8), c = (int)(i - (size_t)r * c8) * 8;
+        float v[8];
+        const float* s = src + (size_t)r * ld_src + c;
+        if (vec && c + 8 <= cols) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c + e < cols) ? s[e] : 0.f;
+        }
+        uint4 oh, ol;
+        hs_split2(v[0] * scale, v[1] * scale, oh.x, ol.x);
+        hs_split2(v[2] * scale, v[3] * scale, oh.y, ol.y);
+        hs_split2(v[4] * scale, v[5] * scale, oh.z, ol.z);
+        hs_split2(v[6] * scale, v[7] * scale, oh.w, ol.w);
+        uint16_t* d = dst + (size_t)r * ldh + (c >> 4) * 32 + (c & 8);
+        *reinterpret_cast<uint4*>(d) = oh;
+        *reinterpret_cast<uint4*>(d + 16) = ol;
+    }
+}
+
+}  // namespace csi

@@ -383,6 +383,85 @@ def test_hip_path_matches_committed_oracle_fixture(pkg, golden_dir):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([g['ls'].real, g['ls'].imag], -1)) < TOL
 
 
+# ------------------------------------------------------------------------------------ split-f16 engine
+HS_CASES = [
+    (8, 2, 40, (64, 48)),          # two hidden layers: cast layer 0, fused pair layer (hs out), regressor
+    (4, 1, 70, (128,)),            # one hidden layer: the fused pair kernel IS the regressor (fp32 out)
+    (16, 2, 9, (64, 32, 48)),      # three hidden layers: hs -> hs generic layer in between
+    (32, 4, 9, (1024, 1024)),      # the shipped model; ragged last row tile (1152 rows)
+    (12, 3, 11, (48, 80)),         # Nt not a power of two (rows of one (packet, rx) straddle tiles)
+    (128, 1, 3, (64, 64)),
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', HS_CASES)
+def test_split_f16_engine_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden):
+    """fp32 contexts run their large GEMMs on the f16 matrix cores with split (hi + lo) operands
+    (gemm_hs.hip.h); 'f32_engine' = 1 forces that engine at any size.  Same 1e-5 contract as the native
+    fp32 MFMA kernels, and both engines must agree far inside it."""
+    rng = np.random.default_rng(nt * 77 + npkt)
+    w_re, w_im = _weights(oracle, 4321 + nt, nt, hidden)
+    pow2 = (nt & (nt - 1)) == 0
+    P = _pilot(rng, nt, orthogonal=pow2)
+    if pow2:
+        ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=0.0)[0]
+    else:
+        ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', 1)
+    s_re, s_im = e.predict(ltf)
+    e.set_option('f32_engine', 0)
+    n_re, n_im = e.predict(ltf)
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+    assert rel_rows(n_re, r_re) < TOL and rel_rows(n_im, r_im) < TOL
+    assert rel_rows(s_re, n_re) < 5e-6
+    assert not np.array_equal(s_re, n_re), 'the option did not switch engines'
+    assert oracle.nmse_subk(r_re + 1j * r_im, s_re + 1j * s_im) < 1e-10
+
+
+@pytest.mark.parametrize('gain', [1e-3, 1.0, 60.0])
+def test_split_f16_engine_input_scale(pkg, oracle, gain):
+    """The f16 halves have a finite range: the engine scales operands by powers of two.  Results must
+    hold the contract for preambles well below and above unit power."""
+    rng = np.random.default_rng(5)
+    nt, nr, npkt, hidden = 8, 2, 24, (64, 64)
+    w_re, w_im = _weights(oracle, 99, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = gain * oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=10.0)[0]
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', 1)
+    s_re, s_im = e.predict(ltf)
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+
+
+def test_split_f16_engine_is_the_default_for_large_calls(pkg, oracle):
+    """Automatic mode: the per-pair layers of a call that fills the chip take the split engine, a small
+    call stays on the native kernels (bit-identical to 'f32_engine' = 0)."""
+    rng = np.random.default_rng(11)
+    nt, nr, hidden = 32, 4, (256, 256)
+    w_re, w_im = _weights(oracle, 7, nt, hidden)
+    P = _pilot(rng, nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    big = oracle.make_structured_packets(rng, 300, nr, oracle.hadamard(nt), snr_db=5.0)[0]     # 38400 rows
+    a_re, _ = e.predict(big)
+    e.set_option('f32_engine', 0)
+    n_re, _ = e.predict(big)
+    assert not np.array_equal(a_re, n_re), 'automatic mode did not use the split engine'
+    assert rel_rows(a_re, n_re) < 5e-6
+    e.set_option('f32_engine', -1)
+    small = big[:2]
+    a_re, _ = e.predict(small)
+    e.set_option('f32_engine', 0)
+    n_re, _ = e.predict(small)
+    assert np.array_equal(a_re, n_re)
+    e.set_option('f32_engine', -1)
+    g_re, _ = e.predict(big)
+    r_re, _ = oracle.predict_packets(big[:16].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=16)
+    assert rel_rows(g_re[:16], r_re) < TOL
+
+
 # ------------------------------------------------------------------------------------ bf16 mode
 BF16_TOL_IMPL = 4e-3     # vs the bf16-operand emulation: only accumulation-order induced bf16 re-roundings
 BF16_TOL_FMT = 3e-2      # vs the fp64 oracle: the format error of 8-bit-mantissa operands (NOT the fp32 contract)
