@@ -13,9 +13,17 @@ Data: i.i.d. CN(0,1) preambles generated on the device (csi_synth_white) and ran
 weights of the shipped architecture - the reference ships neither datasets nor weights.  The
 arithmetic is data-independent (dense fp32), so noise level does not change the work.
 
+Arithmetic: fp32 in, fp32 accumulate, fp32 out.  The library's fp32 contexts run GEMMs that fill the
+chip on the f16 matrix cores with split operands (x = hi + lo halves, 3 MFMA per product,
+gemm_hs.hip.h): same 1e-5 contract (the line carries the measured error against the fp64 oracle),
+~2.6x the fp32 MFMA rate.  `--engine native` times the fp32 MFMA kernels instead; the default run
+also reports them as `native_fp32_engine` for comparison.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     - dominant kernel (pair_dense_gemm) TFLOP/s from HIP events on the library's own
-                 stream, against the 157.3 TFLOP/s fp32 matrix peak of gfx950
+                 stream: algorithmic flops / time against the ceiling of the engine that ran -
+                 2500 / 3 TFLOP/s for the split engine (f16 dense MFMA peak over the three products
+                 per fp32 multiply), 157.3 TFLOP/s for the fp32 MFMA kernels
   cpu_baseline - the reference's per-packet naive fp32 loop restated on the host cores
                  (oracle/cpu_baseline.py), timed on a bounded sample (rank 0, N = 1 only)
 """
@@ -32,7 +40,8 @@ sys.path.insert(0, REPO)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
-BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense, v_mfma_f32_32x32x16_bf16
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense, v_mfma_f32_32x32x16_bf16 (the same for v_mfma_f32_32x32x16_f16)
+SPLIT_PRODUCTS = 3                  # f16 MFMAs per fp32-grade multiply on the split engine
 
 
 def main():
@@ -50,6 +59,9 @@ def main():
     ap.add_argument('--workspace-gb', type=float, default=0.0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32 = the headline fp32 path; bf16 = BASELINE config 3 (use with --nt 64 --packets 5000)')
+    ap.add_argument('--engine', default='auto', choices=['auto', 'native', 'split'],
+                    help='fp32 contexts: auto = split-f16 engine for GEMMs that fill the chip (library default), '
+                         'native = fp32 MFMA kernels only, split = split engine wherever the shapes allow')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
     ap.add_argument('--host-path', type=int, default=0,
                     help='also time the host-buffer (PCIe-inclusive) entry points on this many packets')
@@ -88,6 +100,9 @@ def main():
     d_hre, d_him = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
     eng.synchronize()
 
+    if args.dtype == 'f32':
+        eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
+
     def step():
         if not args.no_ls:
             eng.ls_estimate_device(d_re, d_im, npkt, d_hre, d_him)
@@ -113,6 +128,7 @@ def main():
     eng.profile_enable(False)
     pairs_per_step = npkt * nr * nt * world
     value = pairs_per_step * args.steps / dt
+    split_engine = args.dtype == 'f32' and eng.get_option('hs_launches') > 0
 
     # ---- cpu_baseline leg (rank 0, N = 1, after the timed region): the only place that touches oracle/.
     # It runs the CPU restatement of the reference on a bounded sample of the very same packets - timed
@@ -147,6 +163,29 @@ def main():
             'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'], 'cpu_model': r['cpu_model'],
             'dnn_one_large_batch': {'value': r['batched_dnn_pairs_per_s'], 'packets': r['batched_packets']},
             'gpu_over_cpu': value / r['pairs_per_s']}
+
+    # the same steps on the fp32 MFMA kernels, for comparison (outside the headline timed region)
+    native = None
+    if split_engine and world == 1:
+        eng.set_option('f32_engine', 0)
+        step(); eng.synchronize()
+        eng.profile_enable(True); eng.profile_reset()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.synchronize()
+        dn = time.perf_counter() - t1
+        pn = eng.profile()['pair_dense_gemm']
+        eng.profile_enable(False)
+        ntf = pn['flops'] / max(pn['ms'], 1e-9) / 1e9
+        native = {'value': pairs_per_step * args.steps / dn, 'ms_per_step': dn / args.steps * 1e3,
+                  'pair_dense_gemm_tflops': ntf, 'frac_of_fp32_mfma_peak': ntf / FP32_MATRIX_PEAK_TFLOPS,
+                  'what': "same steps with f32_engine = 0 (v_mfma_f32_32x32x2_f32 kernels)"}
+        if args.check > 0:
+            from oracle import csi_oracle as o
+            kc = min(args.check, npkt)
+            native['dnn_rel_err'] = max(o.row_rel_err(d_ore.download(0, kc), r_re), o.row_rel_err(d_oim.download(0, kc), r_im))
+        eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
 
     # one-packet latency (the reference's literal per-packet call, DNN.py:346), device-resident, outside the timed region
     latency = None
@@ -200,7 +239,14 @@ def main():
     dom = prof['pair_dense_gemm']
     dom_ms = dom['ms'] / max(dom['launches'], 1)
     achieved = dom['flops'] / max(dom['ms'], 1e-9) / 1e9          # TFLOP/s
-    mfma_peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MATRIX_PEAK_TFLOPS
+    if args.dtype == 'bf16':
+        mfma_peak, peak_note = BF16_MATRIX_PEAK_TFLOPS, 'dense bf16 MFMA peak'
+    elif split_engine:
+        mfma_peak = BF16_MATRIX_PEAK_TFLOPS / SPLIT_PRODUCTS
+        peak_note = ('split-f16 engine: dense f16 MFMA peak (2500 TFLOP/s) / 3 MFMA products per fp32-grade multiply; '
+                     'achieved counts each multiply-add of the algorithm once (executed f16 flops are 3x)')
+    else:
+        mfma_peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'
     kernels = {}
     for name, p in prof.items():
         if p['launches']:
@@ -220,6 +266,9 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': args.dtype,
+        'arithmetic': ('fp32 operands, fp32 accumulate, fp32 results; GEMM products on the f16 matrix cores with split (hi + lo) '
+                       'operands, 3 MFMA per product - error vs the fp64 oracle in parity_check (contract 1e-5)') if split_engine else
+                      ('fp32 MFMA' if args.dtype == 'f32' else 'bf16 operands, fp32 accumulate'),
         'data': 'synthetic',
         'config': {'workload': '%sNt=%d Nr=%d, %d packets/GPU/step%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
                        'configs[1]: ' if (nt, nr, npkt, args.dtype) == (32, 4, 4000, 'f32') else ('configs[2]: ' if (nt, nr, npkt, args.dtype) == (64, 4, 5000, 'bf16') else ''), nt, nr, npkt,
@@ -227,14 +276,18 @@ def main():
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,
-                     'unit': 'TFLOP/s', 'frac': achieved / mfma_peak,
-                     'traffic': hbm_per_launch('pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
+                     'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
+                     'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
+                     'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
+                     'traffic': hbm_per_launch('gemm_hs_pp_pair' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,
         'parity_check': check,
         'latency': latency,
     }
+    if native:
+        out['native_fp32_engine'] = native
     if host_path:
         out['host_path_pcie_inclusive'] = host_path
     if 'ls_estimate' in kernels:

@@ -18,7 +18,7 @@ CSI_DTYPE_F32 = 0
 CSI_DTYPE_BF16 = 1
 
 STATUS_NAMES = {0: 'CSI_OK', -1: 'CSI_ERR_INVALID_ARG', -2: 'CSI_ERR_NOT_READY', -3: 'CSI_ERR_HIP',
-                -4: 'CSI_ERR_NO_DEVICE', -5: 'CSI_ERR_NOMEM'}
+                -4: 'CSI_ERR_NO_DEVICE', -5: 'CSI_ERR_NOMEM', -6: 'CSI_ERR_RANGE'}
 
 
 class CsiError(RuntimeError):
@@ -76,6 +76,7 @@ SYMBOLS = {
     'csi_train_end': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int]),
     'csi_synchronize': (ctypes.c_int, [_ctx]),
     'csi_set_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
+    'csi_get_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),
     'csi_device_free': (ctypes.c_int, [_ctx, _vp]),
     'csi_host_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),

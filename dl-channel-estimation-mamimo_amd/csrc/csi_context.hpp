@@ -127,6 +127,10 @@ struct csi_ctx {
     int f32_engine = -1;         // "f32_engine" option: fp32 contexts, 0 = native fp32 MFMA kernels, 1 = split-f16 kernels (gemm_hs.hip.h)
                                  // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)
     int hs_act_shift = 4;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
+    unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
+    int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
+    int64_t hs_checked = 0;
+    int64_t hs_range_fallbacks = 0;
     int hs_in_shift = 4;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)

@@ -52,6 +52,21 @@ int hs_layer0_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) 
     return real;
 }
 
+// Range guard: has any split-engine GEMM since the last check converted an operand near / beyond the
+// f16 limit?  The caller has synchronised the stream.  *hit = the magnitude seen (0 = none).
+int hs_range_check(csi_ctx* c, float* hit) {
+    *hit = 0.f;
+    if (!c->hs_peak || c->hs_launches == c->hs_checked) return CSI_OK;
+    c->hs_checked = c->hs_launches;
+    unsigned bits = 0;
+    HIP_TRY(c, hipMemcpy(&bits, c->hs_peak, sizeof(bits), hipMemcpyDeviceToHost));
+    if (bits) {
+        std::memcpy(hit, &bits, 4);
+        HIP_TRY(c, hipMemset(c->hs_peak, 0, sizeof(bits)));
+    }
+    return CSI_OK;
+}
+
 template <typename Kern>
 int hs_dynamic_lds(csi_ctx* c, Kern kern, size_t bytes, size_t* have) {
     if (*have < bytes) {
@@ -70,6 +85,8 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     g.k_per_split = kps;
     g.tiles_n = (h1 + PP_BN - 1) / PP_BN;
     g.acc_scale = std::ldexp(1.f, -(c->hs_in_shift + l0.wshift));
+    g.peak = c->hs_peak;
+    ++c->hs_launches;
     const double flops = 2.0 * (double)M1 * h1 * K;
     const double bytes = 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits);
     ProfScope ps(c, K_LAYER0_LTF, flops, bytes);
@@ -91,6 +108,8 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
 template <int EPI, bool OUT_HS>
 int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
     g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    g.peak = c->hs_peak;
+    ++c->hs_launches;
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M / src.nt * g.K + (double)src.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
@@ -108,6 +127,8 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
 template <int EPI, bool OUT_HS>
 int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
     g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
+    g.peak = c->hs_peak;
+    ++c->hs_launches;
     g.k_per_split = (g.K + HS_G - 1) / HS_G * HS_G;
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);

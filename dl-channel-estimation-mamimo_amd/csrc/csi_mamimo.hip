@@ -154,6 +154,10 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
         c->err = "hipStreamCreate failed";
         return bail(CSI_ERR_HIP);
     }
+    if (hipMalloc((void**)&c->hs_peak, 256) != hipSuccess || hipMemset(c->hs_peak, 0, 256) != hipSuccess) {
+        c->err = "device allocation failed";
+        return bail(CSI_ERR_NOMEM);
+    }
     // LS constants.  Twiddles in double on the host so the table is correctly rounded.
     std::vector<float> tw(2 * LS_FFT);
     for (int u = 0; u < LS_FFT; ++u) {
@@ -209,6 +213,7 @@ void csi_destroy(csi_ctx* c) {
     for (int d = 0; d < 2; ++d) tr_free(c->trainer[d]);
     delete c->hostpipe;
     if (c->P) hipFree(c->P);
+    if (c->hs_peak) hipFree(c->hs_peak);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->tw) hipFree(c->tw);
     if (c->bin_pos) hipFree(c->bin_pos);
@@ -571,6 +576,27 @@ int csi_lmmse_estimate(csi_ctx* c, const float* h_re, const float* h_im, int64_t
     return CSI_OK;
 }
 
+int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!name || !value) return fail(c, CSI_ERR_INVALID_ARG, "csi_get_option: null argument");
+    const std::string n(name);
+    if (n == "use_graph") *value = c->use_graph;
+    else if (n == "force_tile") *value = c->force_pair_tile;
+    else if (n == "xcd_order") *value = c->xcd_order;
+    else if (n == "ls_fft_first_max") *value = c->ls_fft_first_max;
+    else if (n == "small_call_overlap") *value = c->small_call_overlap;
+    else if (n == "f32_engine") *value = c->f32_engine;
+    else if (n == "hs_act_shift") *value = c->hs_act_shift;
+    else if (n == "hs_in_shift") *value = c->hs_in_shift;
+    else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
+    else if (n == "host_threads") *value = c->host_threads;
+    else if (n == "ls_kernel") *value = c->ls_kernel;
+    else if (n == "hs_launches") *value = c->hs_launches;                    // read-only counters
+    else if (n == "hs_range_fallbacks") *value = c->hs_range_fallbacks;
+    else return fail(c, CSI_ERR_INVALID_ARG, "csi_get_option: unknown option '%s'", name);
+    return CSI_OK;
+}
+
 int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (!name) return fail(c, CSI_ERR_INVALID_ARG, "csi_set_option: null name");
@@ -780,6 +806,12 @@ int csi_train_end(csi_ctx* c, int model, int commit) {
 int csi_synchronize(csi_ctx* c) {
     if (!c) return CSI_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float hit = 0.f;
+    int rc = hs_range_check(c, &hit);
+    if (rc) return rc;
+    if (hit > 0.f)
+        return fail(c, CSI_ERR_RANGE, "split-f16 engine: an operand reached %.4g after scaling (f16 limit 65504) in a device-pointer call since the "
+                    "last check - the outputs of those calls are not valid; lower hs_in_shift / hs_act_shift or set f32_engine to 0 and run them again", (double)hit);
     return CSI_OK;
 }
 
@@ -799,7 +831,19 @@ int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t np
         return fail(c, CSI_ERR_INVALID_ARG, "csi_predict: bad argument");
     if (npkt == 0) return CSI_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
+    rc = host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
+    if (rc) return rc;
+    // range guard of the split-f16 engine: an operand beyond the f16 range -> the same call again on the
+    // fp32 MFMA kernels (the caller's buffers are still here), so that this entry point never returns inf
+    float hit = 0.f;
+    rc = hs_range_check(c, &hit);
+    if (rc || hit == 0.f) return rc;
+    ++c->hs_range_fallbacks;
+    const int engine = c->f32_engine;
+    c->f32_engine = 0;
+    rc = host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
+    c->f32_engine = engine;
+    return rc;
 }
 
 int csi_ls_estimate(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* h_re, float* h_im) {

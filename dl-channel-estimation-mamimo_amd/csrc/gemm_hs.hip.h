@@ -49,7 +49,18 @@ struct GemmHsArgs {
     const float* bias;
     const float* scale;    // BN scale / shift
     const float* shift;
+    unsigned* peak;        // range guard (may be null): atomicMax of the bits of the largest scaled operand
+                           // magnitude a kernel converted, recorded only above HS_PEAK_REPORT
 };
+
+// |s*x| above 65504 becomes inf in the hi half.  Kernels that convert operands keep a running maximum
+// (a v_max3 per three values) and report it once per lane at the end if it came near the limit, so
+// that the host can tell the caller / fall back to the fp32 MFMA kernels (csi_mamimo.hip).
+constexpr float HS_PEAK_REPORT = 60000.f;
+__device__ __forceinline__ float hs_absmax(float m, float a, float b) { return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+__device__ __forceinline__ void hs_report_peak(unsigned* peak, float m) {
+    if (peak && m > HS_PEAK_REPORT) atomicMax(peak, __builtin_bit_cast(unsigned, m));
+}
 
 // (a, b) -> packed hi halves, packed lo halves
 __device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -74,6 +85,7 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
     const float as = g.acc_scale;
     if constexpr (OUT_HS) {
         const float os = g.out_scale;
+        float pk = 0.f;
         uint32_t* ep = reinterpret_cast<uint32_t*>(lds) + wave * 4096;
         const int cg = lane & 7;
         const int col8 = n0 + wn * 64 + cg * 8;
@@ -95,7 +107,10 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
                         if (EPI == EPI_BIAS) { v0 += bias; v1 += bias; }
                         if (EPI == EPI_BIAS_RELU_AFFINE) { v0 = fmaf(fmaxf(v0 + bias, 0.f), sc, sh); v1 = fmaf(fmaxf(v1 + bias, 0.f), sc, sh); }
                         uint32_t h, l;
-                        hs_split2(v0 * os, v1 * os, h, l);
+                        v0 *= os;
+                        v1 *= os;
+                        pk = hs_absmax(pk, v0, v1);
+                        hs_split2(v0, v1, h, l);
                         const int row = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // rows row, row + 1
                         ep[row * 64 + nj * 32 + l31] = (h & 0xffffu) | (l << 16);
                         ep[(row + 1) * 64 + nj * 32 + l31] = (h >> 16) | (l & 0xffff0000u);
@@ -124,6 +139,7 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        hs_report_peak(g.peak, pk);
     } else {
         const int wrow = m0 + wm * 128 + 4 * hi;
 #pragma unroll
@@ -396,6 +412,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         }
     }
     f32x4 lv[2], tv[2];
+    float apk = 0.f;                    // largest |scaled A operand| this lane converted
     auto load_a = [&](int sub) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -419,6 +436,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
             }
         }
         uint4 oh, ol;
+        apk = hs_absmax(hs_absmax(hs_absmax(hs_absmax(apk, v[0][0], v[0][1]), v[0][2], v[0][3]), v[1][0], v[1][1]), v[1][2], v[1][3]);
         hs_split2(v[0][0], v[0][1], oh.x, ol.x);
         hs_split2(v[0][2], v[0][3], oh.y, ol.y);
         hs_split2(v[1][0], v[1][1], oh.z, ol.z);
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     for (; u + D < nsub; ++u) subtile(u, std::true_type{});
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
+    hs_report_peak(g.peak, apk);
     hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
 }
 

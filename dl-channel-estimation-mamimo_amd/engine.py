@@ -109,8 +109,15 @@ class CsiEngine:
         self._check(self._lib.csi_synchronize(self._ctx))
 
     def set_option(self, name, value):
-        """Tuning knobs of csi_set_option: 'use_graph', 'force_tile', 'xcd_order', 'ls_fft_first_max', 'ls_kernel'."""
+        """Tuning knobs of csi_set_option: 'use_graph', 'force_tile', 'xcd_order', 'ls_fft_first_max', 'ls_kernel',
+        'f32_engine' (-1 automatic / 0 fp32 MFMA kernels / 1 split-f16 engine), 'hs_in_shift', 'hs_act_shift', ..."""
         self._check(self._lib.csi_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name):
+        """Current value of a csi_set_option knob, or of the counters 'hs_launches' / 'hs_range_fallbacks'."""
+        v = ctypes.c_int64(0)
+        self._check(self._lib.csi_get_option(self._ctx, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def empty(self, shape):
         return DeviceArray(self, shape)

@@ -51,7 +51,8 @@ typedef enum {
     CSI_ERR_NOT_READY = -2,     /* predict before weights / pilot were loaded             */
     CSI_ERR_HIP = -3,           /* a HIP runtime call failed; text in csi_last_error       */
     CSI_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                                */
-    CSI_ERR_NOMEM = -5          /* device allocation failed                                */
+    CSI_ERR_NOMEM = -5,         /* device allocation failed                                */
+    CSI_ERR_RANGE = -6          /* split-f16 engine: an operand left the f16 range (csi_synchronize) */
 } csi_status;
 
 typedef enum {
@@ -189,6 +190,15 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
  *   "small_call_overlap" 1 (default): calls of at most 64 rx preambles run the real and the imag model on
  *                         two streams side by side (they are launch-latency bound); 0: one after the other
+ *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
+ *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
+ *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
+ *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels; 0: fp32 MFMA kernels only;
+ *                         1: split engine wherever the layer shapes allow (hidden widths multiples of 16)
+ *   "hs_in_shift", "hs_act_shift"  split engine: preamble samples / hidden activations are carried times
+ *                         2^shift (default 4, i.e. magnitudes up to 4094).  An operand beyond the f16 range
+ *                         is detected on the device: csi_predict repeats the call on the fp32 MFMA kernels
+ *                         by itself, after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
@@ -198,6 +208,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix - chosen
  *                         automatically then); a choice the kernel cannot serve falls back */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
+/* Current value of an option, or of the read-only counters "hs_launches" (split-engine GEMMs launched)
+ * and "hs_range_fallbacks" (csi_predict calls repeated on the fp32 MFMA kernels). */
+int  csi_get_option(csi_ctx* ctx, const char* name, int64_t* value);
 
 /* Device-memory plumbing so that a host program needs no other GPU runtime. */
 int  csi_device_malloc(csi_ctx* ctx, void** dptr, int64_t bytes);

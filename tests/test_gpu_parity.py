@@ -462,6 +462,38 @@ def test_split_f16_engine_is_the_default_for_large_calls(pkg, oracle):
     assert rel_rows(g_re[:16], r_re) < TOL
 
 
+def test_split_f16_engine_range_guard(pkg, oracle):
+    """Preambles whose scaled samples leave the f16 range: csi_predict repeats the call on the fp32 MFMA
+    kernels by itself (results still inside the contract); after a device-pointer call csi_synchronize
+    reports CSI_ERR_RANGE instead of handing back inf / nan silently."""
+    rng = np.random.default_rng(3)
+    nt, nr, npkt, hidden = 8, 2, 20, (64, 64)
+    w_re, w_im = _weights(oracle, 17, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = 3.0e4 * oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=10.0)[0]
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', 1)
+    s_re, s_im = e.predict(ltf)
+    assert e.get_option('hs_range_fallbacks') == 1 and e.get_option('f32_engine') == 1
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+    d_re, d_im = e.empty((npkt, nr, 320 * nt)), e.empty((npkt, nr, 320 * nt))
+    d_re.upload(np.ascontiguousarray(ltf.real, np.float32)); d_im.upload(np.ascontiguousarray(ltf.imag, np.float32))
+    o_re, o_im = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, o_re, o_im)
+    with pytest.raises(pkg.CsiError) as ei:
+        e.synchronize()
+    assert ei.value.code == -6 and 'f16' in str(ei.value)
+    e.synchronize()                                     # the condition is reported once
+    e.set_option('hs_in_shift', -6)                     # smaller scales serve the same data on the split engine
+    e.set_option('hs_act_shift', -6)
+    n0 = e.get_option('hs_launches')
+    e.predict_device(d_re, d_im, npkt, o_re, o_im)
+    e.synchronize()
+    assert e.get_option('hs_launches') > n0
+    assert rel_rows(o_re.download(), r_re) < TOL
+
+
 # ------------------------------------------------------------------------------------ bf16 mode
 BF16_TOL_IMPL = 4e-3     # vs the bf16-operand emulation: only accumulation-order induced bf16 re-roundings
 BF16_TOL_FMT = 3e-2      # vs the fp64 oracle: the format error of 8-bit-mantissa operands (NOT the fp32 contract)
