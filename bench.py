@@ -279,7 +279,7 @@ def main():
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
-                     'traffic': hbm_per_launch('gemm_hs_pp_pair' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
+                     'traffic': hbm_per_launch('gemm_hs_pp_pair_kernel<2' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,
