@@ -128,6 +128,7 @@ struct csi_ctx {
                                  // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)
     int hs_act_shift = 4;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
+    size_t hs_lds_attr[3] = {0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out)
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;

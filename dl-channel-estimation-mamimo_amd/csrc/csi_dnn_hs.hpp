@@ -91,9 +91,8 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     const double bytes = 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits);
     ProfScope ps(c, K_LAYER0_LTF, flops, bytes);
     auto kern = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
-    static thread_local size_t have = 0;
     const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
-    int rc = hs_dynamic_lds(c, kern, lds, &have);
+    int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[0]);
     if (rc) return rc;
     PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
     const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
@@ -114,9 +113,8 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
     const double bytes = 4.0 * ((double)g.M / src.nt * g.K + (double)src.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
     auto kern = gemm_hs_pp_pair_kernel<EPI, OUT_HS, false>;
-    static thread_local size_t have = 0;
     const size_t lds = (size_t)(PPP_RING_FLOATS + 2 * g.K) * sizeof(float);
-    int rc = hs_dynamic_lds(c, kern, lds, &have);
+    int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
     if (rc) return rc;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
     hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, c->hs_act_shift));

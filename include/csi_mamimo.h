@@ -73,7 +73,7 @@ typedef struct {
     float   bn_eps;                  /* keras BatchNormalization epsilon, 1e-3              */
     int32_t dtype;                   /* csi_dtype                                           */
     int32_t device;                  /* HIP device ordinal                                  */
-    int64_t workspace_bytes;         /* cap for activation workspace; 0 = default (1 GiB)   */
+    int64_t workspace_bytes;         /* cap for activation workspace; 0 = default (4 GiB fp32, 8 GiB bf16) */
 } csi_config;
 
 /* One named weight tensor on the host.  Names are the keras ones:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised shape sweep (not collected by pytest; GPU box: python tests/fuzz_shapes.py [cases] [seed]):
-random Nt / Nr / packet counts / hidden widths / depth / BatchNormalization on-off / dtype, the shared
+random Nt / Nr / packet counts / hidden widths / depth / BatchNormalization on-off / dtype / GEMM engine, the shared
 layer-0 path, the literal path and the LS estimate against the oracle."""
 import os
 import sys
@@ -26,11 +26,16 @@ def main():
         nt = int(rng.choice([4, 8, 12, 16, 20, 32, 40, 64]))
         nr = int(rng.choice([1, 2, 3, 4, 8]))
         npkt = int(rng.integers(1, 30))
+        if nt <= 16 and rng.random() < 0.3:
+            npkt = int(rng.integers(60, 160))            # several 256-row tiles per GEMM
         nh = int(rng.integers(1, 4))
         hidden = tuple(int(8 * rng.integers(1, 33)) for _ in range(nh))
         use_bn = bool(rng.integers(0, 2))
         dtype = 'bf16' if rng.random() < 0.3 else 'f32'
         tile = int(rng.choice([0, 0, 128, 256]))
+        engine = int(rng.choice([-1, 0, 1, 1]))            # fp32 contexts: automatic / fp32 MFMA kernels / split-f16 engine
+        if engine == 1 and rng.random() < 0.8:
+            hidden = tuple(int(16 * rng.integers(1, 17)) for _ in range(nh))     # widths the split engine serves
         w_re = o.make_weights(rng, 321 * nt, hidden, 234, use_bn=use_bn)
         w_im = o.make_weights(rng, 321 * nt, hidden, 234, use_bn=use_bn)
         P = o.hadamard(nt) if (nt & (nt - 1)) == 0 and rng.random() < 0.5 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
@@ -40,6 +45,8 @@ def main():
         e.load_weights('imag', w_im)
         e.set_pilot(P)
         e.set_option('force_tile', tile)
+        if dtype == 'f32':
+            e.set_option('f32_engine', engine)
         o_re, o_im = e.predict(ltf)
         h = e.ls_estimate(ltf)
         k = min(npkt, 4)
@@ -57,7 +64,7 @@ def main():
         err_ls = rel(np.concatenate([h[:k].real, h[:k].imag], -1), np.concatenate([ref.real, ref.imag], -1))
         ok = err < tol and err_lit < tol and err_ls < 1e-5 and np.isfinite(o_re).all() and np.isfinite(h.view(np.float32)).all()
         bad += not ok
-        print(f'{i:3d} nt={nt:3d} nr={nr} npkt={npkt:3d} hidden={hidden} bn={int(use_bn)} {dtype} tile={tile:3d} '
+        print(f'{i:3d} nt={nt:3d} nr={nr} npkt={npkt:3d} hidden={hidden} bn={int(use_bn)} {dtype} tile={tile:3d} engine={engine:2d} hs={e.get_option("hs_launches"):2d} '
               f'dnn={err:.2e} literal={err_lit:.2e} ls={err_ls:.2e} {"ok" if ok else "FAIL"}')
     print('FAILURES:', bad)
     return 1 if bad else 0
