@@ -264,6 +264,50 @@ def predict_packets_bf16(ltf, P, w_real, w_imag):
     return outs[0], outs[1]
 
 
+# ---------------------------------------------------------------------------
+# Emulation of the split-f16 GEMM engine of fp32 contexts (csrc/gemm_hs.hip.h): every operand is
+# carried as hi + lo float16 halves of 2^shift * x and a product is a_hi*b_hi + a_hi*b_lo + a_lo*b_hi.
+# Accumulation here is fp64, so this isolates the REPRESENTATION error of the scheme (the device
+# accumulates in fp32 like the fp32 MFMA path does).
+# ---------------------------------------------------------------------------
+def split_f16(x, shift):
+    """(hi, lo) float64 arrays with hi + lo ~= 2^shift * x, both exactly float16 numbers."""
+    xs = np.asarray(x, dtype=np.float32) * np.float32(2.0 ** shift)
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def weight_shift(w):
+    """Power of two that puts the largest |w| into [2^12, 2^13) (csi_load_weights)."""
+    m = float(np.max(np.abs(w)))
+    return 13 - int(np.frexp(m)[1]) if m > 0 else 0
+
+
+def dense_split_f16(a, w, a_shift):
+    """a [M,K] @ w [K,N] with split operands and the dropped lo*lo term, scaled back."""
+    sw = weight_shift(w)
+    a_hi, a_lo = split_f16(a, a_shift)
+    w_hi, w_lo = split_f16(w, sw)
+    return (a_hi @ w_hi + a_hi @ w_lo + a_lo @ w_hi) * 2.0 ** -(a_shift + sw)
+
+
+def fc_forward_split_f16(x, w, in_shift=4, act_shift=4):
+    """Literal network, every dense product through dense_split_f16; bias / relu / BN in fp32."""
+    eps = float(w.get('bn_eps', BN_EPS))
+    h = np.asarray(x, dtype=np.float32)
+    i = 0
+    while f'fc_dense{i}.kernel' in w:
+        z = dense_split_f16(h, w[f'fc_dense{i}.kernel'], in_shift if i == 0 else act_shift) + w[f'fc_dense{i}.bias'].astype(np.float64)
+        z = np.maximum(z.astype(np.float32), np.float32(0))
+        if f'bn{i}.gamma' in w:
+            z = bn_inference(z, w[f'bn{i}.gamma'].astype(np.float32), w[f'bn{i}.beta'].astype(np.float32),
+                             w[f'bn{i}.moving_mean'].astype(np.float32), w[f'bn{i}.moving_variance'].astype(np.float32), eps)
+        h = z
+        i += 1
+    return (dense_split_f16(h, w['fc_regressor.kernel'], in_shift if i == 0 else act_shift) + w['fc_regressor.bias'].astype(np.float64)).astype(np.float32)
+
+
 def predict_packets_shared(ltf, P, w_real, w_imag, dtype=np.float64):
     """Same function as predict_packets evaluated with layer 0 shared across the Nt pairs of an rx
     antenna (z0 = LTF.W0[:lenLTF] + P_t.W0[lenLTF:] + b0) - algebraically identical, Nt times

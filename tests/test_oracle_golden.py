@@ -195,3 +195,27 @@ def test_oracle_reproduces_its_committed_fixture(oracle, golden_dir):
     np.testing.assert_allclose(o_re, g['dnn_real'], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(o_im, g['dnn_imag'], rtol=1e-12, atol=1e-12)
     np.testing.assert_array_equal(oracle.recombine(o_re, o_im), g['csi'])
+
+
+def test_split_f16_operands_are_fp32_grade(oracle):
+    """The GPU's split-f16 engine carries fp32 operands as hi + lo float16 halves and drops lo*lo
+    (gemm_hs.hip.h).  Its representation error, isolated here with fp64 accumulation, must sit far
+    below the 1e-5 contract - at the level of fp32 rounding itself - over a wide range of magnitudes."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(4096).astype(np.float32)
+    for shift in (-6, 0, 4, 8):
+        hi, lo = oracle.split_f16(x, shift)
+        err = np.abs((hi + lo) * 2.0 ** -shift - x.astype(np.float64))
+        big = np.abs(x) * 2.0 ** shift >= 2.0 ** -3            # lo is a normal float16 there
+        assert np.all(err[big] <= 2.0 ** -22 * np.abs(x[big]))
+        assert np.all(err <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -25 * 2.0 ** -shift))
+    nt = 4
+    w = oracle.make_weights(rng, 321 * nt, [64, 48], 234)
+    for gain in (1e-2, 1.0, 50.0):
+        xs = (gain * rng.standard_normal((24, 321 * nt))).astype(np.float32)
+        ref = oracle.fc_forward(xs, w, np.float64)
+        got = oracle.fc_forward_split_f16(xs, w)
+        f32 = oracle.fc_forward(xs, w, np.float32)
+        e_split = oracle.row_rel_err(got, ref)
+        assert e_split < 5e-7, (gain, e_split)
+        assert e_split < 3 * max(oracle.row_rel_err(f32, ref), 1e-7)       # no worse than plain fp32 evaluation
