@@ -96,19 +96,18 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj) {
                 const int colc = min(n0 + wn * 64 + nj * 32 + l31, g.N - 1);
-                float bias = 0.f, sc = 1.f, sh = 0.f;
+                // out = os * (bn(relu(as * acc + bias)))  with os folded into the per-column constants
+                float bias = 0.f, sc = os, sh = 0.f;
                 if (EPI != EPI_RAW) bias = g.bias[colc];
-                if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc]; sh = g.shift[colc]; }
+                if (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[colc] * os; sh = g.shift[colc] * os; }
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        float v0 = acc[2 * half + m2][nj][r] * as, v1 = acc[2 * half + m2][nj][r + 1] * as;
-                        if (EPI == EPI_BIAS) { v0 += bias; v1 += bias; }
-                        if (EPI == EPI_BIAS_RELU_AFFINE) { v0 = fmaf(fmaxf(v0 + bias, 0.f), sc, sh); v1 = fmaf(fmaxf(v1 + bias, 0.f), sc, sh); }
+                        float v0 = fmaf(acc[2 * half + m2][nj][r], as, bias), v1 = fmaf(acc[2 * half + m2][nj][r + 1], as, bias);
+                        if (EPI == EPI_BIAS_RELU_AFFINE) { v0 = fmaf(fmaxf(v0, 0.f), sc, sh); v1 = fmaf(fmaxf(v1, 0.f), sc, sh); }
+                        else { v0 *= sc; v1 *= sc; }
                         uint32_t h, l;
-                        v0 *= os;
-                        v1 *= os;
                         pk = hs_absmax(pk, v0, v1);
                         hs_split2(v0, v1, h, l);
                         const int row = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // rows row, row + 1
