@@ -462,6 +462,30 @@ def test_split_f16_engine_is_the_default_for_large_calls(pkg, oracle):
     assert rel_rows(g_re[:16], r_re) < TOL
 
 
+def test_split_f16_engine_under_graph_replay(pkg, oracle):
+    """use_graph: the captured launch sequence of a large call contains the split-engine kernels
+    (dynamic LDS, range-guard pointer); replays must reproduce the eager result bit for bit."""
+    rng = np.random.default_rng(12)
+    nt, nr, npkt, hidden = 16, 4, 200, (128, 64)
+    w_re, w_im = _weights(oracle, 8, nt, hidden)
+    P = _pilot(rng, nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', 1)
+    d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
+    e.synth_white(5, 0, npkt, d_re, d_im)
+    o_re, o_im = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+    eager = o_re.download()
+    e.set_option('use_graph', 1)
+    for _ in range(4):
+        e.predict_device(d_re, d_im, npkt, o_re, o_im); e.synchronize()
+        assert np.array_equal(o_re.download(), eager)
+    assert e.get_option('hs_launches') > 0
+    ltf = d_re.download(0, 4) + 1j * d_im.download(0, 4)
+    r_re, _ = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=4)
+    assert rel_rows(eager[:4], r_re) < TOL
+
+
 def test_split_f16_engine_range_guard(pkg, oracle):
     """Preambles whose scaled samples leave the f16 range: csi_predict repeats the call on the fp32 MFMA
     kernels by itself (results still inside the contract); after a device-pointer call csi_synchronize
