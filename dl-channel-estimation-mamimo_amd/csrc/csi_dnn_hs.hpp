@@ -53,15 +53,18 @@ int hs_layer0_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) 
 }
 
 // Range guard: has any split-engine GEMM since the last check converted an operand near / beyond the
-// f16 limit?  The caller has synchronised the stream.  *hit = the magnitude seen (0 = none).
-int hs_range_check(csi_ctx* c, float* hit) {
+// f16 limit (*hit = the magnitude seen), or a row whose scaled magnitudes all sat in the f16 denormal
+// range (*low)?  The caller has synchronised the stream.
+int hs_range_check(csi_ctx* c, float* hit, bool* low) {
     *hit = 0.f;
+    *low = false;
     if (!c->hs_peak || c->hs_launches == c->hs_checked) return CSI_OK;
     c->hs_checked = c->hs_launches;
-    unsigned bits = 0;
-    HIP_TRY(c, hipMemcpy(&bits, c->hs_peak, sizeof(bits), hipMemcpyDeviceToHost));
-    if (bits) {
-        std::memcpy(hit, &bits, 4);
+    unsigned bits[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(bits, c->hs_peak, sizeof(bits), hipMemcpyDeviceToHost));
+    if (bits[0] || bits[1]) {
+        std::memcpy(hit, &bits[0], 4);
+        *low = bits[1] != 0;
         HIP_TRY(c, hipMemset(c->hs_peak, 0, sizeof(bits)));
     }
     return CSI_OK;

@@ -807,11 +807,15 @@ int csi_synchronize(csi_ctx* c) {
     if (!c) return CSI_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float hit = 0.f;
-    int rc = hs_range_check(c, &hit);
+    bool low = false;
+    int rc = hs_range_check(c, &hit, &low);
     if (rc) return rc;
     if (hit > 0.f)
         return fail(c, CSI_ERR_RANGE, "split-f16 engine: an operand reached %.4g after scaling (f16 limit 65504) in a device-pointer call since the "
                     "last check - the outputs of those calls are not valid; lower hs_in_shift / hs_act_shift or set f32_engine to 0 and run them again", (double)hit);
+    if (low)
+        return fail(c, CSI_ERR_RANGE, "split-f16 engine: a row of operands stayed below %.3g after scaling in a device-pointer call since the last check - "
+                    "its results may miss the 1e-5 contract; raise hs_in_shift / hs_act_shift or set f32_engine to 0 and run those calls again", (double)HS_LOW_REPORT);
     return CSI_OK;
 }
 
@@ -833,11 +837,13 @@ int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t np
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     rc = host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
     if (rc) return rc;
-    // range guard of the split-f16 engine: an operand beyond the f16 range -> the same call again on the
+    // range guard of the split-f16 engine: an operand beyond the f16 range, or a row of operands deep in
+    // its denormal range -> the same call again on the
     // fp32 MFMA kernels (the caller's buffers are still here), so that this entry point never returns inf
     float hit = 0.f;
-    rc = hs_range_check(c, &hit);
-    if (rc || hit == 0.f) return rc;
+    bool low = false;
+    rc = hs_range_check(c, &hit, &low);
+    if (rc || (hit == 0.f && !low)) return rc;
     ++c->hs_range_fallbacks;
     const int engine = c->f32_engine;
     c->f32_engine = 0;

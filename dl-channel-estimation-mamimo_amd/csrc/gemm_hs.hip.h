@@ -49,18 +49,8 @@ struct GemmHsArgs {
     const float* bias;
     const float* scale;    // BN scale / shift
     const float* shift;
-    unsigned* peak;        // range guard (may be null): atomicMax of the bits of the largest scaled operand
-                           // magnitude a kernel converted, recorded only above HS_PEAK_REPORT
+    unsigned* peak;        // range guard (may be null): two words, see hs_report_peak
 };
-
-// |s*x| above 65504 becomes inf in the hi half.  Kernels that convert operands keep a running maximum
-// (a v_max3 per three values) and report it once per lane at the end if it came near the limit, so
-// that the host can tell the caller / fall back to the fp32 MFMA kernels (csi_mamimo.hip).
-constexpr float HS_PEAK_REPORT = 60000.f;
-__device__ __forceinline__ float hs_absmax(float m, float a, float b) { return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
-__device__ __forceinline__ void hs_report_peak(unsigned* peak, float m) {
-    if (peak && m > HS_PEAK_REPORT) atomicMax(peak, __builtin_bit_cast(unsigned, m));
-}
 
 // (a, b) -> packed hi halves, packed lo halves
 __device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -70,6 +60,23 @@ __device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32
     const f16x2 l = __builtin_convertvector(r, f16x2);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// Range guard.  |s*x| above 65504 becomes inf in the hi half; below the f16 normal range the lo half is
+// a denormal with an absolute error of 2^-25, i.e. a row whose scaled magnitudes are all tiny loses
+// relative accuracy (rms 0.016 -> 2e-6, rms 0.003 -> 1e-5).  Kernels that convert operands keep a
+// running maximum per lane (one v_max3 per two values; in the A-generating kernels a lane converts ONE
+// matrix row, so its maximum is a row maximum) and report once at their end: peak[0] = atomicMax of
+// the bits of any magnitude above HS_PEAK_REPORT, peak[1] |= 1 if a lane's non-zero maximum stayed
+// below HS_LOW_REPORT.  The host then tells the caller / repeats the call on the fp32 MFMA kernels
+// (csi_mamimo.hip).
+constexpr float HS_PEAK_REPORT = 60000.f;
+constexpr float HS_LOW_REPORT = 0.0625f;
+__device__ __forceinline__ float hs_absmax(float m, float a, float b) { return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+__device__ __forceinline__ void hs_report_peak(unsigned* peak, float m, bool row_maximum) {
+    if (!peak) return;
+    if (m > HS_PEAK_REPORT) atomicMax(peak, __builtin_bit_cast(unsigned, m));
+    if (row_maximum && m > 0.f && m < HS_LOW_REPORT) atomicOr(peak + 1, 1u);
 }
 
 // Epilogue of the hs ping-pong kernels (8 waves as 2 x 4, 128 x 64 per wave).  fp32 output straight
@@ -138,7 +145,7 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        hs_report_peak(g.peak, pk);
+        hs_report_peak(g.peak, pk, false);       // a lane holds two COLUMNS here (a dead feature may be tiny everywhere)
     } else {
         const int wrow = m0 + wm * 128 + 4 * hi;
 #pragma unroll
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     for (; u + D < nsub; ++u) subtile(u, std::true_type{});
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
-    hs_report_peak(g.peak, apk);
+    hs_report_peak(g.peak, apk, true);
     hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
 }
 

@@ -509,6 +509,12 @@ def test_split_f16_engine_range_guard(pkg, oracle):
         e.synchronize()
     assert ei.value.code == -6 and 'f16' in str(ei.value)
     e.synchronize()                                     # the condition is reported once
+    # the low side: preambles so small that the lo halves are all denormal -> same guard
+    tiny = 1.0e-9 * ltf
+    t_re, t_im = e.predict(tiny)
+    assert e.get_option('hs_range_fallbacks') == 2
+    q_re, q_im = oracle.predict_packets(tiny.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(t_re, q_re) < TOL and rel_rows(t_im, q_im) < TOL
     e.set_option('hs_in_shift', -6)                     # smaller scales serve the same data on the split engine
     e.set_option('hs_act_shift', -6)
     n0 = e.get_option('hs_launches')
