@@ -46,6 +46,8 @@ const char* const kKernelNames[K_COUNT] = {
 
 thread_local std::string g_create_error;
 
+constexpr int HS_IN_SHIFT_AUTO = 99;      // "hs_in_shift" option: scale chosen per launch from the data
+
 struct Layer {
     float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)   fp32 mode
     int ldw = 0;
@@ -132,7 +134,7 @@ struct csi_ctx {
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
-    int hs_in_shift = 4;         // split-f16: the preamble samples times 2^hs_in_shift
+    int hs_in_shift = HS_IN_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)

@@ -87,9 +87,23 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     g.M = M1; g.N = h1; g.K = K;
     g.k_per_split = kps;
     g.tiles_n = (h1 + PP_BN - 1) / PP_BN;
-    g.acc_scale = std::ldexp(1.f, -(c->hs_in_shift + l0.wshift));
+    const bool auto_scale = c->hs_in_shift == HS_IN_SHIFT_AUTO;
+    const int in_shift = auto_scale ? 0 : c->hs_in_shift;
+    g.acc_scale = std::ldexp(1.f, -(in_shift + l0.wshift));
     g.peak = c->hs_peak;
+    g.wshift = l0.wshift;
     ++c->hs_launches;
+    if (auto_scale) {
+        // magnitude estimate of these rows (about 1 sample in 64), stream-ordered in front of the GEMM
+        unsigned* dyn = c->hs_peak + 8;
+        HIP_TRY(c, hipMemsetAsync(dyn, 0, sizeof(unsigned), c->stream));
+        const size_t n4 = (size_t)M1 * ldx / 4;
+        const size_t step = std::max<size_t>(1, n4 / ((size_t)1 << 21));
+        const unsigned blocks = (unsigned)std::min<size_t>((n4 / step + 255) / 256, 1024);
+        hipLaunchKernelGGL(hs_absmax_sample_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, c->stream, x, n4, step, dyn);
+        HIP_TRY(c, hipGetLastError());
+        g.dyn_max = dyn;
+    }
     const double flops = 2.0 * (double)M1 * h1 * K;
     const double bytes = 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits);
     ProfScope ps(c, K_LAYER0_LTF, flops, bytes);
@@ -100,7 +114,7 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
     const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
     hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
-                       std::ldexp(1.f, c->hs_in_shift));
+                       std::ldexp(1.f, in_shift));
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }

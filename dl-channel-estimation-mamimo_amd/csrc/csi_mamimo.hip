@@ -623,7 +623,8 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         drop_graphs(c);
         c->f32_engine = (int)value;
     } else if (n == "hs_act_shift" || n == "hs_in_shift") {
-        if (value < -8 || value > 14) return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14", name);
+        if (!(n == "hs_in_shift" && value == HS_IN_SHIFT_AUTO) && (value < -8 || value > 14))
+            return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14%s", name, n == "hs_in_shift" ? " or 99 (automatic)" : "");
         drop_graphs(c);
         (n == "hs_act_shift" ? c->hs_act_shift : c->hs_in_shift) = (int)value;
     } else if (n == "bf16_fused_h1") {

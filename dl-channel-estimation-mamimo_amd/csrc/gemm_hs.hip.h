@@ -50,6 +50,8 @@ struct GemmHsArgs {
     const float* scale;    // BN scale / shift
     const float* shift;
     unsigned* peak;        // range guard (may be null): two words, see hs_report_peak
+    const unsigned* dyn_max;   // CAST mode, automatic input scale: bits of a (sampled) max |x| of this launch's rows,
+    int wshift;                //   written earlier on the stream by hs_absmax_sample_kernel; scale = 2^(14 - exponent)
 };
 
 // (a, b) -> packed hi halves, packed lo halves
@@ -384,6 +386,16 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
             sv_l[i] = ps.s0[i] * in_scale;
             hv_l[i] = ps.t0[i] * in_scale;
         }
+    // automatic input scale (layer 0): the sampled maximum lands in [2^13, 2^14) - a factor 4 of head room
+    // for samples the estimate did not see, every value down to 2^-17 of the maximum with a normal lo half
+    float a_scale = in_scale, acc_scale = g.acc_scale;
+    if (CAST && g.dyn_max) {
+        const unsigned bits = __builtin_amdgcn_readfirstlane(*g.dyn_max);
+        const int e = (int)((bits >> 23) & 0xffu) - 126;                       // frexp exponent of the maximum (0 -> -126)
+        const int n = bits == 0 ? 0 : max(-100, min(100, 14 - e));
+        a_scale = __builtin_bit_cast(float, (unsigned)(n + 127) << 23);
+        acc_scale = __builtin_bit_cast(float, (unsigned)(max(-126, min(126, -n - g.wshift)) + 127) << 23);
+    }
 
     // ---- B side: pieces 2w, 2w+1 of the 16 B pieces of a sub-tile
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb + 2 * kbeg), 0, 0x7fffffff, 0x00020000);
@@ -429,8 +441,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     auto gen_a = [&](int sub, int slot) {
         f32x4 v[2];
         if (CAST) {
-            v[0] = lv[0] * in_scale;
-            v[1] = lv[1] * in_scale;
+            v[0] = lv[0] * a_scale;
+            v[1] = lv[1] * a_scale;
         } else {
             const int k = sub * HS_G + 8 * kh;
 #pragma unroll
@@ -528,7 +540,32 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
     hs_report_peak(g.peak, apk, true);
-    hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
+    GemmHsArgs ge = g;
+    ge.acc_scale = acc_scale;
+    hs_epilogue<EPI, OUT_HS>(acc, ge, lds, m0, n0, wave, lane);
+}
+
+// out = atomicMax(bits of |x|) over a strided sample of x (every `step`-th float4; everything when the
+// array is small): the magnitude estimate behind the automatic input scale.  out is zeroed on the
+// stream before the launch; positive floats order like their bit patterns.  inf / nan are skipped (they
+// would poison the scale; the data itself then trips the range guard or propagates as nan).
+__global__ __launch_bounds__(256) void hs_absmax_sample_kernel(const float* __restrict__ x, size_t n4, size_t step, unsigned* __restrict__ out) {
+    __shared__ unsigned smax;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * step;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * step; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = __builtin_fabsf(v[e]);
+            if (a < 3.0e38f) m = __builtin_fmaxf(m, a);
+        }
+    }
+    atomicMax(&smax, __builtin_bit_cast(unsigned, m));
+    __syncthreads();
+    if (threadIdx.x == 0 && smax) atomicMax(out, smax);
 }
 
 // dst (hs [rows][ldh]) = split(scale * src[rows][cols]) with zero padding up to ldh / 2 columns.

@@ -195,10 +195,13 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
  *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels; 0: fp32 MFMA kernels only;
  *                         1: split engine wherever the layer shapes allow (hidden widths multiples of 16)
- *   "hs_in_shift", "hs_act_shift"  split engine: preamble samples / hidden activations are carried times
- *                         2^shift (default 4, i.e. magnitudes up to 4094).  An operand beyond the f16 range
- *                         is detected on the device: csi_predict repeats the call on the fp32 MFMA kernels
- *                         by itself, after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
+ *   "hs_in_shift"      split engine: the preamble samples are carried times 2^shift.  99 (default): chosen per
+ *                         launch on the device from a sampled maximum of the data, so that it lands at
+ *                         2^13..2^14 (any input scaling is served); -8..14: fixed
+ *   "hs_act_shift"     split engine: hidden activations are carried times 2^shift (default 4: magnitudes
+ *                         0.004 .. 4094).  Operands that leave the f16 range at either end are detected
+ *                         on the device: csi_predict repeats the call on the fp32 MFMA kernels by itself,
+ *                         after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned

@@ -420,7 +420,7 @@ def test_split_f16_engine_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden)
     assert oracle.nmse_subk(r_re + 1j * r_im, s_re + 1j * s_im) < 1e-10
 
 
-@pytest.mark.parametrize('gain', [1e-3, 1.0, 60.0])
+@pytest.mark.parametrize('gain', [1e-3, 1e-2, 1.0, 60.0])
 def test_split_f16_engine_input_scale(pkg, oracle, gain):
     """The f16 halves have a finite range: the engine scales operands by powers of two.  Results must
     hold the contract for preambles well below and above unit power."""
@@ -434,6 +434,8 @@ def test_split_f16_engine_input_scale(pkg, oracle, gain):
     s_re, s_im = e.predict(ltf)
     r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
     assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+    if True:
+        assert e.get_option('hs_range_fallbacks') == 0 and e.get_option('hs_launches') > 0       # served by the engine itself
 
 
 def test_split_f16_engine_is_the_default_for_large_calls(pkg, oracle):
@@ -487,36 +489,42 @@ def test_split_f16_engine_under_graph_replay(pkg, oracle):
 
 
 def test_split_f16_engine_range_guard(pkg, oracle):
-    """Preambles whose scaled samples leave the f16 range: csi_predict repeats the call on the fp32 MFMA
+    """Operands that leave the f16 range after scaling: csi_predict repeats the call on the fp32 MFMA
     kernels by itself (results still inside the contract); after a device-pointer call csi_synchronize
-    reports CSI_ERR_RANGE instead of handing back inf / nan silently."""
+    reports CSI_ERR_RANGE instead of handing back inf / nan silently.  The preamble scale is chosen from
+    the data (any input gain is served); the hidden activations use a fixed shift."""
     rng = np.random.default_rng(3)
     nt, nr, npkt, hidden = 8, 2, 20, (64, 64)
     w_re, w_im = _weights(oracle, 17, nt, hidden)
     P = _pilot(rng, nt)
-    ltf = 3.0e4 * oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=10.0)[0]
+    base = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=10.0)[0]
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
     e.set_option('f32_engine', 1)
-    s_re, s_im = e.predict(ltf)
-    assert e.get_option('hs_range_fallbacks') == 1 and e.get_option('f32_engine') == 1
-    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
-    assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+
+    def check(ltf, fallbacks):
+        s_re, s_im = e.predict(ltf)
+        assert e.get_option('hs_range_fallbacks') == fallbacks and e.get_option('f32_engine') == 1
+        r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+        assert rel_rows(s_re, r_re) < TOL and rel_rows(s_im, r_im) < TOL
+        return r_re
+
+    check(1.0e-12 * base, 0)                            # automatic input scale: tiny and
+    check(2.0e2 * base, 0)                              # large preambles stay on the engine
+    huge = 3.0e4 * base                                 # ... until the hidden activations overflow
+    r_re = check(huge, 1)
+    e.set_option('hs_in_shift', 4)                      # fixed input scale: lo halves all denormal -> low-side guard
+    check(1.0e-5 * base, 2)
+    e.set_option('hs_in_shift', 99)
+
     d_re, d_im = e.empty((npkt, nr, 320 * nt)), e.empty((npkt, nr, 320 * nt))
-    d_re.upload(np.ascontiguousarray(ltf.real, np.float32)); d_im.upload(np.ascontiguousarray(ltf.imag, np.float32))
+    d_re.upload(np.ascontiguousarray(huge.real, np.float32)); d_im.upload(np.ascontiguousarray(huge.imag, np.float32))
     o_re, o_im = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
     e.predict_device(d_re, d_im, npkt, o_re, o_im)
     with pytest.raises(pkg.CsiError) as ei:
         e.synchronize()
     assert ei.value.code == -6 and 'f16' in str(ei.value)
     e.synchronize()                                     # the condition is reported once
-    # the low side: preambles so small that the lo halves are all denormal -> same guard
-    tiny = 1.0e-9 * ltf
-    t_re, t_im = e.predict(tiny)
-    assert e.get_option('hs_range_fallbacks') == 2
-    q_re, q_im = oracle.predict_packets(tiny.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
-    assert rel_rows(t_re, q_re) < TOL and rel_rows(t_im, q_im) < TOL
-    e.set_option('hs_in_shift', -6)                     # smaller scales serve the same data on the split engine
-    e.set_option('hs_act_shift', -6)
+    e.set_option('hs_act_shift', -8)                    # a smaller activation scale serves the same data on the engine
     n0 = e.get_option('hs_launches')
     e.predict_device(d_re, d_im, npkt, o_re, o_im)
     e.synchronize()
