@@ -46,7 +46,7 @@ const char* const kKernelNames[K_COUNT] = {
 
 thread_local std::string g_create_error;
 
-constexpr int HS_IN_SHIFT_AUTO = 99;      // "hs_in_shift" option: scale chosen per launch from the data
+constexpr int HS_SHIFT_AUTO = 99;         // "hs_in_shift" / "hs_act_shift" options: scale chosen from the data / from the model
 
 struct Layer {
     float* Wt = nullptr;      // [out][ldw] (K-major, ldw = in rounded up to 32, zero padded)   fp32 mode
@@ -56,6 +56,7 @@ struct Layer {
     uint16_t* Wh = nullptr;   // [out][ldwh] split-f16 ("hs", gemm_hs.hip.h) copy of Wt * 2^wshift; layer 0: LTF columns only
     int ldwh = 0;             // halves per row = 2 * (in rounded up to 16)
     int wshift = 0;
+    int ashift = 4;           // split engine: this layer's OUTPUT activations are carried times 2^ashift (from its BN vectors at load)
     float* bias = nullptr;    // [out]
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
     float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
@@ -128,13 +129,13 @@ struct csi_ctx {
     std::vector<GraphEntry> graphs;
     int f32_engine = -1;         // "f32_engine" option: fp32 contexts, 0 = native fp32 MFMA kernels, 1 = split-f16 kernels (gemm_hs.hip.h)
                                  // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)
-    int hs_act_shift = 4;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
+    int hs_act_shift = HS_SHIFT_AUTO;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
     size_t hs_lds_attr[3] = {0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out)
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
-    int hs_in_shift = HS_IN_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
+    int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)

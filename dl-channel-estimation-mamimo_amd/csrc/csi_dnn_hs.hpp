@@ -87,7 +87,7 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     g.M = M1; g.N = h1; g.K = K;
     g.k_per_split = kps;
     g.tiles_n = (h1 + PP_BN - 1) / PP_BN;
-    const bool auto_scale = c->hs_in_shift == HS_IN_SHIFT_AUTO;
+    const bool auto_scale = c->hs_in_shift == HS_SHIFT_AUTO;
     const int in_shift = auto_scale ? 0 : c->hs_in_shift;
     g.acc_scale = std::ldexp(1.f, -(in_shift + l0.wshift));
     g.peak = c->hs_peak;
@@ -121,8 +121,11 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
 
 // first per-pair layer: A generated from (L0, T, bn0); hs output (a hidden layer follows) or fp32
 // output with bias only (the regressor follows layer 0 directly)
+// shift of the OUTPUT activations of hidden layer li
+int hs_act_shift_of(const csi_ctx* c, const Model& m, int li) { return c->hs_act_shift == HS_SHIFT_AUTO ? m.layers[li].ashift : c->hs_act_shift; }
+
 template <int EPI, bool OUT_HS>
-int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
+int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src, int in_shift) {
     g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
     g.peak = c->hs_peak;
     ++c->hs_launches;
@@ -134,7 +137,7 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src) {
     int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
     if (rc) return rc;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
-    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, c->hs_act_shift));
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, in_shift));
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -159,22 +162,22 @@ int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
 int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, float* hbuf1, float* out) {
     const csi_config& cf = c->cfg;
     const int nh = cf.n_hidden, h1 = cf.hidden[0];
-    const float sa = std::ldexp(1.f, c->hs_act_shift);
     const Layer& l1 = m.layers[1];
+    const int s0 = hs_act_shift_of(c, m, 0);
     PairSrc src{l0sum, m.T, m.layers[0].scale, m.layers[0].shift, h1, cf.nt};
     GemmHsArgs p{};
     p.Bt = l1.Wh; p.ldb = l1.ldwh;
     p.M = M2; p.N = l1.out; p.K = h1;
     p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
-    p.acc_scale = std::ldexp(1.f, -(c->hs_act_shift + l1.wshift));
-    p.out_scale = sa;
+    p.acc_scale = std::ldexp(1.f, -(s0 + l1.wshift));
     if (nh == 1) {
         p.C = out; p.ldc = cf.n_out;
-        return hs_launch_pair<EPI_BIAS, false>(c, K_REGRESSOR, p, src);
+        return hs_launch_pair<EPI_BIAS, false>(c, K_REGRESSOR, p, src, s0);
     }
     uint16_t* hb[2] = {reinterpret_cast<uint16_t*>(hbuf0), reinterpret_cast<uint16_t*>(hbuf1)};
     p.C = hb[0]; p.ldc = 2 * l1.out;
-    int rc = hs_launch_pair<EPI_BIAS_RELU_AFFINE, true>(c, K_PAIR_DENSE, p, src);
+    p.out_scale = std::ldexp(1.f, hs_act_shift_of(c, m, 1));
+    int rc = hs_launch_pair<EPI_BIAS_RELU_AFFINE, true>(c, K_PAIR_DENSE, p, src, s0);
     if (rc) return rc;
     int cur = 0;
     for (int li = 2; li <= nh; ++li) {
@@ -184,12 +187,12 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         q.Bt = l.Wh; q.ldb = l.ldwh;
         q.M = M2; q.N = l.out; q.K = l.in;
         q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
-        q.acc_scale = std::ldexp(1.f, -(c->hs_act_shift + l.wshift));
-        q.out_scale = sa;
+        q.acc_scale = std::ldexp(1.f, -(hs_act_shift_of(c, m, li - 1) + l.wshift));
         if (li == nh) {
             q.C = out; q.ldc = cf.n_out;
             rc = hs_launch_gemm<EPI_BIAS, false>(c, K_REGRESSOR, q);
         } else {
+            q.out_scale = std::ldexp(1.f, hs_act_shift_of(c, m, li));
             q.C = hb[cur ^ 1]; q.ldc = 2 * l.out;
             rc = hs_launch_gemm<EPI_BIAS_RELU_AFFINE, true>(c, K_DENSE_HIDDEN, q);
             cur ^= 1;

@@ -331,6 +331,17 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 sc[o] = inv;
                 sh[o] = be->data[o] - mu->data[o] * inv;
             }
+            // split-f16 engine: scale of this layer's output activations.  BatchNormalization output =
+            // beta + gamma * (standardised relu), so |beta| + 6 |gamma| bounds it to six moving standard
+            // deviations; put that bound at 2^10..2^11 - 32x of head room for outliers before the range
+            // guard takes over, and values down to 2^-13 of the bound keep a normal lo half
+            float amax = 0.f;
+            for (int o = 0; o < out; ++o) amax = std::max(amax, std::fabs(be->data[o]) + 6.f * std::fabs(ga->data[o]));
+            int ea = 0;
+            if (amax > 0.f && std::isfinite(amax)) {
+                std::frexp(amax, &ea);
+                L.ashift = std::max(-8, std::min(14, 11 - ea));
+            }
         }
         if (!reg) {
             rc = upload(c, &L.scale, sc.data(), out);
@@ -623,8 +634,7 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         drop_graphs(c);
         c->f32_engine = (int)value;
     } else if (n == "hs_act_shift" || n == "hs_in_shift") {
-        if (!(n == "hs_in_shift" && value == HS_IN_SHIFT_AUTO) && (value < -8 || value > 14))
-            return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14%s", name, n == "hs_in_shift" ? " or 99 (automatic)" : "");
+        if (value != HS_SHIFT_AUTO && (value < -8 || value > 14)) return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14 or 99 (automatic)", name);
         drop_graphs(c);
         (n == "hs_act_shift" ? c->hs_act_shift : c->hs_in_shift) = (int)value;
     } else if (n == "bf16_fused_h1") {

@@ -198,10 +198,11 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "hs_in_shift"      split engine: the preamble samples are carried times 2^shift.  99 (default): chosen per
  *                         launch on the device from a sampled maximum of the data, so that it lands at
  *                         2^13..2^14 (any input scaling is served); -8..14: fixed
- *   "hs_act_shift"     split engine: hidden activations are carried times 2^shift (default 4: magnitudes
- *                         0.004 .. 4094).  Operands that leave the f16 range at either end are detected
- *                         on the device: csi_predict repeats the call on the fp32 MFMA kernels by itself,
- *                         after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
+ *   "hs_act_shift"     split engine: hidden activations are carried times 2^shift.  99 (default): per layer from
+ *                         its BatchNormalization vectors at load (|beta| + 6 |gamma| lands at 2^10..2^11; 2^4
+ *                         without BN); -8..14: fixed.  Operands that leave the f16 range at either end are
+ *                         detected on the device: csi_predict repeats the call on the fp32 MFMA kernels by
+ *                         itself, after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
