@@ -94,12 +94,13 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     g.wshift = l0.wshift;
     ++c->hs_launches;
     if (auto_scale) {
-        // magnitude estimate of these rows (about 1 sample in 64), stream-ordered in front of the GEMM
+        // magnitude estimate of these rows (1-KiB blocks, at most ~16 MiB of them), stream-ordered in front of the GEMM
         unsigned* dyn = c->hs_peak + 8;
         HIP_TRY(c, hipMemsetAsync(dyn, 0, sizeof(unsigned), c->stream));
         const size_t n4 = (size_t)M1 * ldx / 4;
-        const size_t step = std::max<size_t>(1, n4 / ((size_t)1 << 21));
-        const unsigned blocks = (unsigned)std::min<size_t>((n4 / step + 255) / 256, 1024);
+        const size_t nblk = (n4 + 63) / 64;                                   // 1-KiB blocks
+        const size_t step = std::max<size_t>(1, nblk / 16384);                // at most ~16 MiB are read
+        const unsigned blocks = (unsigned)std::min<size_t>((nblk / step + 3) / 4, 1024);
         hipLaunchKernelGGL(hs_absmax_sample_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, c->stream, x, n4, step, dyn);
         HIP_TRY(c, hipGetLastError());
         g.dyn_max = dyn;

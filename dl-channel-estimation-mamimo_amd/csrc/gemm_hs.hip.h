@@ -545,17 +545,21 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     hs_epilogue<EPI, OUT_HS>(acc, ge, lds, m0, n0, wave, lane);
 }
 
-// out = atomicMax(bits of |x|) over a strided sample of x (every `step`-th float4; everything when the
-// array is small): the magnitude estimate behind the automatic input scale.  out is zeroed on the
-// stream before the launch; positive floats order like their bit patterns.  inf / nan are skipped (they
-// would poison the scale; the data itself then trips the range guard or propagates as nan).
+// out = atomicMax(bits of |x|) over a sample of x: one 1-KiB block (64 float4, read coalesced by a
+// wave) out of every `step` blocks - everything when the array is small: the magnitude estimate behind
+// the automatic input scale.  out is zeroed on the stream before the launch; positive floats order like
+// their bit patterns.  inf / nan are skipped (they would poison the scale; the data itself then trips
+// the range guard or propagates as nan).
 __global__ __launch_bounds__(256) void hs_absmax_sample_kernel(const float* __restrict__ x, size_t n4, size_t step, unsigned* __restrict__ out) {
     __shared__ unsigned smax;
     if (threadIdx.x == 0) smax = 0;
     __syncthreads();
     float m = 0.f;
-    const size_t stride = (size_t)gridDim.x * blockDim.x * step;
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * step; i < n4; i += stride) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t blk = wave * step; blk * 64 < n4; blk += nwaves * step) {
+        const size_t i = blk * 64 + lane;
+        if (i >= n4) continue;
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
