@@ -241,7 +241,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         int kps = 0;
         const int hs_splits = (hs_ok && !l0) ? hs_layer0_splits(c, M1, h1, cf.len_ltf, &kps) : 0;
         if (hs_splits) {
-            rc = hs_launch_layer0(c, m.layers[0], d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps, hs_splits, slabs);
+            rc = hs_launch_layer0(c, m, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps, hs_splits, slabs);
             if (rc) return rc;
             l0 = slabs;
         }

@@ -80,7 +80,8 @@ int hs_dynamic_lds(csi_ctx* c, Kern kern, size_t bytes, size_t* have) {
 }
 
 // layer 0: slabs[z][M1][h1] = (X[M1][K] * W0[0:K, :]) over k range z, X converted inside the kernel
-int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
+int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
+    const Layer& l0 = m.layers[0];
     GemmHsArgs g{};
     g.Bt = l0.Wh; g.ldb = l0.ldwh;
     g.C = slabs; g.ldc = h1;
@@ -94,12 +95,12 @@ int hs_launch_layer0(csi_ctx* c, const Layer& l0, const float* x, int ldx, int M
     g.wshift = l0.wshift;
     ++c->hs_launches;
     if (auto_scale) {
-        // magnitude estimate of these rows (1-KiB blocks, at most ~16 MiB of them), stream-ordered in front of the GEMM
-        unsigned* dyn = c->hs_peak + 8;
+        // magnitude estimate of these rows (1-KiB blocks, at most ~4 MiB of them), stream-ordered in front of the GEMM
+        unsigned* dyn = c->hs_peak + 8 + (&m == &c->model[1] ? 1 : 0);      // one word per component model (small calls run them on two streams)
         HIP_TRY(c, hipMemsetAsync(dyn, 0, sizeof(unsigned), c->stream));
         const size_t n4 = (size_t)M1 * ldx / 4;
         const size_t nblk = (n4 + 63) / 64;                                   // 1-KiB blocks
-        const size_t step = std::max<size_t>(1, nblk / 16384);                // at most ~16 MiB are read
+        const size_t step = std::max<size_t>(1, nblk / 4096);                 // at most ~4 MiB (a million samples) are read
         const unsigned blocks = (unsigned)std::min<size_t>((nblk / step + 3) / 4, 1024);
         hipLaunchKernelGGL(hs_absmax_sample_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, c->stream, x, n4, step, dyn);
         HIP_TRY(c, hipGetLastError());
