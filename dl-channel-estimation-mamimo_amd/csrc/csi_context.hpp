@@ -135,6 +135,8 @@ struct csi_ctx {
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
+    int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
+                                 // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024: 40 packets); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)

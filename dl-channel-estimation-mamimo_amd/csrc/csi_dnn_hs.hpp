@@ -8,7 +8,6 @@
 namespace {
 
 constexpr int HS_L0_MAX_SPLITS = 8;
-constexpr long HS_MIN_BLOCKS = 128;             // automatic mode: at least half a round of 256 CUs
 
 // shapes the kernels can serve: every hidden width a multiple of 16 (hs groups), bn0 vectors of the
 // first per-pair layer in LDS behind the ring, split weights present
@@ -28,7 +27,7 @@ long hs_tiles(int M, int N) { return (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_
 // per-pair layers of a chunk of M2 rows on the split engine?
 bool hs_tail_wanted(const csi_ctx* c, int M2, int n1) {
     if (c->force_pair_tile == 128) return false;
-    return c->f32_engine == 1 || c->force_pair_tile == 256 || hs_tiles(M2, n1) >= HS_MIN_BLOCKS;
+    return c->f32_engine == 1 || c->force_pair_tile == 256 || hs_tiles(M2, n1) >= c->hs_min_blocks;
 }
 
 // Split-K of the layer-0 product on the split engine: the count (<= 8, >= 512 k-columns each) whose
@@ -47,7 +46,7 @@ int hs_layer0_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) 
     const int kps = ((K + best - 1) / best + 63) / 64 * 64;
     const int real = (K + kps - 1) / kps;
     if (kps / HS_G < 3) return 0;
-    if (!(c->f32_engine == 1 || c->force_pair_tile == 256) && hs_tiles(M1, h1) * real < HS_MIN_BLOCKS) return 0;
+    if (!(c->f32_engine == 1 || c->force_pair_tile == 256) && hs_tiles(M1, h1) * real < std::max(c->hs_min_blocks, 128)) return 0;
     *k_per_split = kps;
     return real;
 }

@@ -598,6 +598,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "small_call_overlap") *value = c->small_call_overlap;
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_act_shift") *value = c->hs_act_shift;
+    else if (n == "hs_min_blocks") *value = c->hs_min_blocks;
     else if (n == "hs_in_shift") *value = c->hs_in_shift;
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
     else if (n == "host_threads") *value = c->host_threads;
@@ -633,6 +634,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);
         c->f32_engine = (int)value;
+    } else if (n == "hs_min_blocks") {
+        if (value < 1 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "hs_min_blocks must be 1..65536");
+        drop_graphs(c);
+        c->hs_min_blocks = (int)value;
     } else if (n == "hs_act_shift" || n == "hs_in_shift") {
         if (value != HS_SHIFT_AUTO && (value < -8 || value > 14)) return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14 or 99 (automatic)", name);
         drop_graphs(c);

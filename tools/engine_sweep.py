@@ -25,11 +25,13 @@ def main():
     d_re, d_im = e.empty((nmax, nr, e.len_ltf)), e.empty((nmax, nr, e.len_ltf))
     e.synth_white(7, 0, nmax, d_re, d_im)
     o_re, o_im = e.empty((nmax, nr, nt, 234)), e.empty((nmax, nr, nt, 234))
-    print('packets  rows     fp32-MFMA ms   split ms   auto ms   (M pairs/s: native / split / auto)')
-    for npkt in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 1024, 2048):
+    thr = [int(a) for a in sys.argv[3:]] or [128]
+    print('packets  rows     fp32-MFMA ms   split ms   auto ms at hs_min_blocks =', thr)
+    for npkt in (8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 128, 192, 256, 512, 2048):
         res = []
-        for engine in (0, 1, -1):
+        for engine, mb in [(0, 128), (1, 128)] + [(-1, t) for t in thr]:
             e.set_option('f32_engine', engine)
+            e.set_option('hs_min_blocks', mb)
             ts = []
             for i in range(12):
                 e.synchronize()
@@ -39,8 +41,7 @@ def main():
                 ts.append(time.perf_counter() - t0)
             res.append(float(np.median(ts[4:])))
         pairs = npkt * nr * nt
-        print('%7d %6d   %10.3f  %10.3f %10.3f     %.2f / %.2f / %.2f' % (npkt, pairs, res[0] * 1e3, res[1] * 1e3, res[2] * 1e3,
-                                                                    pairs / res[0] / 1e6, pairs / res[1] / 1e6, pairs / res[2] / 1e6))
+        print('%7d %6d   ' % (npkt, pairs) + '  '.join('%8.3f' % (r * 1e3) for r in res))
 
 
 if __name__ == '__main__':
