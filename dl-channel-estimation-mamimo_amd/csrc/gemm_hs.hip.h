@@ -11,8 +11,10 @@
 // (~2^-22) is below the fp32 accumulation error of a K = 1024 reduction, so the result meets the
 // same 1e-5 norm-relative contract as gemm_f32.hip.h (measured: DESIGN.md 4.6).  The accumulator is
 // multiplied by 2^-(sa+sw) in the epilogue (exact) before bias / relu / BatchNormalization.
-// Range: |s*x| must stay below 65504 - operands are scaled so that the weights' maximum sits at
-// 2^12..2^13 and activations are multiplied by 2^hs_act_shift (default 2^4: |activation| < 4094).
+// Range: |s*x| must stay below 65504 and well above the f16 denormals - weights are scaled at load so
+// that their maximum sits at 2^12..2^13, the preambles per launch from a sampled maximum
+// (hs_absmax_sample_kernel), hidden activations per layer from the BatchNormalization vectors; both
+// ends are guarded on the device (hs_report_peak).
 //
 // Storage ("hs" matrices, 4 bytes per element like fp32).  Row-major, K contiguous, in groups of 16
 // k-columns: 16 hi halves (32 B) followed by the 16 lo halves (32 B).  One 64-byte group of a row is
