@@ -24,10 +24,11 @@ bool hs_static_ok(const csi_ctx* c, const Model& m) {
 
 long hs_tiles(int M, int N) { return (long)((M + PP_BM - 1) / PP_BM) * ((N + PP_BN - 1) / PP_BN); }
 
-// per-pair layers of a chunk of M2 rows on the split engine?
+// per-pair layers of a chunk of M2 rows on the split engine?  ("force_tile" = 128 / 256 keeps addressing the
+// fp32 MFMA kernels of that tile height for small shapes - tests - and 128 excludes this engine)
 bool hs_tail_wanted(const csi_ctx* c, int M2, int n1) {
     if (c->force_pair_tile == 128) return false;
-    return c->f32_engine == 1 || c->force_pair_tile == 256 || hs_tiles(M2, n1) >= c->hs_min_blocks;
+    return c->f32_engine == 1 || hs_tiles(M2, n1) >= c->hs_min_blocks;
 }
 
 // Split-K of the layer-0 product on the split engine: the count (<= 8, >= 512 k-columns each) whose
@@ -46,7 +47,7 @@ int hs_layer0_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) 
     const int kps = ((K + best - 1) / best + 63) / 64 * 64;
     const int real = (K + kps - 1) / kps;
     if (kps / HS_G < 3) return 0;
-    if (!(c->f32_engine == 1 || c->force_pair_tile == 256) && hs_tiles(M1, h1) * real < std::max(c->hs_min_blocks, 128)) return 0;
+    if (c->f32_engine != 1 && hs_tiles(M1, h1) * real < std::max(c->hs_min_blocks, 128)) return 0;
     *k_per_split = kps;
     return real;
 }
