@@ -76,6 +76,9 @@ SYMBOLS = {
     'csi_train_end': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int]),
     'csi_synchronize': (ctypes.c_int, [_ctx]),
     'csi_set_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
+    'csi_nmse': (ctypes.c_int, [_ctx, _fp, _fp, _fp, _fp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    'csi_nmse_device': (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     'csi_get_option': (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     'csi_device_malloc': (ctypes.c_int, [_ctx, ctypes.POINTER(_vp), ctypes.c_int64]),
     'csi_device_free': (ctypes.c_int, [_ctx, _vp]),

@@ -145,6 +145,9 @@ def main(argv=None):
     for d, out, lab in (('real', out_re, packed['labels'].real), ('imag', out_im, packed['labels'].imag)):
         print('%s model: loss (mse vs labels) = %.6e' % (d, float(np.mean((out - lab) ** 2))))          # evaluate(), DNN.py:343
     lab = packed['labels']
+    # the number the MATLAB evaluation reports per estimator (NMSE_subk, BER_test_maMIMO_LTF.m:675-686), here against
+    # the dataset's labels
+    print('NMSE_subk of the DNN estimate vs labels = %.6e' % eng.nmse(lab, out_re + 1j * out_im))
     num = np.linalg.norm((h_ls - lab).reshape(npkt, -1), axis=1)
     print('LS(GPU) vs stored LS labels: max packet rel. error %.3e' % float(np.max(num / np.linalg.norm(lab.reshape(npkt, -1), axis=1))))
     files = ds.export_predictions(args.workdir, packed, out_re, out_im)

@@ -17,6 +17,7 @@
 #include "gemm_hs.hip.h"
 #include "ls_estimate.hip.h"
 #include "lmmse.hip.h"
+#include "metrics.hip.h"
 
 using namespace csi;
 
@@ -37,12 +38,13 @@ enum KernelId {
     K_LMMSE,             // Levinson solve of the LMMSE smoother
     K_TRAIN_GEMM,        // forward / dgrad / wgrad products of csi_train_step
     K_TRAIN_ELEMWISE,    // BatchNormalization, dropout, loss, Adam of csi_train_step
+    K_NMSE,              // per-link NMSE metric
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
     "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson",
-    "train_gemm", "train_elementwise"};
+    "train_gemm", "train_elementwise", "nmse_links"};
 
 thread_local std::string g_create_error;
 

@@ -587,6 +587,62 @@ int csi_lmmse_estimate(csi_ctx* c, const float* h_re, const float* h_im, int64_t
     return CSI_OK;
 }
 
+// ---------------------------------------------------------------- accuracy metric
+int csi_nmse_device(csi_ctx* c, const float* d_ref_re, const float* d_ref_im, const float* d_est_re, const float* d_est_im,
+                    int64_t nlinks, int n_bins, float* d_per_link, double* mean_out) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (nlinks <= 0 || n_bins <= 0 || !d_ref_re || !d_ref_im || !d_est_re || !d_est_im || !mean_out)
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_nmse_device: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // scratch: the per-link ratios (unless the caller wants them) followed by the fp64 sum
+    const size_t need = (d_per_link ? 0 : (size_t)nlinks * sizeof(float)) + 64;
+    int rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, need + 64);
+    if (rc) return rc;
+    float* ratio = d_per_link ? d_per_link : reinterpret_cast<float*>(c->skbuf);
+    double* d_sum = reinterpret_cast<double*>(c->skbuf + ((need - 64 + 63) / 64) * 64);
+    HIP_TRY(c, hipMemsetAsync(d_sum, 0, sizeof(double), c->stream));
+    {
+        ProfScope ps(c, K_NMSE, 8.0 * (double)nlinks * n_bins, 16.0 * (double)nlinks * n_bins);
+        const unsigned blocks = (unsigned)std::min<int64_t>((nlinks + 3) / 4, 8192);
+        hipLaunchKernelGGL(nmse_links_kernel, dim3(blocks), dim3(256), 0, c->stream, d_ref_re, d_ref_im, d_est_re, d_est_im, nlinks, n_bins, ratio);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(nmse_sum_kernel, dim3(1), dim3(1024), 0, c->stream, ratio, nlinks, d_sum);
+        HIP_TRY(c, hipGetLastError());
+    }
+    double sum = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(&sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mean_out = sum / (double)nlinks;
+    return CSI_OK;
+}
+
+int csi_nmse(csi_ctx* c, const float* ref_re, const float* ref_im, const float* est_re, const float* est_im, int64_t nlinks,
+             int n_bins, double* mean_out) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (nlinks <= 0 || n_bins <= 0 || !ref_re || !ref_im || !est_re || !est_im || !mean_out)
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_nmse: bad argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t row = (size_t)n_bins * sizeof(float);
+    const int64_t chunk = std::min<int64_t>(nlinks, std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)(4 * row)));
+    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, 4 * row * (size_t)chunk + 256);
+    if (rc) return rc;
+    float* d[4];
+    for (int i = 0; i < 4; ++i) d[i] = reinterpret_cast<float*>(c->stage) + (size_t)i * chunk * n_bins;
+    const float* h[4] = {ref_re, ref_im, est_re, est_im};
+    double total = 0.0;
+    for (int64_t l0 = 0; l0 < nlinks; l0 += chunk) {
+        const int64_t nl = std::min(chunk, nlinks - l0);
+        for (int i = 0; i < 4; ++i)
+            HIP_TRY(c, hipMemcpyAsync(d[i], h[i] + (size_t)l0 * n_bins, row * (size_t)nl, hipMemcpyHostToDevice, c->stream));
+        double mean = 0.0;
+        rc = csi_nmse_device(c, d[0], d[1], d[2], d[3], nl, n_bins, nullptr, &mean);
+        if (rc) return rc;
+        total += mean * (double)nl;
+    }
+    *mean_out = total / (double)nlinks;
+    return CSI_OK;
+}
+
 int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (!name || !value) return fail(c, CSI_ERR_INVALID_ARG, "csi_get_option: null argument");

@@ -380,6 +380,28 @@ class CsiEngine:
     def ls_estimate_device(self, d_re, d_im, npkt, d_h_re, d_h_im):
         self._check(self._lib.csi_ls_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_h_re.ptr, d_h_im.ptr))
 
+    def nmse(self, h_ref, h_est):
+        """NMSE_subk of the reference's evaluation (BER_test_maMIMO_LTF.m:675-686): per link
+        ||ref - est||^2 / ||ref||^2 over the last axis, mean over all links.  Complex arrays of equal
+        shape [..., n_bins] (e.g. the true channel and ``out_real + 1j * out_imag``)."""
+        h_ref, h_est = np.asarray(h_ref), np.asarray(h_est)
+        if h_ref.shape != h_est.shape or h_ref.ndim < 1 or h_ref.size == 0:
+            raise CsiError(-1, f'h_ref and h_est must have the same non-empty shape, got {h_ref.shape} and {h_est.shape}')
+        n_bins = h_ref.shape[-1]
+        planes = [_f32c(a).reshape(-1, n_bins) for a in (h_ref.real, h_ref.imag, h_est.real, h_est.imag)]
+        out = ctypes.c_double(0.0)
+        self._check(self._lib.csi_nmse(self._ctx, _fp(planes[0]), _fp(planes[1]), _fp(planes[2]), _fp(planes[3]),
+                                       planes[0].shape[0], n_bins, ctypes.byref(out)))
+        return float(out.value)
+
+    def nmse_device(self, d_ref_re, d_ref_im, d_est_re, d_est_im, nlinks, n_bins=N_DATA, d_per_link=None):
+        """The same metric on device-resident planes ([nlinks][n_bins] float32 each); synchronous.
+        ``d_per_link`` (a DeviceArray of nlinks floats) also receives the per-link ratios."""
+        out = ctypes.c_double(0.0)
+        self._check(self._lib.csi_nmse_device(self._ctx, d_ref_re.ptr, d_ref_im.ptr, d_est_re.ptr, d_est_im.ptr, int(nlinks), int(n_bins),
+                                              d_per_link.ptr if d_per_link is not None else None, ctypes.byref(out)))
+        return float(out.value)
+
     def synth_white(self, seed, first_pkt, npkt, d_re, d_im):
         self._check(self._lib.csi_synth_white(self._ctx, int(seed), int(first_pkt), int(npkt), d_re.ptr, d_im.ptr))
 

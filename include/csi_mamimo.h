@@ -18,6 +18,7 @@
  *        generate_maMIMO_LTF.m:336-342, helperMIMOChannelEstimate.m:24-36
  *                                                                   csi_ls_estimate[_device]
  *   LMMSE_ce per link   helperMIMOChannelEstimate.m:37-39, LMMSE_ce.m  csi_lmmse_estimate[_device]
+ *   NMSE_subk           BER_test_maMIMO_LTF.m:675-686                csi_nmse[_device]
  *   --execTime profiler loop                       DNN.py:441-475   csi_profile_*
  *   Model.fit step (noise, BN, dropout, Adam)       DNN.py:272-316   csi_train_*
  *
@@ -126,6 +127,16 @@ int  csi_lmmse_estimate(csi_ctx* ctx, const float* h_re, const float* h_im, int6
                         const float* snr_db, float* out_re, float* out_im);
 int  csi_lmmse_estimate_device(csi_ctx* ctx, const float* d_h_re, const float* d_h_im, int64_t npkt, const float* d_hvec,
                                int L, const float* d_snr_db, float* d_out_re, float* d_out_im);
+
+/* Accuracy metric of the reference's evaluation, NMSE_subk (BER_test_maMIMO_LTF.m:675-686): per link
+ * ||ref - est||^2 / ||ref||^2 over the n_bins bins, mean over the nlinks links ([link][n_bins] planes, e.g.
+ * the [npkt][nr][nt][234] outputs of csi_predict / csi_ls_estimate with nlinks = npkt*nr*nt).  Synchronous;
+ * d_per_link (may be NULL) receives the per-link ratios, e.g. for per-packet averages
+ * (snr_loop_testing.m:44,51,58). */
+int  csi_nmse(csi_ctx* ctx, const float* ref_re, const float* ref_im, const float* est_re, const float* est_im,
+              int64_t nlinks, int n_bins, double* mean_out);
+int  csi_nmse_device(csi_ctx* ctx, const float* d_ref_re, const float* d_ref_im, const float* d_est_re, const float* d_est_im,
+                     int64_t nlinks, int n_bins, float* d_per_link, double* mean_out);
 
 /* ---- On-box fine-tuning: one optimiser step of the reference's fit(),
  * massiveMIMO_CSI_prediction_DNN.py:272-316, for one component model (fp32 contexts only).

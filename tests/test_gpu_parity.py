@@ -383,6 +383,41 @@ def test_hip_path_matches_committed_oracle_fixture(pkg, golden_dir):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([g['ls'].real, g['ls'].imag], -1)) < TOL
 
 
+# ------------------------------------------------------------------------------------ accuracy metric
+def test_nmse_metric_matches_oracle(pkg, oracle):
+    """NMSE_subk (BER_test_maMIMO_LTF.m:675-686) on the device: host-buffer and device-pointer entry
+    points against the oracle; per-link ratios; a ragged link count; determinism."""
+    rng = np.random.default_rng(21)
+    nt, nr, npkt = 8, 2, 37
+    e = pkg.CsiEngine(nt, nr, hidden=(8,))
+    ref = (rng.standard_normal((npkt, nr, nt, 234)) + 1j * rng.standard_normal((npkt, nr, nt, 234))).astype(np.complex64)
+    est = (ref + 0.05 * (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape))).astype(np.complex64)
+    want = oracle.nmse_subk(ref, est)
+    got = e.nmse(ref, est)
+    assert abs(got - want) <= 1e-6 * want
+    assert e.nmse(ref, est) == got
+    assert e.nmse(ref, ref) == 0.0
+    # other bin counts (RICE_RENEW has 52 outputs) and a single link
+    assert abs(e.nmse(ref[0, 0, 0, :52], est[0, 0, 0, :52]) - oracle.nmse_subk(ref[0, 0, 0, :52], est[0, 0, 0, :52])) <= 1e-6 * want
+    d = [e.empty((npkt, nr, nt, 234)) for _ in range(4)]
+    for a, h in zip(d, (ref.real, ref.imag, est.real, est.imag)):
+        a.upload(np.ascontiguousarray(h, np.float32))
+    per = e.empty((npkt * nr * nt,))
+    got_d = e.nmse_device(d[0], d[1], d[2], d[3], npkt * nr * nt, 234, per)
+    assert got_d == got
+    ratios = per.download()
+    num = np.sum(np.abs(ref.astype(np.complex128) - est) ** 2, -1).reshape(-1)
+    den = np.sum(np.abs(ref.astype(np.complex128)) ** 2, -1).reshape(-1)
+    np.testing.assert_allclose(ratios, num / den, rtol=2e-6)
+    # the metric the reference reports for a DNN estimate: DNN output against the true channel
+    w_re, w_im = _weights(oracle, 5, nt, (8,))
+    P = _pilot(rng, nt)
+    e.load_weights('real', w_re); e.load_weights('imag', w_im); e.set_pilot(P)
+    ltf, H = oracle.make_structured_packets(rng, 6, nr, oracle.hadamard(nt), snr_db=5.0)
+    o_re, o_im = e.predict(ltf)
+    assert abs(e.nmse(H, o_re + 1j * o_im) - oracle.nmse_subk(H, o_re + 1j * o_im)) <= 1e-5 * oracle.nmse_subk(H, o_re + 1j * o_im)
+
+
 # ------------------------------------------------------------------------------------ split-f16 engine
 HS_CASES = [
     (8, 2, 40, (64, 48)),          # two hidden layers: cast layer 0, fused pair layer (hs out), regressor
