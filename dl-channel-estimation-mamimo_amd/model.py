@@ -63,9 +63,33 @@ def normalize_keras_names(tensors):
     return out
 
 
+def tensors_from_keras_hdf5(h5file):
+    """Every dataset of an open Keras weights file (``model.save_weights('x.hdf5')`` / the ModelCheckpoint
+    files of DNN.py:279-281: groups ``<layer>/<layer>/kernel:0`` ..., optionally under ``model_weights``)
+    as {path: array}; the paths are what normalize_keras_names expects."""
+    out = {}
+
+    def visit(name, obj):
+        if hasattr(obj, 'shape') and hasattr(obj, 'dtype'):          # a dataset, not a group
+            out[name] = np.asarray(obj[()], dtype=np.float32)
+
+    h5file.visititems(visit)
+    return out
+
+
 def load_weight_file(path):
     """.safetensors | .pt | .npz (np.savez(path, **{v.name: v.numpy() for v in keras_model.weights}) on a
-    Keras host needs nothing but numpy); Keras variable names are normalised."""
+    Keras host needs nothing but numpy) | .hdf5 / .h5 (the reference's own checkpoint files, DNN.py:279-281,334 -
+    read with h5py where that is installed); Keras variable names are normalised."""
+    if path.endswith(('.hdf5', '.h5')):
+        try:
+            import h5py
+        except ImportError:
+            raise CsiError(-1, f'{path}: reading Keras HDF5 weights needs h5py, which is not installed here - on the Keras host run '
+                               'tools/export_keras_weights.py (or np.savez(path, **{v.name: v.numpy() for v in model.weights})) '
+                               'and load the .npz') from None
+        with h5py.File(path, 'r') as f:
+            return normalize_keras_names(tensors_from_keras_hdf5(f))
     if path.endswith('.npz'):
         with np.load(path) as z:
             return normalize_keras_names({k: np.asarray(z[k], dtype=np.float32) for k in z.files})

@@ -292,3 +292,47 @@ def test_c_program_runs_through_the_abi(pkg, tmp_path):
     res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert res.returncode == 0, res.stdout
     assert 'c_api_smoke: abi 1' in res.stdout
+
+
+def test_keras_hdf5_weights_path(pkg, tmp_path):
+    """The reference checkpoints to Keras HDF5 (DNN.py:279-281).  h5py is not in this image: the loader
+    must say so (never guess); the part that does not need h5py - walking the file's groups and mapping
+    Keras' dataset paths, BatchNormalization layers by order - is exercised on a stand-in tree."""
+    from dl_channel_estimation_mamimo_amd import model as M
+    try:
+        import h5py  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    if not have:
+        with pytest.raises(pkg.CsiError) as ei:
+            M.load_weight_file(str(tmp_path / 'real_weights-improvement.hdf5'))
+        assert 'h5py' in str(ei.value) and 'npz' in str(ei.value)
+
+    class Dataset:
+        def __init__(self, a):
+            self._a, self.shape, self.dtype = a, a.shape, a.dtype
+
+        def __getitem__(self, key):
+            return self._a
+
+    class Tree:                                           # h5py.File-like: visititems(callback(name, obj))
+        def __init__(self, items):
+            self.items = items
+
+        def visititems(self, fn):
+            for name, obj in self.items:
+                fn(name, obj)
+
+    rng = np.random.default_rng(0)
+    arrs = {n: rng.standard_normal(s) for n, s in [
+        ('fc_dense0/fc_dense0/kernel:0', (12, 8)), ('fc_dense0/fc_dense0/bias:0', (8,)),
+        ('batch_normalization_4/batch_normalization_4/gamma:0', (8,)), ('batch_normalization_4/batch_normalization_4/beta:0', (8,)),
+        ('batch_normalization_4/batch_normalization_4/moving_mean:0', (8,)), ('batch_normalization_4/batch_normalization_4/moving_variance:0', (8,)),
+        ('fc_regressor/fc_regressor/kernel:0', (8, 5)), ('fc_regressor/fc_regressor/bias:0', (5,))]}
+    tree = Tree([('fc_dense0', object()), ('fc_dense0/fc_dense0', object())] + [(n, Dataset(a)) for n, a in arrs.items()])
+    w = M.normalize_keras_names(M.tensors_from_keras_hdf5(tree))
+    assert set(w) == {'fc_dense0.kernel', 'fc_dense0.bias', 'bn0.gamma', 'bn0.beta', 'bn0.moving_mean', 'bn0.moving_variance',
+                      'fc_regressor.kernel', 'fc_regressor.bias'}
+    np.testing.assert_array_equal(w['bn0.moving_variance'], arrs['batch_normalization_4/batch_normalization_4/moving_variance:0'].astype(np.float32))
+    assert w['fc_dense0.kernel'].dtype == np.float32
