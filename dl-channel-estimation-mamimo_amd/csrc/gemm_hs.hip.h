@@ -242,6 +242,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     constexpr int D = NSUB - 1;
     __shared__ __attribute__((aligned(16))) float lds[NSUB * PP_SUBF];
 
+    auto bar = [] { if (!(DBG & 16)) pp_barrier(); };        // DBG 16: timing probe without barriers (results invalid)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,12 +281,15 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;            // floats
     const int abase = (wm * 128 + l31) * PP_ROWF;
     const int bbase = (PP_BM + wn * 64 + l31) * PP_ROWF;
+    bool skip_reads = false;           // DBG 32: timing probe, fragments read once (results invalid)
     auto read_a = [&](int slot, int c, f16x8 (&a)[4]) {
+        if ((DBG & 32) && skip_reads) return;
         const float* st = lds + slot * PP_SUBF + abase + xo[c];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + i * 32 * PP_ROWF));
     };
     auto read_b = [&](int slot, int c, f16x8 (&b)[2]) {
+        if ((DBG & 32) && skip_reads) return;
         const float* st = lds + slot * PP_SUBF + bbase + xo[c];
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + j * 32 * PP_ROWF));
@@ -305,11 +309,12 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
 #pragma unroll
         for (int u = 0; u < PP_PW; ++u) issue(t, t, u);
     pp_wait_vm_lgkm_rt(PP_PW * (npro - 1));
-    pp_barrier();                       // sub-tile 0 visible to every wave
+    bar();                       // sub-tile 0 visible to every wave
     read_a(0, 0, f.a_hi);
     read_b(0, 1, f.b_lo);
+    if (DBG & 32) { read_a(0, 1, f.a_lo); read_b(0, 0, f.b_hi); skip_reads = true; }
     pp_wait_lgkm();
-    if (wm == 1) pp_barrier();          // group 1 runs one segment behind
+    if (wm == 1) bar();          // group 1 runs one segment behind
 
     int slot = 0, fill = D % NSUB;
     int u = 0;
@@ -318,31 +323,31 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
         issue(u + D, fill, 0);
         issue(u + D, fill, 1);
         __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        bar();
+        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, !(DBG & 16));
         issue(u + D, fill, 2);
         pp_wait_vm_lgkm<(DBG & 1) ? 0 : PP_PW * (D - 2) + 3>();
         __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
+        bar();
+        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, !(DBG & 16));
         issue(u + D, fill, 3);
         __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        hs_mfma_seg<2>(acc, f, read_a, read_b, true, slot, nslot, true);
+        bar();
+        hs_mfma_seg<2>(acc, f, read_a, read_b, true, slot, nslot, !(DBG & 16));
         slot = nslot;
         fill = fill + 1 == NSUB ? 0 : fill + 1;
     }
     for (; u < nsub; ++u) {
         const int r = nsub - 1 - u;      // sub-tiles still to come after this one
         const int nslot = slot + 1 == NSUB ? 0 : slot + 1;
-        pp_barrier();
-        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        bar();
+        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, !(DBG & 16));
         if (r >= 1) pp_wait_vm_lgkm_rt(PP_PW * (r - 1));
         __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
-        pp_barrier();
-        hs_mfma_seg<2>(acc, f, read_a, read_b, r >= 1, slot, nslot, !(wm == 1 && r == 0));
+        bar();
+        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, !(DBG & 16));
+        bar();
+        hs_mfma_seg<2>(acc, f, read_a, read_b, r >= 1, slot, nslot, !(wm == 1 && r == 0) && !(DBG & 16));
         slot = nslot;
     }
 

@@ -203,6 +203,14 @@ int main(int argc, char** argv) {
         printf("   no stores     %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 9>), grid, dim3(PP_THREADS), 0, 0, gh); });
         printf("   no stores/DMA %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 25>), grid, dim3(PP_THREADS), 0, 0, gh); });
+        printf("   ... and no barriers %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 57>), grid, dim3(PP_THREADS), 0, 0, gh); });
+        printf("   ... and no fragment reads (MFMA only) %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 41>), grid, dim3(PP_THREADS), 0, 0, gh); });
+        printf("   MFMA + barriers, no reads/DMA/stores %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 16>), grid, dim3(PP_THREADS), 0, 0, gh); });
+        printf("   full kernel, no barriers (invalid results) %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), grid, dim3(PP_THREADS), 0, 0, g); });
         printf("generic hs->fp32 %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
