@@ -42,6 +42,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f3
 HBM_PEAK_GBS = 8000.0
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense, v_mfma_f32_32x32x16_bf16 (the same for v_mfma_f32_32x32x16_f16)
 SPLIT_PRODUCTS = 3                  # f16 MFMAs per fp32-grade multiply on the split engine
+SPLIT_SUSTAINED_TFLOPS = 555.0      # MFMA-only ablation of the split kernel on this part (tools/hs_probe.hip): 1.67 PFLOP/s executed / 3
 
 
 def main():
@@ -279,6 +280,7 @@ def main():
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
+                     'frac_of_sustained_mfma_rate': achieved / SPLIT_SUSTAINED_TFLOPS if split_engine else None,
                      'traffic': hbm_per_launch('gemm_hs_pp_pair_kernel<2' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
