@@ -856,8 +856,10 @@ def test_hipgraph_replay_matches_eager(pkg, oracle):
         e.set_option('no_such_option', 1)
 
 
-def test_full_size_properties_config2(pkg, oracle):
-    """BASELINE config 2 at FULL size (Nt=32, Nr=4, 4000 device-generated packets = 512 000 pairs,
+@pytest.mark.parametrize('engine', [-1, 0])
+def test_full_size_properties_config2(pkg, oracle, engine):
+    """(engine -1: the library default, i.e. the split-f16 engine at this size; 0: the fp32 MFMA kernels.)
+    BASELINE config 2 at FULL size (Nt=32, Nr=4, 4000 device-generated packets = 512 000 pairs,
     shipped model), checked through size-independent properties plus the oracle on a random subset:
       * bit-identical results over two runs (no race in the LDS-DMA ring at full occupancy)
       * packets are independent: a packet alone gives the result it had inside the batch
@@ -868,11 +870,13 @@ def test_full_size_properties_config2(pkg, oracle):
     w_re, w_im = _weights(oracle, 1234, nt, hidden)
     P = oracle.hadamard(nt)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', engine)
     d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
     e.synth_white(99, 0, npkt, d_re, d_im)
     d_ore, d_oim = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
     e.predict_device(d_re, d_im, npkt, d_ore, d_oim)
     e.synchronize()
+    assert (e.get_option('hs_launches') > 0) == (engine != 0)
     o_re, o_im = d_ore.download(), d_oim.download()
     assert np.isfinite(o_re).all() and np.isfinite(o_im).all()
     e.predict_device(d_re, d_im, npkt, d_ore, d_oim)
