@@ -426,6 +426,9 @@ HS_CASES = [
     (32, 4, 9, (1024, 1024)),      # the shipped model; ragged last row tile (1152 rows)
     (12, 3, 11, (48, 80)),         # Nt not a power of two (rows of one (packet, rx) straddle tiles)
     (128, 1, 3, (64, 64)),
+    (4, 2, 40, (2048, 32)),        # wide first layer: bn0 vectors of 2048 / 4096 columns behind the LDS ring
+    (4, 1, 70, (4096,)),           # (160 KiB in all at 4096, the widest the fused kernel serves)
+    (4, 1, 30, (16, 16)),          # one sub-tile per GEMM
 ]
 
 
