@@ -60,6 +60,7 @@ struct Layer {
     int wshift = 0;
     int ashift = 4;           // split engine: this layer's OUTPUT activations are carried times 2^ashift (from its BN vectors at load)
     float* bias = nullptr;    // [out]
+    float* bias_hs = nullptr; // [out]  split engine (layers >= 1): bias + (BN shift of the previous layer) . W
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
     float* shift = nullptr;   // [out]  BN: beta - mean * scale        (0 without BN)
     int in = 0, out = 0;
@@ -132,6 +133,7 @@ struct csi_ctx {
     int f32_engine = -1;         // "f32_engine" option: fp32 contexts, 0 = native fp32 MFMA kernels, 1 = split-f16 kernels (gemm_hs.hip.h)
                                  // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)
     int hs_act_shift = HS_SHIFT_AUTO;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
+    float* hs_zero = nullptr;    // zeros, widest hidden layer: the BN shift the split-engine kernels see (it lives in the next layer's bias)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
     size_t hs_lds_attr[3] = {0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out)
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
@@ -262,6 +264,7 @@ void free_layer(Layer& l) {
     if (l.Wb) hipFree(l.Wb);
     if (l.Wh) hipFree(l.Wh);
     if (l.bias) hipFree(l.bias);
+    if (l.bias_hs) hipFree(l.bias_hs);
     if (l.scale) hipFree(l.scale);
     if (l.shift) hipFree(l.shift);
     l = Layer();

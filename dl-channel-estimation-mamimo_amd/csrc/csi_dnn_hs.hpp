@@ -17,8 +17,8 @@ bool hs_static_ok(const csi_ctx* c, const Model& m) {
     if (cf.hidden[0] > 4096) return false;
     for (int i = 0; i < cf.n_hidden; ++i)
         if (cf.hidden[i] % HS_G) return false;
-    for (const Layer& l : m.layers)
-        if (!l.Wh) return false;
+    for (size_t i = 0; i < m.layers.size(); ++i)
+        if (!m.layers[i].Wh || (i >= 1 && !m.layers[i].bias_hs)) return false;
     return true;
 }
 
@@ -166,11 +166,13 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
     const int nh = cf.n_hidden, h1 = cf.hidden[0];
     const Layer& l1 = m.layers[1];
     const int s0 = hs_act_shift_of(c, m, 0);
-    PairSrc src{l0sum, m.T, m.layers[0].scale, m.layers[0].shift, h1, cf.nt};
+    // every BatchNormalization shift lives in the NEXT layer's bias (Layer::bias_hs): activations = relu(.) * scale
+    // keep the zeros of the relu
+    PairSrc src{l0sum, m.T, m.layers[0].scale, c->hs_zero, h1, cf.nt};
     GemmHsArgs p{};
     p.Bt = l1.Wh; p.ldb = l1.ldwh;
     p.M = M2; p.N = l1.out; p.K = h1;
-    p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
+    p.bias = l1.bias_hs; p.scale = l1.scale; p.shift = c->hs_zero;
     p.acc_scale = std::ldexp(1.f, -(s0 + l1.wshift));
     if (nh == 1) {
         p.C = out; p.ldc = cf.n_out;
@@ -188,7 +190,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         q.A = hb[cur]; q.lda = 2 * l.in;
         q.Bt = l.Wh; q.ldb = l.ldwh;
         q.M = M2; q.N = l.out; q.K = l.in;
-        q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+        q.bias = l.bias_hs; q.scale = l.scale; q.shift = c->hs_zero;
         q.acc_scale = std::ldexp(1.f, -(hs_act_shift_of(c, m, li - 1) + l.wshift));
         if (li == nh) {
             q.C = out; q.ldc = cf.n_out;

@@ -66,6 +66,7 @@ static double time_ms(F&& launch, int iters = 7) {
 int main(int argc, char** argv) {
     const bool timing = argc > 1 && std::string(argv[1]) == "time";
     const float in_mag = argc > 2 ? atof(argv[2]) : 1.f;
+    const bool relu_zeros = argc > 3 && std::string(argv[3]) == "relu";     // A operands with ~50 % exact zeros (power experiment)
     const int nt = 32, K = 1024, N = 1024, NO = 234;
     const int M = timing ? 262144 : 1000 * 1 + 24;        // ragged last tile in the check
     const int M1 = (M + nt - 1) / nt;
@@ -75,8 +76,10 @@ int main(int argc, char** argv) {
     auto hW2 = rnd((size_t)NO * K, 0.07f, false);
     auto hb = rnd(N, 0.1f), hsc = rnd(N, 0.3f), hsh = rnd(N, 0.1f);
     for (auto& v : hsc) v = 1.f + v;
+    if (relu_zeros) for (auto& v : hA) v = std::max(v, 0.f);
     auto hL0 = rnd((size_t)M1 * K, in_mag), hT = rnd((size_t)nt * K, in_mag), hs0 = rnd(K, 0.3f), ht0 = rnd(K, 0.1f);
     for (auto& v : hs0) v = 1.f + v;
+    if (relu_zeros) for (auto& v : ht0) v = 0.f;
     float *A = dput(hA), *W = dput(hW), *W2 = dput(hW2), *b = dput(hb), *sc = dput(hsc), *sh = dput(hsh);
     float *L0 = dput(hL0), *T = dput(hT);
     const int sa = 4;
