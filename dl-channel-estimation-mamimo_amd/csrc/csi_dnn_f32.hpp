@@ -278,11 +278,14 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         }
         GemmArgs p{};
         p.A = l0; p.lda = h1;
-        p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = m.layers[0].shift; p.nt = nt;
+        // BatchNormalization shifts live in the next layer's bias (Layer::bias_hs, csi_load_weights): the
+        // activations keep the exact zeros of the relu, on which the matrix pipe draws less power
+        const bool fold = m.layers[1].bias_hs != nullptr;
+        p.T = m.T; p.s0 = m.layers[0].scale; p.t0 = fold ? c->hs_zero : m.layers[0].shift; p.nt = nt;
         p.M = M2; p.K = h1;
         const Layer& l1 = m.layers[1];
         p.Bt = l1.Wt; p.ldb = l1.ldw; p.N = l1.out;
-        p.bias = l1.bias; p.scale = l1.scale; p.shift = l1.shift;
+        p.bias = fold ? l1.bias_hs : l1.bias; p.scale = l1.scale; p.shift = fold ? c->hs_zero : l1.shift;
         p.k_per_split = ((h1 + G_BK - 1) / G_BK) * G_BK;
         if (nh == 1) {
             p.C = out_chunk; p.ldc = cf.n_out;
@@ -300,7 +303,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
             q.A = hbuf[cur]; q.lda = l.in;
             q.Bt = l.Wt; q.ldb = l.ldw;
             q.M = M2; q.N = l.out; q.K = l.in;
-            q.bias = l.bias; q.scale = l.scale; q.shift = l.shift;
+            q.bias = fold ? l.bias_hs : l.bias; q.scale = l.scale; q.shift = fold ? c->hs_zero : l.shift;
             q.k_per_split = ((l.in + G_BK - 1) / G_BK) * G_BK;
             if (li == nh) {
                 q.C = out_chunk; q.ldc = cf.n_out;
