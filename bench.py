@@ -9,9 +9,15 @@ Workload (N = 1): BASELINE.json configs[1] - Nt=32, Nr=4, 500 packets at each of
 workload on its own packet shard (weak scaling); the weights are broadcast once from rank 0
 over RCCL before the timed region and there is no collective in the data path.
 
-Data: i.i.d. CN(0,1) preambles generated on the device (csi_synth_white) and random-initialised
-weights of the shipped architecture - the reference ships neither datasets nor weights.  The
-arithmetic is data-independent (dense fp32), so noise level does not change the work.
+Data: the batch the pipeline feeds config 2 with - 500 structured sounding packets (8-tap channels,
+reference amplitude scaling) at EACH of the 8 SNR levels, all 4000 in one launch (synth.mixed_snr_batch;
+`--input white` = i.i.d. CN(0,1) generated on the device, the default for batches beyond 8000 packets) -
+and random-initialised weights of the shipped architecture: the reference ships neither datasets nor weights.
+
+Ranks: `--gpus N` under torchrun (WORLD_SIZE set) uses the ranks it is given; WITHOUT torchrun it starts
+N ranks itself (one process per GPU, RCCL; CSI_DIST_BACKEND=gloo lets ranks share a GPU for a dry
+run).  `n_gpus` in the line is the number of ranks that executed the step.  `--scaling weak` (default):
+`--packets` per GPU; `--scaling strong`: `--packets` in total, sharded by contiguous packet ranges.
 
 Arithmetic: fp32 in, fp32 accumulate, fp32 out.  The library's fp32 contexts run GEMMs that fill the
 chip on the f16 matrix cores with split operands (x = hi + lo halves, 3 MFMA per product,
@@ -42,7 +48,28 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f3
 HBM_PEAK_GBS = 8000.0
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense, v_mfma_f32_32x32x16_bf16 (the same for v_mfma_f32_32x32x16_f16)
 SPLIT_PRODUCTS = 3                  # f16 MFMAs per fp32-grade multiply on the split engine
-SPLIT_SUSTAINED_TFLOPS = 555.0      # MFMA-only ablation of the split kernel on this part (tools/hs_probe.hip): 1.67 PFLOP/s executed / 3
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start N ranks of this script (one process per GPU,
+    LOCAL_RANK i -> device i) with a private rendezvous on 127.0.0.1, forward rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit('bench.py: rank exit codes %s' % rcs)
 
 
 def main():
@@ -52,7 +79,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--nt', type=int, default=32)
     ap.add_argument('--nr', type=int, default=4)
-    ap.add_argument('--packets', type=int, default=4000, help='packets per GPU per step')
+    ap.add_argument('--packets', type=int, default=4000, help='packets per step: per GPU (--scaling weak) or in total (--scaling strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--input', default='auto', choices=['auto', 'mixed-snr', 'white'],
+                    help='mixed-snr = structured packets, packets/8 at each of {-25..10} dB in one launch (host-generated); '
+                         'white = CN(0,1) generated on the device; auto = mixed-snr up to 8000 packets per GPU')
+    ap.add_argument('--no-latency', action='store_true', help='skip the one-packet latency loop (profiling runs)')
     ap.add_argument('--hidden', type=int, nargs='+', default=[1024, 1024])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
@@ -64,20 +96,44 @@ def main():
                     help='fp32 contexts: auto = split-f16 engine for GEMMs that fill the chip (library default), '
                          'native = fp32 MFMA kernels only, split = split engine wherever the shapes allow')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
-    ap.add_argument('--host-path', type=int, default=0,
-                    help='also time the host-buffer (PCIe-inclusive) entry points on this many packets')
+    ap.add_argument('--host-path', type=int, default=4000,
+                    help='also time the host-buffer (PCIe-inclusive) entry points on this many packets (0 = skip; rank 0, N = 1)')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import dl_channel_estimation_mamimo_amd as pkg
     rank, world, local = pkg.dist.env_rank_world()
+    backend = os.environ.get('CSI_DIST_BACKEND', 'nccl')
     if world > 1:
         # RCCL over xGMI; CSI_DIST_BACKEND=gloo lets several ranks share one GPU for a dry run
-        pkg.dist.init_process_group(os.environ.get('CSI_DIST_BACKEND', 'nccl'))
-    n_gpus = max(args.gpus, world)
+        pkg.dist.init_process_group(backend)
+        assert pkg.dist.world_size() == world
+    n_gpus = world                       # the ranks that execute the step - never the flag
+    if args.rendezvous_only:
+        lo, hi = pkg.dist.shard_range(args.packets, rank, world) if args.scaling == 'strong' else (rank * args.packets, (rank + 1) * args.packets)
+        seen = pkg.dist.all_reduce_sum(1.0)
+        pkts = pkg.dist.all_reduce_sum(float(hi - lo))
+        pkg.dist.barrier()
+        if rank == 0:
+            print(json.dumps({'rendezvous_only': True, 'n_gpus': n_gpus, 'ranks_seen': int(seen), 'requested': args.gpus,
+                              'packets_per_step': int(pkts), 'scaling': args.scaling, 'backend': backend if world > 1 else None}))
+        return
 
-    nt, nr, npkt, hidden = args.nt, args.nr, args.packets, tuple(args.hidden)
+    nt, nr, hidden = args.nt, args.nr, tuple(args.hidden)
+    if args.scaling == 'strong':
+        first, last = pkg.dist.shard_range(args.packets, rank, world)     # fixed total, contiguous packet ranges
+    else:
+        first, last = rank * args.packets, (rank + 1) * args.packets      # fixed work per GPU
+    npkt = last - first
+    total_pkts = args.packets if args.scaling == 'strong' else args.packets * world
     import torch
     ndev = max(torch.cuda.device_count(), 1)
+    if world > 1 and backend == 'nccl' and world > ndev:
+        sys.exit('bench.py: %d ranks but %d GPUs visible (CSI_DIST_BACKEND=gloo shares a GPU for a dry run)' % (world, ndev))
     eng = pkg.CsiEngine(nt, nr, hidden=hidden, n_out=234, use_bn=True, device=local % ndev, dtype=args.dtype,
                         workspace_bytes=int(args.workspace_gb * 2**30))
 
@@ -93,10 +149,16 @@ def main():
     eng.load_weights('imag', wts['imag'])
     eng.set_pilot(wts['P']['pilot'])
 
-    # this rank's packet shard, generated in HBM
-    first = rank * npkt
+    # this rank's packet shard, resident in HBM before the timed region
     d_re, d_im = eng.empty((npkt, nr, eng.len_ltf)), eng.empty((npkt, nr, eng.len_ltf))
-    eng.synth_white(2024 + 1, first, npkt, d_re, d_im)
+    mixed = args.input == 'mixed-snr' or (args.input == 'auto' and npkt <= 8000 and npkt % 8 == 0)
+    if mixed:
+        assert npkt % 8 == 0, 'mixed-snr input needs a multiple of 8 packets per rank'
+        for p0, snr, blk in pkg.synth.mixed_snr_batch(2024 + 1 + 1000 * rank, nr, wts['P']['pilot'], per_level=npkt // 8):
+            d_re.upload(np.ascontiguousarray(blk.real), first=p0)
+            d_im.upload(np.ascontiguousarray(blk.imag), first=p0)
+    else:
+        eng.synth_white(2024 + 1, first, npkt, d_re, d_im)
     d_ore, d_oim = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
     d_hre, d_him = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
     eng.synchronize()
@@ -127,9 +189,13 @@ def main():
 
     prof = eng.profile()
     eng.profile_enable(False)
-    pairs_per_step = npkt * nr * nt * world
+    pairs_per_step = total_pkts * nr * nt          # all ranks together
     value = pairs_per_step * args.steps / dt
     split_engine = args.dtype == 'f32' and eng.get_option('hs_launches') > 0
+    # range guard of the split-f16 engine over the timed steps: a hit would have made eng.synchronize() raise
+    # (CSI_ERR_RANGE) above; the counters go into the line
+    guard = {'hs_launches': eng.get_option('hs_launches'), 'hs_range_fallbacks': eng.get_option('hs_range_fallbacks'),
+             'csi_synchronize': 'clean'} if args.dtype == 'f32' else None
 
     # ---- cpu_baseline leg (rank 0, N = 1, after the timed region): the only place that touches oracle/.
     # It runs the CPU restatement of the reference on a bounded sample of the very same packets - timed
@@ -139,9 +205,12 @@ def main():
     if rank == 0 and world == 1 and args.check > 0:
         from oracle import csi_oracle as o
         k = min(args.check, npkt)
-        ltf = d_re.download(0, k) + 1j * d_im.download(0, k)
+        # first and last packets of the batch: with the mixed-SNR input these are the -25 dB and the +10 dB level
+        sel = sorted(set(list(range((k + 1) // 2)) + list(range(npkt - k // 2, npkt))))
+        take = lambda d: np.concatenate([d.download(p, 1) for p in sel])
+        ltf = take(d_re) + 1j * take(d_im)
         r_re, r_im = o.predict_packets(ltf, wts['P']['pilot'], wts['real'], wts['imag'], np.float64, pkt_batch=k)
-        g_re, g_im = d_ore.download(0, k), d_oim.download(0, k)
+        g_re, g_im = take(d_ore), take(d_oim)
         check['dnn_rel_err'] = max(o.row_rel_err(g_re, r_re), o.row_rel_err(g_im, r_im))
         check['dnn_nmse_vs_fp64'] = o.nmse_subk(r_re + 1j * r_im, g_re + 1j * g_im)
         if args.dtype == 'bf16':
@@ -149,8 +218,8 @@ def main():
             check['dnn_rel_err_vs_bf16_emulation'] = max(o.row_rel_err(g_re, b_re), o.row_rel_err(g_im, b_im))
         if not args.no_ls:
             r_ls = o.ls_estimate(ltf, wts['P']['pilot'])
-            check['ls_rel_err'] = max(o.row_rel_err(d_hre.download(0, k), r_ls.real), o.row_rel_err(d_him.download(0, k), r_ls.imag))
-        check['packets'] = k
+            check['ls_rel_err'] = max(o.row_rel_err(take(d_hre), r_ls.real), o.row_rel_err(take(d_him), r_ls.imag))
+        check['packets'] = sel
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
         k = min(npkt, 256)
@@ -184,13 +253,12 @@ def main():
                   'what': "same steps with f32_engine = 0 (v_mfma_f32_32x32x2_f32 kernels)"}
         if args.check > 0:
             from oracle import csi_oracle as o
-            kc = min(args.check, npkt)
-            native['dnn_rel_err'] = max(o.row_rel_err(d_ore.download(0, kc), r_re), o.row_rel_err(d_oim.download(0, kc), r_im))
+            native['dnn_rel_err'] = max(o.row_rel_err(take(d_ore), r_re), o.row_rel_err(take(d_oim), r_im))
         eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
 
     # one-packet latency (the reference's literal per-packet call, DNN.py:346), device-resident, outside the timed region
     latency = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_latency:
         ts = []
         for i in range(40):
             eng.synchronize()
@@ -203,7 +271,7 @@ def main():
         latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6), 'what': 'LS + DNN(real) + DNN(imag) of one packet, device-resident, median of 30 calls'}
 
     host_path = None
-    if rank == 0 and args.host_path > 0:
+    if rank == 0 and world == 1 and args.host_path > 0:
         k = min(args.host_path, npkt)
         h_re, h_im = d_re.download(0, k), d_im.download(0, k)
         o_ls = (np.zeros((k, nr, nt, 234), np.float32), np.zeros((k, nr, nt, 234), np.float32))
@@ -264,23 +332,29 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': args.dtype,
         'arithmetic': ('fp32 operands, fp32 accumulate, fp32 results; GEMM products on the f16 matrix cores with split (hi + lo) '
                        'operands, 3 MFMA per product - error vs the fp64 oracle in parity_check (contract 1e-5)') if split_engine else
                       ('fp32 MFMA' if args.dtype == 'f32' else 'bf16 operands, fp32 accumulate'),
         'data': 'synthetic',
-        'config': {'workload': '%sNt=%d Nr=%d, %d packets/GPU/step%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
-                       'configs[1]: ' if (nt, nr, npkt, args.dtype) == (32, 4, 4000, 'f32') else ('configs[2]: ' if (nt, nr, npkt, args.dtype) == (64, 4, 5000, 'bf16') else ''), nt, nr, npkt,
-                       ' (8 SNR x 500)' if npkt == 4000 else '', 'x'.join(map(str, hidden))),
+        'input': ('structured sounding packets, %d at each of {-25,-20,-15,-10,-5,0,5,10} dB in one launch (synth.mixed_snr_batch)' % (npkt // 8)) if mixed
+                 else 'i.i.d. CN(0,1) generated on the device (csi_synth_white)',
+        'config': {'workload': '%sNt=%d Nr=%d, %d packets/step in total (%d on this rank)%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
+                       'configs[1]: ' if (nt, nr, args.packets, args.dtype) == (32, 4, 4000, 'f32') else
+                       ('configs[2]: ' if (nt, nr, args.packets, args.dtype) == (64, 4, 5000, 'bf16') else
+                        ('configs[3]: ' if (nt, nr, args.packets, args.scaling) == (64, 8, 50000, 'strong') else
+                         ('configs[4]: ' if (nt, nr, args.packets, args.scaling) == (128, 16, 100000, 'strong') else ''))),
+                       nt, nr, total_pkts, npkt, ' (8 SNR x %d)' % (npkt // 8) if mixed else '', 'x'.join(map(str, hidden))),
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
-                   'sharding': 'packets by rank, weights broadcast once' if world > 1 else 'single GPU'},
+                   'ranks': world, 'devices_visible_per_rank': ndev, 'dist_backend': backend if world > 1 else None,
+                   'sharding': ('contiguous packet ranges per rank (%s scaling), weights broadcast once over %s, no collective in the step'
+                                % (args.scaling, 'RCCL' if backend == 'nccl' else backend)) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
-                     'frac_of_sustained_mfma_rate': achieved / SPLIT_SUSTAINED_TFLOPS if split_engine else None,
                      'traffic': hbm_per_launch('gemm_hs_pp_pair_kernel<2' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
@@ -288,6 +362,8 @@ def main():
         'parity_check': check,
         'latency': latency,
     }
+    if guard:
+        out['split_engine_range_guard'] = guard
     if native:
         out['native_fp32_engine'] = native
     if host_path:

@@ -29,10 +29,14 @@ class DeviceArray:
         engine._check(engine._lib.csi_device_malloc(engine._ctx, ctypes.byref(p), self.nbytes))
         self.ptr = p.value or 0
 
-    def upload(self, host):
+    def upload(self, host, first=0):
+        """Copy `host` into rows [first, first + len(host)) along axis 0 (default: the whole array)."""
         host = _f32c(host)
-        assert host.nbytes == self.nbytes, (host.shape, self.shape)
-        self.engine._check(self.engine._lib.csi_memcpy_h2d(self.engine._ctx, self.ptr, host.ctypes.data, self.nbytes))
+        row = self.nbytes // max(self.shape[0], 1)
+        assert host.nbytes % max(row, 1) == 0 and first * row + host.nbytes <= self.nbytes, (host.shape, self.shape, first)
+        if first == 0 and host.nbytes != self.nbytes:
+            assert host.shape[1:] == self.shape[1:], (host.shape, self.shape)
+        self.engine._check(self.engine._lib.csi_memcpy_h2d(self.engine._ctx, self.ptr + first * row, host.ctypes.data, host.nbytes))
         return self
 
     def download(self, first=0, count=None):

@@ -12,8 +12,15 @@ PARITY PIN STATUS (see DESIGN.md "Oracle"):
     imported the reference's own pure-numpy code (``massiveMIMO_dataGenerator.py``,
     ``inference.py``) in the build container and the outputs are committed under
     ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them.
+  * the OFDM demodulation convention (a-1: symbol split, CP window 64..319, un-scaled 256-FFT,
+    DC in the middle) is PINNED against the reference's own numpy statement of it,
+    ``massiveMIMO_dataGenerator.py:425-453`` (method 'reshape'), executed by
+    ``tests/golden/make_golden.py``; its per-symbol spectra are committed as
+    ``tests/golden/ref_ofdm_reshape_nt4.npz`` and ``ofdm_demod`` reproduces them
+    (``test_ofdm_demod_matches_reference_reshape_method``).  The MATLAB ``ofdmdemod`` call
+    itself (generate_maMIMO_LTF.m:336-338) cannot run here.
   * the Dense / BatchNormalization / Dropout arithmetic (a-4..a-7) lives in TensorFlow
-    2.3 (README.md:27-28) and the LS estimate (a-1, a-2) in MATLAB R2020b + toolboxes
+    2.3 (README.md:27-28) and the LS despread (a-2) in MATLAB R2020b + toolboxes
     (README.md:29-30); neither is vendored nor installable here and the reference has
     no tests, golden vectors or weights.  For those rows: PARITY UNPINNED.  They are
     restated from the call sites and the published layer definitions, and checked by

@@ -13,6 +13,15 @@ What is exercised, and how:
     an INPUT of that code; its own arithmetic - dtype check, X.real/X.imag split,
     ``real + 1j*imag``, null re-insertion, ifftshift - is what gets recorded)
     -> ref_inference_rice.npz
+  * massiveMIMO_dataGenerator.DataGenerator with method='reshape' (massiveMIMO_dataGenerator.py:425-458,
+    "THIS METHOD PERFORMS COMPLETE OFDM DEMODULATION"): the reference's own numpy statement of the OFDM
+    demodulation convention - column-major split into numSym symbols of FFTLength + CPLen samples,
+    cyclic-prefix removal index list, per-symbol FFT, fftshift - run on the same small dataset.  The
+    batch rows it returns keep only the REAL part of one symbol's spectrum (a complex array assigned
+    into a float array), so besides those rows the generator's own intermediate arrays (input2D,
+    afterCPRemoval, afterFFT before and after the shift) are recorded through a line tracer on
+    __data_generation: they are the reference's variables, read while the reference's code runs -
+    nothing is recomputed here.                                              -> ref_ofdm_reshape_nt4.npz
 
 TensorFlow is not installed here.  The two reference modules only need the NAMES
 ``tensorflow.keras`` / ``tensorflow.keras.utils.Sequence`` to import (inference.py:4,
@@ -109,6 +118,87 @@ def golden_datagen():
     print('wrote ref_datagen_nt4.npz', {k: np.asarray(v).shape for k, v in out.items()})
 
 
+def golden_ofdm_reshape():
+    """Runs DataGenerator(method='reshape') (massiveMIMO_dataGenerator.py:425-458) on the Nt=4 dataset and
+    records (a) the batches it returns and (b) its intermediate arrays, captured by a tracer."""
+    import warnings
+    import massiveMIMO_dataGenerator as gen
+    rng = np.random.default_rng(20240901)                 # the same dataset as golden_datagen()
+    npkt, nr, nt = 3, 2, 4
+    ds, keys, P_matlab = make_dataset(rng, npkt, nr, nt)
+    n = npkt * nr * nt
+    prm = dict(ds['simParams'])
+    # prm['ltf_freqdom'] is commented out in the reference's loadDataset (:40-42); the method appends it to
+    # every row, so any 234-vector serves - a recognisable ramp
+    prm['ltf_freqdom'] = np.arange(1, 235, dtype=np.float64)
+    code = gen.DataGenerator._DataGenerator__data_generation.__code__
+    first_line = code.co_firstlineno
+    captured = {}                                          # d -> sample position -> dict of arrays
+
+    def tracer_for(d):
+        store = captured.setdefault(d, [])
+        state = {'last': None, 'i_seen': None}
+
+        def local_trace(frame, event, arg):
+            if event not in ('line', 'return'):
+                return local_trace
+            loc = frame.f_locals
+            # afterFFT is bound at :452 (the FFT) and re-bound at :453 (fftshift): a NEW object in that name is
+            # the first binding of loop iteration i (before the shift) or the second (after it); between
+            # iterations the name still holds the previous sample's array, which is not new
+            a = loc.get('afterFFT')
+            if a is None or a is state['last']:
+                return local_trace
+            state['last'] = a
+            if loc['i'] != state['i_seen']:
+                state['i_seen'] = loc['i']
+                store.append({'i': int(loc['i']), 'sampleIx': int(loc['sampleIx']), 'input2D': loc['input2D'].copy(),
+                              'afterCPRemoval': loc['afterCPRemoval'].copy(), 'noCP_ix': np.array(loc['noCP_ix']),
+                              'fft_pre_shift': np.array(a).copy()})
+            else:
+                assert 'fft_post_shift' not in store[-1]
+                store[-1]['fft_post_shift'] = np.array(a).copy()
+            return local_trace
+
+        def global_trace(frame, event, arg):
+            if event == 'call' and frame.f_code is code:
+                state['last'], state['i_seen'] = None, None
+                return local_trace
+            return None
+        return global_trace
+
+    out = {'npkt': npkt, 'nr': nr, 'nt': nt, 'ds_X': ds['X'], 'ds_P': ds['P'], 'P_matlab': P_matlab,
+           'ltf_freqdom': prm['ltf_freqdom'], 'ref_first_line': first_line,
+           'ds_ltf_real': np.stack([ds['LTF'][k]['real'] for k in keys]),
+           'ds_ltf_imag': np.stack([ds['LTF'][k]['imag'] for k in keys])}
+    for d in ('real', 'imag'):
+        g = gen.DataGenerator(list(range(n)), ds, d, prm, datasource='matlab_maMimo', method='reshape',
+                              batch_size=nt * nr, shuffle=False)
+        rows = []
+        sys.settrace(tracer_for(d))
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')            # ComplexWarning: the reference drops the imaginary part (:454)
+                for b in range(len(g)):
+                    X, y, _ = g[b]
+                    rows.append(np.asarray(X))
+        finally:
+            sys.settrace(None)
+        out[f'{d}_X'] = np.stack(rows)                     # [npkt, Nt*Nr, 256 + Nt + 234]
+        recs = captured[d]
+        assert len(recs) == n and all('fft_post_shift' in r for r in recs), (len(recs), [sorted(r) for r in recs[:2]])
+        assert [r['sampleIx'] for r in recs] == list(range(n))
+        # the Nt samples of an rx antenna share the preamble: keep iTx = 0 of every (packet, rx)
+        sel = [r for r in recs if r['sampleIx'] % nt == 0]
+        out[f'{d}_input2D'] = np.stack([r['input2D'] for r in sel])                # [npkt*nr, 320, Nt]
+        out[f'{d}_afterCPRemoval'] = np.stack([r['afterCPRemoval'] for r in sel])  # [npkt*nr, 256, Nt]
+        out[f'{d}_fft_pre_shift'] = np.stack([r['fft_pre_shift'] for r in sel])    # complex [npkt*nr, 256, Nt]
+        out[f'{d}_fft_post_shift'] = np.stack([r['fft_post_shift'] for r in sel])
+        out['noCP_ix'] = recs[0]['noCP_ix']
+    np.savez_compressed(os.path.join(OUT, 'ref_ofdm_reshape_nt4.npz'), **out)
+    print('wrote ref_ofdm_reshape_nt4.npz', {k: np.asarray(v).shape for k, v in out.items()})
+
+
 class _StandInModel:
     """Deterministic stand-in for a loaded keras model: float32 [bs, n_in] -> [bs, n_out]."""
 
@@ -158,3 +248,4 @@ if __name__ == '__main__':
     sys.path.insert(0, REF)
     golden_datagen()
     golden_inference()
+    golden_ofdm_reshape()

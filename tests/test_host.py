@@ -336,3 +336,68 @@ def test_keras_hdf5_weights_path(pkg, tmp_path):
                       'fc_regressor.kernel', 'fc_regressor.bias'}
     np.testing.assert_array_equal(w['bn0.moving_variance'], arrs['batch_normalization_4/batch_normalization_4/moving_variance:0'].astype(np.float32))
     assert w['fc_dense0.kernel'].dtype == np.float32
+
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus N` without torchrun must really run N ranks (round-1 verdict: it measured
+    one GPU and labelled it N).  --rendezvous-only walks the launch path - self-spawn, rendezvous on
+    127.0.0.1, all-reduce of a rank count, rank-0 line - without GPU work: n_gpus is the number of ranks
+    that answered, and strong scaling shards a fixed total."""
+    line = _bench(['--gpus', '2', '--rendezvous-only', '--scaling', 'strong', '--packets', '50001'], {'CSI_DIST_BACKEND': 'gloo'})
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['packets_per_step'] == 50001 and line['scaling'] == 'strong'
+    line = _bench(['--gpus', '3', '--rendezvous-only', '--packets', '4000'], {'CSI_DIST_BACKEND': 'gloo'})
+    assert line['n_gpus'] == 3 and line['ranks_seen'] == 3 and line['packets_per_step'] == 12000 and line['scaling'] == 'weak'
+    line = _bench(['--gpus', '1', '--rendezvous-only'], {})
+    assert line['n_gpus'] == 1 and line['ranks_seen'] == 1
+
+
+def test_bench_under_torchrun_env_uses_the_given_ranks():
+    """Launched the driver's way (torch.distributed.run sets RANK / WORLD_SIZE): no self-spawn, n_gpus = WORLD_SIZE."""
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--rendezvous-only'],
+                       env=dict(os.environ, CSI_DIST_BACKEND='gloo'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['ranks_seen'] == 2
+
+
+def test_mixed_snr_batch_generator(pkg, oracle):
+    """The config-2 input generator: levels in the pipeline's order, blocks reproducible one by one, the
+    signal level fixed across levels (only the noise moves), and - noise off - the LS estimate of a packet
+    is the channel it was built from (so the generator speaks the oracle's OFDM / pilot conventions)."""
+    jobs = pkg.synth.mixed_snr_jobs(11, per_level=6, block=4)
+    assert [(j[0], j[1], j[2]) for j in jobs[:4]] == [(0, 4, -25.0), (4, 2, -25.0), (6, 4, -20.0), (10, 2, -20.0)]
+    assert jobs[-1][0] + jobs[-1][1] == 48
+    P = pkg.synth.hadamard(4)
+    blocks = list(pkg.synth.mixed_snr_batch(11, 2, P, per_level=6, block=4, threads=2))
+    assert [b[0] for b in blocks] == [j[0] for j in jobs]
+    for (first, snr, blk), job in zip(blocks, jobs):
+        assert blk.dtype == np.complex64 and blk.shape == (job[1], 2, 1280)
+        np.testing.assert_array_equal(blk, pkg.synth.mixed_snr_block(job, 2, P))
+    big = {lv: np.concatenate([b[2] for b in pkg.synth.mixed_snr_batch(5, 2, P, per_level=40, levels=(lv,), block=40)]) for lv in (-25, 10)}
+    p_lo, p_hi = (float(np.mean(np.abs(big[lv]) ** 2)) for lv in (-25, 10))
+    # power = S (1 + 10^(-snr/10)) with the same S: ratio (1 + 316.2) / (1 + 0.1)
+    assert abs(p_lo / p_hi / (317.2 / 1.1) - 1.0) < 0.15
+    x = pkg.synth.structured_packets(np.random.default_rng(1), 2, 2, pkg.synth.hadamard(8), snr_db=300.0)
+    h = oracle.ls_estimate(x.astype(np.complex128) / pkg.synth.AMP_SCALE, oracle.hadamard(8))
+    rng = np.random.default_rng(1)
+    decay = (np.exp(-0.5 * np.arange(8)) / np.sqrt(2)).astype(np.float32)
+    cir = rng.standard_normal((4, 8, 8), dtype=np.float32) * decay + 1j * (rng.standard_normal((4, 8, 8), dtype=np.float32) * decay)
+    H = np.fft.fftshift(np.fft.fft(cir, n=256, axis=-1), axes=-1)[..., oracle.data_carrier_indices() - 1].reshape(2, 2, 8, 234)
+    assert np.abs(h - H).max() / np.abs(H).max() < 2e-6
+    assert np.array_equal(pkg.synth.vht_ltf_sequence(), oracle.vht_ltf_256().astype(np.float32))

@@ -69,6 +69,57 @@ def test_inference_recombine_and_postprocess_match_reference(oracle, golden_dir)
     assert list(g['model_calls_real']) == ['<f8', str(x.shape[0])]
 
 
+def _reference_spectra(g):
+    """Complex per-symbol spectra [npkt*nr, 256, nt] as the REFERENCE computed them (un-shifted FFT bin order):
+    its 'reshape' method transforms the real and the imaginary plane of a preamble separately
+    (massiveMIMO_dataGenerator.py:436,452 with d = 'real' / 'imag'); the transform of the complex preamble is
+    their sum F(re) + j F(im) (linearity - the only step taken here)."""
+    return g['real_fft_pre_shift'] + 1j * g['imag_fft_pre_shift']
+
+
+def test_ofdm_demod_matches_reference_reshape_method(oracle, golden_dir):
+    """Pins row a-1 (OFDM demodulation convention) to the reference's own numpy statement of it,
+    massiveMIMO_dataGenerator.py:425-453, executed by tests/golden/make_golden.py: column-major split into
+    Nt symbols of 320 samples (:437-439), CP removal = samples 64..319 of each symbol (:442-443), un-scaled
+    256-point FFT along the symbol (:452), DC moved to the middle of the frequency axis (:453)."""
+    g = np.load(os.path.join(golden_dir, 'ref_ofdm_reshape_nt4.npz'))
+    nt, nr, npkt = int(g['nt']), int(g['nr']), int(g['npkt'])
+    # what the reference did, as recorded from its own variables
+    assert g['noCP_ix'].tolist() == list(range(64, 320))
+    for d in ('real', 'imag'):
+        ltf = g[f'ds_ltf_{d}']
+        np.testing.assert_array_equal(g[f'{d}_input2D'], ltf.reshape(npkt * nr, nt, 320).transpose(0, 2, 1))     # order='F' split
+        np.testing.assert_array_equal(g[f'{d}_afterCPRemoval'], g[f'{d}_input2D'][:, 64:320, :])
+    spec = _reference_spectra(g)                                         # [pr, 256 bins, nt symbols]
+    ltf = g['ds_ltf_real'] + 1j * g['ds_ltf_imag']                       # [pr, 1280]
+    # the oracle: same window, same transform, DC in the middle, then the 234 data bins
+    rx = oracle.ofdm_demod(ltf, nt)                                      # [pr, 234, nt]
+    want = np.fft.fftshift(spec, axes=1)[:, oracle.data_carrier_indices() - 1, :]
+    np.testing.assert_allclose(rx, want, rtol=0, atol=1e-11 * np.abs(want).max())
+    # the known defect of the reference's line :453 (np.fft.fftshift without axes also rotates the SYMBOL
+    # axis by Nt/2): its recorded output equals the frequency shift the oracle applies plus that rotation
+    for d in ('real', 'imag'):
+        pre, post = g[f'{d}_fft_pre_shift'], g[f'{d}_fft_post_shift']
+        np.testing.assert_array_equal(post, np.roll(np.fft.fftshift(pre, axes=1), nt // 2, axis=2))
+        # ... and the rows it hands to the network keep the real part of column iTx of that array (:454-455)
+        X = g[f'{d}_X'].reshape(npkt * nr, nt, -1)
+        for t in range(nt):
+            np.testing.assert_array_equal(X[:, t, :256], post[:, :, t].real)
+            np.testing.assert_array_equal(X[:, t, 256:256 + nt], np.broadcast_to(g['ds_P'][:, t], (npkt * nr, nt)))
+        np.testing.assert_array_equal(X[:, :, 256 + nt:], np.broadcast_to(g['ltf_freqdom'], (npkt * nr, nt, 234)))
+
+
+def test_ls_estimate_on_reference_spectra(oracle, golden_dir):
+    """LS (a-2) fed with the reference-computed spectra equals the oracle's full time-domain LS path on the
+    same preambles - the OFDM half of ls_estimate is the pinned one."""
+    g = np.load(os.path.join(golden_dir, 'ref_ofdm_reshape_nt4.npz'))
+    nt = int(g['nt'])
+    rx = np.fft.fftshift(_reference_spectra(g), axes=1)[:, oracle.data_carrier_indices() - 1, :]
+    h_from_ref = np.swapaxes(oracle.ls_from_rxsym(rx, g['P_matlab']), -1, -2)          # [pr, nt, 234]
+    h = oracle.ls_estimate(g['ds_ltf_real'] + 1j * g['ds_ltf_imag'], g['P_matlab'])
+    np.testing.assert_allclose(h, h_from_ref, rtol=0, atol=1e-11 * np.abs(h_from_ref).max())
+
+
 def test_postprocess_index_map(oracle):
     o = np.arange(1, 53)[None, :].astype(np.complex128)
     y = oracle.postprocess_rice_renew(o).real.astype(int)[0]
