@@ -51,9 +51,12 @@ def build_parser():
 def _find_weights(modeldir, d):
     from .model import WEIGHT_FILE
     for cand in (os.path.join(modeldir, d + '_keras_model', WEIGHT_FILE),
+                 os.path.join(modeldir, d + '_weights-improvement.hdf5'),             # the reference's own checkpoint name, DNN.py:279-281
+                 os.path.join(modeldir, d + '_weights-improvement.h5'),
                  os.path.join(modeldir, d + '_weights-improvement.safetensors'),
                  os.path.join(modeldir, d + '_weights-improvement.pt'),
-                 os.path.join(modeldir, d + '_weights-improvement.npz')):
+                 os.path.join(modeldir, d + '_weights-improvement.npz'),
+                 os.path.join(modeldir, d + '_keras_model')):                         # a TF SavedModel directory (DNN.py:411)
         if os.path.exists(cand):
             return cand
     print('Given model directory holds no weights for the %s model. Aborting...' % d)
@@ -92,9 +95,14 @@ def train_main(args):
         print('Working on *', d, '* model')
         tr = ds.SampleGenerator(train_ids, data, d, batch_size=args.bs, shuffle=True, seed=args.seed)
         va = ds.SampleGenerator(val_ids, data, d, batch_size=args.bs, shuffle=True, seed=args.seed + 1)
-        if len(tr) == 0 or len(va) == 0:
-            print('Not enough samples for one batch of %d in the training / validation split. Aborting...' % args.bs)
-            sys.exit(0)
+        # decided by all ranks together: a rank leaving alone would strand the others in the gradient all-reduce
+        enough = min(len(tr), len(va))
+        if world > 1:
+            enough = int(dist.all_reduce_min(enough))
+        if enough == 0:
+            print('Not enough samples for one batch of %d in the training / validation split%s. Aborting...'
+                  % (args.bs, ' of at least one rank' if world > 1 else ''))
+            sys.exit(2)
         init = load_weight_file(_find_weights(args.init, d)) if args.init else None
         if world > 1 and init is None:
             # identical initial tensors on every rank: rank 0 draws them (Glorot through a scratch trainer), all receive
@@ -127,14 +135,29 @@ def main(argv=None):
     from .engine import CsiEngine
     from .model import CSIModel, load_weight_file
 
-    packed = ds.packets_from_dataset(ds.load_dataset(args.x))
+    data = ds.load_dataset(args.x)
+    packed = ds.packets_from_dataset(data)
+    if args.valSameTrain:
+        print('WARNING! Validation SAME AS Training!')                 # DNN.py:130-133: every packet is tested
+    else:
+        # DNN.py:125-128 + loadDataset (massiveMIMO_dataGenerator.py:46-55): the test set is the LAST
+        # floor(Npkt * valTrainRatio) packets, exported as files 1..n
+        print('Validation separate from Training')
+        _, val_ids = ds.split_train_val(data, args.valTrainRatio)
+        n_val = len(val_ids) // (packed['nt'] * packed['nr'])
+        first = packed['npkt'] - n_val
+        packed = dict(packed, ltf=packed['ltf'][first:], labels=packed['labels'][first:], npkt=n_val)
+        if n_val == 0:
+            print('The validation split holds no packet (valTrainRatio %.3g of %d packets). Aborting...' % (args.valTrainRatio, first))
+            sys.exit(0)
     nt, nr, npkt = packed['nt'], packed['nr'], packed['npkt']
     eng = CsiEngine(nt, nr, hidden=args.nn, n_out=packed['labels'].shape[-1], use_bn=args.useBN,
                     device=args.device, dtype=args.dtype)
+    models = {}
     for d in ('real', 'imag'):
         print('Working on *', d, '* model')
-        m = CSIModel(eng, d).load_weights(load_weight_file(_find_weights(modeldir, d)))
-        m.summary()
+        models[d] = CSIModel(eng, d).load_weights(load_weight_file(_find_weights(modeldir, d)))
+        models[d].summary()
     eng.set_pilot(packed['pilot'])
     if args.execTime:
         eng.profile_enable(True)
@@ -151,6 +174,9 @@ def main(argv=None):
     num = np.linalg.norm((h_ls - lab).reshape(npkt, -1), axis=1)
     print('LS(GPU) vs stored LS labels: max packet rel. error %.3e' % float(np.max(num / np.linalg.norm(lab.reshape(npkt, -1), axis=1))))
     files = ds.export_predictions(args.workdir, packed, out_re, out_im)
+    for d in ('real', 'imag'):
+        # DNN.py:411 CSI_predictor.save(<workdir>/<d>_keras_model): the folder inference.CSIPredictor loads
+        models[d].save(os.path.join(args.workdir, d + '_keras_model'), pilot=packed['pilot'])
     print('%d packets (%d pair-channels) in %.3f s incl. host transfers; wrote %d .mat files to %s'
           % (npkt, npkt * nr * nt, dt, len(files['real']) + len(files['imag']), args.workdir))
     if args.execTime:

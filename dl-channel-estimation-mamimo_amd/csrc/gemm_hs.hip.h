@@ -362,8 +362,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
 //   CAST mode:  A[m][k] = split( in_scale * X[m][k] )  from fp32 rows (layer 0), split-K over z.
 // Every wave owns 32 A rows (lane -> row, 8-column half of the 16-column sub-tile): per sub-tile it
 // turns the 8 (+8) values it requested one sub-tile earlier into 16 B of hi and 16 B of lo, writes
-// both chunks at their swizzled places (rows are permuted over the lanes so that each 16-lane
-// ds_write_b128 group covers all 64 banks), requests the next values, and issues its two B pieces
+// both chunks at their swizzled places (rows are permuted over the lanes so that each 8-lane
+// ds_write_b128 group covers all 32 banks), requests the next values, and issues its two B pieces
 // (one in P0, one in P1) D = 3 sub-tiles ahead.  One vmcnt(2) per sub-tile: the values are older
 // than the two B pieces issued behind them, and the wait retires every older B piece as well -
 // including sub-tile u+1, which P2(u) prefetches two barriers later.
@@ -417,9 +417,15 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
                                                  16, voff[u], sub * 64, 0, 0);
     };
-    // ---- A side: row 32w + perm(lane >> 1) (bits 2 and 3 swapped), k half lane & 1
+    // ---- A side: row 32w + perm(lane >> 1), k half lane & 1.  ds_write_b128 is serviced in groups of 8
+    // CONTIGUOUS lanes against 32 banks ((a / 4) mod 32, MI355X_MICROARCH.md "LDS"): the 8 lanes of a group
+    // must hit 8 different (row & 1, 16-byte chunk) pairs.  The chunk is (k half or 2 + k half) ^ ((row >> 2) & 3),
+    // so a group's four rows have to differ in bit 0 and in bit 3: lane bit 1 -> row bit 0, lane bit 2 ->
+    // row bit 3, lane bits 3, 4, 5 -> row bits 1, 2, 4.  (Round 1 mapped lane bit 2 to row bit 1: the four
+    // rows of a group shared the swizzle and every store was a 2-way conflict, SQ_LDS_BANK_CONFLICT 7.4e7
+    // per launch at config 2.)
     const int ridx = lane >> 1, kh = lane & 1;
-    const int arow = 32 * wave + ((ridx & 3) | ((ridx & 4) << 1) | ((ridx & 8) >> 1) | (ridx & 16));
+    const int arow = 32 * wave + ((ridx & 1) | ((ridx & 2) << 2) | ((ridx & 4) >> 1) | ((ridx & 8) >> 1) | (ridx & 16));
     const int aswz = (arow >> 2) & 3;
     const int a_hi_off = arow * PP_ROWF + ((kh ^ aswz) << 2);            // floats inside a sub-tile
     const int a_lo_off = arow * PP_ROWF + (((2 + kh) ^ aswz) << 2);

@@ -54,11 +54,17 @@ def evaluate(engine, model, gen, resident=False):
 
 
 def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, weights=None, method='default_SNR',
-        snr_levels=SNR_LEVELS_MAMIMO, es_patience=25, rlr_patience=20, rlr_factor=0.1, min_lr=None, seed=0,
+        snr_levels=SNR_LEVELS_MAMIMO, es_patience=25, rlr_patience=20, rlr_factor=0.1, rlr_min_delta=1e-4, min_lr=None, seed=0,
         verbose=True, commit=True, data_parallel=False, resident=None):
     """Trains one component model ('real' / 'imag') and returns the history dict
     {'loss': [...], 'val_loss': [...], 'lr': [...]}.  With commit the best weights (lowest val_loss,
     EarlyStopping restore_best_weights) become the engine's inference model.
+
+    Callback semantics are keras 2.3's for the arguments the reference passes (DNN.py:285-286):
+    EarlyStopping(patience 25) has min_delta 0 - an epoch improves when val_loss < best; ReduceLROnPlateau
+    (factor 0.1, patience 20) keeps the keras DEFAULT min_delta = 1e-4 - an epoch improves only when
+    val_loss < best - 1e-4, so at late-training loss levels the learning rate drops although the early
+    stopping counter still sees improvements (``rlr_min_delta``).
 
     data_parallel (torch.distributed initialised, one process per GPU, every rank calling fit with its
     own shard of batches and the same seed / initial weights): each step is backward -> one flat
@@ -126,7 +132,7 @@ def fit(engine, model, train_gen, val_gen, epochs=500, lr=1e-4, dropout=0.15, we
                     print(f'Epoch {ep + 1}: early stopping')
                 break
         # ReduceLROnPlateau keeps its own best / wait (keras resets wait to 0 after a reduction)
-        if val < rlr_best:
+        if val < rlr_best - rlr_min_delta:
             rlr_best, rlr_wait = val, 0
         else:
             rlr_wait += 1

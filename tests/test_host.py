@@ -401,3 +401,69 @@ def test_mixed_snr_batch_generator(pkg, oracle):
     H = np.fft.fftshift(np.fft.fft(cir, n=256, axis=-1), axes=-1)[..., oracle.data_carrier_indices() - 1].reshape(2, 2, 8, 234)
     assert np.abs(h - H).max() / np.abs(H).max() < 2e-6
     assert np.array_equal(pkg.synth.vht_ltf_sequence(), oracle.vht_ltf_256().astype(np.float32))
+
+
+class _FakeTrainEngine:
+    """Stands in for CsiEngine in trainer.fit: the validation loss of epoch e is scripted, so that the two
+    callback schedules can be pinned without a GPU."""
+
+    def __init__(self, val_losses):
+        self.val = list(val_losses)
+        self.epoch = 0
+        self.lr_calls = []
+        self.loaded = None
+
+    def train_begin(self, model, weights=None, lr=1e-4, dropout=0.15, seed=0):
+        self.lr = lr
+
+    def train_step(self, model, rows, y, noise_std=0.0):
+        return 1.0
+
+    def train_eval(self, model, rows, y):
+        v = self.val[min(self.epoch, len(self.val) - 1)]
+        self.epoch += 1
+        return v
+
+    def train_weights(self, model):
+        return {'epoch': np.array([self.epoch])}          # epoch counter AFTER the evaluation that was best
+
+    def train_set_lr(self, model, lr):
+        self.lr_calls.append((self.epoch, lr))
+
+    def train_end(self, model, commit=True):
+        pass
+
+    def load_weights(self, model, w):
+        self.loaded = w
+
+
+def test_fit_callback_schedules_follow_keras_defaults(pkg):
+    """EarlyStopping(patience, min_delta 0) and ReduceLROnPlateau(patience, factor, keras default
+    min_delta 1e-4) as the reference configures them (DNN.py:285-286), on scripted validation losses."""
+    gen = [([np.zeros((4, 8), np.float32), np.zeros((4, 2), np.float32)], np.zeros((4, 3), np.float32), None)]
+    # improvements of 2e-5 per epoch: real improvements for EarlyStopping, none (< 1e-4 within its patience) for ReduceLROnPlateau
+    vals = [1.0 - 2e-5 * e for e in range(12)]
+    eng = _FakeTrainEngine(vals)
+    h = pkg.trainer.fit(eng, 'real', gen, gen, epochs=12, lr=1e-3, method='default', es_patience=4, rlr_patience=3,
+                        verbose=False, commit=True)
+    assert len(h['val_loss']) == 12                               # never stopped early: every epoch improved (min_delta 0)
+    # ReduceLROnPlateau: best = epoch 1 (1.0); epochs 2, 3, 4 are not < best - 1e-4 -> wait 3 = patience -> x0.1 after epoch 4
+    assert eng.lr_calls[0][0] == 4 and abs(eng.lr_calls[0][1] - 1e-4) < 1e-12
+    assert h['lr'][0] == 1e-3 and min(h['lr']) >= 1e-5 - 1e-18     # min_lr = lr * 0.01 (DNN.py:286)
+    assert eng.loaded['epoch'][0] == 12                            # best weights = last epoch (restore_best_weights)
+    # with min_delta 0 (the pre-fix behaviour) the same run never reduces the rate
+    eng0 = _FakeTrainEngine(vals)
+    pkg.trainer.fit(eng0, 'real', gen, gen, epochs=12, lr=1e-3, method='default', es_patience=4, rlr_patience=3,
+                    rlr_min_delta=0.0, verbose=False)
+    assert eng0.lr_calls == []
+    # plateau: early stopping fires `patience` epochs after the best one and hands back the best weights;
+    # the rate is reduced once on the way (wait reaches 3 at epoch 5), keras order [earlystop, reduce_lr]
+    vals = [0.5, 0.4, 0.45, 0.46, 0.47, 0.48, 0.49, 0.5]
+    eng = _FakeTrainEngine(vals)
+    h = pkg.trainer.fit(eng, 'real', gen, gen, epochs=50, lr=1e-3, method='default', es_patience=4, rlr_patience=3, verbose=False)
+    assert len(h['val_loss']) == 6 and h['best_val_loss'] == 0.4 and eng.loaded['epoch'][0] == 2
+    assert eng.lr_calls == [(5, 1e-4)]
+    # the rate never goes below min_lr and is not "reduced" again once there
+    eng = _FakeTrainEngine([1.0] * 40)
+    h = pkg.trainer.fit(eng, 'real', gen, gen, epochs=40, lr=1e-3, method='default', es_patience=100, rlr_patience=2, verbose=False)
+    assert [round(l, 9) for _, l in eng.lr_calls] == [1e-4, 1e-5]
