@@ -16,7 +16,7 @@ from .model import CSIModel, load_weight_file, config_from_weights, WEIGHT_FILE,
 class CSIPredictor:
 
     def __init__(self, model_path, experiment='RICE_RENEW', verbose=False, device=0, pilot=None,
-                 workspace_bytes=0):
+                 workspace_bytes=0, nr=None):
         self.path = model_path
         self.experiment = experiment
         self.verbose = verbose
@@ -24,17 +24,41 @@ class CSIPredictor:
         self.workspace_bytes = workspace_bytes
         self.engine = None
         self._pilot = pilot
+        self._nr = nr
+        self._any_nr = False
         self.model_real, self.model_imag = self.load_model()
 
     # inference.py:14-22
     def load_model(self):
+        """``<model_path>/{real,imag}_keras_model`` - either the folder CSIModel.save writes (weights.safetensors +
+        config.json) or the TF SavedModel directory the reference's test run leaves there (DNN.py:411), whose
+        ``variables/`` bundle is read directly (keras_files.py).  A SavedModel carries neither the pilot matrix
+        (pass ``pilot=`` or call set_pilot) nor the rx-antenna count: packets are independent per rx antenna, so
+        without ``nr=`` any [nPkt, nRx, lenLTF] batch is accepted."""
         dirs = {d: os.path.join(self.path, d + '_keras_model') for d in ('real', 'imag')}
         weights, cfg = {}, None
         for d, p in dirs.items():
-            weights[d] = load_weight_file(os.path.join(p, WEIGHT_FILE))
-            with open(os.path.join(p, CONFIG_FILE)) as f:
-                c = json.load(f)
-            cfg = cfg or c
+            if os.path.exists(os.path.join(p, WEIGHT_FILE)):
+                weights[d] = load_weight_file(os.path.join(p, WEIGHT_FILE))
+                with open(os.path.join(p, CONFIG_FILE)) as f:
+                    c = json.load(f)
+                cfg = cfg or c
+            else:
+                weights[d] = load_weight_file(p)            # SavedModel directory (raises if it is neither)
+        if cfg is None:
+            w = weights['real']
+            d_in = int(w['fc_dense0.kernel'].shape[0])
+            two_input = self.experiment == 'matlab_maMimo'
+            if two_input and d_in % 321:
+                print('[CSIPredictor] ERROR: the saved model has %d inputs, not 321*nTx (LTF samples + pilot row).' % d_in)
+                sys.exit(-1)
+            hidden, i = [], 0
+            while f'fc_dense{i}.kernel' in w:
+                hidden.append(int(w[f'fc_dense{i}.kernel'].shape[1]))
+                i += 1
+            cfg = dict(nt=d_in // 321 if two_input else 0, nr=self._nr or 1, len_ltf=d_in, hidden=hidden,
+                       n_out=int(w['fc_regressor.kernel'].shape[1]), use_bn='bn0.gamma' in w, bn_eps=1e-3)
+            self._any_nr = two_input and self._nr is None
         nt, nr = int(cfg['nt']), int(cfg.get('nr', 1))
         if nt > 0:
             shape = config_from_weights(weights['real'], nt)
@@ -67,7 +91,13 @@ class CSIPredictor:
         if self.experiment == 'matlab_maMimo':
             # X complex [npkt, nr, len_ltf]: both component models over all nt*nr pairs of each
             # packet, dataset sample order (mk.py:62) -> [npkt, nr, nt, n_out]
-            output_real, output_imag = self.engine.predict(X)
+            if self._any_nr:        # engine built for one rx antenna per item: [nPkt, nRx, L] -> [nPkt*nRx, 1, L] and back
+                npkt, nrx = X.shape[:2]
+                output_real, output_imag = self.engine.predict(X.reshape(npkt * nrx, 1, X.shape[2]))
+                output_real = output_real.reshape(npkt, nrx, *output_real.shape[2:])
+                output_imag = output_imag.reshape(npkt, nrx, *output_imag.shape[2:])
+            else:
+                output_real, output_imag = self.engine.predict(X)
         else:
             bs = X.shape[0]   # assumes num. of samples in the first dimension
             output_real = self.model_real.predict(X.real, batch_size=bs)
@@ -78,7 +108,11 @@ class CSIPredictor:
     def ls_estimate(self, input_batch: np.ndarray):
         """LS pilot estimate of the same packets (helperMIMOChannelEstimate.m), complex64
         [npkt, nr, nt, 234]; matlab_maMimo only."""
-        return self.engine.ls_estimate(self.preprocess_data(input_batch))
+        X = self.preprocess_data(input_batch)
+        if self._any_nr:
+            h = self.engine.ls_estimate(X.reshape(X.shape[0] * X.shape[1], 1, X.shape[2]))
+            return h.reshape(X.shape[0], X.shape[1], *h.shape[2:])
+        return self.engine.ls_estimate(X)
 
     # inference.py:35-46
     def preprocess_data(self, input_batch):
@@ -89,8 +123,9 @@ class CSIPredictor:
                 sys.exit(-1)
             if self.experiment == 'matlab_maMimo':
                 e = self.engine
-                if input_batch.ndim != 3 or input_batch.shape[1:] != (e.nr, e.len_ltf):
-                    print('[CSIPredictor] ERROR: Input batch must have shape [nPkt, %d, %d].' % (e.nr, e.len_ltf))
+                ok = input_batch.ndim == 3 and input_batch.shape[2] == e.len_ltf and (self._any_nr or input_batch.shape[1] == e.nr)
+                if not ok:
+                    print('[CSIPredictor] ERROR: Input batch must have shape [nPkt, %s, %d].' % ('nRx' if self._any_nr else e.nr, e.len_ltf))
                     sys.exit(-1)
             prep_data = input_batch
         else:

@@ -1,0 +1,657 @@
+"""Readers for the model files the REFERENCE writes, with no TensorFlow / h5py dependency:
+
+  * ``<d>_weights-improvement.hdf5`` - the Keras-2.3 HDF5 weight checkpoint of
+    massiveMIMO_CSI_prediction_DNN.py:279-281,319 (``ModelCheckpoint`` / ``save_weights``), loaded there by
+    ``load_weights`` (:334).  Layout (keras ``hdf5_format.save_weights_to_hdf5_group``): root attribute
+    ``layer_names`` (fixed-length strings, model layer order), one group per layer with attribute
+    ``weight_names`` and one contiguous little-endian dataset per weight at ``<layer>/<weight name>`` -
+    weight names contain a '/', so the datasets sit one group deeper (``fc_dense0/fc_dense0/kernel:0``).
+    Whole-model ``.h5`` files (``model.save('x.h5')``) carry the same tree under ``/model_weights``.
+  * ``<d>_keras_model/`` - the TF SavedModel directory of :411 (``CSI_predictor.save``), read by
+    inference.py:15-16: the tensors live in ``variables/variables.index`` (an SSTable of
+    ``BundleEntryProto`` records) + ``variables/variables.data-?????-of-?????`` (raw little-endian bytes).
+
+Both return ``{keras variable path: float32 ndarray}`` in model order; ``model.normalize_keras_names`` maps the
+paths to the container's names (BatchNormalization layers by order, as load-by-topology does).
+
+Only what those writers emit is understood (HDF5: superblock 0-3, version-1/2 object headers, symbol-table
+groups and compact link messages, contiguous / compact datasets of fixed-point or IEEE float type,
+fixed- and variable-length string attributes; TensorBundle: uncompressed or snappy-compressed index blocks,
+DT_FLOAT / DT_HALF / DT_DOUBLE / integer tensors without slices).  Anything else raises ``KerasFileError`` naming
+the construct - never a silent wrong answer."""
+import os
+import struct
+
+import numpy as np
+
+
+class KerasFileError(ValueError):
+    pass
+
+
+# =====================================================================================================
+# HDF5 (the subset libhdf5 1.8 / 1.10 writes for h5py files without chunking or compression)
+# =====================================================================================================
+_H5_SIG = b'\x89HDF\r\n\x1a\n'
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class _H5Type:
+    def __init__(self, cls, size, dtype=None, strpad=0, base=None, vlen_string=False):
+        self.cls, self.size, self.dtype, self.strpad, self.base, self.vlen_string = cls, size, dtype, strpad, base, vlen_string
+
+
+class Hdf5File:
+    """Minimal read-only HDF5 object model: ``f[path]`` -> ``Hdf5Group`` / ``Hdf5Dataset``; ``.attrs`` dicts;
+    ``group.keys()`` in stored (name) order."""
+
+    def __init__(self, path):
+        with open(path, 'rb') as fh:
+            self.buf = fh.read()
+        self.path = path
+        base = 0
+        while True:
+            if self.buf[base:base + 8] == _H5_SIG:
+                break
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(self.buf):
+                raise KerasFileError(f'{path}: not an HDF5 file (no superblock signature)')
+        ver = self.buf[base + 8]
+        if ver in (0, 1):
+            self.so, self.sl = self.buf[base + 13], self.buf[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            self.base = self._off(p)
+            p += 4 * self.so                                   # base, free-space, end-of-file, driver-info addresses
+            # root group symbol-table entry: link name offset, object header address, cache type, reserved, scratch
+            self.root_addr = self._off(p + self.so)
+        elif ver in (2, 3):
+            self.so, self.sl = self.buf[base + 9], self.buf[base + 10]
+            p = base + 12
+            self.base = self._off(p)
+            self.root_addr = self._off(p + 3 * self.so)
+        else:
+            raise KerasFileError(f'{path}: HDF5 superblock version {ver} is not supported')
+        if self.so not in (4, 8) or self.sl not in (4, 8):
+            raise KerasFileError(f'{path}: HDF5 offset / length sizes {self.so}/{self.sl} are not supported')
+        self.base += 0 if ver in (0, 1) else 0
+        self.root = Hdf5Group(self, self.root_addr, '/')
+
+    # ---- primitive readers
+    def _u(self, p, n):
+        return int.from_bytes(self.buf[p:p + n], 'little')
+
+    def _off(self, p):
+        return self._u(p, self.so)
+
+    def _len(self, p):
+        return self._u(p, self.sl)
+
+    def __getitem__(self, path):
+        node = self.root
+        for part in [q for q in path.split('/') if q]:
+            node = node[part]
+        return node
+
+    # ---- object headers -> list of (type, flags, payload offset, payload size)
+    def messages(self, addr):
+        a = addr + self.base
+        buf = self.buf
+        out = []
+        if buf[a:a + 4] == b'OHDR':
+            if buf[a + 4] != 2:
+                raise KerasFileError(f'{self.path}: object header version {buf[a + 4]} at {addr:#x}')
+            flags = buf[a + 5]
+            p = a + 6
+            if flags & 0x20:
+                p += 16                                        # access / modification / change / birth times
+            if flags & 0x10:
+                p += 4                                         # max compact / min dense attributes
+            szb = 1 << (flags & 3)
+            chunk = self._u(p, szb)
+            p += szb
+            blocks = [(p, p + chunk)]
+            while blocks:
+                q, end = blocks.pop(0)
+                while q + 4 <= end:
+                    mtype, msize, mflags = buf[q], self._u(q + 1, 2), buf[q + 3]
+                    q += 4 + (2 if flags & 0x04 else 0)
+                    if q + msize > end:
+                        break
+                    if mtype == 0x10:
+                        co, cl = self._off(q) + self.base, self._len(q + self.so)
+                        if buf[co:co + 4] != b'OCHK':
+                            raise KerasFileError(f'{self.path}: bad object header continuation at {co:#x}')
+                        blocks.append((co + 4, co + cl - 4))
+                    elif mtype != 0:
+                        out.append((mtype, mflags, q, msize))
+                    q += msize
+            return out
+        if buf[a] != 1:
+            raise KerasFileError(f'{self.path}: object header version {buf[a]} at {addr:#x} is not supported')
+        nmsg, hsize = self._u(a + 2, 2), self._u(a + 8, 4)
+        blocks = [(a + 16, a + 16 + hsize)]
+        while blocks and len(out) < nmsg + 64:
+            q, end = blocks.pop(0)
+            while q + 8 <= end:
+                mtype, msize, mflags = self._u(q, 2), self._u(q + 2, 2), buf[q + 4]
+                q += 8
+                if mtype == 0x10:
+                    blocks.append((self._off(q) + self.base, self._off(q) + self.base + self._len(q + self.so)))
+                elif mtype != 0:
+                    out.append((mtype, mflags, q, msize))
+                q += msize
+        return out
+
+    # ---- datatype / dataspace messages
+    def parse_type(self, p):
+        buf = self.buf
+        cls, ver = buf[p] & 0x0f, buf[p] >> 4
+        b0, b1 = buf[p + 1], buf[p + 2]
+        size = self._u(p + 4, 4)
+        if cls == 0:                                           # fixed point
+            dt = np.dtype(('>' if b0 & 1 else '<') + ('i' if b0 & 8 else 'u') + str(size))
+            return _H5Type(cls, size, dt)
+        if cls == 1:                                           # IEEE float (libhdf5 native float types only)
+            if size not in (2, 4, 8):
+                raise KerasFileError(f'{self.path}: {size}-byte floating-point type')
+            exp_size, mant_size = buf[p + 13], buf[p + 15]
+            if (size, exp_size, mant_size) not in ((2, 5, 10), (4, 8, 23), (8, 11, 52)):
+                raise KerasFileError(f'{self.path}: non-IEEE float layout (exponent {exp_size}, mantissa {mant_size} bits)')
+            return _H5Type(cls, size, np.dtype(('>' if b0 & 1 else '<') + 'f' + str(size)))
+        if cls == 3:                                           # fixed-length string
+            return _H5Type(cls, size, np.dtype('S' + str(size)), strpad=b0 & 0x0f)
+        if cls == 9:                                           # variable length: (type 1 = string) of a base type
+            base = self.parse_type(p + 8)
+            return _H5Type(cls, size, None, base=base, vlen_string=(b0 & 0x0f) == 1)
+        raise KerasFileError(f'{self.path}: HDF5 datatype class {cls} is not supported')
+
+    def parse_space(self, p):
+        buf = self.buf
+        ver, rank, flags = buf[p], buf[p + 1], buf[p + 2]
+        if ver == 1:
+            q = p + 8
+        elif ver == 2:
+            if buf[p + 3] == 2:
+                return None                                    # null dataspace
+            q = p + 4
+        else:
+            raise KerasFileError(f'{self.path}: dataspace message version {ver}')
+        return tuple(self._len(q + i * self.sl) for i in range(rank))
+
+    def global_heap_object(self, addr, index):
+        a = addr + self.base
+        if self.buf[a:a + 4] != b'GCOL':
+            raise KerasFileError(f'{self.path}: bad global heap collection at {addr:#x}')
+        end = a + self._len(a + 8)
+        q = a + 8 + self.sl
+        while q + 8 + self.sl <= end:
+            idx, size = self._u(q, 2), self._len(q + 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return self.buf[q + 8 + self.sl:q + 8 + self.sl + size]
+            q += 8 + self.sl + ((size + 7) & ~7)
+        raise KerasFileError(f'{self.path}: global heap object {index} not found at {addr:#x}')
+
+    def decode(self, typ, shape, raw):
+        """raw bytes of `shape` elements of `typ` -> ndarray / list of bytes"""
+        n = int(np.prod(shape)) if shape else 1
+        if typ.cls == 9:
+            if not typ.vlen_string:
+                raise KerasFileError(f'{self.path}: variable-length sequences are not supported')
+            vals, step = [], 4 + self.so + 4
+            for i in range(n):
+                q = i * step
+                length = int.from_bytes(raw[q:q + 4], 'little')
+                addr = int.from_bytes(raw[q + 4:q + 4 + self.so], 'little')
+                idx = int.from_bytes(raw[q + 4 + self.so:q + 8 + self.so], 'little')
+                vals.append(self.global_heap_object(addr, idx)[:length] if length else b'')
+            return np.array(vals, dtype=object).reshape(shape) if shape else vals[0]
+        arr = np.frombuffer(raw, dtype=typ.dtype, count=n)
+        if typ.cls == 3:
+            # numpy 'S' drops trailing NULs itself (null-terminated / null-padded); space padding is stripped here
+            arr = np.array([bytes(v).rstrip(b' ') if typ.strpad == 2 else bytes(v) for v in arr], dtype=object) if typ.strpad == 2 else arr
+        arr = arr.reshape(shape) if shape else arr.reshape(())
+        return arr
+
+    def attributes(self, addr):
+        out = {}
+        for mtype, _, p, size in self.messages(addr):
+            if mtype != 0x0c:
+                continue
+            buf = self.buf
+            ver = buf[p]
+            nsz, tsz, ssz = self._u(p + 2, 2), self._u(p + 4, 2), self._u(p + 6, 2)
+            q = p + 8 + (1 if ver == 3 else 0)
+            pad = (lambda x: (x + 7) & ~7) if ver == 1 else (lambda x: x)
+            if ver not in (1, 2, 3):
+                raise KerasFileError(f'{self.path}: attribute message version {ver}')
+            name = buf[q:q + nsz].split(b'\0')[0].decode('utf8')
+            q += pad(nsz)
+            if ver >= 2 and buf[p + 1] & 3:
+                raise KerasFileError(f'{self.path}: attribute {name!r} uses a shared datatype / dataspace')
+            typ = self.parse_type(q)
+            q += pad(tsz)
+            shape = self.parse_space(q)
+            q += pad(ssz)
+            if shape is None:
+                out[name] = None
+                continue
+            n = int(np.prod(shape)) if shape else 1
+            out[name] = self.decode(typ, shape, buf[q:q + n * typ.size])
+        return out
+
+
+class Hdf5Dataset:
+    def __init__(self, f, addr, name):
+        self.file, self.addr, self.name = f, addr, name
+        typ = shape = layout = None
+        for mtype, _, p, size in f.messages(addr):
+            if mtype == 0x03:
+                typ = f.parse_type(p)
+            elif mtype == 0x01:
+                shape = f.parse_space(p)
+            elif mtype == 0x08:
+                layout = (p, size)
+            elif mtype == 0x0b:
+                raise KerasFileError(f'{f.path}: dataset {name} has a filter pipeline (compression) - not what keras save_weights writes')
+        if typ is None or shape is None or layout is None:
+            raise KerasFileError(f'{f.path}: {name} is not a dataset (no datatype / dataspace / layout message)')
+        self.type, self.shape, self._layout = typ, shape, layout
+
+    @property
+    def attrs(self):
+        return self.file.attributes(self.addr)
+
+    def read(self):
+        f = self.file
+        p, _ = self._layout
+        buf = f.buf
+        ver = buf[p]
+        nbytes = (int(np.prod(self.shape)) if self.shape else 1) * self.type.size
+        if ver in (3, 4):
+            cls = buf[p + 1]
+            if cls == 1:                                       # contiguous
+                addr = f._off(p + 2)
+                if addr == _UNDEF & ((1 << (8 * f.so)) - 1):
+                    return np.zeros(self.shape, self.type.dtype)        # never written: fill value 0
+                raw = buf[addr + f.base:addr + f.base + nbytes]
+            elif cls == 0:                                     # compact
+                raw = buf[p + 4:p + 4 + f._u(p + 2, 2)][:nbytes]
+            else:
+                raise KerasFileError(f'{f.path}: dataset {self.name} is chunked - not what keras save_weights writes')
+        elif ver in (1, 2):
+            rank, cls = buf[p + 1], buf[p + 2]
+            if cls == 1:
+                addr = f._off(p + 8)
+                raw = buf[addr + f.base:addr + f.base + nbytes]
+            elif cls == 0:
+                q = p + 8 + 4 * rank
+                raw = buf[q + 4:q + 4 + f._u(q, 4)][:nbytes]
+            else:
+                raise KerasFileError(f'{f.path}: dataset {self.name} is chunked - not what keras save_weights writes')
+        else:
+            raise KerasFileError(f'{f.path}: data layout message version {ver}')
+        if len(raw) != nbytes:
+            raise KerasFileError(f'{f.path}: dataset {self.name} is truncated ({len(raw)} of {nbytes} bytes)')
+        return f.decode(self.type, self.shape, raw)
+
+
+class Hdf5Group:
+    def __init__(self, f, addr, name):
+        self.file, self.addr, self.name = f, addr, name
+        self._links = None
+
+    @property
+    def attrs(self):
+        return self.file.attributes(self.addr)
+
+    def _load(self):
+        if self._links is not None:
+            return
+        f, links = self.file, {}
+        for mtype, _, p, size in f.messages(self.addr):
+            if mtype == 0x11:                                  # symbol table: B-tree v1 of symbol nodes + local heap of names
+                btree, heap = f._off(p), f._off(p + f.so)
+                h = heap + f.base
+                if f.buf[h:h + 4] != b'HEAP':
+                    raise KerasFileError(f'{f.path}: bad local heap at {heap:#x}')
+                data = f._off(h + 8 + 2 * f.sl) + f.base
+                self._walk_btree(btree, data, links)
+            elif mtype == 0x06:                                # link message (new-style compact group)
+                buf = f.buf
+                flags = buf[p + 1]
+                q = p + 2
+                ltype = 0
+                if flags & 0x08:
+                    ltype = buf[q]
+                    q += 1
+                if flags & 0x04:
+                    q += 8
+                if flags & 0x10:
+                    q += 1
+                lsz = 1 << (flags & 3)
+                nlen = f._u(q, lsz)
+                q += lsz
+                nm = buf[q:q + nlen].decode('utf8')
+                q += nlen
+                if ltype == 0:
+                    links[nm] = f._off(q)
+            elif mtype == 0x02:
+                # link info: dense storage when the fractal-heap address is defined
+                buf = f.buf
+                q = p + 2 + (8 if buf[p + 1] & 1 else 0)
+                if f._off(q) != _UNDEF & ((1 << (8 * f.so)) - 1):
+                    raise KerasFileError(f'{f.path}: group {self.name} uses dense link storage (libver="latest" with > 8 links) - not supported')
+        self._links = links
+
+    def _walk_btree(self, addr, heap_data, links):
+        f = self.file
+        a = addr + f.base
+        buf = f.buf
+        if buf[a:a + 4] == b'SNOD':
+            n = f._u(a + 6, 2)
+            q = a + 8
+            esz = 2 * f.so + 24
+            for i in range(n):
+                noff, oaddr = f._off(q), f._off(q + f.so)
+                s = heap_data + noff
+                links[buf[s:buf.index(b'\0', s)].decode('utf8')] = oaddr
+                q += esz
+            return
+        if buf[a:a + 4] != b'TREE' or buf[a + 4] != 0:
+            raise KerasFileError(f'{f.path}: bad group B-tree node at {addr:#x}')
+        n = f._u(a + 6, 2)
+        q = a + 8 + 2 * f.so + f.sl                           # skip siblings and key 0
+        for i in range(n):
+            self._walk_btree(f._off(q), heap_data, links)
+            q += f.so + f.sl
+
+    def keys(self):
+        self._load()
+        return list(self._links)
+
+    def __contains__(self, k):
+        self._load()
+        return k in self._links
+
+    def __getitem__(self, k):
+        self._load()
+        if k not in self._links:
+            raise KeyError(f'{self.name}: no member {k!r}')
+        addr = self._links[k]
+        full = self.name.rstrip('/') + '/' + k
+        kinds = {m[0] for m in self.file.messages(addr)}
+        return Hdf5Dataset(self.file, addr, full) if 0x08 in kinds else Hdf5Group(self.file, addr, full)
+
+
+def _as_names(v):
+    if v is None:
+        return []
+    return [bytes(x).decode('utf8') if not isinstance(x, str) else x for x in np.asarray(v).reshape(-1).tolist()]
+
+
+def read_keras_hdf5_weights(path):
+    """{'<layer>/<weight name>': float32 ndarray} of a Keras HDF5 weights / whole-model file, in the order keras
+    itself walks them when loading by topology: root attribute ``layer_names``, per layer ``weight_names``
+    (attributes split into ``name0, name1, ...`` chunks by keras for very long lists are re-joined)."""
+    f = Hdf5File(path)
+    root = f.root
+    if 'layer_names' not in root.attrs and 'model_weights' in root:
+        root = root['model_weights']                                            # model.save('x.h5')
+
+    def listed(attrs, key):
+        if key in attrs:
+            return _as_names(attrs[key])
+        out, i = [], 0
+        while f'{key}{i}' in attrs:
+            out += _as_names(attrs[f'{key}{i}'])
+            i += 1
+        if i == 0:
+            raise KerasFileError(f'{path}: no {key!r} attribute - not a keras weights file')
+        return out
+
+    out = {}
+    for layer in listed(root.attrs, 'layer_names'):
+        g = root[layer]
+        for wname in listed(g.attrs, 'weight_names'):
+            node = g
+            for part in wname.split('/'):
+                node = node[part]
+            if not isinstance(node, Hdf5Dataset):
+                raise KerasFileError(f'{path}: {layer}/{wname} is not a dataset')
+            out[f'{layer}/{wname}' if not wname.startswith(layer + '/') else wname] = np.asarray(node.read(), dtype=np.float32)
+    return out
+
+
+# =====================================================================================================
+# TF SavedModel variables (TensorBundle): variables.index (SSTable) + variables.data-*
+# =====================================================================================================
+_TABLE_MAGIC = 0xdb4775248b80fb57
+_DT = {1: '<f4', 2: '<f8', 3: '<i4', 4: 'u1', 5: '<i2', 6: 'i1', 9: '<i8', 10: '?', 17: '<u2', 19: '<f2', 22: '<u4', 23: '<u8'}
+
+
+def _varint(b, p):
+    v = shift = 0
+    while True:
+        c = b[p]
+        p += 1
+        v |= (c & 0x7f) << shift
+        if c < 0x80:
+            return v, p
+        shift += 7
+
+
+def _snappy_decompress(src):
+    n, p = _varint(src, 0)
+    out = bytearray()
+    while p < len(src):
+        tag = src[p]
+        p += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(src[p:p + nb], 'little')
+                p += nb
+            ln += 1
+            out += src[p:p + ln]
+            p += ln
+            continue
+        if kind == 1:
+            ln, off = ((tag >> 2) & 7) + 4, ((tag >> 5) << 8) | src[p]
+            p += 1
+        elif kind == 2:
+            ln, off = (tag >> 2) + 1, int.from_bytes(src[p:p + 2], 'little')
+            p += 2
+        else:
+            ln, off = (tag >> 2) + 1, int.from_bytes(src[p:p + 4], 'little')
+            p += 4
+        if off == 0 or off > len(out):
+            raise KerasFileError('corrupt snappy block in variables.index')
+        for _ in range(ln):
+            out.append(out[-off])
+    if len(out) != n:
+        raise KerasFileError('corrupt snappy block in variables.index (length)')
+    return bytes(out)
+
+
+def _table_block(buf, off, size):
+    """contents of the block at (off, size): 1-byte compression type + 4-byte crc follow it"""
+    raw, ctype = buf[off:off + size], buf[off + size]
+    if ctype == 1:
+        raw = _snappy_decompress(raw)
+    elif ctype != 0:
+        raise KerasFileError(f'variables.index: block compression type {ctype}')
+    return raw
+
+
+def _block_entries(block):
+    """(key, value) pairs of one SSTable block (prefix-compressed keys, restart array at the end)"""
+    nrestart = struct.unpack('<I', block[-4:])[0]
+    end = len(block) - 4 - 4 * nrestart
+    p, key = 0, b''
+    while p < end:
+        shared, p = _varint(block, p)
+        non_shared, p = _varint(block, p)
+        vlen, p = _varint(block, p)
+        key = key[:shared] + block[p:p + non_shared]
+        p += non_shared
+        yield key, block[p:p + vlen]
+        p += vlen
+
+
+def _proto_fields(b):
+    """flat protobuf wire parse -> list of (field number, wire type, value)"""
+    p, out = 0, []
+    while p < len(b):
+        tag, p = _varint(b, p)
+        fn, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, p = _varint(b, p)
+        elif wt == 1:
+            v, p = b[p:p + 8], p + 8
+        elif wt == 2:
+            ln, p = _varint(b, p)
+            v, p = b[p:p + ln], p + ln
+        elif wt == 5:
+            v, p = b[p:p + 4], p + 4
+        else:
+            raise KerasFileError(f'variables.index: protobuf wire type {wt}')
+        out.append((fn, wt, v))
+    return out
+
+
+_CRC32C_TABLE = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli), the checksum TensorBundle stores (masked) per tensor."""
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        t = np.arange(256, dtype=np.uint32)
+        for _ in range(8):
+            t = np.where(t & 1, (t >> 1) ^ np.uint32(0x82F63B78), t >> 1).astype(np.uint32)
+        _CRC32C_TABLE = t
+    t = _CRC32C_TABLE
+    crc = np.uint32(crc ^ 0xFFFFFFFF)
+    # byte-serial table walk, vectorised 4 Ki bytes at a time is not possible (serial dependency): plain loop on a
+    # python int is fast enough for the few MB checked here
+    c = int(crc)
+    tab = t.tolist()
+    for byte in memoryview(data).cast('B') if not isinstance(data, (bytes, bytearray)) else data:
+        c = tab[(c ^ byte) & 0xff] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _unmask_crc(masked):
+    rot = (masked - 0xa282ead8) & 0xFFFFFFFF
+    return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
+
+
+def read_tensor_bundle(prefix, verify_crc=False):
+    """{key: ndarray} of the tensor bundle ``<prefix>.index`` + ``<prefix>.data-xxxxx-of-yyyyy`` in key order
+    (keys of object-based checkpoints look like ``layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE``)."""
+    with open(prefix + '.index', 'rb') as fh:
+        buf = fh.read()
+    if len(buf) < 48 or struct.unpack('<Q', buf[-8:])[0] != _TABLE_MAGIC:
+        raise KerasFileError(f'{prefix}.index: not a TensorBundle index (table magic)')
+    foot = buf[-48:]
+    _, p = _varint(foot, 0)                                    # metaindex handle: offset, size
+    _, p = _varint(foot, p)
+    ioff, p = _varint(foot, p)
+    isize, p = _varint(foot, p)
+    entries = []
+    for _, handle in _block_entries(_table_block(buf, ioff, isize)):
+        boff, q = _varint(handle, 0)
+        bsize, q = _varint(handle, q)
+        entries += list(_block_entries(_table_block(buf, boff, bsize)))
+    num_shards, shards = 1, {}
+    out = {}
+    for key, val in entries:
+        if key == b'':                                         # BundleHeaderProto: num_shards = 1, endianness = 2
+            for fn, wt, v in _proto_fields(val):
+                if fn == 1:
+                    num_shards = v
+                if fn == 2 and v != 0:
+                    raise KerasFileError(f'{prefix}.index: big-endian bundle')
+            continue
+        dtype = shard = offset = size = 0
+        shape, crc, sliced = [], None, False
+        for fn, wt, v in _proto_fields(val):
+            if fn == 1:
+                dtype = v
+            elif fn == 2:
+                for f2, _, v2 in _proto_fields(v):             # TensorShapeProto.dim
+                    if f2 == 2:
+                        dim = [x for f3, _, x in _proto_fields(v2) if f3 == 1]
+                        shape.append(dim[0] if dim else 0)
+            elif fn == 3:
+                shard = v
+            elif fn == 4:
+                offset = v
+            elif fn == 5:
+                size = v
+            elif fn == 6:
+                crc = struct.unpack('<I', v)[0]
+            elif fn == 7:
+                sliced = True
+        name = key.decode('utf8')
+        if dtype == 7 or dtype == 21 or dtype not in _DT:      # DT_STRING (the object graph) / DT_VARIANT / others: not weights
+            continue
+        if sliced:
+            raise KerasFileError(f'{prefix}.index: tensor {name} is stored in slices (partitioned variable)')
+        if shard not in shards:
+            fn_ = '%s.data-%05d-of-%05d' % (prefix, shard, num_shards)
+            with open(fn_, 'rb') as fh:
+                shards[shard] = fh.read()
+        raw = shards[shard][offset:offset + size]
+        dt = np.dtype(_DT[dtype])
+        n = int(np.prod(shape)) if shape else 1
+        if len(raw) != size or n * dt.itemsize != size:
+            raise KerasFileError(f'{prefix}: tensor {name} has {size} bytes for shape {shape} of {dt}')
+        if verify_crc and crc is not None and crc32c(raw) != _unmask_crc(crc):
+            raise KerasFileError(f'{prefix}: checksum mismatch in tensor {name}')
+        out[name] = np.frombuffer(raw, dtype=dt).reshape(shape).copy()
+    return out
+
+
+_BN_VARS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
+
+
+def read_savedmodel_variables(model_dir, verify_crc=False):
+    """Weights of a Keras model saved as a TF SavedModel directory (DNN.py:411), as keras-style paths in model
+    order.  The object-based checkpoint names the tensors by position - ``layer_with_weights-<i>/<attribute>`` with i
+    counting the layers that own weights, in model order - which is all load-by-topology needs: a layer with
+    kernel + bias is a Dense layer, one with gamma / beta / moving_mean / moving_variance a BatchNormalization;
+    the Dense layers are fc_dense0.. in order and the last one is fc_regressor (DNN.py:211-227)."""
+    prefix = os.path.join(model_dir, 'variables', 'variables')
+    if not os.path.exists(prefix + '.index'):
+        raise KerasFileError(f'{model_dir}: no variables/variables.index - not a SavedModel directory')
+    tensors = read_tensor_bundle(prefix, verify_crc=verify_crc)
+    layers = {}
+    for key, val in tensors.items():
+        parts = key.split('/')
+        if len(parts) >= 4 and parts[0].startswith('layer_with_weights-') and parts[2:4] == ['.ATTRIBUTES', 'VARIABLE_VALUE']:
+            layers.setdefault(int(parts[0].split('-')[1]), {})[parts[1]] = val
+    if not layers:
+        raise KerasFileError(f'{model_dir}: no layer_with_weights-* variables in the checkpoint')
+    dense = [i for i in sorted(layers) if 'kernel' in layers[i]]
+    out, n_dense, n_bn = {}, 0, 0
+    for i in sorted(layers):
+        lw = layers[i]
+        if 'kernel' in lw:
+            name = 'fc_regressor' if i == dense[-1] else f'fc_dense{n_dense}'
+            n_dense += 1
+            out[f'{name}/kernel:0'] = np.asarray(lw['kernel'], np.float32)
+            if 'bias' in lw:
+                out[f'{name}/bias:0'] = np.asarray(lw['bias'], np.float32)
+        elif all(v in lw for v in _BN_VARS):
+            name = 'batch_normalization' + (f'_{n_bn}' if n_bn else '')
+            n_bn += 1
+            for v in _BN_VARS:
+                out[f'{name}/{v}:0'] = np.asarray(lw[v], np.float32)
+        else:
+            raise KerasFileError(f'{model_dir}: layer_with_weights-{i} has variables {sorted(lw)} - neither Dense nor BatchNormalization')
+    return out

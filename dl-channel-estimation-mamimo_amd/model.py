@@ -1,7 +1,8 @@
 """Weight container and the ``tf.keras.Model``-shaped object the reference script drives
 (massiveMIMO_CSI_prediction_DNN.py:231-234 build, :334 load_weights, :346 predict, :411 save).
 
-Weight container (TensorFlow / h5py are not available, so this is the build's own format):
+Weight container (the build's own format; the reference's Keras HDF5 checkpoints and SavedModel
+directories are read as well, keras_files.py):
 a ``.safetensors`` (or torch ``.pt``) file holding, per component model d in {real, imag},
   fc_dense{i}.kernel [in,out]  fc_dense{i}.bias [out]
   bn{i}.gamma / .beta / .moving_mean / .moving_variance [out]        (when --useBN)
@@ -63,33 +64,17 @@ def normalize_keras_names(tensors):
     return out
 
 
-def tensors_from_keras_hdf5(h5file):
-    """Every dataset of an open Keras weights file (``model.save_weights('x.hdf5')`` / the ModelCheckpoint
-    files of DNN.py:279-281: groups ``<layer>/<layer>/kernel:0`` ..., optionally under ``model_weights``)
-    as {path: array}; the paths are what normalize_keras_names expects."""
-    out = {}
-
-    def visit(name, obj):
-        if hasattr(obj, 'shape') and hasattr(obj, 'dtype'):          # a dataset, not a group
-            out[name] = np.asarray(obj[()], dtype=np.float32)
-
-    h5file.visititems(visit)
-    return out
-
-
 def load_weight_file(path):
     """.safetensors | .pt | .npz (np.savez(path, **{v.name: v.numpy() for v in keras_model.weights}) on a
-    Keras host needs nothing but numpy) | .hdf5 / .h5 (the reference's own checkpoint files, DNN.py:279-281,334 -
-    read with h5py where that is installed); Keras variable names are normalised."""
+    Keras host needs nothing but numpy) | .hdf5 / .h5 - the reference's own checkpoint files
+    (DNN.py:279-281,334) and whole-model .h5 files | a TF SavedModel directory (DNN.py:411, inference.py:15-16).
+    The last two are read by keras_files.py without h5py / TensorFlow; Keras variable names are normalised."""
+    if os.path.isdir(path):
+        from .keras_files import read_savedmodel_variables
+        return normalize_keras_names(read_savedmodel_variables(path))
     if path.endswith(('.hdf5', '.h5')):
-        try:
-            import h5py
-        except ImportError:
-            raise CsiError(-1, f'{path}: reading Keras HDF5 weights needs h5py, which is not installed here - on the Keras host run '
-                               'tools/export_keras_weights.py (or np.savez(path, **{v.name: v.numpy() for v in model.weights})) '
-                               'and load the .npz') from None
-        with h5py.File(path, 'r') as f:
-            return normalize_keras_names(tensors_from_keras_hdf5(f))
+        from .keras_files import read_keras_hdf5_weights
+        return normalize_keras_names(read_keras_hdf5_weights(path))
     if path.endswith('.npz'):
         with np.load(path) as z:
             return normalize_keras_names({k: np.asarray(z[k], dtype=np.float32) for k in z.files})

@@ -683,6 +683,39 @@ def test_csipredictor_twin_mamimo_end_to_end(pkg, oracle, tmp_path):
     assert ex.value.code == -1
 
 
+def test_reference_model_files_load_and_predict(pkg, oracle, golden_dir, tmp_path):
+    """a-10 end to end: ``CSIModel.load_weights('<d>_weights-improvement.hdf5')`` (DNN.py:334) on the
+    libhdf5-written Keras checkpoints and ``CSIPredictor(model_path)`` (inference.py:15-16) on SavedModel
+    directories ``<d>_keras_model/`` - no h5py / TensorFlow - must predict what the oracle computes from the
+    tensors that were written into those files."""
+    import shutil
+    exp = np.load(os.path.join(golden_dir, 'keras_weights_expected.npz'))
+    nt, nr, npkt = int(exp['nt']), 3, 5
+    w = {d: {k[len(d) + 1:]: exp[k] for k in exp.files if k.startswith(d + '.')} for d in ('real', 'imag')}
+    rng = np.random.default_rng(41)
+    P = _pilot(rng, nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0]
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w['real'], w['imag'], np.float64, pkt_batch=npkt)
+    # Keras HDF5 checkpoints through the keras-shaped model object
+    e = pkg.CsiEngine(nt, nr, hidden=(16, 8))
+    for d in ('real', 'imag'):
+        shutil.copy(os.path.join(golden_dir, f'keras_weights_{d}.hdf5'), tmp_path / f'{d}_weights-improvement.hdf5')
+        pkg.CSIModel(e, d).load_weights(str(tmp_path / f'{d}_weights-improvement.hdf5'))
+    e.set_pilot(P)
+    o_re, o_im = e.predict(ltf)
+    assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
+    x = oracle.samples_from_packets(ltf[:2].astype(np.complex64), P.astype(np.float32), 'imag')
+    assert rel_rows(pkg.CSIModel(e, 'imag').load_weights(str(tmp_path / 'imag_weights-improvement.hdf5')).predict(x),
+                    oracle.fc_forward(x, w['imag'], np.float64)) < TOL
+    # SavedModel directories through the deployment wrapper (no config.json, no pilot, no rx count inside)
+    pred = pkg.CSIPredictor(os.path.join(golden_dir, 'savedmodel_fixture'), experiment='matlab_maMimo', pilot=P)
+    h = pred.inference(ltf.astype(np.complex128))
+    assert h.shape == (npkt, nr, nt, 234)
+    assert rel_rows(h.real, r_re) < TOL and rel_rows(h.imag, r_im) < TOL
+    h1 = pkg.CSIPredictor(os.path.join(golden_dir, 'savedmodel_fixture'), experiment='matlab_maMimo', pilot=P, nr=nr).inference(ltf.astype(np.complex128))
+    np.testing.assert_array_equal(h1, h)
+
+
 def test_csipredictor_twin_rice_renew_single_input(pkg, oracle, golden_dir, tmp_path):
     """The reference's implemented experiment: single-input FC model, 52 outputs re-inserted
     into 64 bins.  Input/recombination/post-processing behaviour is pinned by the golden

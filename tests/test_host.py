@@ -294,48 +294,71 @@ def test_c_program_runs_through_the_abi(pkg, tmp_path):
     assert 'c_api_smoke: abi 1' in res.stdout
 
 
-def test_keras_hdf5_weights_path(pkg, tmp_path):
-    """The reference checkpoints to Keras HDF5 (DNN.py:279-281).  h5py is not in this image: the loader
-    must say so (never guess); the part that does not need h5py - walking the file's groups and mapping
-    Keras' dataset paths, BatchNormalization layers by order - is exercised on a stand-in tree."""
-    from dl_channel_estimation_mamimo_amd import model as M
-    try:
-        import h5py  # noqa: F401
-        have = True
-    except ImportError:
-        have = False
-    if not have:
-        with pytest.raises(pkg.CsiError) as ei:
-            M.load_weight_file(str(tmp_path / 'real_weights-improvement.hdf5'))
-        assert 'h5py' in str(ei.value) and 'npz' in str(ei.value)
+def test_keras_hdf5_checkpoint_reader_on_libhdf5_written_fixture(pkg, golden_dir, tmp_path):
+    """The reference checkpoints to Keras HDF5 (<d>_weights-improvement.hdf5, DNN.py:279-281,319) and loads it by
+    topology (:334).  tests/golden/keras_weights_{real,imag}.hdf5 were written by the genuine libhdf5 1.10.6 in
+    keras' layout (make_keras_hdf5_fixture.py; layers without weights, BatchNormalization auto-numbers 0,1 / 2,3,
+    fixed- and variable-length string attributes); the dependency-free reader must return exactly the tensors
+    that went in, BatchNormalization layers matched by order."""
+    from dl_channel_estimation_mamimo_amd import keras_files as kf
+    exp = np.load(os.path.join(golden_dir, 'keras_weights_expected.npz'))
+    for d, bn in (('real', ('batch_normalization', 'batch_normalization_1')), ('imag', ('batch_normalization_2', 'batch_normalization_3'))):
+        path = os.path.join(golden_dir, f'keras_weights_{d}.hdf5')
+        f = kf.Hdf5File(path)
+        names = [bytes(x).decode() for x in f.root.attrs['layer_names']]
+        assert names[4:] == ['fc_dense0', bn[0], 'drop0', 'fc_dense1', bn[1], 'fc_regressor'] and len(names) == 10
+        assert bytes(f.root.attrs['backend'][()]) == b'tensorflow' and f.root.attrs['keras_version'] == b'2.4.0'
+        assert sorted(f.root.keys()) == sorted(names)
+        assert f.root['drop0'].attrs['weight_names'].shape == (0,)                 # h5py stores np.asarray([]) for such layers
+        ds = f[f'/fc_dense0/fc_dense0/kernel:0']
+        assert ds.shape == (1284, 16) and ds.type.dtype == np.dtype('<f4')
+        raw = kf.read_keras_hdf5_weights(path)
+        assert list(raw)[:3] == ['fc_dense0/kernel:0', 'fc_dense0/bias:0', f'{bn[0]}/gamma:0']      # layer_names / weight_names order
+        w = pkg.load_weight_file(path)
+        want = {k[len(d) + 1:]: exp[k] for k in exp.files if k.startswith(d + '.')}
+        assert set(w) == set(want) and len(w) == 14
+        for k in want:
+            assert w[k].dtype == np.float32
+            np.testing.assert_array_equal(w[k], want[k])
+    # whole-model .h5 files carry the same tree under /model_weights - not in the fixture; damaged files must fail loudly
+    blob = open(os.path.join(golden_dir, 'keras_weights_real.hdf5'), 'rb').read()
+    (tmp_path / 'cut.hdf5').write_bytes(blob[:60000])
+    with pytest.raises((kf.KerasFileError, IndexError, ValueError)):
+        pkg.load_weight_file(str(tmp_path / 'cut.hdf5'))
+    (tmp_path / 'junk.hdf5').write_bytes(b'not an hdf5 file' * 100)
+    with pytest.raises(kf.KerasFileError):
+        pkg.load_weight_file(str(tmp_path / 'junk.hdf5'))
 
-    class Dataset:
-        def __init__(self, a):
-            self._a, self.shape, self.dtype = a, a.shape, a.dtype
 
-        def __getitem__(self, key):
-            return self._a
-
-    class Tree:                                           # h5py.File-like: visititems(callback(name, obj))
-        def __init__(self, items):
-            self.items = items
-
-        def visititems(self, fn):
-            for name, obj in self.items:
-                fn(name, obj)
-
-    rng = np.random.default_rng(0)
-    arrs = {n: rng.standard_normal(s) for n, s in [
-        ('fc_dense0/fc_dense0/kernel:0', (12, 8)), ('fc_dense0/fc_dense0/bias:0', (8,)),
-        ('batch_normalization_4/batch_normalization_4/gamma:0', (8,)), ('batch_normalization_4/batch_normalization_4/beta:0', (8,)),
-        ('batch_normalization_4/batch_normalization_4/moving_mean:0', (8,)), ('batch_normalization_4/batch_normalization_4/moving_variance:0', (8,)),
-        ('fc_regressor/fc_regressor/kernel:0', (8, 5)), ('fc_regressor/fc_regressor/bias:0', (5,))]}
-    tree = Tree([('fc_dense0', object()), ('fc_dense0/fc_dense0', object())] + [(n, Dataset(a)) for n, a in arrs.items()])
-    w = M.normalize_keras_names(M.tensors_from_keras_hdf5(tree))
-    assert set(w) == {'fc_dense0.kernel', 'fc_dense0.bias', 'bn0.gamma', 'bn0.beta', 'bn0.moving_mean', 'bn0.moving_variance',
-                      'fc_regressor.kernel', 'fc_regressor.bias'}
-    np.testing.assert_array_equal(w['bn0.moving_variance'], arrs['batch_normalization_4/batch_normalization_4/moving_variance:0'].astype(np.float32))
-    assert w['fc_dense0.kernel'].dtype == np.float32
+def test_savedmodel_variables_reader_is_self_consistent(pkg, golden_dir, tmp_path):
+    """SavedModel directories (DNN.py:411 -> inference.py:15-16): variables.index is an SSTable of BundleEntryProto,
+    variables.data-* raw bytes.  TensorFlow is not available, so the fixture comes from the repository's own writer
+    (make_savedmodel_fixture.py) - a self-consistency test of the reader (several index blocks, prefix-compressed
+    keys, checksums, the object-graph string tensor and optimizer variables to step over), NOT a pin."""
+    from dl_channel_estimation_mamimo_amd import keras_files as kf
+    assert kf.crc32c(b'123456789') == 0xE3069283                                 # CRC-32C check value
+    exp = np.load(os.path.join(golden_dir, 'keras_weights_expected.npz'))
+    for d in ('real', 'imag'):
+        mdir = os.path.join(golden_dir, 'savedmodel_fixture', f'{d}_keras_model')
+        t = kf.read_tensor_bundle(os.path.join(mdir, 'variables', 'variables'), verify_crc=True)
+        assert len(t) == 20 and t['optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE'].dtype == np.int64
+        assert '_CHECKPOINTABLE_OBJECT_GRAPH' not in t
+        w = pkg.load_weight_file(mdir)
+        want = {k[len(d) + 1:]: exp[k] for k in exp.files if k.startswith(d + '.')}
+        assert set(w) == set(want)
+        for k in want:
+            np.testing.assert_array_equal(w[k], want[k])
+    # a flipped byte in the data file is caught by the per-tensor checksum
+    import shutil
+    shutil.copytree(os.path.join(golden_dir, 'savedmodel_fixture', 'real_keras_model'), tmp_path / 'm')
+    dat = tmp_path / 'm' / 'variables' / 'variables.data-00000-of-00001'
+    b = bytearray(dat.read_bytes())
+    b[5000] ^= 0x40
+    dat.write_bytes(bytes(b))
+    with pytest.raises(kf.KerasFileError):
+        kf.read_tensor_bundle(str(tmp_path / 'm' / 'variables' / 'variables'), verify_crc=True)
+    with pytest.raises(kf.KerasFileError):
+        pkg.load_weight_file(str(tmp_path))                                       # a directory that is no SavedModel
 
 
 def _bench(args, env_extra):
