@@ -58,7 +58,8 @@ struct Layer {
     uint16_t* Wh = nullptr;   // [out][ldwh] split-f16 ("hs", gemm_hs.hip.h) copy of Wt * 2^wshift; layer 0: LTF columns only
     int ldwh = 0;             // halves per row = 2 * (in rounded up to 16)
     int wshift = 0;
-    int ashift = 4;           // split engine: this layer's OUTPUT activations are carried times 2^ashift (from its BN vectors at load)
+    int ashift = 4;           // split engine: this layer's OUTPUT activations are carried times 2^ashift (from its BN vectors at load);
+                              // layer 0: its relu output BEFORE BatchNormalization (the scale lives in layer 1's split weights)
     float* bias = nullptr;    // [out]
     float* bias_hs = nullptr; // [out]  split engine (layers >= 1): bias + (BN shift of the previous layer) . W
     float* scale = nullptr;   // [out]  BN: gamma * rsqrt(var + eps)   (1 without BN)
@@ -71,6 +72,8 @@ struct Model {
     float* W0p = nullptr;        // [nt][H1] pilot rows of fc_dense0.kernel, row-major
     float* W0rm = nullptr;       // [lenLTF][H1] LTF rows of fc_dense0.kernel as stored (skinny layer-0 kernel)
     float* T = nullptr;          // [nt][H1] pilot table incl. bias
+    float* T_hs = nullptr;       // [nt][H1] 2^T_hs_shift * T: what the split-f16 pair kernel adds (gemm_hs.hip.h)
+    int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
     bool loaded = false;
     bool table_ok = false;
 };
@@ -277,7 +280,9 @@ void free_model(Model& m) {
     if (m.W0rm) hipFree(m.W0rm);
     m.W0rm = nullptr;
     if (m.T) hipFree(m.T);
-    m.W0p = m.T = nullptr;
+    if (m.T_hs) hipFree(m.T_hs);
+    m.W0p = m.T = m.T_hs = nullptr;
+    m.T_hs_shift = HS_SHIFT_AUTO;
     m.loaded = m.table_ok = false;
 }
 

@@ -160,9 +160,10 @@ int build_pilot_table(csi_ctx* c, Model& m) {
     }
     ProfScope ps(c, K_PILOT_TABLE, 2.0 * nt * nt * h1, 4.0 * (nt * nt + 2.0 * nt * h1));
     hipLaunchKernelGGL(pilot_table_kernel, dim3((h1 + 255) / 256, nt), dim3(256), 0, c->stream,
-                       c->P, m.W0p, m.layers[0].bias, m.T, nt, h1);
+                       c->P, m.W0p, m.layers[0].bias, m.T, nt, h1, 1.0f);
     HIP_TRY(c, hipGetLastError());
     m.table_ok = true;
+    m.T_hs_shift = HS_SHIFT_AUTO;       // the split engine's pre-scaled copy is rebuilt on its next use
     return CSI_OK;
 }
 

@@ -9,12 +9,10 @@ namespace {
 
 constexpr int HS_L0_MAX_SPLITS = 8;
 
-// shapes the kernels can serve: every hidden width a multiple of 16 (hs groups), bn0 vectors of the
-// first per-pair layer in LDS behind the ring, split weights present
+// shapes the kernels can serve: every hidden width a multiple of 16 (hs groups), split weights present
 bool hs_static_ok(const csi_ctx* c, const Model& m) {
     const csi_config& cf = c->cfg;
     if (c->f32_engine == 0 || cf.dtype != CSI_DTYPE_F32 || cf.nt <= 0 || (cf.len_ltf % HS_G) != 0) return false;
-    if (cf.hidden[0] > 4096) return false;
     for (int i = 0; i < cf.n_hidden; ++i)
         if (cf.hidden[i] % HS_G) return false;
     for (size_t i = 0; i < m.layers.size(); ++i)
@@ -135,7 +133,7 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src, int in
     const double bytes = 4.0 * ((double)g.M / src.nt * g.K + (double)src.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
     auto kern = gemm_hs_pp_pair_kernel<EPI, OUT_HS, false>;
-    const size_t lds = (size_t)(PPP_RING_FLOATS + 2 * g.K) * sizeof(float);
+    const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
     int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
     if (rc) return rc;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
@@ -166,9 +164,22 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
     const int nh = cf.n_hidden, h1 = cf.hidden[0];
     const Layer& l1 = m.layers[1];
     const int s0 = hs_act_shift_of(c, m, 0);
-    // every BatchNormalization shift lives in the NEXT layer's bias (Layer::bias_hs): activations = relu(.) * scale
-    // keep the zeros of the relu
-    PairSrc src{l0sum, m.T, m.layers[0].scale, c->hs_zero, h1, cf.nt};
+    // bn0 is not applied by the pair kernel: its scale multiplies the rows of layer 1's split weights, its shift
+    // (like every later BatchNormalization shift) lives in layer 1's bias (Layer::bias_hs) - A = relu(2^s0 L0 + Ts)
+    // with Ts = 2^s0 T, a copy of the pilot table rebuilt when the table or the shift changes
+    if (m.T_hs_shift != s0) {
+        const size_t bytes = ((size_t)cf.nt * h1 + G_SLACK_FLOATS) * sizeof(float);
+        if (!m.T_hs) {
+            if (hipMalloc((void**)&m.T_hs, bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "pilot table allocation failed");
+            HIP_TRY(c, hipMemsetAsync(m.T_hs, 0, bytes, c->stream));
+        }
+        ProfScope ps(c, K_PILOT_TABLE, 2.0 * cf.nt * cf.nt * h1, 4.0 * (cf.nt * cf.nt + 2.0 * cf.nt * h1));
+        hipLaunchKernelGGL(pilot_table_kernel, dim3((h1 + 255) / 256, cf.nt), dim3(256), 0, c->stream, c->P, m.W0p, m.layers[0].bias, m.T_hs,
+                           cf.nt, h1, std::ldexp(1.f, s0));
+        HIP_TRY(c, hipGetLastError());
+        m.T_hs_shift = s0;
+    }
+    PairSrc src{l0sum, m.T_hs, nullptr, nullptr, h1, cf.nt};
     GemmHsArgs p{};
     p.Bt = l1.Wh; p.ldb = l1.ldwh;
     p.M = M2; p.N = l1.out; p.K = h1;

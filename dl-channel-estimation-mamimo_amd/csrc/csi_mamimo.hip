@@ -254,6 +254,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
     m.layers.resize(cf.n_hidden + 1);
     int fan_in = c->d_in;
     std::vector<float> prev_shift;          // BN shift of the previous layer (split engine: folded into this layer's bias)
+    std::vector<float> prev_scale;          // BN scale of the previous layer (split engine, layer 1 only: folded into the split weights)
     for (int li = 0; li <= cf.n_hidden; ++li) {
         const bool reg = li == cf.n_hidden;
         const std::string base = reg ? std::string("fc_regressor") : "fc_dense" + std::to_string(li);
@@ -300,9 +301,17 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             // hi + lo halves in groups of 16 k-columns; layer 0 keeps its LTF columns only (the pilot
             // rows live in the table T)
             const int kh = (li == 0 && cf.nt > 0) ? cf.len_ltf : fan_in;
+            // layer 1 (the first per-pair layer; the regressor when there is one hidden layer) on the shared-layer-0
+            // path: the pair kernel generates A = relu(L0 + T) without bn0, so bn0's scale multiplies the rows of
+            // this copy - (relu(z) sc) W = relu(z) (diag(sc) W) - and bn0's shift sits in bias_hs below
+            const bool fold_scale = li == 1 && cf.nt > 0 && !prev_scale.empty();
+            auto wv = [&](int o, int i) {
+                const float w = wt[(size_t)o * L.ldw + i];
+                return fold_scale ? (float)((double)w * (double)prev_scale[i]) : w;
+            };
             float wmax = 0.f;
             for (int o = 0; o < out; ++o)
-                for (int i = 0; i < kh; ++i) wmax = std::max(wmax, std::fabs(wt[(size_t)o * L.ldw + i]));
+                for (int i = 0; i < kh; ++i) wmax = std::max(wmax, std::fabs(wv(o, i)));
             int e = 0;
             if (wmax > 0.f && std::isfinite(wmax)) std::frexp(wmax, &e);
             L.wshift = std::max(-40, std::min(40, 13 - e));
@@ -311,7 +320,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             std::vector<uint16_t> wh((size_t)out * L.ldwh, 0);
             for (int o = 0; o < out; ++o)
                 for (int i = 0; i < kh; ++i) {
-                    const float x = wt[(size_t)o * L.ldw + i] * ws;
+                    const float x = wv(o, i) * ws;
                     const _Float16 hi = (_Float16)x;
                     const _Float16 lo = (_Float16)(x - (float)hi);
                     uint16_t* d = &wh[(size_t)o * L.ldwh + (i >> 4) * 32 + (i & 15)];
@@ -357,12 +366,16 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 sc[o] = inv;
                 sh[o] = be->data[o] - mu->data[o] * inv;
             }
-            // split-f16 engine: scale of this layer's output activations.  BatchNormalization output =
-            // beta + gamma * (standardised relu), so |beta| + 6 |gamma| bounds it to six moving standard
-            // deviations; put that bound at 2^10..2^11 - 32x of head room for outliers before the range
-            // guard takes over, and values down to 2^-13 of the bound keep a normal lo half
+            // split-f16 engine: scale of the activations this layer hands on.  Layers >= 1 hand on relu * scale
+            // (BatchNormalization output minus its shift): beta + gamma * (standardised relu) is bounded by
+            // |beta| + 6 |gamma| at six moving standard deviations.  Layer 0 on the shared path hands on the bare
+            // relu (see fold_scale above): moving_mean + 6 moving standard deviations bounds it.  The bound is put
+            // at 2^10..2^11 - 32x of head room for outliers before the range guard takes over, and values down to
+            // 2^-13 of the bound keep a normal lo half
             float amax = 0.f;
-            for (int o = 0; o < out; ++o) amax = std::max(amax, std::fabs(be->data[o]) + 6.f * std::fabs(ga->data[o]));
+            for (int o = 0; o < out; ++o)
+                amax = std::max(amax, (li == 0 && cf.nt > 0) ? std::fabs(mu->data[o]) + 6.f * std::sqrt(std::max(va->data[o], 0.f) + cf.bn_eps)
+                                                             : std::fabs(be->data[o]) + 6.f * std::fabs(ga->data[o]));
             int ea = 0;
             if (amax > 0.f && std::isfinite(amax)) {
                 std::frexp(amax, &ea);
@@ -389,6 +402,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             }
         }
         prev_shift = sh;
+        prev_scale = sc;
         fan_in = out;
     }
     m.loaded = true;

@@ -792,16 +792,17 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ slabs, int S, i
     }
 }
 
-// T[t][n] = b0[n] + sum_i P[t][i] * W0p[i][n]   (W0p = rows lenLTF.. of fc_dense0.kernel)
+// T[t][n] = scale * (b0[n] + sum_i P[t][i] * W0p[i][n])   (W0p = rows lenLTF.. of fc_dense0.kernel; scale = 1, or the
+// power of two the split-f16 pair kernel carries its A operand at - exact, so that copy is bit for bit scale * T)
 __global__ void pilot_table_kernel(const float* __restrict__ P, const float* __restrict__ W0p,
                                    const float* __restrict__ b0, float* __restrict__ T,
-                                   int nt, int h1) {
+                                   int nt, int h1, float scale) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
     if (n >= h1) return;
     float acc = 0.f;
     for (int i = 0; i < nt; ++i) acc = fmaf(P[t * nt + i], W0p[(size_t)i * h1 + n], acc);
-    T[(size_t)t * h1 + n] = acc + b0[n];
+    T[(size_t)t * h1 + n] = (acc + b0[n]) * scale;
 }
 
 }  // namespace csi

@@ -54,7 +54,19 @@ struct GemmHsArgs {
     unsigned* peak;        // range guard (may be null): two words, see hs_report_peak
     const unsigned* dyn_max;   // CAST mode, automatic input scale: bits of a (sampled) max |x| of this launch's rows,
     int wshift;                //   written earlier on the stream by hs_absmax_sample_kernel; scale = 2^(14 - exponent)
+    const unsigned long long* stamps;   // timing probe (tools/hs_probe.hip), null otherwise: hs_stamp
 };
+
+// Optional per-workgroup time stamps (timing probes; null in the library): wave 0 writes (shader cycles, 10-ns
+// wall ticks) at kernel entry, after the prologue, after the main loop and after the epilogue.
+__device__ __forceinline__ void hs_stamp(const unsigned long long* base, int i) {
+    if (!base) return;
+    if (threadIdx.x == 0) {
+        unsigned long long* p = const_cast<unsigned long long*>(base) + ((size_t)blockIdx.x * 4 + i) * 2;
+        p[0] = __builtin_readcyclecounter();
+        p[1] = wall_clock64();
+    }
+}
 
 // (a, b) -> packed hi halves, packed lo halves
 __device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -64,6 +76,21 @@ __device__ __forceinline__ void hs_split2(float a, float b, uint32_t& hi, uint32
     const f16x2 l = __builtin_convertvector(r, f16x2);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// lo halves of two values whose packed hi halves are `hi`:  f16(a - f32(hi.lo)) | f16(b - f32(hi.hi)) << 16.
+// v_fma_mixlo/hi_f16 take the f16 operand as it is (op_sel_hi), evaluate hi * (-1) + x in fp32 - exact, the
+// difference of x and its own 11-bit rounding is an fp32 number - and round once to f16: one VALU per value
+// instead of v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk_f16_f32, and bit-identical to hs_split2.
+__device__ __forceinline__ uint32_t hs_lo_pair(float a, float b, uint32_t hi) {
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t hs_hi_pair(float a, float b) {
+    const f32x2 x = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
 }
 
 // Range guard.  |s*x| above 65504 becomes inf in the hi half; below the f16 normal range the lo half is
@@ -252,6 +279,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
     if (tm * PP_BM >= g.M) return;
+    hs_stamp(g.stamps, 0);
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -316,6 +344,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     pp_wait_lgkm();
     if (wm == 1) bar();          // group 1 runs one segment behind
 
+    hs_stamp(g.stamps, 1);
     int slot = 0, fill = D % NSUB;
     int u = 0;
     for (; u < nsub - D; ++u) {
@@ -351,28 +380,46 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
         slot = nslot;
     }
 
+    hs_stamp(g.stamps, 2);
     if ((DBG & 8) && g.M > 0) return;
     hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
+    hs_stamp(g.stamps, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
 // A operand produced in the kernel (PairSrc as in gemm_bf16.hip.h):
-//   pair mode:  A[(pr,t)][k] = split( in_scale * bn0( relu( L0[pr][k] + T[t][k] ) ) )   - the scale is
-//               folded into the LDS copy of s0 / t0, so it costs no multiply in the loop;
+//   pair mode:  A[(pr,t)][k] = split( relu( in_scale * L0[pr][k] + Ts[t][k] ) ),   Ts = in_scale * T (a pre-scaled
+//               copy of the pilot table, in_scale a power of two): one fma and one max per value.  Neither half of
+//               that layer's BatchNormalization is applied here - the library folds the SCALE into the rows of the
+//               next layer's split weights and the SHIFT into its bias at load (csi_load_weights: Layer::Wh of
+//               layer 1, Layer::bias_hs), which keeps the exact zeros of the relu in A and takes a vector read,
+//               four packed multiplies and their power out of every sub-tile (measured -7 % on the kernel; the
+//               matrix pipe is power-bound, so what counts is energy, not issue slots - DESIGN.md 4.6);
 //   CAST mode:  A[m][k] = split( in_scale * X[m][k] )  from fp32 rows (layer 0), split-K over z.
-// Every wave owns 32 A rows (lane -> row, 8-column half of the 16-column sub-tile): per sub-tile it
-// turns the 8 (+8) values it requested one sub-tile earlier into 16 B of hi and 16 B of lo, writes
-// both chunks at their swizzled places (rows are permuted over the lanes so that each 8-lane
-// ds_write_b128 group covers all 32 banks), requests the next values, and issues its two B pieces
-// (one in P0, one in P1) D = 3 sub-tiles ahead.  One vmcnt(2) per sub-tile: the values are older
-// than the two B pieces issued behind them, and the wait retires every older B piece as well -
-// including sub-tile u+1, which P2(u) prefetches two barriers later.
-template <int EPI, bool OUT_HS, bool CAST = false>
+// Every wave owns 32 A rows (lane -> row, 8-column half of the 16-column sub-tile).  The conversion of a
+// sub-tile is spread over the load segments of TWO phases so that neither outlasts the partner group's
+// 8-MFMA segment (256 cycles of the SIMD's matrix pipe; a load segment that is longer stalls both groups
+// at the next barrier - round 1 did all of it in P0: ~85 instructions, ~60 of them VALU beside the
+// partner's MFMAs, and measured 1.60 ms against 1.44 for the kernel without generation):
+//   P0: wait for the 8 (+8) values requested one sub-tile earlier, relu / scale, 4 x v_cvt_pk_f16_f32,
+//       ds_write_b128 of the hi chunk
+//   P1: 8 x v_fma_mix{lo,hi}_f16 (lo halves), ds_write_b128 of the lo chunk, range-guard maximum, THEN the
+//       requests for the next values
+//   P2: both B pieces (LDS-DMA, D = 3 sub-tiles ahead)
+// Both chunks go to their swizzled places (rows are permuted over the lanes so that each 8-lane
+// ds_write_b128 group covers all 32 banks).  All vector-memory operations of a sub-tile are issued behind
+// its last ds_write: hipcc inserts s_waitcnt vmcnt(0) in front of any ds_write that follows an LDS-DMA in
+// flight (possible alias), which would put the L2 latency of the fresh requests on the critical path.
+// One vmcnt(0) per sub-tile (top of P0) retires the values and the B pieces issued behind them four
+// segments earlier - including sub-tile u+1, which P2(u) prefetches two barriers later.  RAW: the hi chunk
+// of sub-tile u+2 is written in P0(u) and first read in P2(u+1), the lo chunk in P1(u) and first read in
+// P1(u+2); every MFMA segment ends with lgkmcnt(0) in front of its closing barrier, which also retires the
+// chunk written in front of it.  WAR: B slot of sub-tile u+3 = slot of u-1, last read in P0(u-1).
+// DBG (timing probes of tools/hs_probe.hip, results invalid): 1 = no L0 / T / X requests, 2 = no conversion (VALU, ds_write)
+template <int EPI, bool OUT_HS, bool CAST = false, int DBG = 0>
 __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const GemmHsArgs g, const PairSrc ps, const float in_scale) {
     constexpr int NSUB = 4, D = 3;
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring + 2 * K floats (s0 | t0)
-    float* sv_l = lds + NSUB * PP_SUBF;
-    float* hv_l = sv_l + g.K;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -383,16 +430,12 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
     if (tm * PP_BM >= g.M) return;
+    hs_stamp(g.stamps, 0);
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
     const int kbeg = CAST ? blockIdx.z * g.k_per_split : 0;
     const int kend = CAST ? min(g.K, kbeg + g.k_per_split) : g.K;
     const int nsub = (kend - kbeg + HS_G - 1) / HS_G;
 
-    if (!CAST)
-        for (int i = tid; i < g.K; i += PP_THREADS) {
-            sv_l[i] = ps.s0[i] * in_scale;
-            hv_l[i] = ps.t0[i] * in_scale;
-        }
     // automatic input scale (layer 0): the sampled maximum lands in [2^13, 2^14) - a factor 4 of head room
     // for samples the estimate did not see, every value down to 2^-17 of the maximum with a normal lo half
     float a_scale = in_scale, acc_scale = g.acc_scale;
@@ -442,39 +485,44 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
             trow = ps.T + (size_t)t * ps.ldl + 8 * kh;
         }
     }
-    f32x4 lv[2], tv[2];
+    f32x4 lv[2] = {}, tv[2] = {};
     float apk = 0.f;                    // largest |scaled A operand| this lane converted
     auto load_a = [&](int sub) {
+        if (DBG & 1) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             lv[h] = *reinterpret_cast<const f32x4*>(lrow + sub * HS_G + 4 * h);
             if (!CAST) tv[h] = *reinterpret_cast<const f32x4*>(trow + sub * HS_G + 4 * h);
         }
     };
-    auto gen_a = [&](int sub, int slot) {
-        f32x4 v[2];
+    f32x4 gv[2];                        // the 8 scaled A values of the sub-tile in conversion (P0 -> P1)
+    uint4 gh;                           // ... and their packed hi halves
+    auto gen_hi = [&](int sub, int slot) {
+        if (DBG & 2) return;
         if (CAST) {
-            v[0] = lv[0] * a_scale;
-            v[1] = lv[1] * a_scale;
+            gv[0] = lv[0] * a_scale;
+            gv[1] = lv[1] * a_scale;
         } else {
-            const int k = sub * HS_G + 8 * kh;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 s = *reinterpret_cast<const f32x4*>(sv_l + k + 4 * h);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(hv_l + k + 4 * h);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[h][e] = fmaf(fmaxf(lv[h][e] + tv[h][e], 0.f), s[e], b[e]);
-            }
+                for (int e = 0; e < 4; ++e) gv[h][e] = fmaxf(fmaf(lv[h][e], in_scale, tv[h][e]), 0.f);
         }
-        uint4 oh, ol;
-        apk = hs_absmax(hs_absmax(hs_absmax(hs_absmax(apk, v[0][0], v[0][1]), v[0][2], v[0][3]), v[1][0], v[1][1]), v[1][2], v[1][3]);
-        hs_split2(v[0][0], v[0][1], oh.x, ol.x);
-        hs_split2(v[0][2], v[0][3], oh.y, ol.y);
-        hs_split2(v[1][0], v[1][1], oh.z, ol.z);
-        hs_split2(v[1][2], v[1][3], oh.w, ol.w);
-        float* st = lds + slot * PP_SUBF;
-        *reinterpret_cast<uint4*>(st + a_hi_off) = oh;
-        *reinterpret_cast<uint4*>(st + a_lo_off) = ol;
+        gh.x = hs_hi_pair(gv[0][0], gv[0][1]);
+        gh.y = hs_hi_pair(gv[0][2], gv[0][3]);
+        gh.z = hs_hi_pair(gv[1][0], gv[1][1]);
+        gh.w = hs_hi_pair(gv[1][2], gv[1][3]);
+        *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + a_hi_off) = gh;
+    };
+    auto gen_lo = [&](int slot) {
+        if (DBG & 2) return;
+        uint4 ol;
+        ol.x = hs_lo_pair(gv[0][0], gv[0][1], gh.x);
+        ol.y = hs_lo_pair(gv[0][2], gv[0][3], gh.y);
+        ol.z = hs_lo_pair(gv[1][0], gv[1][1], gh.z);
+        ol.w = hs_lo_pair(gv[1][2], gv[1][3], gh.w);
+        *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + a_lo_off) = ol;
+        apk = hs_absmax(hs_absmax(hs_absmax(hs_absmax(apk, gv[0][0], gv[0][1]), gv[0][2], gv[0][3]), gv[1][0], gv[1][1]), gv[1][2], gv[1][3]);
     };
 
     const int fswz = (l31 >> 2) & 3;
@@ -504,12 +552,12 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     HsFrags f;
 
     // ---- prologue: B sub-tiles 0..2 in flight, A sub-tiles 0 and 1 generated synchronously
-    __syncthreads();                    // s0 / t0 staged
     const int npro = min(nsub, D);
     for (int t = 0; t < npro; ++t) { issue_b(t, t, 0); issue_b(t, t, 1); }
     for (int t = 0; t < min(nsub, 2); ++t) {
         load_a(t);
-        gen_a(t, t);                    // the compiler waits for the loads it just issued
+        gen_hi(t, t);                   // the compiler waits for the loads it just issued
+        gen_lo(t);
     }
     pp_wait_vm_lgkm<0>();
     if (nsub > 2) load_a(2);            // consumed in P0 of sub-tile 0
@@ -519,31 +567,33 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     pp_wait_lgkm();
     if (wm == 1) pp_barrier();          // group 1 runs one segment behind
 
+    hs_stamp(g.stamps, 1);
     int slot = 0;
     auto subtile = [&](int u, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const int nslot = (slot + 1) & 3;
         const bool has_a = STEADY || u + 2 < nsub, nxt_a = STEADY || u + 3 < nsub, has_b = STEADY || u + D < nsub;
         const bool last = !STEADY && u == nsub - 1;
-        // P0
-        if (has_a) {
-            if (STEADY) pp_wait_vm_lgkm<2>(); else pp_wait_vm_lgkm<0>();
-            gen_a(u + 2, (slot + 2) & 3);
-            if (nxt_a) load_a(u + 3);
-        } else {
-            pp_wait_vm_lgkm<0>();       // tail: every outstanding B piece has landed
-        }
-        if (has_b) issue_b(u + D, (slot + D) & 3, 0);
-        pp_wait_lgkm();                 // the A image is written before the barrier publishes it
+        // P0: every memory operation of this wave has landed (the values requested in P1 of the previous
+        // sub-tile, and behind them its two B pieces); no new one is issued before the lo chunk is written -
+        // hipcc puts s_waitcnt vmcnt(0) in front of a ds_write that follows an LDS-DMA still in flight
+        pp_wait_vm_lgkm<0>();
+        if (has_a) gen_hi(u + 2, (slot + 2) & 3);       // its ds_write retires with the lgkmcnt(0) that closes the MFMA segment
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P1
-        if (has_b) issue_b(u + D, (slot + D) & 3, 1);
+        if (has_a) gen_lo((slot + 2) & 3);
+        if (nxt_a) load_a(u + 3);
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P2
+        if (has_b) {
+            issue_b(u + D, (slot + D) & 3, 0);
+            issue_b(u + D, (slot + D) & 3, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         hs_mfma_seg<2>(acc, f, read_a, read_b, !last, slot, nslot, !(wm == 1 && last));
         slot = nslot;
@@ -552,10 +602,12 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     for (; u + D < nsub; ++u) subtile(u, std::true_type{});
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
+    hs_stamp(g.stamps, 2);
     hs_report_peak(g.peak, apk, true);
     GemmHsArgs ge = g;
     ge.acc_scale = acc_scale;
     hs_epilogue<EPI, OUT_HS>(acc, ge, lds, m0, n0, wave, lane);
+    hs_stamp(g.stamps, 3);
 }
 
 // out = atomicMax(bits of |x|) over a sample of x: one 1-KiB block (64 float4, read coalesced by a

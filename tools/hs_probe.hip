@@ -63,10 +63,50 @@ static double time_ms(F&& launch, int iters = 7) {
     return ts[ts.size() / 2];
 }
 
+// hs_lo_pair (v_fma_mix) against hs_split2 (cvt / sub / cvt) on every kind of value: must agree bit for bit
+__global__ void split_check_kernel(const float* x, size_t n, unsigned* mismatches, unsigned* first) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; 2 * i + 1 < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        uint32_t h0, l0;
+        hs_split2(a, b, h0, l0);
+        const uint32_t h1 = hs_hi_pair(a, b), l1 = hs_lo_pair(a, b, h1);
+        if (h0 != h1 || l0 != l1) {
+            if (atomicAdd(mismatches, 1u) == 0) { first[0] = __builtin_bit_cast(unsigned, a); first[1] = __builtin_bit_cast(unsigned, b); first[2] = l0; first[3] = l1; }
+        }
+    }
+}
+static int split_check() {
+    const size_t n = 1 << 24;
+    std::vector<float> h(n);
+    std::mt19937 r(11);
+    for (size_t i = 0; i < n; ++i) {
+        // random bit patterns with a biased exponent range that covers f16 normals, denormals, overflow and zero
+        const unsigned mant = r() & 0x7fffffu, sign = (r() & 1u) << 31;
+        const unsigned ex = 127 - 40 + (r() % 64);
+        unsigned bits = sign | (ex << 23) | mant;
+        if (i % 97 == 0) bits = sign;                       // +-0
+        if (i % 101 == 0) bits = sign | (ex << 23);         // powers of two (ties)
+        memcpy(&h[i], &bits, 4);
+    }
+    float* d = dput(h);
+    unsigned* cnt; CK(hipMalloc(&cnt, 32)); CK(hipMemset(cnt, 0, 32));
+    hipLaunchKernelGGL(split_check_kernel, dim3(1024), dim3(256), 0, 0, d, n, cnt, cnt + 1);
+    CK(hipDeviceSynchronize());
+    unsigned res[5];
+    CK(hipMemcpy(res, cnt, 20, hipMemcpyDeviceToHost));
+    printf("split check: %u mismatches of %zu pairs between v_fma_mix lo halves and cvt/sub/cvt", res[0], n / 2);
+    if (res[0]) printf(" (first: a=%08x b=%08x lo %08x vs %08x)", res[1], res[2], res[3], res[4]);
+    printf("\n");
+    return res[0] != 0;
+}
+
 int main(int argc, char** argv) {
-    const bool timing = argc > 1 && std::string(argv[1]) == "time";
+    if (argc > 1 && std::string(argv[1]) == "split") return split_check();
+    const bool timing = argc > 1 && (std::string(argv[1]) == "time" || std::string(argv[1]) == "loop");
     const float in_mag = argc > 2 ? atof(argv[2]) : 1.f;
     const bool relu_zeros = argc > 3 && std::string(argv[3]) == "relu";     // A operands with ~50 % exact zeros (power experiment)
+    const bool stamps = argc > 4 && std::string(argv[4]) == "stamps";       // per-workgroup phase timing
+    const bool loop = argc > 1 && std::string(argv[1]) == "loop";           // loop <mag> <relu|-> <mfma|hs2hs|pair|regressor> <seconds>: for tools/power_probe.sh
     const int nt = 32, K = 1024, N = 1024, NO = 234;
     const int M = timing ? 262144 : 1000 * 1 + 24;        // ragged last tile in the check
     const int M1 = (M + nt - 1) / nt;
@@ -79,7 +119,7 @@ int main(int argc, char** argv) {
     if (relu_zeros) for (auto& v : hA) v = std::max(v, 0.f);
     auto hL0 = rnd((size_t)M1 * K, in_mag), hT = rnd((size_t)nt * K, in_mag), hs0 = rnd(K, 0.3f), ht0 = rnd(K, 0.1f);
     for (auto& v : hs0) v = 1.f + v;
-    if (relu_zeros) for (auto& v : ht0) v = 0.f;
+    for (auto& v : ht0) v = 0.f;          // the pair kernel applies no BN shift (the library folds it into the next layer's bias)
     float *A = dput(hA), *W = dput(hW), *W2 = dput(hW2), *b = dput(hb), *sc = dput(hsc), *sh = dput(hsh);
     float *L0 = dput(hL0), *T = dput(hT);
     const int sa = 4;
@@ -90,7 +130,17 @@ int main(int argc, char** argv) {
     uint16_t* Ah = to_hs(A, K, M, K, &lda, std::ldexp(1.f, sa));
     uint16_t* Wh = to_hs(W, K, N, K, &ldb, std::ldexp(1.f, sw));
     uint16_t* W2h = to_hs(W2, K, NO, K, &ldb2, std::ldexp(1.f, sw2));
-    float *s0 = dput(hs0), *t0 = dput(ht0);
+    // pair kernel operands as the library prepares them: bn0's scale folded into the rows of the weights, the pilot
+    // table pre-scaled by the (power-of-two) activation scale
+    std::vector<float> hWf(hW.size()), hTs(hT.size());
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) hWf[(size_t)n * K + k] = (float)((double)hW[(size_t)n * K + k] * hs0[k]);
+    for (size_t i = 0; i < hT.size(); ++i) hTs[i] = std::ldexp(hT[i], sa);
+    const int swf = wshift(hWf);
+    int ldbf;
+    float* Wf = dput(hWf);
+    uint16_t* Wfh = to_hs(Wf, K, N, K, &ldbf, std::ldexp(1.f, swf));
+    float* Ts = dput(hTs);
 
     float* C; CK(hipMalloc(&C, (size_t)M * N * 4 + 4096));
     uint16_t* Ch; CK(hipMalloc(&Ch, (size_t)M * 2 * N * 2 + 4096)); CK(hipMemset(Ch, 0, (size_t)M * 2 * N * 2 + 4096));
@@ -106,8 +156,9 @@ int main(int argc, char** argv) {
     gr.acc_scale = std::ldexp(1.f, -(sa + sw2));
     dim3 gridr(pp_grid(tiles_m, 1));
     GemmHsArgs gp = gh;                                   // pair kernel: A generated from L0 / T
-    PairSrc ps{L0, T, s0, t0, K, nt};
-    const size_t lds_pair = (size_t)(PPP_RING_FLOATS + 2 * K) * 4;
+    gp.Bt = Wfh; gp.ldb = ldbf; gp.acc_scale = std::ldexp(1.f, -(sa + swf));
+    PairSrc ps{L0, Ts, nullptr, nullptr, K, nt};
+    const size_t lds_pair = (size_t)PPP_RING_FLOATS * 4;
     auto kpair = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false>;
     auto kcast = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
     CK(hipFuncSetAttribute((const void*)kpair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
@@ -198,6 +249,63 @@ int main(int argc, char** argv) {
         return 0;
     }
     const double fl = 2.0 * M * N * K;
+    if (loop) {
+        const std::string mode = argc > 4 ? argv[4] : "hs2hs";
+        const double secs = argc > 5 ? atof(argv[5]) : 4.0;
+        auto one = [&] {
+            if (mode == "mfma") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 57>), grid, dim3(PP_THREADS), 0, 0, gh);
+            else if (mode == "pair") hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa));
+            else if (mode == "regressor") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr);
+            else hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh);
+        };
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        one(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        int n = 0;
+        float ms = 0;
+        do {
+            for (int i = 0; i < 50; ++i) one();
+            n += 50;
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        } while (ms < secs * 1e3);
+        printf("loop %s: %d launches, %.3f ms each\n", mode.c_str(), n, ms / n);
+        return 0;
+    }
+    if (stamps) {
+        // where a workgroup's time goes: entry -> prologue done -> main loop done -> epilogue done (wave 0), in shader
+        // cycles and in wall time, averaged over all workgroups of a launch; plus the launch's span
+        unsigned long long* st; CK(hipMalloc(&st, (size_t)grid.x * 8 * 8)); 
+        auto report = [&](const char* name, auto&& launch, unsigned nblocks) {
+            launch(); CK(hipDeviceSynchronize());
+            CK(hipMemset(st, 0, (size_t)grid.x * 8 * 8));
+            launch(); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)nblocks * 8);
+            CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            double cyc[3] = {0, 0, 0}, wall[3] = {0, 0, 0};
+            unsigned long long t_min = ~0ull, t_max = 0; size_t n = 0;
+            for (unsigned b = 0; b < nblocks; ++b) {
+                const unsigned long long* p = &h[(size_t)b * 8];
+                if (!p[0] || !p[6]) continue;               // tile outside the matrix
+                for (int i = 0; i < 3; ++i) { cyc[i] += (double)(p[2 * (i + 1)] - p[2 * i]); wall[i] += (double)(p[2 * (i + 1) + 1] - p[2 * i + 1]); }
+                t_min = std::min(t_min, p[1]); t_max = std::max(t_max, p[7]); ++n;
+            }
+            printf("%-18s %zu workgroups: prologue %.0f cyc (%.2f us)  main loop %.0f cyc (%.2f us)  epilogue %.0f cyc (%.2f us)  | clock %.2f GHz | launch span %.1f us\n",
+                   name, n, cyc[0] / n, wall[0] / n / 100, cyc[1] / n, wall[1] / n / 100, cyc[2] / n, wall[2] / n / 100,
+                   (cyc[0] + cyc[1] + cyc[2]) / (wall[0] + wall[1] + wall[2]) / 10.0, (t_max - t_min) / 100.0);
+        };
+        GemmHsArgs a = gh; a.stamps = st;
+        report("generic hs->hs", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, a); }, grid.x);
+        a = g; a.stamps = st;
+        report("generic hs->fp32", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), grid, dim3(PP_THREADS), 0, 0, a); }, grid.x);
+        a = gp; a.stamps = st;
+        report("pair (fused A)", [&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, a, ps, std::ldexp(1.f, sa)); }, grid.x);
+        a = gc; a.stamps = st;
+        report("cast (A fp32)", [&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, pc, 16.f); }, grid.x);
+        a = gr; a.stamps = st;
+        report("regressor N=234", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, a); }, gridr.x);
+        printf("(ideal main loop: 64 sub-tiles x 48 MFMA x 32 cycles = 98304 cycles of the SIMD's matrix pipe)\n");
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         double ms;
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh); });
@@ -218,6 +326,20 @@ int main(int argc, char** argv) {
         printf("generic hs->fp32 %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
         printf("pair (fused A)   %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        {
+            auto k1 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 1>;
+            auto k2 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 2>;
+            auto k3 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 3>;
+            CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
+            CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
+            CK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
+            ms = time_ms([&] { hipLaunchKernelGGL(k1, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            printf("   pair, no L0/T requests (invalid)      %.3f ms\n", ms);
+            ms = time_ms([&] { hipLaunchKernelGGL(k2, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            printf("   pair, no conversion (invalid)         %.3f ms\n", ms);
+            ms = time_ms([&] { hipLaunchKernelGGL(k3, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            printf("   pair, neither (invalid)               %.3f ms\n", ms);
+        }
         ms = time_ms([&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, gc, pc, 16.f); });
         printf("cast (A fp32)    %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr); });
