@@ -61,6 +61,7 @@ SYMBOLS = {
     'csi_predict_samples': (ctypes.c_int, [_ctx, ctypes.c_int, _fp, ctypes.c_int64, _fp]),
     'csi_ls_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, _fp]),
     'csi_ls_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'csi_estimate_c128': (ctypes.c_int, [_ctx, _vp, ctypes.c_int64, _vp, _vp]),
     'csi_lmmse_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, ctypes.c_int, _fp, _fp, _fp]),
     'csi_lmmse_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'csi_train_begin': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(CsiTrainConfig), ctypes.POINTER(CsiTensor), ctypes.c_int]),
@@ -113,8 +114,9 @@ def build_library(force=False, verbose=False):
         if all(os.path.getmtime(s) <= so_m for s in srcs if os.path.exists(s)):
             return _SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    # host side: AVX2 (x86-64-v3) for the staging loops of the host pipeline - every host of an MI355X has it
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
-           _SRC, '-o', _SO]
+           '-Xarch_host', '-march=x86-64-v3', _SRC, '-o', _SO]
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

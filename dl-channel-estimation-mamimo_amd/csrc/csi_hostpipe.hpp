@@ -94,6 +94,15 @@ struct csi_hostpipe {
             if (o < bytes) std::memcpy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o));
         });
     }
+    // f(begin, end) over [0, n) in contiguous parts of >= min_part elements on the pool
+    void parallel_range(size_t n, size_t min_part, const std::function<void(size_t, size_t)>& f) {
+        const int parts = (int)std::min<size_t>(workers.size() + 1, std::max<size_t>(1, n / std::max<size_t>(min_part, 1)));
+        const size_t per = (n + parts - 1) / parts;
+        parallel(parts, [&](int i) {
+            const size_t b = (size_t)i * per, e = std::min(n, b + per);
+            if (b < e) f(b, e);
+        });
+    }
     ~csi_hostpipe() {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -137,7 +146,9 @@ int hp_get(csi_ctx* c, csi_hostpipe** out) {
             HIP_TRY(c, hipEventCreateWithFlags(&h->ev_out[s], hipEventDisableTiming));
         }
         int nt = c->host_threads;
-        if (nt <= 0) nt = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 4));
+        // copies and complex128 / complex64 conversions are DRAM-bound streams: one thread moves ~5-10 GB/s, the PCIe link
+        // wants ~100 GB/s of staging in both directions together
+        if (nt <= 0) nt = (int)std::min<unsigned>(24, std::max<unsigned>(2, std::thread::hardware_concurrency() / 8));
         h->start(nt - 1);
     }
     *out = c->hostpipe;
@@ -302,6 +313,118 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CSI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// complex128 in, complex64 out: the arrays the reference's deployment wrapper receives and returns
+// (inference.py:24-32: np.complex128 batch in, ``output_real + 1j*output_imag`` out).  The split into the two
+// float32 planes the kernels read, and the interleave of the two result planes, happen in the staging copies
+// of the pipeline (host threads, chunk by chunk, beside the uploads / kernels / downloads of the neighbouring
+// chunks) instead of as whole-array numpy passes in front of and behind the call.  One upload serves both
+// estimators: dnn_c64 and / or ls_c64 may be null.
+int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t npkt, float* dnn_c64, float* ls_c64) {
+    const csi_config& cf = c->cfg;
+    int rc = CSI_OK;
+    const size_t in_n = (size_t)cf.nr * cf.len_ltf;                     // samples per packet
+    const size_t in_pkt = in_n * sizeof(float);                          // one plane
+    const size_t dnn_n = dnn_c64 ? (size_t)cf.nr * cf.nt * cf.n_out : 0, ls_n = ls_c64 ? (size_t)cf.nr * cf.nt * LS_NDATA : 0;
+    const size_t out_pkt = (dnn_n + ls_n) * sizeof(float);              // one plane of everything that comes back
+    int64_t chunk = std::max<int64_t>(1, (int64_t)65536 / std::max(1, cf.nr * cf.nt));
+    chunk = std::max<int64_t>(chunk, ((int64_t)8 << 20) / (int64_t)in_pkt);
+    chunk = std::min(chunk, npkt);
+    rc = hp_reserve(c, h, 2 * in_pkt * chunk, 2 * out_pkt * chunk, true, true);
+    if (rc) return rc;
+    const int64_t nchunks = (npkt + chunk - 1) / chunk;
+    auto np_of = [&](int64_t i) { return std::min(chunk, npkt - i * chunk); };
+    auto stage_in = [&](int64_t i, int s) {                              // complex128 -> two float32 planes in pinned[s]
+        const int64_t np = np_of(i);
+        const double* src = in + (size_t)i * chunk * in_n * 2;
+        float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
+        float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
+        h->parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) {
+            for (size_t j = b; j < e; ++j) {
+                p_re[j] = (float)src[2 * j];
+                p_im[j] = (float)src[2 * j + 1];
+            }
+        });
+    };
+    auto drain = [&](int64_t i) -> int {                                 // two float32 planes -> complex64, after the D2H of chunk i
+        const int s = (int)(i & 1);
+        HIP_TRY(c, hipEventSynchronize(h->ev_out[s]));
+        const int64_t np = np_of(i);
+        const float* p = reinterpret_cast<const float*>(h->pin_out[s]);
+        auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
+            h->parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) {
+                for (size_t j = b; j < e; ++j) {
+                    dst[2 * j] = re[j];
+                    dst[2 * j + 1] = im[j];
+                }
+            });
+        };
+        // pinned[s] layout = device[s] output layout: dnn re | dnn im | ls re | ls im, each sized for `chunk` packets
+        if (dnn_c64) weave(p, p + dnn_n * chunk, dnn_c64 + (size_t)i * chunk * dnn_n * 2, (size_t)np * dnn_n);
+        if (ls_c64) weave(p + 2 * dnn_n * chunk, p + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)i * chunk * ls_n * 2, (size_t)np * ls_n);
+        return CSI_OK;
+    };
+    for (int64_t i = 0; i < nchunks; ++i) {
+        const int s = (int)(i & 1);
+        const int64_t np = np_of(i);
+        float* d_re = reinterpret_cast<float*>(h->dev[s]);
+        float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
+        float* d_out = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
+        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
+        if (i >= 2) HIP_TRY(c, hipEventSynchronize(h->ev_in[s]));      // pinned_in[s] uploaded (chunk i-2)
+        stage_in(i, s);
+        HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
+        HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
+        HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
+        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
+        if (ls_c64) {
+            rc = csi_ls_estimate_device(c, d_re, d_im, np, d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk);
+            if (rc) return rc;
+        }
+        if (dnn_c64) {
+            rc = csi_predict_device(c, d_re, d_im, np, d_out, d_out + dnn_n * chunk);
+            if (rc) return rc;
+        }
+        HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
+        if (i >= 2) { rc = drain(i - 2); if (rc) return rc; }
+        HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
+        // one D2H per plane actually filled (np of chunk packets)
+        if (dnn_c64) {
+            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s], d_out, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + dnn_n * chunk * sizeof(float), d_out + dnn_n * chunk, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+        }
+        if (ls_c64) {
+            const size_t o = 2 * dnn_n * chunk;
+            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + o * sizeof(float), d_out + o, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + (o + ls_n * chunk) * sizeof(float), d_out + o + ls_n * chunk, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+        }
+        HIP_TRY(c, hipEventRecord(h->ev_out[s], h->s_out));
+    }
+    for (int64_t i = std::max<int64_t>(0, nchunks - 2); i < nchunks; ++i) {
+        rc = drain(i);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+int hp_estimate_c128(csi_ctx* c, const double* in, int64_t npkt, float* dnn_c64, float* ls_c64) {
+    csi_hostpipe* h = nullptr;
+    int rc = hp_get(c, &h);
+    if (rc) return rc;
+    rc = hp_estimate_c128_impl(c, h, in, npkt, dnn_c64, ls_c64);
+    if (rc) {
+        const std::string keep = c->err;
+        hipStreamSynchronize(h->s_in);
+        hipStreamSynchronize(c->stream);
+        hipStreamSynchronize(h->s_out);
+        (void)hipGetLastError();
+        c->err = keep;
+    }
+    return rc;
 }
 
 }  // namespace

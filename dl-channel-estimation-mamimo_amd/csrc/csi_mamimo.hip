@@ -1,6 +1,6 @@
 // csi_mamimo.hip - C-ABI (include/csi_mamimo.h) and host-side orchestration of the MI355X
 // channel-estimation hot path.  gfx950 only; built with
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csi_mamimo.hip -o libcsi_mamimo.so
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Xarch_host -march=x86-64-v3 csi_mamimo.hip -o libcsi_mamimo.so
 //
 // What runs where (reference call sites in include/csi_mamimo.h):
 //   csi_predict*        layer 0 once per (packet, rx)  -> gemm_f32_kernel<EPI_RAW> (optional split-K)
@@ -961,6 +961,28 @@ int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t np
     const int engine = c->f32_engine;
     c->f32_engine = 0;
     rc = host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
+    c->f32_engine = engine;
+    return rc;
+}
+
+int csi_estimate_c128(csi_ctx* c, const double* ltf_c128, int64_t npkt, float* dnn_c64, float* ls_c64) {
+    int rc = check_ready(c, dnn_c64 != nullptr);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!ltf_c128 || (!dnn_c64 && !ls_c64))))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_estimate_c128: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    rc = hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, ls_c64);
+    if (rc || !dnn_c64) return rc;
+    // range guard of the split-f16 engine, as in csi_predict: repeat the DNN on the fp32 MFMA kernels
+    float hit = 0.f;
+    bool low = false;
+    rc = hs_range_check(c, &hit, &low);
+    if (rc || (hit == 0.f && !low)) return rc;
+    ++c->hs_range_fallbacks;
+    const int engine = c->f32_engine;
+    c->f32_engine = 0;
+    rc = hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, nullptr);
     c->f32_engine = engine;
     return rc;
 }

@@ -35,6 +35,7 @@ namespace csi {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HS_G = 16;                       // k-columns per group (= per ping-pong sub-tile)
 
@@ -115,7 +116,8 @@ __device__ __forceinline__ void hs_report_peak(unsigned* peak, float m, bool row
 // wave-private LDS image [64 rows][64 columns]; a lane then owns 8 columns of a row, separates the
 // planes with two v_perm_b32 per word pair and stores 16 B of hi and 16 B of lo (the 8 lanes of a
 // row write 256 contiguous bytes).  The ring is idle by then (see pp_epilogue).
-template <int EPI, bool OUT_HS>
+// NOSTORE (timing probe): everything but the global stores (they sit behind a condition that is false at run time).
+template <int EPI, bool OUT_HS, bool NOSTORE = false>
 __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArgs& g, float* lds, int m0, int n0, int wave, int lane) {
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -145,9 +147,8 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
                         float v0 = fmaf(acc[2 * half + m2][nj][r], as, bias), v1 = fmaf(acc[2 * half + m2][nj][r + 1], as, bias);
                         if (EPI == EPI_BIAS_RELU_AFFINE) { v0 = fmaf(fmaxf(v0, 0.f), sc, sh); v1 = fmaf(fmaxf(v1, 0.f), sc, sh); }
                         else { v0 *= sc; v1 *= sc; }
-                        uint32_t h, l;
                         pk = hs_absmax(pk, v0, v1);
-                        hs_split2(v0, v1, h, l);
+                        const uint32_t h = hs_hi_pair(v0, v1), l = hs_lo_pair(v0, v1, h);
                         const int row = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // rows row, row + 1
                         ep[row * 64 + nj * 32 + l31] = (h & 0xffffu) | (l << 16);
                         ep[(row + 1) * 64 + nj * 32 + l31] = (h >> 16) | (l & 0xffff0000u);
@@ -167,7 +168,7 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
                 vh.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u);  vl.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x07060302u);
                 vh.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u);  vl.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u);
                 const int row = m0 + wm * 128 + half * 64 + rl;
-                if (col8 < g.N && (full_rows || row < g.M)) {
+                if (col8 < g.N && (full_rows || row < g.M) && (!NOSTORE || g.M < 0)) {
                     *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = vh;
                     *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc + 16) = vl;
                 }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
 
     hs_stamp(g.stamps, 2);
     if ((DBG & 8) && g.M > 0) return;
-    hs_epilogue<EPI, OUT_HS>(acc, g, lds, m0, n0, wave, lane);
+    hs_epilogue<EPI, OUT_HS, (DBG & 64) != 0>(acc, g, lds, m0, n0, wave, lane);   // DBG 64: epilogue without its global stores
     hs_stamp(g.stamps, 3);
 }
 
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         }
     }
     f32x4 lv[2] = {}, tv[2] = {};
-    float apk = 0.f;                    // largest |scaled A operand| this lane converted
+    float apk = 0.f;
+    u16x2 apk16 = {0, 0};              // pair mode: running maximum of the hi halves (bit patterns)                    // largest |scaled A operand| this lane converted
     auto load_a = [&](int sub) {
         if (DBG & 1) return;
 #pragma unroll
@@ -522,7 +524,14 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         ol.z = hs_lo_pair(gv[1][0], gv[1][1], gh.z);
         ol.w = hs_lo_pair(gv[1][2], gv[1][3], gh.w);
         *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + a_lo_off) = ol;
-        apk = hs_absmax(hs_absmax(hs_absmax(hs_absmax(apk, gv[0][0], gv[0][1]), gv[0][2], gv[0][3]), gv[1][0], gv[1][1]), gv[1][2], gv[1][3]);
+        if (CAST) {
+            apk = hs_absmax(hs_absmax(hs_absmax(hs_absmax(apk, gv[0][0], gv[0][1]), gv[0][2], gv[0][3]), gv[1][0], gv[1][1]), gv[1][2], gv[1][3]);
+        } else {
+            // relu output: no sign, so the f16 bit patterns of the hi halves order like unsigned integers (inf on top) -
+            // four packed 16-bit maxima instead of six fp32 ones
+            apk16 = __builtin_elementwise_max(__builtin_elementwise_max(apk16, __builtin_bit_cast(u16x2, gh.x)), __builtin_bit_cast(u16x2, gh.y));
+            apk16 = __builtin_elementwise_max(__builtin_elementwise_max(apk16, __builtin_bit_cast(u16x2, gh.z)), __builtin_bit_cast(u16x2, gh.w));
+        }
     };
 
     const int fswz = (l31 >> 2) & 3;
@@ -603,6 +612,10 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
     hs_stamp(g.stamps, 2);
+    if (!CAST) {
+        const uint16_t top = apk16[0] > apk16[1] ? apk16[0] : apk16[1];
+        apk = top >= 0x7c00u ? __builtin_inff() : (float)__builtin_bit_cast(_Float16, top);
+    }
     hs_report_peak(g.peak, apk, true);
     GemmHsArgs ge = g;
     ge.acc_scale = acc_scale;

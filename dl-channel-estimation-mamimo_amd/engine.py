@@ -339,6 +339,34 @@ class CsiEngine:
         h.imag = h_im
         return h
 
+    def estimate(self, ltf, dnn=True, ls=True, out=None):
+        """Both estimators on the arrays of the reference's deployment wrapper (inference.py:24-32): ``ltf``
+        complex128 [npkt, nr, len_ltf] in, complex64 [npkt, nr, nt, n_out] (DNN) and / or [npkt, nr, nt, 234] (LS)
+        out - one upload for both, the real / imag split and the complex assembly done inside the library's
+        staging copies (csi_estimate_c128).  Returns (dnn, ls); an estimator that was not asked for is None.
+        ``out=(dnn_buf, ls_buf)`` reuses complex64 arrays."""
+        ltf = np.ascontiguousarray(ltf, dtype=np.complex128)
+        if ltf.ndim != 3 or ltf.shape[1:] != (self.nr, self.len_ltf):
+            raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {ltf.shape}')
+        npkt = ltf.shape[0]
+        bufs = []
+        for want, width, given in ((dnn, self.n_out, out[0] if out else None), (ls, N_DATA, out[1] if out else None)):
+            if not want:
+                bufs.append(None)
+                continue
+            shape = (npkt, self.nr, self.nt, width)
+            if given is None:
+                given = np.empty(shape, dtype=np.complex64)
+            elif given.dtype != np.complex64 or given.shape != shape or not given.flags['C_CONTIGUOUS']:
+                raise CsiError(-1, f'out arrays must be C-contiguous complex64 {shape}')
+            bufs.append(given)
+        if bufs[0] is None and bufs[1] is None:
+            raise CsiError(-1, 'estimate: nothing asked for')
+        self._check(self._lib.csi_estimate_c128(self._ctx, ltf.ctypes.data, npkt,
+                                                bufs[0].ctypes.data if bufs[0] is not None else None,
+                                                bufs[1].ctypes.data if bufs[1] is not None else None))
+        return bufs[0], bufs[1]
+
     def pinned_empty(self, shape, dtype=np.float32):
         """numpy array in pinned host memory (csi_host_malloc); freed with the array."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize

@@ -89,15 +89,16 @@ class CSIPredictor:
     def inference(self, input_batch: np.ndarray):
         X = self.preprocess_data(input_batch)
         if self.experiment == 'matlab_maMimo':
-            # X complex [npkt, nr, len_ltf]: both component models over all nt*nr pairs of each
-            # packet, dataset sample order (mk.py:62) -> [npkt, nr, nt, n_out]
+            # X complex128 [npkt, nr, len_ltf]: both component models over all nt*nr pairs of each packet, dataset
+            # sample order (mk.py:62) -> complex64 [npkt, nr, nt, n_out].  The X.real / X.imag split of :29-30 and
+            # the ``real + 1j*imag`` of :31 happen inside the library's staging copies (csi_estimate_c128)
             if self._any_nr:        # engine built for one rx antenna per item: [nPkt, nRx, L] -> [nPkt*nRx, 1, L] and back
                 npkt, nrx = X.shape[:2]
-                output_real, output_imag = self.engine.predict(X.reshape(npkt * nrx, 1, X.shape[2]))
-                output_real = output_real.reshape(npkt, nrx, *output_real.shape[2:])
-                output_imag = output_imag.reshape(npkt, nrx, *output_imag.shape[2:])
+                out, _ = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=True, ls=False)
+                out = out.reshape(npkt, nrx, *out.shape[2:])
             else:
-                output_real, output_imag = self.engine.predict(X)
+                out, _ = self.engine.estimate(X, dnn=True, ls=False)
+            return self.postprocess_data(out)
         else:
             bs = X.shape[0]   # assumes num. of samples in the first dimension
             output_real = self.model_real.predict(X.real, batch_size=bs)
@@ -108,11 +109,16 @@ class CSIPredictor:
     def ls_estimate(self, input_batch: np.ndarray):
         """LS pilot estimate of the same packets (helperMIMOChannelEstimate.m), complex64
         [npkt, nr, nt, 234]; matlab_maMimo only."""
+        return self.estimate(input_batch, dnn=False)[1]
+
+    def estimate(self, input_batch: np.ndarray, dnn=True, ls=True):
+        """(DNN estimate, LS estimate) of the same packets with ONE upload of the preambles; matlab_maMimo only."""
         X = self.preprocess_data(input_batch)
         if self._any_nr:
-            h = self.engine.ls_estimate(X.reshape(X.shape[0] * X.shape[1], 1, X.shape[2]))
-            return h.reshape(X.shape[0], X.shape[1], *h.shape[2:])
-        return self.engine.ls_estimate(X)
+            npkt, nrx = X.shape[:2]
+            outs = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=dnn, ls=ls)
+            return tuple(None if o is None else o.reshape(npkt, nrx, *o.shape[2:]) for o in outs)
+        return self.engine.estimate(X, dnn=dnn, ls=ls)
 
     # inference.py:35-46
     def preprocess_data(self, input_batch):

@@ -12,6 +12,8 @@
  *   dataset['P'] fed as seq_p     massiveMIMO_dataGenerator.py:311  csi_set_pilot
  *   Model.predict(generator) over packets, batch = nTX*nRX
  *        DNN.py:339-346 + sample assembly dataGenerator.py:299-316  csi_predict[_device]
+ *   CSIPredictor.inference: X.real / X.imag -> predict x2 ->
+ *        real + 1j*imag on complex128 batches    inference.py:24-32  csi_estimate_c128
  *   Model.predict(x, batch_size=bs)              inference.py:29-30
  *        / DNN.py:434,470  (arbitrary rows [B, lenLTF+Nt])          csi_predict_samples
  *   ofdmdemod + helperMIMOChannelEstimate
@@ -119,6 +121,14 @@ int  csi_ls_estimate(csi_ctx* ctx, const float* ltf_re, const float* ltf_im, int
 int  csi_ls_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
                             float* d_h_re, float* d_h_im);
 
+/* Both estimators on the arrays the reference's deployment wrapper handles (inference.py:24-32: a numpy
+ * complex128 batch in, ``output_real + 1j*output_imag`` = complex64 out): ltf_c128 [npkt][nr][len_ltf] as
+ * interleaved (re, im) doubles; dnn_c64 [npkt][nr][nt][n_out] and ls_c64 [npkt][nr][nt][234] as interleaved
+ * (re, im) floats, either may be NULL.  One upload of the preambles serves both; the complex128 -> 2 x float32
+ * split and the complex64 interleave run in the staging copies of the host pipeline, chunk by chunk beside the
+ * transfers and kernels, instead of as whole-array passes in the caller (X.real / X.imag, inference.py:29-31). */
+int  csi_estimate_c128(csi_ctx* ctx, const double* ltf_c128, int64_t npkt, float* dnn_c64, float* ls_c64);
+
 /* LMMSE smoothing of an LS estimate (the 'hDmmse' output of helperMIMOChannelEstimate.m:37-39,
  * LMMSE_ce.m:23-39 with Nfft = Np = 234, Nps = 1).  h_re / h_im: LS estimate [npkt][nr][nt][234];
  * hvec [npkt][L]: the vector the reference passes as LMMSE_ce's 'h' (generate_maMIMO_LTF.m:342
@@ -219,7 +229,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
- *                         slots of the host-buffer entry points (0 = automatic, up to 8)
+ *                         slots of the host-buffer entry points (0 = automatic: cores / 8, between 2 and 24)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
  *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
  *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix - chosen

@@ -859,6 +859,39 @@ def test_host_pipeline_many_chunks_pinned_and_pageable(pkg, oracle):
 
 
 # ------------------------------------------------------------------------------------ device path
+def test_estimate_c128_matches_plane_entry_points(pkg, oracle):
+    """csi_estimate_c128 - complex128 preambles in, complex64 DNN and LS estimates out, one upload, the real / imag
+    split and the complex assembly inside the pipeline's staging copies - must return exactly what csi_predict and
+    csi_ls_estimate return for the float32 planes of the same packets: many chunks (Nt=4, Nr=2: 8192-packet chunks),
+    a ragged last chunk, either output alone, caller-provided buffers, and the deployment wrapper on top of it."""
+    rng = np.random.default_rng(21)
+    nt, nr, npkt, hidden = 4, 2, 20011, (64, 32)
+    w_re, w_im = _weights(oracle, 21, nt, hidden)
+    P = _pilot(rng, nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    x = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt)))        # complex128
+    p_re, p_im = e.predict(x)
+    h = e.ls_estimate(x)
+    dnn, ls = e.estimate(x)
+    assert dnn.dtype == np.complex64 and dnn.shape == (npkt, nr, nt, 234) and ls.dtype == np.complex64
+    np.testing.assert_array_equal(dnn.real, p_re)
+    np.testing.assert_array_equal(dnn.imag, p_im)
+    np.testing.assert_array_equal(ls, h)
+    only_ls = e.estimate(x[:700], dnn=False)
+    assert only_ls[0] is None
+    np.testing.assert_array_equal(only_ls[1], h[:700])
+    buf = np.zeros((3, nr, nt, 234), np.complex64)
+    got, none = e.estimate(x[5:8], ls=False, out=(buf, None))
+    assert got is buf and none is None
+    np.testing.assert_array_equal(buf.real, e.predict(x[5:8])[0])        # (a 3-packet call takes other kernels than the big batch)
+    r_re, r_im = oracle.predict_packets(x[:4].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=4)
+    assert rel_rows(dnn[:4].real, r_re) < TOL and rel_rows(dnn[:4].imag, r_im) < TOL
+    with pytest.raises(pkg.CsiError):
+        e.estimate(x[:2], dnn=False, ls=False)
+    with pytest.raises(pkg.CsiError):
+        e.estimate(x[:2, :1])
+
+
 def test_device_resident_path_and_profile(pkg, oracle):
     rng = np.random.default_rng(41)
     nt, nr, npkt, hidden = 8, 2, 16, (64, 64)

@@ -66,6 +66,25 @@ def main():
             moved = re.nbytes + im.nbytes + ore.nbytes + oim.nbytes
             print(f'{"pinned  " if pinned else "pageable"} {name:16s} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
                   f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions)')
+    # the deployment surface: complex128 numpy batch in, complex64 numpy estimates out (csi_estimate_c128), by staging threads
+    x = np.empty((npkt, nr, 320 * nt), np.complex128)
+    x.real = rng.standard_normal(x.shape[1:])
+    x.imag = x.real
+    dnn = np.zeros((npkt, nr, nt, 234), np.complex64)
+    ls = np.zeros((npkt, nr, nt, 234), np.complex64)
+    for threads in ([a.threads] if a.threads else [0, 4, 8, 16, 24, 32, 48]):
+        e.set_option('host_threads', threads)
+        for what, kw in (('DNN + LS', dict(out=(dnn, ls))), ('DNN only', dict(ls=False, out=(dnn, None)))):
+            e.estimate(x, **kw)
+            ts = []
+            for _ in range(a.reps):
+                t0 = time.perf_counter()
+                e.estimate(x, **kw)
+                ts.append(time.perf_counter() - t0)
+            t = min(ts)
+            moved = x.nbytes // 2 + dnn.nbytes + (ls.nbytes if 'LS' in what else 0)
+            print(f'c128 -> c64 {what:9s} host_threads={threads:2d} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
+                  f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions)')
 
 
 if __name__ == '__main__':

@@ -312,6 +312,8 @@ int main(int argc, char** argv) {
         printf("generic hs->hs   %.3f ms  %.0f TF fp32-equivalent (%.0f TF f16 executed)\n", ms, fl / ms / 1e9, 3 * fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 8>), grid, dim3(PP_THREADS), 0, 0, gh); });
         printf("   no stores     %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 64>), grid, dim3(PP_THREADS), 0, 0, gh); });
+        printf("   epilogue arithmetic + LDS staging, no global stores %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 9>), grid, dim3(PP_THREADS), 0, 0, gh); });
         printf("   no stores/DMA %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 25>), grid, dim3(PP_THREADS), 0, 0, gh); });
