@@ -78,11 +78,13 @@ struct Model {
     bool table_ok = false;
 };
 
-struct GraphEntry {           // one captured csi_predict_device call
+struct GraphEntry {           // one captured csi_predict_device / csi_estimate_device call
     const void* in_re; const void* in_im; void* out_re; void* out_im;
+    void* h_re; void* h_im;   // LS outputs (csi_estimate_device), null for csi_predict_device
     int64_t npkt;
     int seen;                 // eager runs with this key so far (capture happens on the 2nd call)
     hipGraphExec_t exec;
+    int64_t hs_launches = 0;  // split-engine GEMMs inside the graph (a replay owes them to the range-guard bookkeeping)
 };
 
 struct ProfSpan {
@@ -132,6 +134,8 @@ struct csi_ctx {
     size_t stage_bytes = 0;
     int xcd_order = -1;          // option "xcd_order": -1 auto, 0 linear tile order, 1 XCD super-tile order
     bool use_graph = false;
+    bool in_graph_call = false;  // csi_estimate_device is running the content of a (future) graph: no second-stream fork inside
+    int64_t graph_replays = 0;   // hipGraphLaunch count ("graph_replays", read-only)
     std::vector<GraphEntry> graphs;
     int f32_engine = -1;         // "f32_engine" option: fp32 contexts, 0 = native fp32 MFMA kernels, 1 = split-f16 kernels (gemm_hs.hip.h)
                                  // wherever the shapes allow, -1 = split-f16 once a GEMM fills the chip (default)

@@ -90,6 +90,50 @@ int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     return CSI_OK;
 }
 
+// hipGraph replay of a device-pointer call ("use_graph"): the 1st call with a key runs eagerly (it sizes every
+// buffer), the 2nd is captured - the whole launch sequence of the call: range-guard memsets, magnitude sample,
+// layer 0 (+ slab sum), per-pair layers, regressor, for both component models and every packet chunk, and the LS
+// kernel for csi_estimate_device - later calls replay it.  Any reallocation / weight / pilot / option change
+// drops the cache.  Calls that fork a second stream (small_call_overlap) or profile per kernel run eagerly.
+template <typename Run>
+int graph_or_run(csi_ctx* c, const GraphEntry& key, Run&& run) {
+    if (!c->use_graph || c->prof_on) return run();
+    auto same = [&](const GraphEntry& g) {
+        return g.in_re == key.in_re && g.in_im == key.in_im && g.out_re == key.out_re && g.out_im == key.out_im && g.h_re == key.h_re &&
+               g.h_im == key.h_im && g.npkt == key.npkt;
+    };
+    GraphEntry* ge = nullptr;
+    for (auto& g : c->graphs)
+        if (same(g)) ge = &g;
+    if (!ge) {
+        if (c->graphs.size() >= 16) drop_graphs(c);
+        c->graphs.push_back(key);
+        ge = &c->graphs.back();
+    }
+    if (ge->exec) {
+        ++c->graph_replays;
+        c->hs_launches += ge->hs_launches;         // the replayed kernels feed the range guard like eager ones
+        HIP_TRY(c, hipGraphLaunch(ge->exec, c->stream));
+        return CSI_OK;
+    }
+    if (ge->seen++ == 0) return run();
+    const int64_t launches = c->hs_launches;
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run();
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e_end != hipSuccess) return fail(c, CSI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) return fail(c, CSI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e_inst));
+    for (auto& g : c->graphs)
+        if (same(g)) { g.exec = exec; g.hs_launches = c->hs_launches - launches; }
+    HIP_TRY(c, hipGraphLaunch(exec, c->stream));
+    return CSI_OK;
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -460,7 +504,7 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         }
         // small call: the two component models are independent and each is a chain of short,
         // launch-latency-bound kernels - run the imag model on a second stream with its own scratch
-        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && npkt * c->cfg.nr <= 64;
+        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && npkt * c->cfg.nr <= 64;
         if (!overlap) {
             int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
             if (r) return r;
@@ -490,38 +534,28 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->aux_join, 0));
         return CSI_OK;
     };
-    if (!c->use_graph || c->prof_on) return run();
+    return graph_or_run(c, GraphEntry{d_ltf_re, d_ltf_im, d_out_re, d_out_im, nullptr, nullptr, npkt, 0, nullptr}, run);
+}
 
-    // hipGraph replay: 1st call with a key runs eagerly (sizes every buffer), 2nd call captures,
-    // later calls replay.  Any reallocation / weight / pilot change drops the cache.
-    GraphEntry* ge = nullptr;
-    for (auto& g : c->graphs)
-        if (g.in_re == d_ltf_re && g.in_im == d_ltf_im && g.out_re == d_out_re && g.out_im == d_out_im && g.npkt == npkt) ge = &g;
-    if (!ge) {
-        if (c->graphs.size() >= 16) drop_graphs(c);
-        c->graphs.push_back(GraphEntry{d_ltf_re, d_ltf_im, d_out_re, d_out_im, npkt, 0, nullptr});
-        ge = &c->graphs.back();
-    }
-    if (ge->exec) {
-        HIP_TRY(c, hipGraphLaunch(ge->exec, c->stream));
-        return CSI_OK;
-    }
-    if (ge->seen++ == 0) return run();
-    const GraphEntry key = *ge;               // run() may not reallocate now, but keep a copy anyway
-    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    rc = run();
-    hipGraph_t graph = nullptr;
-    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-    if (e_end != hipSuccess) return fail(c, CSI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
-    hipGraphExec_t exec = nullptr;
-    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (e_inst != hipSuccess) return fail(c, CSI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e_inst));
-    for (auto& g : c->graphs)
-        if (g.in_re == key.in_re && g.in_im == key.in_im && g.out_re == key.out_re && g.out_im == key.out_im && g.npkt == key.npkt) g.exec = exec;
-    HIP_TRY(c, hipGraphLaunch(exec, c->stream));
-    return CSI_OK;
+int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_out_re, float* d_out_im,
+                        float* d_h_re, float* d_h_im) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!d_ltf_re || !d_ltf_im || !d_out_re || !d_out_im || !d_h_re || !d_h_im)))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_estimate_device: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    auto run = [&]() -> int {
+        const bool g = c->use_graph;
+        c->use_graph = false;                      // the two calls below are the graph's content, not graphs of their own
+        c->in_graph_call = g;
+        int r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
+        if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+        c->use_graph = g;
+        c->in_graph_call = false;
+        return r;
+    };
+    return graph_or_run(c, GraphEntry{d_ltf_re, d_ltf_im, d_out_re, d_out_im, d_h_re, d_h_im, npkt, 0, nullptr}, run);
 }
 
 int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_h_re,
@@ -700,7 +734,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
     else if (n == "host_threads") *value = c->host_threads;
     else if (n == "ls_kernel") *value = c->ls_kernel;
-    else if (n == "hs_launches") *value = c->hs_launches;                    // read-only counters
+    else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
+    else if (n == "hs_launches") *value = c->hs_launches;
     else if (n == "hs_range_fallbacks") *value = c->hs_range_fallbacks;
     else return fail(c, CSI_ERR_INVALID_ARG, "csi_get_option: unknown option '%s'", name);
     return CSI_OK;

@@ -409,6 +409,10 @@ class CsiEngine:
     def predict_device(self, d_re, d_im, npkt, d_out_re, d_out_im):
         self._check(self._lib.csi_predict_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr))
 
+    def estimate_device(self, d_re, d_im, npkt, d_out_re, d_out_im, d_h_re, d_h_im):
+        """LS + DNN of device-resident packets as one call (one hipGraph under 'use_graph')."""
+        self._check(self._lib.csi_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr, d_h_re.ptr, d_h_im.ptr))
+
     def ls_estimate_device(self, d_re, d_im, npkt, d_h_re, d_h_im):
         self._check(self._lib.csi_ls_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_h_re.ptr, d_h_im.ptr))
 

@@ -120,6 +120,12 @@ int  csi_ls_estimate(csi_ctx* ctx, const float* ltf_re, const float* ltf_im, int
                      float* h_re, float* h_im);
 int  csi_ls_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
                             float* d_h_re, float* d_h_im);
+/* LS + DNN of device-resident packets as ONE unit (the per-packet work of generate_maMIMO_LTF.m:336-342 plus
+ * DNN.py:346): with "use_graph" the whole launch sequence - LS kernel, range-guard memsets, magnitude sample,
+ * layer 0, per-pair layers, regressor, both component models, every packet chunk - is captured into one hipGraph
+ * on the 2nd identical call and replayed afterwards. */
+int  csi_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt,
+                         float* d_out_re, float* d_out_im, float* d_h_re, float* d_h_im);
 
 /* Both estimators on the arrays the reference's deployment wrapper handles (inference.py:24-32: a numpy
  * complex128 batch in, ``output_real + 1j*output_imag`` = complex64 out): ltf_c128 [npkt][nr][len_ltf] as

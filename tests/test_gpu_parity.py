@@ -962,6 +962,66 @@ def test_hipgraph_replay_matches_eager(pkg, oracle):
         e.set_option('no_such_option', 1)
 
 
+def test_hipgraph_config5_scale_multi_chunk(pkg, oracle):
+    """BASELINE configs[4] shape (Nt=128, Nr=16, shipped model, "hipGraph-captured batched inference"): 520 packets =
+    1 064 960 pair rows per component model, more than the 4 GiB workspace holds, so one call is TWO packet chunks
+    - LS kernel, range-guard memsets, magnitude sample, layer 0 (K = 40 960), slab sum, per-pair layer, regressor,
+    x 2 models x 2 chunks in ONE captured graph (csi_estimate_device).  Replays must reproduce the eager results bit
+    for bit, follow new data in the same buffers, keep the split engine's range-guard bookkeeping alive, and the
+    sampled packets must meet the contract."""
+    nt, nr, npkt, hidden = 128, 16, 520, (1024, 1024)
+    w_re, w_im = _weights(oracle, 128, nt, hidden)
+    P = oracle.hadamard(nt)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    d_re, d_im = e.empty((npkt, nr, e.len_ltf)), e.empty((npkt, nr, e.len_ltf))
+    e.synth_white(55, 0, npkt, d_re, d_im)
+    outs = [e.empty((npkt, nr, nt, 234)) for _ in range(4)]            # dnn re, dnn im, ls re, ls im
+    e.estimate_device(d_re, d_im, npkt, *outs)
+    e.synchronize()
+    eager = [o.download() for o in outs]
+    n_eager = e.get_option('hs_launches')
+    assert n_eager >= 2 * 2 * 3                                          # two chunks x two models x (layer 0, pair, regressor)
+    e.set_option('use_graph', 1)
+    for it in range(4):                                                  # eager, capture, replay, replay
+        for o in outs:
+            e._check(e._lib.csi_memcpy_h2d(e._ctx, o.ptr, np.zeros(1024, np.float32).ctypes.data, 4096))    # dirty the heads
+        before = e.get_option('hs_launches')
+        e.estimate_device(d_re, d_im, npkt, *outs)
+        e.synchronize()                                                  # range guard checked after replays too
+        assert e.get_option('hs_launches') - before == n_eager
+        for o, ref in zip(outs, eager):
+            np.testing.assert_array_equal(o.download(), ref)
+    assert e.get_option('graph_replays') == 2
+    # new data in the same buffers: the graph reads it (and the magnitude sample re-derives the input scale)
+    e.synth_white(56, 0, npkt, d_re, d_im)
+    e.estimate_device(d_re, d_im, npkt, *outs)
+    e.synchronize()
+    assert e.get_option('graph_replays') == 3
+    pick = [0, 259, 260, npkt - 1]                                       # both sides of the chunk boundary
+    for p in pick:
+        ltf = d_re.download(p, 1) + 1j * d_im.download(p, 1)
+        r_re, r_im = oracle.predict_packets_shared(ltf, P, w_re, w_im)
+        assert rel_rows(outs[0].download(p, 1), r_re) < TOL and rel_rows(outs[1].download(p, 1), r_im) < TOL, p
+        ref = oracle.ls_estimate(ltf, P)
+        assert rel_rows(np.concatenate([outs[2].download(p, 1), outs[3].download(p, 1)], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL, p
+    # a range-guard hit inside a replayed graph is still reported
+    e.set_option('use_graph', 0)
+    e.set_option('use_graph', 1)
+    big = e.empty((4, nr, e.len_ltf))
+    big.upload(np.full((4, nr, e.len_ltf), 3.0e4, np.float32))
+    o4 = [e.empty((4, nr, nt, 234)) for _ in range(4)]
+    e.set_option('f32_engine', 1)
+    hits = 0
+    for it in range(3):
+        e.estimate_device(big, big, 4, *o4)
+        try:
+            e.synchronize()
+        except pkg.CsiError as err:
+            assert err.code == -6
+            hits += 1
+    assert hits == 3 and e.get_option('graph_replays') == 4
+
+
 @pytest.mark.parametrize('engine', [-1, 0])
 def test_full_size_properties_config2(pkg, oracle, engine):
     """(engine -1: the library default, i.e. the split-f16 engine at this size; 0: the fp32 MFMA kernels.)
