@@ -55,6 +55,9 @@ struct Layer {
     int ldw = 0;
     bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
     int ldwb = 0;
+    uint16_t* Wh_f = nullptr; // regressor behind ONE per-pair layer: Wh with that layer's BN scale folded into its rows (fused kernel)
+    int wshift_f = 0;
+    int ashift_pre = 4;       // like ashift for this layer's relu output BEFORE BatchNormalization (its scale lives in the next weights)
     uint16_t* Wh = nullptr;   // [out][ldwh] split-f16 ("hs", gemm_hs.hip.h) copy of Wt * 2^wshift; layer 0: LTF columns only
     int ldwh = 0;             // halves per row = 2 * (in rounded up to 16)
     int wshift = 0;
@@ -126,8 +129,8 @@ struct csi_ctx {
     // (a one-packet call is launch-latency bound: 12 short kernels in a row; see csi_predict_device)
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    char *aux_ws = nullptr, *aux_l0skinny = nullptr, *aux_skbuf = nullptr;
-    size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0;
+    char *aux_ws = nullptr, *aux_l0skinny = nullptr, *aux_skbuf = nullptr, *aux_fuse_ws = nullptr;
+    size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0, aux_fuse_ws_bytes = 0;
     int small_call_overlap = 1;  // "small_call_overlap" option
     // staging for host-buffer entry points
     char* stage = nullptr;
@@ -142,10 +145,15 @@ struct csi_ctx {
     int hs_act_shift = HS_SHIFT_AUTO;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
     float* hs_zero = nullptr;    // zeros, widest hidden layer: the BN shift the split-engine kernels see (it lives in the next layer's bias)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
-    size_t hs_lds_attr[3] = {0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out)
+    size_t hs_lds_attr[4] = {0, 0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out) / pair + fused regressor
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
+    int hs_fuse_regressor = 0;   // "hs_fuse_regressor": two hidden layers -> the regressor runs inside the pair kernel (h2 stays on the CU).
+                                 // Off by default: measured SLOWER (2.45 vs 1.88 ms per 262144 rows, profiles/r02_hs_probe.txt) - the
+                                 // partial sums the four column tiles exchange cost what the h2 round trip cost
+    char* fuse_ws = nullptr;     // its partial-sum slabs + row-tile flags
+    size_t fuse_ws_bytes = 0;
     int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024: 40 packets); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
@@ -270,6 +278,7 @@ void free_layer(Layer& l) {
     if (l.Wt) hipFree(l.Wt);
     if (l.Wb) hipFree(l.Wb);
     if (l.Wh) hipFree(l.Wh);
+    if (l.Wh_f) hipFree(l.Wh_f);
     if (l.bias) hipFree(l.bias);
     if (l.bias_hs) hipFree(l.bias_hs);
     if (l.scale) hipFree(l.scale);

@@ -58,13 +58,16 @@ int hs_range_check(csi_ctx* c, float* hit, bool* low) {
     *low = false;
     if (!c->hs_peak || c->hs_launches == c->hs_checked) return CSI_OK;
     c->hs_checked = c->hs_launches;
-    unsigned bits[2] = {0, 0};
+    unsigned bits[3] = {0, 0, 0};
     HIP_TRY(c, hipMemcpy(bits, c->hs_peak, sizeof(bits), hipMemcpyDeviceToHost));
-    if (bits[0] || bits[1]) {
+    if (bits[0] || bits[1] || bits[2]) {
         std::memcpy(hit, &bits[0], 4);
         *low = bits[1] != 0;
         HIP_TRY(c, hipMemset(c->hs_peak, 0, sizeof(bits)));
     }
+    if (bits[2])
+        return fail(c, CSI_ERR_HIP, "fused regressor: a workgroup waited 2 s for the partial sums of its row tile - results of the calls since the "
+                    "last check are not valid (set hs_fuse_regressor to 0 and report this)");
     return CSI_OK;
 }
 
@@ -114,7 +117,7 @@ int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1
     PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
     const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
     hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
-                       std::ldexp(1.f, in_shift));
+                       std::ldexp(1.f, in_shift), PairRegArgs{});
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -122,7 +125,10 @@ int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1
 // first per-pair layer: A generated from (L0, T, bn0); hs output (a hidden layer follows) or fp32
 // output with bias only (the regressor follows layer 0 directly)
 // shift of the OUTPUT activations of hidden layer li
-int hs_act_shift_of(const csi_ctx* c, const Model& m, int li) { return c->hs_act_shift == HS_SHIFT_AUTO ? m.layers[li].ashift : c->hs_act_shift; }
+// (pre: the consumer reads this layer's bare relu output - its BatchNormalization scale sits in the consumer's weights)
+int hs_act_shift_of(const csi_ctx* c, const Model& m, int li, bool pre = false) {
+    return c->hs_act_shift == HS_SHIFT_AUTO ? (pre ? m.layers[li].ashift_pre : m.layers[li].ashift) : c->hs_act_shift;
+}
 
 template <int EPI, bool OUT_HS>
 int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src, int in_shift) {
@@ -137,7 +143,7 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src, int in
     int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
     if (rc) return rc;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
-    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, in_shift));
+    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, in_shift), PairRegArgs{});
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -163,7 +169,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
     const csi_config& cf = c->cfg;
     const int nh = cf.n_hidden, h1 = cf.hidden[0];
     const Layer& l1 = m.layers[1];
-    const int s0 = hs_act_shift_of(c, m, 0);
+    const int s0 = hs_act_shift_of(c, m, 0, true);
     // bn0 is not applied by the pair kernel: its scale multiplies the rows of layer 1's split weights, its shift
     // (like every later BatchNormalization shift) lives in layer 1's bias (Layer::bias_hs) - A = relu(2^s0 L0 + Ts)
     // with Ts = 2^s0 T, a copy of the pilot table rebuilt when the table or the shift changes
@@ -188,6 +194,39 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
     if (nh == 1) {
         p.C = out; p.ldc = cf.n_out;
         return hs_launch_pair<EPI_BIAS, false>(c, K_REGRESSOR, p, src, s0);
+    }
+    const Layer& lr = m.layers[nh];
+    if (nh == 2 && c->hs_fuse_regressor && lr.Wh_f && cf.n_out <= PP_BN && l1.out % PP_BN == 0) {
+        // regressor inside the pair kernel: h2 never leaves the CU (hs_fused_regressor)
+        const int tiles_m = (M2 + PP_BM - 1) / PP_BM, tiles_n = l1.out / PP_BN;
+        const size_t slab_bytes = (size_t)(tiles_n - 1) * M2 * cf.n_out * sizeof(float);
+        int rc = ensure_bytes(c, &c->fuse_ws, &c->fuse_ws_bytes, slab_bytes + ((size_t)tiles_m + 64) * sizeof(unsigned));
+        if (rc) return rc;
+        const int s1 = hs_act_shift_of(c, m, 1, true);
+        PairRegArgs rg{};
+        rg.B2 = lr.Wh_f; rg.ldb2 = lr.ldwh; rg.n2 = cf.n_out;
+        rg.bias2 = lr.bias_hs;
+        rg.out = out;
+        rg.slabs = reinterpret_cast<float*>(c->fuse_ws);
+        rg.flags = reinterpret_cast<unsigned*>(c->fuse_ws + slab_bytes);
+        rg.err = c->hs_peak + 2;
+        rg.acc_scale2 = std::ldexp(1.f, -(s1 + lr.wshift_f));
+        p.out_scale = std::ldexp(1.f, s1);
+        p.tiles_n = tiles_n;
+        p.peak = c->hs_peak;
+        HIP_TRY(c, hipMemsetAsync(rg.flags, 0, (size_t)tiles_m * sizeof(unsigned), c->stream));
+        ++c->hs_launches;
+        const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
+        const double bytes = 4.0 * ((double)M2 / cf.nt * h1 + (double)cf.nt * h1 + (double)l1.out * h1 + (double)cf.n_out * l1.out +
+                                    (double)M2 * cf.n_out * (2.0 * (tiles_n - 1) + 1.0));
+        ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
+        auto kern = gemm_hs_pp_pair_kernel<EPI_RAW, false, false, 0, true>;
+        rc = hs_dynamic_lds(c, kern, (size_t)PR_LDS_FLOATS * sizeof(float), &c->hs_lds_attr[3]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, tiles_n)), dim3(PP_THREADS), (size_t)PR_LDS_FLOATS * sizeof(float), c->stream, p, src,
+                           std::ldexp(1.f, s0), rg);
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
     }
     uint16_t* hb[2] = {reinterpret_cast<uint16_t*>(hbuf0), reinterpret_cast<uint16_t*>(hbuf1)};
     p.C = hb[0]; p.ldc = 2 * l1.out;

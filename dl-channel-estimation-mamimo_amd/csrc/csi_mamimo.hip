@@ -268,6 +268,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->P) hipFree(c->P);
     if (c->hs_peak) hipFree(c->hs_peak);
     if (c->hs_zero) hipFree(c->hs_zero);
+    if (c->fuse_ws) hipFree(c->fuse_ws);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->tw) hipFree(c->tw);
     if (c->bin_pos) hipFree(c->bin_pos);
@@ -277,6 +278,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->aux_ws) hipFree(c->aux_ws);
     if (c->aux_l0skinny) hipFree(c->aux_l0skinny);
     if (c->aux_skbuf) hipFree(c->aux_skbuf);
+    if (c->aux_fuse_ws) hipFree(c->aux_fuse_ws);
     if (c->aux_fork) hipEventDestroy(c->aux_fork);
     if (c->aux_join) hipEventDestroy(c->aux_join);
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
@@ -375,6 +377,31 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             if (hipMalloc((void**)&L.Wh, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
             HIP_TRY(c, hipMemset(L.Wh, 0, hbytes));
             HIP_TRY(c, hipMemcpy(L.Wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+            if (reg && li == 2 && cf.nt > 0 && !prev_scale.empty()) {
+                // the regressor behind ONE per-pair layer (the shipped 2-hidden-layer network): a second copy with that
+                // layer's BN scale folded into the rows, for the kernel that runs the regressor behind the pair layer
+                // without h2 leaving the CU (gemm_hs.hip.h: hs_fused_regressor); the unfused path keeps Wh
+                float fmax = 0.f;
+                for (int o = 0; o < out; ++o)
+                    for (int i = 0; i < kh; ++i) fmax = std::max(fmax, std::fabs((float)((double)wt[(size_t)o * L.ldw + i] * (double)prev_scale[i])));
+                int ef = 0;
+                if (fmax > 0.f && std::isfinite(fmax)) std::frexp(fmax, &ef);
+                L.wshift_f = std::max(-40, std::min(40, 13 - ef));
+                const float wsf = std::ldexp(1.f, L.wshift_f);
+                std::fill(wh.begin(), wh.end(), 0);
+                for (int o = 0; o < out; ++o)
+                    for (int i = 0; i < kh; ++i) {
+                        const float x = (float)((double)wt[(size_t)o * L.ldw + i] * (double)prev_scale[i]) * wsf;
+                        const _Float16 hi = (_Float16)x;
+                        const _Float16 lo = (_Float16)(x - (float)hi);
+                        uint16_t* d = &wh[(size_t)o * L.ldwh + (i >> 4) * 32 + (i & 15)];
+                        std::memcpy(d, &hi, 2);
+                        std::memcpy(d + 16, &lo, 2);
+                    }
+                if (hipMalloc((void**)&L.Wh_f, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
+                HIP_TRY(c, hipMemset(L.Wh_f, 0, hbytes));
+                HIP_TRY(c, hipMemcpy(L.Wh_f, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+            }
         }
         rc = upload(c, &L.bias, b->data, out);
         if (rc) return rc;
@@ -410,21 +437,26 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 sc[o] = inv;
                 sh[o] = be->data[o] - mu->data[o] * inv;
             }
-            // split-f16 engine: scale of the activations this layer hands on.  Layers >= 1 hand on relu * scale
-            // (BatchNormalization output minus its shift): beta + gamma * (standardised relu) is bounded by
-            // |beta| + 6 |gamma| at six moving standard deviations.  Layer 0 on the shared path hands on the bare
-            // relu (see fold_scale above): moving_mean + 6 moving standard deviations bounds it.  The bound is put
-            // at 2^10..2^11 - 32x of head room for outliers before the range guard takes over, and values down to
+            // split-f16 engine: scale of the activations this layer hands on.  Where the next kernel reads relu * scale
+            // (BatchNormalization output minus its shift; Layer::ashift): beta + gamma * (standardised relu) is bounded
+            // by |beta| + 6 |gamma| at six moving standard deviations.  Where it reads the bare relu because the scale
+            // sits in the next layer's weights (layer 0 on the shared path, the pair layer in front of the fused
+            // regressor; Layer::ashift_pre): moving_mean + 6 moving standard deviations.  The bound is put at
+            // 2^10..2^11 - 32x of head room for outliers before the range guard takes over, and values down to
             // 2^-13 of the bound keep a normal lo half
-            float amax = 0.f;
-            for (int o = 0; o < out; ++o)
-                amax = std::max(amax, (li == 0 && cf.nt > 0) ? std::fabs(mu->data[o]) + 6.f * std::sqrt(std::max(va->data[o], 0.f) + cf.bn_eps)
-                                                             : std::fabs(be->data[o]) + 6.f * std::fabs(ga->data[o]));
-            int ea = 0;
-            if (amax > 0.f && std::isfinite(amax)) {
-                std::frexp(amax, &ea);
-                L.ashift = std::max(-8, std::min(14, 11 - ea));
+            float amax = 0.f, amax_pre = 0.f;
+            for (int o = 0; o < out; ++o) {
+                amax = std::max(amax, std::fabs(be->data[o]) + 6.f * std::fabs(ga->data[o]));
+                amax_pre = std::max(amax_pre, std::fabs(mu->data[o]) + 6.f * std::sqrt(std::max(va->data[o], 0.f) + cf.bn_eps));
             }
+            auto shift_for = [](float bound, int dflt) {
+                int ea = 0;
+                if (!(bound > 0.f) || !std::isfinite(bound)) return dflt;
+                std::frexp(bound, &ea);
+                return std::max(-8, std::min(14, 11 - ea));
+            };
+            L.ashift = shift_for(amax, L.ashift);
+            L.ashift_pre = shift_for(amax_pre, L.ashift_pre);
         }
         if (!reg) {
             rc = upload(c, &L.scale, sc.data(), out);
@@ -504,7 +536,8 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         }
         // small call: the two component models are independent and each is a chain of short,
         // launch-latency-bound kernels - run the imag model on a second stream with its own scratch
-        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && npkt * c->cfg.nr <= 64;
+        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call &&
+                             (npkt * c->cfg.nr <= 64 || c->small_call_overlap == 2);       // 2: any size (experiment: tails of one model's kernels under the other's)
         if (!overlap) {
             int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
             if (r) return r;
@@ -522,6 +555,7 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
             std::swap(c->ws, c->aux_ws); std::swap(c->ws_bytes, c->aux_ws_bytes);
             std::swap(c->l0skinny, c->aux_l0skinny); std::swap(c->l0skinny_bytes, c->aux_l0skinny_bytes);
             std::swap(c->skbuf, c->aux_skbuf); std::swap(c->skbuf_bytes, c->aux_skbuf_bytes);
+            std::swap(c->fuse_ws, c->aux_fuse_ws); std::swap(c->fuse_ws_bytes, c->aux_fuse_ws_bytes);
         };
         swap_scratch();                                   // imag model: aux stream, aux scratch
         int r = predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
@@ -730,6 +764,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_act_shift") *value = c->hs_act_shift;
     else if (n == "hs_min_blocks") *value = c->hs_min_blocks;
+    else if (n == "hs_fuse_regressor") *value = c->hs_fuse_regressor;
     else if (n == "hs_in_shift") *value = c->hs_in_shift;
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
     else if (n == "host_threads") *value = c->host_threads;
@@ -761,11 +796,14 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         c->ls_fft_first_max = (int)value;
         return ls_prepare(c);
     } else if (n == "small_call_overlap") {
-        c->small_call_overlap = value != 0;
+        c->small_call_overlap = value == 2 ? 2 : (value != 0);
     } else if (n == "f32_engine") {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);
         c->f32_engine = (int)value;
+    } else if (n == "hs_fuse_regressor") {
+        drop_graphs(c);
+        c->hs_fuse_regressor = value != 0;
     } else if (n == "hs_min_blocks") {
         if (value < 1 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "hs_min_blocks must be 1..65536");
         drop_graphs(c);

@@ -59,11 +59,12 @@ struct GemmHsArgs {
 };
 
 // Optional per-workgroup time stamps (timing probes; null in the library): wave 0 writes (shader cycles, 10-ns
-// wall ticks) at kernel entry, after the prologue, after the main loop and after the epilogue.
+// wall ticks) at kernel entry, after the prologue, after the main loop and after the epilogue (slots 0..3; the fused
+// regressor stage adds 4 = both halves computed, 5 = flag wait over; 6 slots of 16 bytes per workgroup).
 __device__ __forceinline__ void hs_stamp(const unsigned long long* base, int i) {
     if (!base) return;
     if (threadIdx.x == 0) {
-        unsigned long long* p = const_cast<unsigned long long*>(base) + ((size_t)blockIdx.x * 4 + i) * 2;
+        unsigned long long* p = const_cast<unsigned long long*>(base) + ((size_t)blockIdx.x * 6 + i) * 2;
         p[0] = __builtin_readcyclecounter();
         p[1] = wall_clock64();
     }
@@ -223,7 +224,10 @@ struct HsFrags {
     f16x8 a_hi[4], a_lo[4], b_hi[2], b_lo[2];
 };
 
-template <int PH, typename RdA, typename RdB>
+// SWAP: the operands change places, acc[i][j] then holds the TRANSPOSED 32x32 tile - lanes run over the rows of A
+// (a lane owns one activation row), registers over the columns (four consecutive ones per register quad): the
+// layout the fused regressor stage needs to turn the tile into an A image without a transposition.
+template <int PH, bool SWAP = false, typename RdA, typename RdB>
 __device__ __forceinline__ void hs_mfma_seg(f32x16 (&acc)[4][2], HsFrags& f, RdA&& read_a, RdB&& read_b, bool more, int slot, int nslot,
                                             bool closing_barrier) {
     __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +244,8 @@ __device__ __forceinline__ void hs_mfma_seg(f32x16 (&acc)[4][2], HsFrags& f, RdA
         for (int j = 0; j < 2; ++j) {
             const f16x8 a = PH == 2 ? f.a_lo[i] : f.a_hi[i];
             const f16x8 b = PH == 0 ? f.b_lo[j] : f.b_hi[j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
         }
     constexpr int NRD = PH == 0 ? 2 : (PH == 1 ? 4 : 6);
     if (PH != 2 || more) {
@@ -388,6 +393,240 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
 }
 
 // ---------------------------------------------------------------------------------------------
+// Regressor fused behind the first per-pair layer (two hidden layers, n_out <= 256 - the shipped network): the
+// 256 x 256 tile of h2 = relu(z1) a workgroup has just accumulated never leaves the CU.  It becomes the A operand of
+// a second product  partial[256][n2] = h2_tile[256][256] . W2[k-slice of this column tile][n2]  on the same matrix
+// pipe, and only that partial result (n2 = 234 columns instead of 1024, fp32) goes to memory: the 2.1 GB of h2 a
+// config-2 launch used to write - and the regressor kernel used to read back - disappear, with them the hs
+// conversion for memory, the regressor's A-side DMA and its own prologue / epilogue.
+//   * The first stage runs with SWAPPED MFMA operands, so a lane owns an activation ROW and each register quad four
+//     consecutive columns: relu / scale / split of a quad is two ds_write_b64 (hi | lo) straight into an A image
+//     [16 sub-tiles][128 rows][64 B] in the (now idle) ring - the sub-tile row format of the main loop, same
+//     XOR swizzle, so the fragment reads are the main loop's.
+//   * 128 accumulator registers per lane: no room for a second accumulator set beside the first.  The two wave
+//     groups therefore take turns: group g turns ITS half of the tile (128 rows) into the A image, zeroes its
+//     accumulators and computes its 128 x 256 of the second product (one wave = 32 rows x 8 column tiles, the SIMD's
+//     matrix pipe to itself, 12 MFMAs per quad of column tiles with the next quad's fragments requested under them);
+//     the other group's waves are its DMA engines for the W2 sub-tiles (2 slots of 16 KiB behind the ring; one
+//     workgroup barrier per sub-tile hands a slot back and publishes the next).  160 KiB of LDS in all.
+//   * BatchNormalization of the pair layer: scale folded into the rows of W2, shift into the regressor bias, at load.
+//   * The column tiles of a row tile hold different k-slices of the second product.  Tiles 0 .. tiles_n-2 store their
+//     partial sums in slabs and count themselves in flags[row tile] (release); the LAST column tile waits for the
+//     count (acquire; it is dispatched after the others, so they are running or done), adds slab 0, 1, ... and its own
+//     part in that fixed order, the bias, and writes the output - deterministic, no atomics on data.
+struct PairRegArgs {
+    const uint16_t* B2;    // hs [n2][ldb2 halves]: regressor weights, K-major, rows scaled by the pair layer's BN scale
+    const float* bias2;    // [n2] regressor bias incl. the folded BN shift
+    float* out;            // [M][n2]
+    float* slabs;          // [tiles_n - 1][M][n2]
+    unsigned* flags;       // [row tiles], zero before the launch
+    unsigned* err;         // set to 1 if a wait for the other column tiles timed out (never in a healthy run)
+    int ldb2, n2;
+    float acc_scale2;      // 2^-(activation shift of h2 + weight shift of B2)
+};
+
+constexpr int PR_A_FLOATS = 16 * 128 * PP_ROWF;     // A image of one half tile: 16 sub-tiles x 128 rows x 64 B = 128 KiB
+constexpr int PR_B_FLOATS = 256 * PP_ROWF;          // one W2 sub-tile: 256 rows x 64 B = 16 KiB
+constexpr int PR_LDS_FLOATS = PR_A_FLOATS + 2 * PR_B_FLOATS;
+
+// acc: the SWAPPED first-stage accumulators on entry, the second-stage result (plain layout: lane = column) on exit
+__device__ __forceinline__ void hs_fused_regressor(f32x16 (&acc)[4][2], const GemmHsArgs& g, const PairRegArgs& rg, float* lds, int m0, int n0,
+                                                   int tn, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    float* bring = lds + PR_A_FLOATS;
+    const float as1 = g.acc_scale * g.out_scale;
+    const int fswz = (l31 >> 2) & 3;
+    int xo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xo[c] = ((2 * c + hi) ^ fswz) << 2;
+
+    // W2 sub-tile t of this column tile's k-slice -> slot: 16 one-KiB pieces, 4 per DMA wave
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(rg.B2 + (size_t)2 * n0), 0, 0x7fffffff, 0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = 16 * (wn * 4 + u) + (lane >> 2);
+        const int clog = (lane & 3) ^ ((row >> 2) & 3);
+        voff[u] = (min(row, rg.n2 - 1) * rg.ldb2 + clog * 8) * 2;
+    }
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(bring + (t & 1) * PR_B_FLOATS + (wn * 4 + u) * 256),
+                                                     16, voff[u], t * 64, 0, 0);
+    };
+    u16x2 pk16 = {0, 0};
+    pp_wait_vm_lgkm<0>();
+    pp_barrier();                                   // every wave is out of the main loop: the ring is idle
+
+#pragma unroll 1
+    for (int gsel = 0; gsel < 2; ++gsel) {
+        if (wm == gsel) {
+            // ---- this group's half of the h2 tile -> A image.  acc[i][j][4q + e]: row i*32 + l31, column wn*64 + j*32 + 8q + 4hi + e
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nloc = wn * 64 + j * 32 + 8 * q + 4 * hi;
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n0 + nloc);
+                    b4 *= g.out_scale;
+                    const int kk = nloc >> 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[i][j][4 * q + e], as1, b4[e]), 0.f);
+                        uint2 oh, ol;
+                        oh.x = hs_hi_pair(v[0], v[1]);
+                        oh.y = hs_hi_pair(v[2], v[3]);
+                        ol.x = hs_lo_pair(v[0], v[1], oh.x);
+                        ol.y = hs_lo_pair(v[2], v[3], oh.y);
+                        pk16 = __builtin_elementwise_max(__builtin_elementwise_max(pk16, __builtin_bit_cast(u16x2, oh.x)), __builtin_bit_cast(u16x2, oh.y));
+                        const int row = i * 32 + l31;
+                        float* img = lds + kk * (128 * PP_ROWF) + row * PP_ROWF + 2 * hi;
+                        *reinterpret_cast<uint2*>(img + (((q & 1) ^ fswz) << 2)) = oh;
+                        *reinterpret_cast<uint2*>(img + (((2 + (q & 1)) ^ fswz) << 2)) = ol;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        } else {
+            issue(0);
+            issue(1);
+        }
+        pp_wait_vm_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();                               // A image written, W2 sub-tiles 0 and 1 landed
+
+        if (wm == gsel) {
+            // ---- 32 rows (row tile wn of the half) x 8 column tiles; acc[jt >> 1][jt & 1] = column tile jt
+            f16x8 a_cur[2], a_nxt[2], b_cur[4][2], b_nxt[4][2];
+            const float* abase = lds + (wn * 32 + l31) * PP_ROWF;
+            auto read_a2 = [&](int t, f16x8 (&a)[2]) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a[c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(abase + t * (128 * PP_ROWF) + xo[c]));
+            };
+            auto read_b2 = [&](int t, int quad, f16x8 (&b)[4][2]) {
+                const float* st = bring + (t & 1) * PR_B_FLOATS + (quad * 128 + l31) * PP_ROWF;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) b[jq][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(st + jq * 32 * PP_ROWF + xo[c]));
+            };
+            auto mfma_quad = [&](int quad, const f16x8 (&a)[2], const f16x8 (&b)[4][2]) {
+                // product-major: four independent accumulators between two MFMAs on the same one
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        f32x16& d = acc[(quad * 4 + jq) >> 1][(quad * 4 + jq) & 1];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[pr == 2 ? 1 : 0], b[jq][pr == 0 ? 1 : 0], d, 0, 0, 0);   // a_hi b_lo, a_hi b_hi, a_lo b_hi
+                    }
+            };
+            read_a2(0, a_cur);
+            read_b2(0, 0, b_cur);
+            pp_wait_lgkm();
+#pragma unroll 1
+            for (int t = 0; t < 16; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                read_b2(t, 1, b_nxt);                       // quad 1 of this sub-tile, under the MFMAs of quad 0
+                mfma_quad(0, a_cur, b_cur);
+                __builtin_amdgcn_s_setprio(0);
+                pp_wait_lgkm();                             // the last reads of slot t & 1 are done
+                __builtin_amdgcn_sched_barrier(0);
+                pp_barrier();                               // X_t: slot t & 1 may be refilled, sub-tile t + 1 is visible
+                __builtin_amdgcn_s_setprio(1);
+                if (t + 1 < 16) {
+                    read_a2(t + 1, a_nxt);
+                    read_b2(t + 1, 0, b_cur);               // b_cur is dead once quad 0 has issued (in-order issue)
+                }
+                mfma_quad(1, a_cur, b_nxt);
+                __builtin_amdgcn_s_setprio(0);
+                pp_wait_lgkm();
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a_cur[c] = a_nxt[c];
+            }
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < 16; ++t) {
+                pp_wait_vm_lgkm<0>();                       // sub-tile t + 1 has landed
+                __builtin_amdgcn_sched_barrier(0);
+                pp_barrier();                               // X_t
+                if (t + 2 < 16) issue(t + 2);
+            }
+        }
+    }
+    {
+        const uint16_t top = pk16[0] > pk16[1] ? pk16[0] : pk16[1];
+        hs_report_peak(g.peak, top >= 0x7c00u ? __builtin_inff() : (float)__builtin_bit_cast(_Float16, top), false);
+    }
+    hs_stamp(g.stamps, 4);
+
+    // ---- partial sums out: wave = rows m0 + wm*128 + wn*32 .. +31, lane = column jt*32 + l31
+    const int tiles_n = g.tiles_n;
+    const bool last = tn == tiles_n - 1;
+    const int tm = m0 / PP_BM;
+    if (last && tiles_n > 1) {
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(rg.flags + tm, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(tiles_n - 1)) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > 200000000ll) { atomicOr(rg.err, 1u); break; }       // 2 s: never in a healthy run
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    hs_stamp(g.stamps, 5);
+    const int wrow = m0 + wm * 128 + wn * 32 + 4 * hi;
+    const size_t plane = (size_t)g.M * rg.n2;
+    float* dst = last ? rg.out : rg.slabs + (size_t)tn * plane;
+    const bool full_rows = m0 + PP_BM <= g.M;
+#pragma unroll                                      // (static accumulator indices: a dynamic one would put acc in scratch)
+    for (int jt = 0; jt < 8; ++jt) {
+        const int col = jt * 32 + l31;
+        if (col >= rg.n2) continue;
+        const f32x16 d = acc[jt >> 1][jt & 1] * rg.acc_scale2;
+        f32x16 sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+        if (last) {
+            // slab 0, slab 1, ... in that order, then this tile's own part, then the bias; all 16 loads of a slab are
+            // requested before the first one is used
+#pragma unroll 1
+            for (int s2 = 0; s2 < tiles_n - 1; ++s2) {
+                const float* sp = rg.slabs + (size_t)s2 * plane + col;
+                f32x16 v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow + (r & 3) + 8 * (r >> 2);
+                    v[r] = (full_rows || row < g.M) ? sp[(size_t)row * rg.n2] : 0.f;
+                }
+                sum = s2 == 0 ? v : sum + v;
+            }
+        }
+        const float b2 = last ? rg.bias2[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow + (r & 3) + 8 * (r >> 2);
+            const float v = last ? ((tiles_n > 1 ? sum[r] + d[r] : d[r]) + b2) : d[r];
+            if (full_rows || row < g.M) dst[(size_t)row * rg.n2 + col] = v;
+        }
+    }
+    if (!last) {
+        pp_wait_vm_lgkm<0>();                       // this wave's slab stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(rg.flags + tm, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A operand produced in the kernel (PairSrc as in gemm_bf16.hip.h):
 //   pair mode:  A[(pr,t)][k] = split( relu( in_scale * L0[pr][k] + Ts[t][k] ) ),   Ts = in_scale * T (a pre-scaled
 //               copy of the pilot table, in_scale a power of two): one fma and one max per value.  Neither half of
@@ -417,8 +656,9 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
 // P1(u+2); every MFMA segment ends with lgkmcnt(0) in front of its closing barrier, which also retires the
 // chunk written in front of it.  WAR: B slot of sub-tile u+3 = slot of u-1, last read in P0(u-1).
 // DBG (timing probes of tools/hs_probe.hip, results invalid): 1 = no L0 / T / X requests, 2 = no conversion (VALU, ds_write)
-template <int EPI, bool OUT_HS, bool CAST = false, int DBG = 0>
-__global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const GemmHsArgs g, const PairSrc ps, const float in_scale) {
+// FUSE: the regressor runs behind this layer inside the kernel (hs_fused_regressor above; EPI / OUT_HS are then unused)
+template <int EPI, bool OUT_HS, bool CAST = false, int DBG = 0, bool FUSE = false>
+__global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const GemmHsArgs g, const PairSrc ps, const float in_scale, const PairRegArgs rg) {
     constexpr int NSUB = 4, D = 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring
 
@@ -590,13 +830,13 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         if (has_a) gen_hi(u + 2, (slot + 2) & 3);       // its ds_write retires with the lgkmcnt(0) that closes the MFMA segment
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
-        hs_mfma_seg<0>(acc, f, read_a, read_b, true, slot, nslot, true);
+        hs_mfma_seg<0, FUSE>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P1
         if (has_a) gen_lo((slot + 2) & 3);
         if (nxt_a) load_a(u + 3);
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
-        hs_mfma_seg<1>(acc, f, read_a, read_b, true, slot, nslot, true);
+        hs_mfma_seg<1, FUSE>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P2
         if (has_b) {
             issue_b(u + D, (slot + D) & 3, 0);
@@ -604,7 +844,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
-        hs_mfma_seg<2>(acc, f, read_a, read_b, !last, slot, nslot, !(wm == 1 && last));
+        hs_mfma_seg<2, FUSE>(acc, f, read_a, read_b, !last, slot, nslot, !(wm == 1 && last));
         slot = nslot;
     };
     int u = 0;
@@ -619,7 +859,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     hs_report_peak(g.peak, apk, true);
     GemmHsArgs ge = g;
     ge.acc_scale = acc_scale;
-    hs_epilogue<EPI, OUT_HS>(acc, ge, lds, m0, n0, wave, lane);
+    if constexpr (FUSE) hs_fused_regressor(acc, ge, rg, lds, m0, n0, tn, wave, lane);
+    else hs_epilogue<EPI, OUT_HS>(acc, ge, lds, m0, n0, wave, lane);
     hs_stamp(g.stamps, 3);
 }
 

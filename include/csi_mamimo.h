@@ -222,6 +222,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
  *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels; 0: fp32 MFMA kernels only;
  *                         1: split engine wherever the layer shapes allow (hidden widths multiples of 16)
+ *   "hs_fuse_regressor" split engine, two hidden layers, n_out <= 256: 1 runs the regressor inside the first per-pair
+ *                         layer's kernel (its 256 x 256 tile of activations becomes the A operand of a second product
+ *                         on the CU; only partial sums reach memory).  0 (default): measured slower than two kernels
  *   "hs_min_blocks"    automatic mode: the per-pair layers take the split engine from this many 256x256 workgroups
  *                         on (default 80), layer 0 from max(this, 128)
  *   "hs_in_shift"      split engine: the preamble samples are carried times 2^shift.  99 (default): chosen per

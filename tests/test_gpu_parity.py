@@ -479,6 +479,32 @@ def test_split_f16_engine_matches_fp64_oracle(pkg, oracle, nt, nr, npkt, hidden)
     assert oracle.nmse_subk(r_re + 1j * r_im, s_re + 1j * s_im) < 1e-10
 
 
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(32, 4, 9, (1024, 1024)), (8, 2, 70, (64, 256)), (4, 1, 130, (128, 512))])
+def test_split_f16_fused_regressor_option(pkg, oracle, nt, nr, npkt, hidden):
+    """'hs_fuse_regressor' = 1 (two hidden layers, second width a multiple of 256): the regressor runs inside the pair
+    layer's kernel - swapped-operand first stage, activations tile -> A image in LDS, second product on the same
+    CU, partial sums of the column tiles combined in a fixed order behind a release / acquire flag.  Same contract,
+    run-to-run identical, ragged last row tile, 1 / 2 / 4 column tiles; and the default (two kernels) stays what it was."""
+    rng = np.random.default_rng(nt * 31 + npkt)
+    w_re, w_im = _weights(oracle, 900 + nt, nt, hidden)
+    P = _pilot(rng, nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=3.0)[0]
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('f32_engine', 1)
+    assert e.get_option('hs_fuse_regressor') == 0
+    u_re, u_im = e.predict(ltf)
+    e.set_option('hs_fuse_regressor', 1)
+    f_re, f_im = e.predict(ltf)
+    r_re, r_im = oracle.predict_packets_shared(ltf.astype(np.complex64), P, w_re, w_im)
+    assert rel_rows(f_re, r_re) < TOL and rel_rows(f_im, r_im) < TOL
+    assert rel_rows(u_re, r_re) < TOL
+    assert not np.array_equal(f_re, u_re) and rel_rows(f_re, u_re) < 5e-6
+    g_re, g_im = e.predict(ltf)
+    np.testing.assert_array_equal(g_re, f_re)
+    np.testing.assert_array_equal(g_im, f_im)
+    assert e.get_option('hs_range_fallbacks') == 0
+
+
 @pytest.mark.parametrize('gain', [1e-3, 1e-2, 1.0, 60.0])
 def test_split_f16_engine_input_scale(pkg, oracle, gain):
     """The f16 halves have a finite range: the engine scales operands by powers of two.  Results must

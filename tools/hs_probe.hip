@@ -166,6 +166,33 @@ int main(int argc, char** argv) {
     GemmHsArgs gc = g; gc.C = C; gc.ldc = N;              // CAST: A = fp32 rows, raw output
     PairSrc pc{A, nullptr, nullptr, nullptr, K, 1};
 
+    // ---- fused pair + regressor (hs_fused_regressor): W2 rows scaled by the pair layer's BN scale, its shift in the bias
+    std::vector<float> hW2f(hW2.size()), hb2f(NO);
+    for (int n = 0; n < NO; ++n) {
+        double acc = hb[n];
+        for (int k = 0; k < K; ++k) { hW2f[(size_t)n * K + k] = (float)((double)hW2[(size_t)n * K + k] * hsc[k]); acc += (double)hsh[k] * hW2[(size_t)n * K + k]; }
+        hb2f[n] = (float)acc;
+    }
+    const int sw2f = wshift(hW2f);
+    int ldb2f;
+    float* W2f = dput(hW2f);
+    uint16_t* W2fh = to_hs(W2f, K, NO, K, &ldb2f, std::ldexp(1.f, sw2f));
+    float* b2f = dput(hb2f);
+    const int tiles_nf = N / 256;
+    float* fslabs; CK(hipMalloc(&fslabs, (size_t)(tiles_nf - 1) * M * NO * 4 + 4096));
+    unsigned* fflags; CK(hipMalloc(&fflags, (size_t)(tiles_m + 64) * 4)); CK(hipMemset(fflags, 0, (size_t)(tiles_m + 64) * 4));
+    PairRegArgs rg{};
+    rg.B2 = W2fh; rg.ldb2 = ldb2f; rg.n2 = NO; rg.bias2 = b2f; rg.out = O; rg.slabs = fslabs; rg.flags = fflags; rg.err = fflags + tiles_m + 8;
+    rg.acc_scale2 = std::ldexp(1.f, -(sa + sw2f));
+    GemmHsArgs gf = gp;                     // stage 1 = the pair kernel's operands; its BN scale / shift are NOT applied (folded above)
+    gf.out_scale = std::ldexp(1.f, sa);
+    auto kfuse = gemm_hs_pp_pair_kernel<EPI_RAW, false, false, 0, true>;
+    CK(hipFuncSetAttribute((const void*)kfuse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * 4)));
+    auto launch_fused = [&] {
+        hipMemsetAsync(fflags, 0, (size_t)tiles_m * 4, 0);
+        hipLaunchKernelGGL(kfuse, grid, dim3(PP_THREADS), PR_LDS_FLOATS * 4, 0, gf, ps, std::ldexp(1.f, sa), rg);
+    };
+
     if (!timing) {
         // ---- fp64 references
         std::vector<double> ref((size_t)M * N), refh((size_t)M * N), refraw((size_t)M * N);
@@ -231,16 +258,37 @@ int main(int argc, char** argv) {
             }
         }
         CK(hipMemset(Ch, 0, (size_t)M * 2 * N * 2));
-        hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa));
+        hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{});
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(hh.data(), Ch, hh.size() * 2, hipMemcpyDeviceToHost));
         decode(got);
         printf("pair (A generated), hs out          worst row rel err %.3g\n", rel_rows(refp, got, M, N));
+        // fused pair + regressor: out = (relu(h1 W1 + b) sc + sh) W2 + b2, with sc / sh folded into W2 / b2
+        {
+            std::vector<double> reff((size_t)M * NO);
+            for (int m = 0; m < M; ++m)
+                for (int n = 0; n < NO; ++n) {
+                    double s = 0;
+                    for (int k = 0; k < K; ++k) s += refp[(size_t)m * N + k] * hW2[(size_t)n * K + k];
+                    reff[(size_t)m * NO + n] = s + hb[n];
+                }
+            CK(hipMemset(O, 0, (size_t)M * NO * 4));
+            launch_fused();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(go.data(), O, go.size() * 4, hipMemcpyDeviceToHost));
+            unsigned e = 0; CK(hipMemcpy(&e, rg.err, 4, hipMemcpyDeviceToHost));
+            printf("pair + fused regressor, fp32 out    worst row rel err %.3g   (timeout flag %u)\n", rel_rows(reff, go, M, NO), e);
+            std::vector<float> go2(go.size());
+            launch_fused();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(go2.data(), O, go2.size() * 4, hipMemcpyDeviceToHost));
+            printf("   second run bit-identical: %s\n", memcmp(go.data(), go2.data(), go.size() * 4) == 0 ? "yes" : "NO");
+        }
         // CAST kernel, two K splits
         GemmHsArgs g2 = gc; g2.k_per_split = 512;
         float* slabs; CK(hipMalloc(&slabs, (size_t)2 * M * N * 4 + 4096));
         g2.C = slabs;
-        hipLaunchKernelGGL(kcast, dim3(grid.x, 1, 2), dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, g2, pc, std::ldexp(1.f, sa));
+        hipLaunchKernelGGL(kcast, dim3(grid.x, 1, 2), dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, g2, pc, std::ldexp(1.f, sa), PairRegArgs{});
         CK(hipDeviceSynchronize());
         std::vector<float> s2((size_t)2 * M * N);
         CK(hipMemcpy(s2.data(), slabs, s2.size() * 4, hipMemcpyDeviceToHost));
@@ -254,7 +302,7 @@ int main(int argc, char** argv) {
         const double secs = argc > 5 ? atof(argv[5]) : 4.0;
         auto one = [&] {
             if (mode == "mfma") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 57>), grid, dim3(PP_THREADS), 0, 0, gh);
-            else if (mode == "pair") hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa));
+            else if (mode == "pair") hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{});
             else if (mode == "regressor") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr);
             else hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh);
         };
@@ -274,17 +322,17 @@ int main(int argc, char** argv) {
     if (stamps) {
         // where a workgroup's time goes: entry -> prologue done -> main loop done -> epilogue done (wave 0), in shader
         // cycles and in wall time, averaged over all workgroups of a launch; plus the launch's span
-        unsigned long long* st; CK(hipMalloc(&st, (size_t)grid.x * 8 * 8)); 
+        unsigned long long* st; CK(hipMalloc(&st, (size_t)grid.x * 12 * 8)); 
         auto report = [&](const char* name, auto&& launch, unsigned nblocks) {
             launch(); CK(hipDeviceSynchronize());
-            CK(hipMemset(st, 0, (size_t)grid.x * 8 * 8));
+            CK(hipMemset(st, 0, (size_t)grid.x * 12 * 8));
             launch(); CK(hipDeviceSynchronize());
-            std::vector<unsigned long long> h((size_t)nblocks * 8);
+            std::vector<unsigned long long> h((size_t)nblocks * 12);
             CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
             double cyc[3] = {0, 0, 0}, wall[3] = {0, 0, 0};
             unsigned long long t_min = ~0ull, t_max = 0; size_t n = 0;
             for (unsigned b = 0; b < nblocks; ++b) {
-                const unsigned long long* p = &h[(size_t)b * 8];
+                const unsigned long long* p = &h[(size_t)b * 12];
                 if (!p[0] || !p[6]) continue;               // tile outside the matrix
                 for (int i = 0; i < 3; ++i) { cyc[i] += (double)(p[2 * (i + 1)] - p[2 * i]); wall[i] += (double)(p[2 * (i + 1) + 1] - p[2 * i + 1]); }
                 t_min = std::min(t_min, p[1]); t_max = std::max(t_max, p[7]); ++n;
@@ -298,9 +346,32 @@ int main(int argc, char** argv) {
         a = g; a.stamps = st;
         report("generic hs->fp32", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), grid, dim3(PP_THREADS), 0, 0, a); }, grid.x);
         a = gp; a.stamps = st;
-        report("pair (fused A)", [&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, a, ps, std::ldexp(1.f, sa)); }, grid.x);
+        report("pair (fused A)", [&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, a, ps, std::ldexp(1.f, sa), PairRegArgs{}); }, grid.x);
         a = gc; a.stamps = st;
-        report("cast (A fp32)", [&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, pc, 16.f); }, grid.x);
+        report("cast (A fp32)", [&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, pc, 16.f, PairRegArgs{}); }, grid.x);
+        {   // fused kernel: main loop -> [both halves of the regressor stage] -> [flag wait] -> [output] per column-tile class
+            GemmHsArgs af = gf; af.stamps = st;
+            auto lf = [&] { hipMemsetAsync(fflags, 0, (size_t)tiles_m * 4, 0); hipLaunchKernelGGL(kfuse, grid, dim3(PP_THREADS), PR_LDS_FLOATS * 4, 0, af, ps, std::ldexp(1.f, sa), rg); };
+            lf(); CK(hipDeviceSynchronize());
+            CK(hipMemset(st, 0, (size_t)grid.x * 12 * 8));
+            lf(); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)grid.x * 12);
+            CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int cls = 0; cls < 2; ++cls) {              // 0: column tiles 0..2 (slab writers), 1: the last one (reducer)
+                double w[5] = {0, 0, 0, 0, 0}; size_t n = 0;
+                for (unsigned b = 0; b < grid.x; ++b) {
+                    const unsigned long long* p = &h[(size_t)b * 12];
+                    const int tn = (b >> 3) % tiles_nf;
+                    if (!p[0] || !p[6] || (tn == tiles_nf - 1) != (cls == 1)) continue;
+                    // slots: 0 entry, 1 prologue, 2 main loop, 4 halves done, 5 wait over, 3 end
+                    const int order[6] = {0, 1, 2, 4, 5, 3};
+                    for (int i = 0; i < 5; ++i) w[i] += (double)(p[2 * order[i + 1] + 1] - p[2 * order[i] + 1]);
+                    ++n;
+                }
+                printf("fused %-14s %zu workgroups: prologue %.2f us  main loop %.2f us  regressor stage %.2f us  flag wait %.2f us  output %.2f us\n",
+                       cls ? "reducer tiles" : "slab tiles", n, w[0] / n / 100, w[1] / n / 100, w[2] / n / 100, w[3] / n / 100, w[4] / n / 100);
+            }
+        }
         a = gr; a.stamps = st;
         report("regressor N=234", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, a); }, gridr.x);
         printf("(ideal main loop: 64 sub-tiles x 48 MFMA x 32 cycles = 98304 cycles of the SIMD's matrix pipe)\n");
@@ -326,7 +397,7 @@ int main(int argc, char** argv) {
         printf("   full kernel, no barriers (invalid results) %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), grid, dim3(PP_THREADS), 0, 0, g); });
         printf("generic hs->fp32 %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
-        ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+        ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
         printf("pair (fused A)   %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         {
             auto k1 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 1>;
@@ -335,17 +406,19 @@ int main(int argc, char** argv) {
             CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
             CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
             CK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
-            ms = time_ms([&] { hipLaunchKernelGGL(k1, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            ms = time_ms([&] { hipLaunchKernelGGL(k1, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
             printf("   pair, no L0/T requests (invalid)      %.3f ms\n", ms);
-            ms = time_ms([&] { hipLaunchKernelGGL(k2, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            ms = time_ms([&] { hipLaunchKernelGGL(k2, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
             printf("   pair, no conversion (invalid)         %.3f ms\n", ms);
-            ms = time_ms([&] { hipLaunchKernelGGL(k3, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa)); });
+            ms = time_ms([&] { hipLaunchKernelGGL(k3, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
             printf("   pair, neither (invalid)               %.3f ms\n", ms);
         }
-        ms = time_ms([&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, gc, pc, 16.f); });
+        ms = time_ms([&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, gc, pc, 16.f, PairRegArgs{}); });
         printf("cast (A fp32)    %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr); });
         printf("regressor N=234  %.3f ms  %.0f TF  (%.0f GB/s of hs input)\n", ms, 2.0 * M * NO * K / ms / 1e9, 4.0 * M * K / ms / 1e6);
+        ms = time_ms(launch_fused);
+        printf("pair + fused regressor %.3f ms  %.0f TF (both products)   [pair + regressor kernels above: their sum]\n", ms, (fl + 2.0 * M * NO * K) / ms / 1e9);
     }
     return 0;
 }
