@@ -149,6 +149,7 @@ struct csi_ctx {
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
+    int hs_blocked = 1;          // "hs_blocked": hs activation buffers between split-engine layers in the blocked layout (gemm_hs.hip.h)
     int hs_fuse_regressor = 0;   // "hs_fuse_regressor": two hidden layers -> the regressor runs inside the pair kernel (h2 stays on the CU).
                                  // Off by default: measured SLOWER (2.45 vs 1.88 ms per 262144 rows, profiles/r02_hs_probe.txt) - the
                                  // partial sums the four column tiles exchange cost what the h2 round trip cost

@@ -202,7 +202,9 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         }
     }
     const size_t slab_floats = (size_t)chunk * nr * h1;
-    const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk;
+    // (+ 16 rows per activation buffer: the blocked hs layout addresses whole 16-row blocks)
+    const size_t hid_pad = (size_t)16 * maxh * 4;
+    const size_t per_chunk = slab_floats * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt * (size_t)chunk + 2 * hid_pad;
     int rc = ensure_bytes(c, &c->ws, &c->ws_bytes, per_chunk);
     if (rc) return rc;
 
@@ -214,7 +216,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         float* l0sum = slabs + slab_floats * splits_max;              // unused when splits_max == 1
         float* hbuf[2];
         hbuf[0] = slabs + slab_floats * (splits_max > 1 ? splits_max + 1 : 1);
-        hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh;
+        hbuf[1] = hbuf[0] + (size_t)chunk * nr * nt * maxh + hid_pad / 4;
 
         // layer 0, LTF part: L0[M1][h1] = ltf[M1][len_ltf] * W0[0:len_ltf, :]
         const float* l0 = nullptr;

@@ -230,6 +230,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
     }
     uint16_t* hb[2] = {reinterpret_cast<uint16_t*>(hbuf0), reinterpret_cast<uint16_t*>(hbuf1)};
     p.C = hb[0]; p.ldc = 2 * l1.out;
+    p.c_blk = c->hs_blocked;            // activation matrices between split-engine layers: blocked layout (hs_blk_offset)
     p.out_scale = std::ldexp(1.f, hs_act_shift_of(c, m, 1));
     int rc = hs_launch_pair<EPI_BIAS_RELU_AFFINE, true>(c, K_PAIR_DENSE, p, src, s0);
     if (rc) return rc;
@@ -238,6 +239,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         const Layer& l = m.layers[li];
         GemmHsArgs q{};
         q.A = hb[cur]; q.lda = 2 * l.in;
+        q.a_blk = q.c_blk = c->hs_blocked;
         q.Bt = l.Wh; q.ldb = l.ldwh;
         q.M = M2; q.N = l.out; q.K = l.in;
         q.bias = l.bias_hs; q.scale = l.scale; q.shift = c->hs_zero;

@@ -765,6 +765,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hs_act_shift") *value = c->hs_act_shift;
     else if (n == "hs_min_blocks") *value = c->hs_min_blocks;
     else if (n == "hs_fuse_regressor") *value = c->hs_fuse_regressor;
+    else if (n == "hs_blocked") *value = c->hs_blocked;
     else if (n == "hs_in_shift") *value = c->hs_in_shift;
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
     else if (n == "host_threads") *value = c->host_threads;
@@ -801,6 +802,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);
         c->f32_engine = (int)value;
+    } else if (n == "hs_blocked") {
+        drop_graphs(c);
+        c->hs_blocked = value != 0;
     } else if (n == "hs_fuse_regressor") {
         drop_graphs(c);
         c->hs_fuse_regressor = value != 0;
@@ -1123,16 +1127,19 @@ int csi_predict_samples(csi_ctx* c, int model, const float* x, int64_t B, float*
     const size_t per_row = ((size_t)c->d_in + 2 * (size_t)maxh + cf.n_out) * sizeof(float);
     int64_t chunk = std::max<int64_t>(1, ((int64_t)512 << 20) / (int64_t)per_row);
     chunk = std::min(chunk, B);
-    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, per_row * (size_t)chunk);
+    int rc = ensure_bytes(c, &c->stage, &c->stage_bytes, per_row * (size_t)chunk + G_SLACK_FLOATS * sizeof(float));
     if (rc) return rc;
     float* d_x = reinterpret_cast<float*>(c->stage);
     float* hb[2];
-    hb[0] = d_x + (size_t)chunk * c->d_in;
+    // the staging buffer is shared with csi_nmse / csi_lmmse_estimate (raw caller data): keep G_SLACK_FLOATS of zeros
+    // behind the input rows, the K tail of the last row (d_in is rarely a multiple of the k-tile) reads into them
+    hb[0] = d_x + (size_t)chunk * c->d_in + G_SLACK_FLOATS;
     hb[1] = hb[0] + (size_t)chunk * maxh;
     float* d_y = hb[1] + (size_t)chunk * maxh;
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
         const int64_t nb = std::min(chunk, B - r0);
         HIP_TRY(c, hipMemcpyAsync(d_x, x + (size_t)r0 * c->d_in, (size_t)nb * c->d_in * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_x + (size_t)nb * c->d_in, 0, G_SLACK_FLOATS * sizeof(float), c->stream));
         const float* cur = d_x;
         int cur_ld = c->d_in, w = 0;
         for (int li = 0; li <= cf.n_hidden; ++li) {
@@ -1194,7 +1201,10 @@ int csi_host_malloc(csi_ctx* c, void** ptr, int64_t bytes) {
 }
 
 int csi_host_free(csi_ctx* c, void* ptr) {
-    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!c) {          // a buffer may outlive the context that allocated it (python finalizers run in any order)
+        if (ptr && hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return CSI_ERR_HIP; }
+        return CSI_OK;
+    }
     if (ptr) HIP_TRY(c, hipHostFree(ptr));
     return CSI_OK;
 }

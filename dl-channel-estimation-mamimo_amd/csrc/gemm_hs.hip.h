@@ -56,6 +56,7 @@ struct GemmHsArgs {
     const unsigned* dyn_max;   // CAST mode, automatic input scale: bits of a (sampled) max |x| of this launch's rows,
     int wshift;                //   written earlier on the stream by hs_absmax_sample_kernel; scale = 2^(14 - exponent)
     const unsigned long long* stamps;   // timing probe (tools/hs_probe.hip), null otherwise: hs_stamp
+    int a_blk, c_blk;          // hs ACTIVATION matrices (A input / C output) in the blocked layout, see hs_blk_offset
 };
 
 // Optional per-workgroup time stamps (timing probes; null in the library): wave 0 writes (shader cycles, 10-ns
@@ -68,6 +69,16 @@ __device__ __forceinline__ void hs_stamp(const unsigned long long* base, int i) 
         p[0] = __builtin_readcyclecounter();
         p[1] = wall_clock64();
     }
+}
+
+// Blocked layout of hs activation matrices: [16-row block][k-group of 16][16 rows][64 B], i.e. the 16 rows x 64 B
+// that ONE LDS-DMA piece of the consuming GEMM fetches are 1 KiB of contiguous memory instead of sixteen 64-byte
+// runs 4 KiB apart (row-major).  A layer that reads its A operand once from HBM - the regressor: one column tile, no
+// reuse through L2 - is bound by how HBM likes its requests: 2.6 TB/s row-major at config 2.  The producer's stores
+// stay whole lines: the 8 rows a store instruction covers are adjacent 64-byte runs of one k-group.
+// Offset in halves of (row, k-group) for a matrix of ld halves per row (ld = 2 K):
+__device__ __host__ __forceinline__ size_t hs_blk_offset(int row, int kgroup, int ld) {
+    return ((size_t)(row >> 4) * (ld >> 5) + kgroup) * 512 + (size_t)(row & 15) * 32;
 }
 
 // (a, b) -> packed hi halves, packed lo halves
@@ -131,7 +142,7 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
         const int cg = lane & 7;
         const int col8 = n0 + wn * 64 + cg * 8;
         // halves offset of this lane's 8 columns inside a row: group (col8 / 16), hi part
-        uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (col8 >> 4) * 32 + (col8 & 8);
+        uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (g.c_blk ? 0 : (col8 >> 4) * 32) + (col8 & 8);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -170,8 +181,9 @@ __device__ __forceinline__ void hs_epilogue(f32x16 (&acc)[4][2], const GemmHsArg
                 vh.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u);  vl.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x07060302u);
                 const int row = m0 + wm * 128 + half * 64 + rl;
                 if (col8 < g.N && (full_rows || row < g.M) && (!NOSTORE || g.M < 0)) {
-                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc) = vh;
-                    *reinterpret_cast<uint4*>(cb + (size_t)row * g.ldc + 16) = vl;
+                    uint16_t* d = cb + (g.c_blk ? hs_blk_offset(row, col8 >> 4, g.ldc) : (size_t)row * g.ldc);
+                    *reinterpret_cast<uint4*>(d) = vh;
+                    *reinterpret_cast<uint4*>(d + 16) = vl;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -292,21 +304,25 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     const int nsub = (kend - kbeg + HS_G - 1) / HS_G;
 
     const bool a_side = wave < 4;
-    const uint16_t* tile_base = a_side ? g.A + (size_t)m0 * g.lda + 2 * kbeg : g.Bt + (size_t)n0 * g.ldb + 2 * kbeg;
+    const bool ablk = a_side && g.a_blk;
+    const uint16_t* tile_base = a_side ? (ablk ? g.A + hs_blk_offset(m0, kbeg >> 4, g.lda) : g.A + (size_t)m0 * g.lda + 2 * kbeg)
+                                       : g.Bt + (size_t)n0 * g.ldb + 2 * kbeg;
     const int ld = a_side ? g.lda : g.ldb;
     const int rmax = a_side ? g.M - 1 - m0 : g.N - 1 - n0;
+    const int sstep = ablk ? 1024 : 64;              // bytes from one k-group of a row (block) to the next
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tile_base, 0, 0x7fffffff, 0x00020000);
     int voff[PP_PW];
 #pragma unroll
     for (int u = 0; u < PP_PW; ++u) {
         const int row = 16 * ((wave & 3) * PP_PW + u) + (lane >> 2);
         const int clog = (lane & 3) ^ ((row >> 2) & 3);
-        voff[u] = (min(row, rmax) * ld + clog * 8) * 2;
+        const int rc = min(row, rmax);
+        voff[u] = ablk ? (int)(hs_blk_offset(rc, 0, ld) + clog * 8) * 2 : (rc * ld + clog * 8) * 2;
     }
     auto issue = [&](int sub, int slot, int u) {
         if (DBG & 1) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (wave * PP_PW + u) * 256),
-                                                 16, voff[u], sub * 64, 0, 0);
+                                                 16, voff[u], sub * sstep, 0, 0);
     };
 
     const int fswz = (l31 >> 2) & 3;
@@ -893,7 +909,8 @@ __global__ __launch_bounds__(256) void hs_absmax_sample_kernel(const float* __re
 
 // dst (hs [rows][ldh]) = split(scale * src[rows][cols]) with zero padding up to ldh / 2 columns.
 // One thread = 8 columns of a row: 32 B in, 16 B of hi + 16 B of lo out.
-__global__ void f32_to_hs_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, uint16_t* __restrict__ dst, int ldh, float scale) {
+__global__ void f32_to_hs_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, uint16_t* __restrict__ dst, int ldh, float scale,
+                                 int blocked = 0) {
     const int c8 = ldh >> 4;                                  // 8-column groups per row
     const size_t total = (size_t)rows * c8;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -915,7 +932,7 @@ __global__ void f32_to_hs_kernel(const float* __restrict__ src, int ld_src, int 
         hs_split2(v[2] * scale, v[3] * scale, oh.y, ol.y);
         hs_split2(v[4] * scale, v[5] * scale, oh.z, ol.z);
         hs_split2(v[6] * scale, v[7] * scale, oh.w, ol.w);
-        uint16_t* d = dst + (size_t)r * ldh + (c >> 4) * 32 + (c & 8);
+        uint16_t* d = dst + (blocked ? hs_blk_offset(r, c >> 4, ldh) : (size_t)r * ldh + (c >> 4) * 32) + (c & 8);
         *reinterpret_cast<uint4*>(d) = oh;
         *reinterpret_cast<uint4*>(d + 16) = ol;
     }

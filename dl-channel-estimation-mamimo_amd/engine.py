@@ -374,9 +374,10 @@ class CsiEngine:
         self._check(self._lib.csi_host_malloc(self._ctx, ctypes.byref(p), max(n, 1)))
         buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        lib, ctx, addr = self._lib, self._ctx, p.value
+        lib, addr = self._lib, p.value
         import weakref
-        weakref.finalize(buf, lambda: lib.csi_host_free(ctx, ctypes.c_void_p(addr)))
+        # no context in the finalizer: the array may outlive the engine (csi_host_free accepts NULL for that)
+        weakref.finalize(buf, lambda: lib.csi_host_free(None, ctypes.c_void_p(addr)))
         return arr
 
     def lmmse_estimate(self, h_ls, hvec, snr_db):
@@ -407,6 +408,8 @@ class CsiEngine:
 
     # ------------------------------------------------------------------ device-resident calls
     def predict_device(self, d_re, d_im, npkt, d_out_re, d_out_im):
+        """Asynchronous.  On the split-f16 engine a range-guard hit is reported by the NEXT ``synchronize()`` (CsiError
+        code -6): outputs must not be consumed before it returned cleanly (the host-buffer calls repeat by themselves)."""
         self._check(self._lib.csi_predict_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr))
 
     def estimate_device(self, d_re, d_im, npkt, d_out_re, d_out_im, d_h_re, d_h_im):

@@ -222,6 +222,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
  *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels; 0: fp32 MFMA kernels only;
  *                         1: split engine wherever the layer shapes allow (hidden widths multiples of 16)
+ *   "hs_blocked"       split engine: 1 (default) keeps the hidden activations between its layers in a blocked layout
+ *                         ([16 rows][k-group of 16] = the 1 KiB one LDS-DMA piece of the next GEMM fetches, contiguous),
+ *                         0 row-major (A-B)
  *   "hs_fuse_regressor" split engine, two hidden layers, n_out <= 256: 1 runs the regressor inside the first per-pair
  *                         layer's kernel (its 256 x 256 tile of activations becomes the A operand of a second product
  *                         on the CU; only partial sums reach memory).  0 (default): measured slower than two kernels
@@ -254,7 +257,7 @@ int  csi_device_free(csi_ctx* ctx, void* dptr);
 /* Pinned (page-locked) host memory: buffers from here are DMA'd directly by the host-buffer entry
  * points instead of being staged through the library's own pinned slots. */
 int  csi_host_malloc(csi_ctx* ctx, void** ptr, int64_t bytes);
-int  csi_host_free(csi_ctx* ctx, void* ptr);
+int  csi_host_free(csi_ctx* ctx, void* ptr);          /* ctx may be NULL (a buffer that outlived its context) */
 int  csi_memcpy_h2d(csi_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 int  csi_memcpy_d2h(csi_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 /* i.i.d. CN(0,1) preambles generated on the device by a counter-based RNG (element index

@@ -417,6 +417,19 @@ int main(int argc, char** argv) {
         printf("cast (A fp32)    %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr); });
         printf("regressor N=234  %.3f ms  %.0f TF  (%.0f GB/s of hs input)\n", ms, 2.0 * M * NO * K / ms / 1e9, 4.0 * M * K / ms / 1e6);
+        {   // the same regressor reading its A operand in the blocked activation layout
+            uint16_t* Chb; CK(hipMalloc(&Chb, (size_t)(M + 16) * 2 * N * 2 + 4096)); CK(hipMemset(Chb, 0, (size_t)(M + 16) * 2 * N * 2 + 4096));
+            hipLaunchKernelGGL(f32_to_hs_kernel, dim3(2048), dim3(256), 0, 0, A, K, M, K, Chb, 2 * N, std::ldexp(1.f, sa), 1);
+            GemmHsArgs gb = gr; gb.A = Chb; gb.a_blk = 1;
+            ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gb); });
+            printf("regressor N=234, blocked A  %.3f ms  %.0f TF  (%.0f GB/s of hs input)\n", ms, 2.0 * M * NO * K / ms / 1e9, 4.0 * M * K / ms / 1e6);
+            GemmHsArgs gh2 = gh; gh2.c_blk = 1; gh2.C = Chb;
+            ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh2); });
+            printf("generic hs->hs, blocked C   %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+            GemmHsArgs gh3 = gh2; gh3.A = Chb; gh3.a_blk = 1; gh3.C = Ch;  gh3.c_blk = 0;
+            ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh3); });
+            printf("generic hs->hs, blocked A   %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        }
         ms = time_ms(launch_fused);
         printf("pair + fused regressor %.3f ms  %.0f TF (both products)   [pair + regressor kernels above: their sum]\n", ms, (fl + 2.0 * M * NO * K) / ms / 1e9);
     }
