@@ -35,6 +35,11 @@ static uint16_t* to_hs(const float* d_src, int ld, int rows, int cols, int* ldh,
     CK(hipDeviceSynchronize());
     return d;
 }
+// power experiment: zero the low `bits` mantissa bits of every lo half (hi halves untouched) of an hs matrix
+__global__ void mask_lo_kernel(uint16_t* m, size_t n_groups, unsigned mask) {
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * blockDim.x)
+        for (int i = 0; i < 16; ++i) m[g * 32 + 16 + i] &= (uint16_t)mask;
+}
 static float h2f(uint16_t h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; }
 
 // norm-relative error per row, worst row
@@ -297,6 +302,34 @@ int main(int argc, char** argv) {
         return 0;
     }
     const double fl = 2.0 * M * N * K;
+    if (argc > 4 && std::string(argv[4]) == "masklo") {
+        // does the matrix pipe draw less with fewer significant bits in the lo halves?  MFMA-only form and full kernel,
+        // lo halves of A and W truncated to 10 (as stored), 8, 6, 4, 0 mantissa bits
+        // fresh copies so that every variant starts from the full-precision halves
+        std::vector<uint16_t> a0((size_t)M * lda), w0((size_t)N * ldb);
+        CK(hipMemcpy(a0.data(), Ah, a0.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(w0.data(), Wh, w0.size() * 2, hipMemcpyDeviceToHost));
+        auto run = [&](const char* what, int keep_a, int keep_w) {
+            CK(hipMemcpy(Ah, a0.data(), a0.size() * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(Wh, w0.data(), w0.size() * 2, hipMemcpyHostToDevice));
+            auto mk = [](int keep) { return keep == 0 ? 0u : (0xffffu << (10 - keep)) & 0xffffu; };
+            hipLaunchKernelGGL(mask_lo_kernel, dim3(2048), dim3(256), 0, 0, Ah, (size_t)M * lda / 32, mk(keep_a));
+            hipLaunchKernelGGL(mask_lo_kernel, dim3(256), dim3(256), 0, 0, Wh, (size_t)N * ldb / 32, mk(keep_w));
+            CK(hipDeviceSynchronize());
+            double m1 = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 57>), grid, dim3(PP_THREADS), 0, 0, gh); });
+            double m2 = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh); });
+            printf("%-34s lo mantissa bits A %2d W %2d: MFMA only %.3f ms   full hs->hs %.3f ms\n", what, keep_a, keep_w, m1, m2);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            run("as stored", 10, 10);
+            run("weights only", 10, 8);
+            run("weights only", 10, 6);
+            run("both", 8, 8);
+            run("both", 6, 6);
+            run("as stored (again)", 10, 10);
+        }
+        return 0;
+    }
     if (loop) {
         const std::string mode = argc > 4 ? argv[4] : "hs2hs";
         const double secs = argc > 5 ? atof(argv[5]) : 4.0;
