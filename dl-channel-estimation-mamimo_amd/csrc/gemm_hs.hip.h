@@ -56,6 +56,7 @@ struct GemmHsArgs {
     const unsigned* dyn_max;   // CAST mode, automatic input scale: bits of a (sampled) max |x| of this launch's rows,
     int wshift;                //   written earlier on the stream by hs_absmax_sample_kernel; scale = 2^(14 - exponent)
     const unsigned long long* stamps;   // timing probe (tools/hs_probe.hip), null otherwise: hs_stamp
+    int xcd_cols;              // pair kernel: 1 = a column tile stays on one XCD (weights tile resident in that L2), see hs_tile_of_block
     int a_blk, c_blk;          // hs ACTIVATION matrices (A input / C output) in the blocked layout, see hs_blk_offset
 };
 
@@ -79,6 +80,24 @@ __device__ __forceinline__ void hs_stamp(const unsigned long long* base, int i) 
 // Offset in halves of (row, k-group) for a matrix of ld halves per row (ld = 2 K):
 __device__ __host__ __forceinline__ size_t hs_blk_offset(int row, int kgroup, int ld) {
     return ((size_t)(row >> 4) * (ld >> 5) + kgroup) * 512 + (size_t)(row & 15) * 32;
+}
+
+// Workgroup -> tile.  Workgroup b runs on XCD b % 8 (round-robin dispatch; an affinity for speed, nothing depends on it).
+//   rows-per-XCD (default): XCD x takes row tiles == x (mod 8) and all their column tiles - the A rows of a row tile enter
+//     one L2 once.  Right when A is the big operand (layer 0: 10 MB of preambles per row tile).
+//   columns-per-XCD (xcd_cols, needs 8 % tiles_n == 0): XCD x takes column tile x % tiles_n only - its 1 MiB slice of the
+//     weights stays resident in that 4 MiB L2 instead of the whole 4 MiB matrix competing with the output stream for
+//     it.  Right for the first per-pair layer, whose A side is 32 KB per row tile.
+__device__ __forceinline__ void hs_tile_of_block(const GemmHsArgs& g, int& tm, int& tn) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (g.xcd_cols && (8 % g.tiles_n) == 0) {
+        const int per = 8 / g.tiles_n;                 // row tiles per 8 consecutive workgroups
+        tn = xcd % g.tiles_n;
+        tm = idx * per + xcd / g.tiles_n;
+    } else {
+        tm = (idx / g.tiles_n) * 8 + xcd;
+        tn = idx % g.tiles_n;
+    }
 }
 
 // (a, b) -> packed hi halves, packed lo halves
@@ -294,8 +313,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_kernel(const GemmHsA
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    int tm, tn;
+    hs_tile_of_block(g, tm, tn);
     if (tm * PP_BM >= g.M) return;
     hs_stamp(g.stamps, 0);
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
@@ -684,8 +703,8 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    int tm, tn;
+    hs_tile_of_block(g, tm, tn);
     if (tm * PP_BM >= g.M) return;
     hs_stamp(g.stamps, 0);
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;

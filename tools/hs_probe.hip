@@ -433,6 +433,14 @@ int main(int argc, char** argv) {
         ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
         printf("pair (fused A)   %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
         {
+            GemmHsArgs gx = gp; gx.xcd_cols = 1;
+            ms = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gx, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
+            printf("pair, column tile per XCD  %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+            gx = gh; gx.xcd_cols = 1;
+            ms = time_ms([&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gx); });
+            printf("generic hs->hs, column tile per XCD  %.3f ms  %.0f TF\n", ms, fl / ms / 1e9);
+        }
+        {
             auto k1 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 1>;
             auto k2 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 2>;
             auto k3 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 3>;
