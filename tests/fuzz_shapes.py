@@ -36,6 +36,8 @@ def main():
         engine = int(rng.choice([-1, 0, 1, 1]))            # fp32 contexts: automatic / fp32 MFMA kernels / split-f16 engine
         if engine == 1 and rng.random() < 0.8:
             hidden = tuple(int(16 * rng.integers(1, 17)) for _ in range(nh))     # widths the split engine serves
+            if nh == 2 and rng.random() < 0.5:
+                hidden = (hidden[0], int(256 * rng.integers(1, 4)))              # second width a multiple of 256: the fused regressor applies
         w_re = o.make_weights(rng, 321 * nt, hidden, 234, use_bn=use_bn)
         w_im = o.make_weights(rng, 321 * nt, hidden, 234, use_bn=use_bn)
         P = o.hadamard(nt) if (nt & (nt - 1)) == 0 and rng.random() < 0.5 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
@@ -45,8 +47,12 @@ def main():
         e.load_weights('imag', w_im)
         e.set_pilot(P)
         e.set_option('force_tile', tile)
+        fuse = blocked = 0
         if dtype == 'f32':
             e.set_option('f32_engine', engine)
+            fuse, blocked = int(rng.integers(0, 2)), int(rng.integers(0, 2))       # split engine: fused regressor / activation layout
+            e.set_option('hs_fuse_regressor', fuse)
+            e.set_option('hs_blocked', blocked)
         o_re, o_im = e.predict(ltf)
         h = e.ls_estimate(ltf)
         k = min(npkt, 4)
@@ -64,7 +70,7 @@ def main():
         err_ls = rel(np.concatenate([h[:k].real, h[:k].imag], -1), np.concatenate([ref.real, ref.imag], -1))
         ok = err < tol and err_lit < tol and err_ls < 1e-5 and np.isfinite(o_re).all() and np.isfinite(h.view(np.float32)).all()
         bad += not ok
-        print(f'{i:3d} nt={nt:3d} nr={nr} npkt={npkt:3d} hidden={hidden} bn={int(use_bn)} {dtype} tile={tile:3d} engine={engine:2d} hs={e.get_option("hs_launches"):2d} '
+        print(f'{i:3d} nt={nt:3d} nr={nr} npkt={npkt:3d} hidden={hidden} bn={int(use_bn)} {dtype} tile={tile:3d} engine={engine:2d} fuse={fuse} blk={blocked} hs={e.get_option("hs_launches"):2d} '
               f'dnn={err:.2e} literal={err_lit:.2e} ls={err_ls:.2e} {"ok" if ok else "FAIL"}')
     print('FAILURES:', bad)
     return 1 if bad else 0
