@@ -116,6 +116,9 @@ def train_main(args):
         if rank == 0:
             path = os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.safetensors')
             save_weight_file(path, hist['weights'])
+            # ... and the file the reference itself writes here (DNN.py:319 save_weights): a Keras HDF5 checkpoint that
+            # keras load_weights (DNN.py:334) takes back, so MI355X-trained weights enter the reference's own pipeline
+            save_weight_file(os.path.join(args.modeldir or args.workdir, d + '_weights-improvement.hdf5'), hist['weights'], component=d)
             print('%s model: best val_loss %.6e after %d epochs; weights saved to %s' % (d, hist['best_val_loss'], len(hist['loss']), path))
     return 0
 

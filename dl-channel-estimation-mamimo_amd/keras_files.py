@@ -655,3 +655,174 @@ def read_savedmodel_variables(model_dir, verify_crc=False):
         else:
             raise KerasFileError(f'{model_dir}: layer_with_weights-{i} has variables {sorted(lw)} - neither Dense nor BatchNormalization')
     return out
+
+
+# =====================================================================================================
+# Writing a Keras HDF5 weights file (what DNN.py:319 ``CSI_predictor.save_weights(<d>_weights-improvement.hdf5)``
+# leaves behind), so that weights trained on the MI355X go back into the reference's own pipeline - keras
+# ``load_weights`` (DNN.py:334) and the MATLAB evaluation behind it.  Same subset of the format as the reader, the
+# objects libhdf5 1.10 itself writes for such a file (superblock 0, version-1 object headers, symbol-table groups:
+# B-tree node + symbol nodes + local heap, contiguous little-endian datasets, fixed-length string attributes); the
+# byte patterns of the datatype / dataspace / fill-value messages are the library's own (checked against
+# tests/golden/keras_weights_real.hdf5, which libhdf5 wrote).  tests/test_host.py re-opens the result with the genuine
+# libhdf5 where one is installed.
+# =====================================================================================================
+_LEAF_K, _INTERNAL_K = 4, 16
+_UNDEF8 = b'\xff' * 8
+
+
+def _pad8(b):
+    return b + b'\0' * (-len(b) % 8)
+
+
+def _h5_msg(mtype, data, flags=0):
+    data = _pad8(data)
+    return struct.pack('<HHB3x', mtype, len(data), flags) + data
+
+
+def _h5_dataspace(shape):
+    if shape == ():
+        return struct.pack('<BBBB4x', 1, 0, 0, 0)
+    dims = b''.join(struct.pack('<Q', int(d)) for d in shape)
+    return struct.pack('<BBBB4x', 1, len(shape), 1, 0) + dims + dims            # flags 1: maximum dimensions = dimensions
+
+
+_H5_F32LE = bytes.fromhex('11201f00040000000000200017080017' '7f000000')
+_H5_F64LE = bytes.fromhex('11203f0008000000000040003' '40b0034ff030000')
+
+
+def _h5_string_type(n):
+    return struct.pack('<BBBBI', 0x13, 0x01, 0, 0, max(int(n), 1))            # class 3 v1, null-padded ASCII
+
+
+def _h5_attr(name, dtype, space, payload):
+    nm = name.encode() + b'\0'
+    return _h5_msg(0x0c, struct.pack('<BBHHH', 1, 0, len(nm), len(dtype), len(space)) + _pad8(nm) + _pad8(dtype) + _pad8(space) + payload)
+
+
+def _h5_attr_strings(name, items):
+    """list of str -> what h5py stores for a list of bytes: a 1-D array of fixed-length strings; an empty list is
+    stored as float64 of shape (0,) (numpy's dtype for an empty list) - as keras / h5py do for layers without weights"""
+    if not items:
+        return _h5_attr(name, _H5_F64LE, _h5_dataspace((0,)), b'')
+    raw = [s.encode('utf8') for s in items]
+    n = max(len(r) for r in raw)
+    return _h5_attr(name, _h5_string_type(n), _h5_dataspace((len(raw),)), b''.join(r.ljust(n, b'\0') for r in raw))
+
+
+def _h5_attr_scalar_string(name, value):
+    raw = value.encode('utf8')
+    return _h5_attr(name, _h5_string_type(len(raw)), _h5_dataspace(()), raw)
+
+
+def _h5_object_header(messages):
+    body = b''.join(messages)
+    return struct.pack('<BBHII4x', 1, 0, len(messages), 1, len(body)) + body
+
+
+class _H5Writer:
+    def __init__(self):
+        self.buf = bytearray(96)                    # superblock, filled in last
+
+    def alloc(self, data):
+        off = len(self.buf)
+        self.buf += _pad8(bytes(data))
+        return off
+
+    def dataset(self, arr):
+        arr = np.ascontiguousarray(arr, dtype='<f4')
+        data = self.alloc(arr.tobytes() if arr.size else b'\0' * 8)
+        msgs = [_h5_msg(0x01, _h5_dataspace(arr.shape)), _h5_msg(0x03, _H5_F32LE, flags=1),
+                _h5_msg(0x05, bytes([2, 2, 2, 1, 0, 0, 0, 0]), flags=1),                  # fill value: late allocation, written if set, default
+                _h5_msg(0x08, struct.pack('<BBQQ', 3, 1, data, arr.nbytes))]
+        return self.alloc(_h5_object_header(msgs)), None
+
+    def group(self, members, attr_msgs):
+        """members: {name: (object header address, (btree, heap) or None)} -> (object header address, (btree, heap))"""
+        names = sorted(members, key=lambda s: s.encode('utf8'))
+        # local heap: offset 0 = the empty name, then the names; no free block (free-list head = 1 = H5HL_FREE_NULL)
+        seg, off = bytearray(8), {}
+        for nme in names:
+            off[nme] = len(seg)
+            seg += _pad8(nme.encode('utf8') + b'\0')
+        seg_addr = self.alloc(seg)
+        heap = self.alloc(b'HEAP' + bytes(4) + struct.pack('<QQQ', len(seg), 1, seg_addr))
+        # symbol nodes of <= 2 * leaf K entries, sorted by name
+        per = 2 * _LEAF_K
+        chunks = [names[i:i + per] for i in range(0, len(names), per)] or [[]]
+        if len(chunks) > 2 * _INTERNAL_K:
+            raise KerasFileError('more than %d members in one group' % (per * 2 * _INTERNAL_K))
+        snods = []
+        for ch in chunks:
+            ent = b''
+            for nme in ch:
+                addr, stab = members[nme]
+                if stab:
+                    ent += struct.pack('<QQII', off[nme], addr, 1, 0) + struct.pack('<QQ', *stab)
+                else:
+                    ent += struct.pack('<QQII', off[nme], addr, 0, 0) + bytes(16)
+            snods.append(self.alloc(b'SNOD' + struct.pack('<BBH', 1, 0, len(ch)) + ent.ljust(per * 40, b'\0')))
+        # one B-tree node (level 0): key 0 = empty name, key i+1 = largest name of child i
+        body = struct.pack('<Q', 0)
+        for ch, sn in zip(chunks, snods):
+            body += struct.pack('<QQ', sn, off[ch[-1]] if ch else 0)
+        full = 8 * (2 * _INTERNAL_K + 1) + 8 * 2 * _INTERNAL_K
+        btree = self.alloc(b'TREE' + struct.pack('<BBH', 0, 0, len(chunks) if names else 0) + _UNDEF8 + _UNDEF8 + body.ljust(full, b'\0'))
+        hdr = self.alloc(_h5_object_header([_h5_msg(0x11, struct.pack('<QQ', btree, heap))] + attr_msgs))
+        return hdr, (btree, heap)
+
+    def finish(self, root):
+        hdr, (btree, heap) = root
+        sb = (_H5_SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack('<HHI', _LEAF_K, _INTERNAL_K, 0) +
+              struct.pack('<Q', 0) + _UNDEF8 + struct.pack('<Q', len(self.buf)) + _UNDEF8 +
+              struct.pack('<QQII', 0, hdr, 1, 0) + struct.pack('<QQ', btree, heap))
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_keras_hdf5_weights(path, layers, keras_version='2.4.0', backend='tensorflow'):
+    """``layers``: [(layer name, [(weight name like 'fc_dense0/kernel:0', float32 array), ...]), ...] in model.layers
+    order (layers without weights carry an empty list) -> a file keras' ``load_weights`` reads by topology."""
+    w = _H5Writer()
+    top = {}
+    for lname, weights in layers:
+        members = {}
+        if weights:
+            # weight names contain the layer name and a '/': the datasets sit in an inner group of that name
+            inner = {}
+            for wname, arr in weights:
+                head, _, leaf = wname.partition('/')
+                if head != lname or not leaf or '/' in leaf:
+                    raise KerasFileError(f'weight name {wname!r} is not "<layer>/<variable>" of layer {lname!r}')
+                inner[leaf] = w.dataset(arr)
+            members[lname] = w.group(inner, [])
+        top[lname] = w.group(members, [_h5_attr_strings('weight_names', [n for n, _ in weights])])
+    root = w.group(top, [_h5_attr_strings('layer_names', [n for n, _ in layers]), _h5_attr_scalar_string('backend', backend),
+                         _h5_attr_scalar_string('keras_version', keras_version)])
+    with open(path, 'wb') as fh:
+        fh.write(w.finish(root))
+
+
+def keras_layers_from_weights(weights, component='real', dropout=True):
+    """Container-named tensors -> the ``layers`` list of write_keras_hdf5_weights for the reference's model
+    (DNN.py:176-234): inputs, flatten, concatenate, then per hidden layer fc_dense<i> / batch_normalization[_k] /
+    drop<i> (between hidden layers only, :222), fc_regressor.  BatchNormalization auto-numbers continue from the real to
+    the imag model, which is built second in the same process."""
+    n_hidden = 0
+    while f'fc_dense{n_hidden}.kernel' in weights:
+        n_hidden += 1
+    use_bn = 'bn0.gamma' in weights
+    k = 0 if component == 'real' else 1
+    sfx = lambda base, i: base + (f'_{i}' if i else '')
+    out = [(f'input_{1 + 2 * k}', []), (sfx('flatten', k), []), (f'input_{2 + 2 * k}', []), (sfx('concatenate', k), [])]
+    f32 = lambda a: np.asarray(a, np.float32)
+    for i in range(n_hidden):
+        out.append((f'fc_dense{i}', [(f'fc_dense{i}/kernel:0', f32(weights[f'fc_dense{i}.kernel'])), (f'fc_dense{i}/bias:0', f32(weights[f'fc_dense{i}.bias']).ravel())]))
+        if use_bn:
+            bn = sfx('batch_normalization', k * n_hidden + i)
+            out.append((bn, [(f'{bn}/{v}:0', f32(weights[f'bn{i}.{v}']).ravel()) for v in _BN_VARS]))
+        if dropout and i < n_hidden - 1:
+            out.append((f'drop{i}', []))
+    out.append(('fc_regressor', [('fc_regressor/kernel:0', f32(weights['fc_regressor.kernel'])), ('fc_regressor/bias:0', f32(weights['fc_regressor.bias']).ravel())]))
+    return out

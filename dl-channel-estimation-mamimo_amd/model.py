@@ -20,9 +20,18 @@ WEIGHT_FILE = 'weights.safetensors'
 CONFIG_FILE = 'config.json'
 
 
-def save_weight_file(path, weights):
-    """weights: dict name -> float32 ndarray.  Format by extension (.safetensors | .pt | .npz)."""
+def save_weight_file(path, weights, component=None):
+    """weights: dict name -> float32 ndarray.  Format by extension: .safetensors | .pt | .npz | .hdf5 / .h5 - the
+    last is a Keras HDF5 weights file in the layout of the reference's own checkpoints (DNN.py:279-281,319), which
+    keras ``load_weights`` reads by topology (keras_files.write_keras_hdf5_weights); ``component`` ('real' / 'imag',
+    default: from the file name) only selects keras' auto-numbering of the layer names."""
     tensors = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items() if isinstance(v, np.ndarray)}
+    if path.endswith(('.hdf5', '.h5')):
+        from .keras_files import write_keras_hdf5_weights, keras_layers_from_weights
+        if component is None:
+            component = 'imag' if os.path.basename(path).startswith('imag') else 'real'
+        write_keras_hdf5_weights(path, keras_layers_from_weights({k: v for k, v in tensors.items() if k != 'pilot'}, component))
+        return
     if path.endswith('.npz'):
         np.savez(path, **tensors)
     elif path.endswith('.pt'):

@@ -330,6 +330,68 @@ def test_keras_hdf5_checkpoint_reader_on_libhdf5_written_fixture(pkg, golden_dir
         pkg.load_weight_file(str(tmp_path / 'junk.hdf5'))
 
 
+def test_keras_hdf5_writer_output_opens_in_libhdf5(pkg, golden_dir, tmp_path):
+    """DNN.py:319 leaves <d>_weights-improvement.hdf5 behind; `cli --train` does the same through
+    keras_files.write_keras_hdf5_weights.  The written file must (a) come back unchanged through the reader and
+    (b) open in the GENUINE HDF5 library with keras' layout - layer_names / weight_names attributes, datasets at
+    <layer>/<layer>/<variable>:0 - where a libhdf5 is installed (this image: /opt/conda/lib, driven through ctypes)."""
+    import ctypes
+    from dl_channel_estimation_mamimo_amd import keras_files as kf
+    exp = np.load(os.path.join(golden_dir, 'keras_weights_expected.npz'))
+    w = {k[5:]: exp[k] for k in exp.files if k.startswith('imag.')}
+    path = str(tmp_path / 'imag_weights-improvement.hdf5')
+    pkg.save_weight_file(path, w)                                   # component from the file name
+    back = pkg.load_weight_file(path)
+    assert set(back) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(back[k].ravel(), np.asarray(w[k]).ravel())
+    f = kf.Hdf5File(path)
+    names = [bytes(x).decode() for x in f.root.attrs['layer_names']]
+    assert names == ['input_3', 'flatten_1', 'input_4', 'concatenate_1', 'fc_dense0', 'batch_normalization_2', 'drop0', 'fc_dense1',
+                     'batch_normalization_3', 'fc_regressor']
+    # byte-level agreement with the file libhdf5 wrote for the same tensors: identical dataset object-header messages
+    ref = kf.Hdf5File(os.path.join(golden_dir, 'keras_weights_imag.hdf5'))
+    for ds in ('/fc_dense0/fc_dense0/kernel:0', '/batch_normalization_3/batch_normalization_3/moving_variance:0'):
+        mine = {t: bytes(f.buf[p:p + n]) for t, _, p, n in f.messages(f[ds].addr) if t in (1, 3, 5)}
+        theirs = {t: bytes(ref.buf[p:p + n]) for t, _, p, n in ref.messages(ref[ds].addr) if t in (1, 3, 5)}
+        assert mine == theirs, ds
+    lib_path = '/opt/conda/lib/libhdf5.so.103'
+    if not os.path.exists(lib_path):
+        pytest.skip('no libhdf5 in this image to cross-check with')
+    lib = ctypes.CDLL(lib_path)
+    hid = ctypes.c_int64
+    lib.H5open()
+    lib.H5Fopen.restype = hid; lib.H5Fopen.argtypes = [ctypes.c_char_p, ctypes.c_uint, hid]
+    lib.H5Dopen2.restype = hid; lib.H5Dopen2.argtypes = [hid, ctypes.c_char_p, hid]
+    lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, ctypes.c_void_p]
+    lib.H5Aopen.restype = hid; lib.H5Aopen.argtypes = [hid, ctypes.c_char_p, hid]
+    lib.H5Aget_type.restype = hid; lib.H5Aget_type.argtypes = [hid]
+    lib.H5Aread.argtypes = [hid, hid, ctypes.c_void_p]
+    lib.H5Gopen2.restype = hid; lib.H5Gopen2.argtypes = [hid, ctypes.c_char_p, hid]
+    for fn in ('H5Dclose', 'H5Aclose', 'H5Tclose', 'H5Gclose', 'H5Fclose'):
+        getattr(lib, fn).argtypes = [hid]
+    fid = lib.H5Fopen(path.encode(), 0, 0)
+    assert fid >= 0, 'libhdf5 refuses the file'
+    f32 = hid.in_dll(lib, 'H5T_NATIVE_FLOAT_g').value
+    for name, key in (('/fc_dense0/fc_dense0/kernel:0', 'fc_dense0.kernel'), ('/fc_regressor/fc_regressor/bias:0', 'fc_regressor.bias'),
+                      ('/batch_normalization_2/batch_normalization_2/gamma:0', 'bn0.gamma')):
+        did = lib.H5Dopen2(fid, name.encode(), 0)
+        assert did >= 0, name
+        out = np.zeros(np.asarray(w[key]).shape, np.float32)
+        assert lib.H5Dread(did, f32, 0, 0, 0, out.ctypes.data) >= 0
+        np.testing.assert_array_equal(out, w[key])
+        lib.H5Dclose(did)
+    aid = lib.H5Aopen(fid, b'layer_names', 0)
+    tid = lib.H5Aget_type(aid)
+    raw = np.zeros(10, 'S21')
+    assert lib.H5Aread(aid, tid, raw.ctypes.data) >= 0
+    assert [x.decode() for x in raw] == names
+    lib.H5Tclose(tid); lib.H5Aclose(aid)
+    gid = lib.H5Gopen2(fid, b'/drop0', 0)
+    assert gid >= 0
+    lib.H5Gclose(gid); lib.H5Fclose(fid)
+
+
 def test_savedmodel_variables_reader_is_self_consistent(pkg, golden_dir, tmp_path):
     """SavedModel directories (DNN.py:411 -> inference.py:15-16): variables.index is an SSTable of BundleEntryProto,
     variables.data-* raw bytes.  TensorFlow is not available, so the fixture comes from the repository's own writer

@@ -269,6 +269,9 @@ def test_cli_train_then_test(pkg, oracle, tmp_path, capsys):
     for d in ('real', 'imag'):
         w = pkg.load_weight_file(str(work / f'{d}_weights-improvement.safetensors'))
         assert w['fc_dense0.kernel'].shape == (321 * nt, 32) and np.isfinite(w['fc_regressor.kernel']).all()
+        # ... and, like DNN.py:319, a Keras HDF5 checkpoint with the same tensors
+        k = pkg.load_weight_file(str(work / f'{d}_weights-improvement.hdf5'))
+        assert set(k) == set(w) and all(np.array_equal(k[n].ravel(), w[n].ravel()) for n in w)
     outdir = tmp_path / 'out'
     outdir.mkdir()
     rc = cli.main(['--test', '-x', str(tmp_path / 'train.b'), '--modeldir', str(work), '-d', str(outdir), '--nn', '32', '16',
