@@ -1,4 +1,4 @@
-"""Readers for the model files the REFERENCE writes, with no TensorFlow / h5py dependency:
+"""Readers (and an HDF5 writer) for the model files the REFERENCE writes, with no TensorFlow / h5py dependency:
 
   * ``<d>_weights-improvement.hdf5`` - the Keras-2.3 HDF5 weight checkpoint of
     massiveMIMO_CSI_prediction_DNN.py:279-281,319 (``ModelCheckpoint`` / ``save_weights``), loaded there by
@@ -73,7 +73,6 @@ class Hdf5File:
             raise KerasFileError(f'{path}: HDF5 superblock version {ver} is not supported')
         if self.so not in (4, 8) or self.sl not in (4, 8):
             raise KerasFileError(f'{path}: HDF5 offset / length sizes {self.so}/{self.sl} are not supported')
-        self.base += 0 if ver in (0, 1) else 0
         self.root = Hdf5Group(self, self.root_addr, '/')
 
     # ---- primitive readers
@@ -208,11 +207,10 @@ class Hdf5File:
                 vals.append(self.global_heap_object(addr, idx)[:length] if length else b'')
             return np.array(vals, dtype=object).reshape(shape) if shape else vals[0]
         arr = np.frombuffer(raw, dtype=typ.dtype, count=n)
-        if typ.cls == 3:
-            # numpy 'S' drops trailing NULs itself (null-terminated / null-padded); space padding is stripped here
-            arr = np.array([bytes(v).rstrip(b' ') if typ.strpad == 2 else bytes(v) for v in arr], dtype=object) if typ.strpad == 2 else arr
-        arr = arr.reshape(shape) if shape else arr.reshape(())
-        return arr
+        if typ.cls == 3 and typ.strpad == 2:
+            # numpy 'S' drops trailing NULs itself (null-terminated / null-padded strings); space padding is stripped here
+            arr = np.array([bytes(v).rstrip(b' ') for v in arr], dtype=typ.dtype)
+        return arr.reshape(shape) if shape else arr.reshape(())
 
     def attributes(self, addr):
         out = {}
