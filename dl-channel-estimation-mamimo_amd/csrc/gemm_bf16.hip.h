@@ -535,8 +535,12 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
 
+    // pair mode: a COLUMN tile per XCD - its slice of the weights stays resident in that L2 (the A side is 32 KB per row
+    // tile); layer 0 (CAST, 10+ MB of preambles per row tile): row tiles per XCD (gemm_hs.hip.h: hs_tile_of_block)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+    const bool cols = !CAST && (8 % g.tiles_n) == 0;
+    const int tm = cols ? idx * (8 / g.tiles_n) + xcd / g.tiles_n : (idx / g.tiles_n) * 8 + xcd;
+    const int tn = cols ? xcd % g.tiles_n : idx % g.tiles_n;
     if (tm * PP_BM >= g.M) return;
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
     const int kbeg = CAST ? blockIdx.z * g.k_per_split : 0;

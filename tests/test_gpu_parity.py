@@ -1128,10 +1128,10 @@ def test_config5_shape_long_accumulation(pkg, oracle):
 
 
 def test_full_size_properties_config3_bf16(pkg, oracle):
-    """BASELINE config 3 shape (Nt=64, Nr=4, bf16) on 1000 device-generated packets = 256 000 pairs:
+    """BASELINE config 3 at FULL size (Nt=64, Nr=4, bf16, 5000 device-generated packets = 1 280 000 pairs):
     run-to-run determinism and the bf16-emulation oracle on sampled packets."""
     rng = np.random.default_rng(3)
-    nt, nr, npkt, hidden = 64, 4, 1000, (1024, 1024)
+    nt, nr, npkt, hidden = 64, 4, 5000, (1024, 1024)
     w_re, w_im = _weights(oracle, 64, nt, hidden)
     P = oracle.hadamard(nt)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
