@@ -86,6 +86,33 @@ inline void hp_weave_c64(const float* __restrict__ re, const float* __restrict__
     }
 }
 
+// plain copy whose destination is not read again by this core (user -> pinned staging, pinned staging -> the caller's
+// result array): streaming stores; glibc's memcpy switches to them only beyond a threshold tied to the (huge) L3 here
+inline void hp_stream_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
+#ifdef CSI_HOST_AVX2
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;
+    if (bytes >= 4096 + head) {
+        std::memcpy(d, s, head);
+        d += head; s += head; bytes -= head;
+        size_t i = 0;
+        for (; i + 128 <= bytes; i += 128) {
+            const __m256 a = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i)), b = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 32));
+            const __m256 c = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 64)), e = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 96));
+            _mm256_stream_ps(reinterpret_cast<float*>(d + i), a);
+            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 32), b);
+            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 64), c);
+            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 96), e);
+        }
+        _mm_sfence();
+        std::memcpy(d + i, s + i, bytes - i);
+        return;
+    }
+#endif
+    std::memcpy(dst, src, bytes);
+}
+
 }  // namespace
 
 struct csi_hostpipe {
@@ -155,7 +182,7 @@ struct csi_hostpipe {
         const size_t per = ((bytes + parts - 1) / parts + 63) & ~(size_t)63;
         parallel(parts, [&](int i) {
             const size_t o = (size_t)i * per;
-            if (o < bytes) std::memcpy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o));
+            if (o < bytes) hp_stream_copy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o));
         });
     }
     // f(begin, end) over [0, n) in contiguous parts of >= min_part elements on the pool
