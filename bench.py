@@ -85,6 +85,9 @@ def main():
                     help='mixed-snr = structured packets, packets/8 at each of {-25..10} dB in one launch (host-generated); '
                          'white = CN(0,1) generated on the device; auto = mixed-snr up to 8000 packets per GPU')
     ap.add_argument('--no-latency', action='store_true', help='skip the one-packet latency loop (profiling runs)')
+    ap.add_argument('--graph', action='store_true',
+                    help='time replays of ONE hipGraph holding the whole step (csi_estimate_device + use_graph: LS, both DNNs, every chunk) - '
+                         'BASELINE configs[4]; the per-kernel HIP-event breakdown then comes from one extra eager step outside the timed region')
     ap.add_argument('--hidden', type=int, nargs='+', default=[1024, 1024])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
@@ -167,15 +170,26 @@ def main():
         eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
 
     def step():
+        if args.graph:
+            eng.estimate_device(d_re, d_im, npkt, d_ore, d_oim, d_hre, d_him)
+            return
         if not args.no_ls:
             eng.ls_estimate_device(d_re, d_im, npkt, d_hre, d_him)
         eng.predict_device(d_re, d_im, npkt, d_ore, d_oim)
 
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    eng.profile_enable(True)
-    eng.profile_reset()
+    if args.graph:
+        assert not args.no_ls, '--graph times the whole step (LS + DNN)'
+        eng.set_option('use_graph', 1)
+        for _ in range(max(args.warmup, 4)):      # eager (allocates, which resets the graph cache), eager, capture, first replay
+            step()
+        eng.synchronize()
+        assert eng.get_option('graph_replays') >= 1
+    else:
+        for _ in range(args.warmup):
+            step()
+        eng.synchronize()
+        eng.profile_enable(True)                  # per-kernel HIP events on the library's stream (forces eager launches)
+        eng.profile_reset()
 
     pkg.dist.barrier()
     eng.synchronize()
@@ -187,6 +201,13 @@ def main():
     dt = time.perf_counter() - t0
     dt = pkg.dist.all_reduce_max(dt)
 
+    graph_replays = eng.get_option('graph_replays') if args.graph else 0
+    if args.graph:                                 # kernel breakdown: one eager step with events, outside the timed region
+        eng.set_option('use_graph', 0)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        step()
+        eng.synchronize()
     prof = eng.profile()
     eng.profile_enable(False)
     pairs_per_step = total_pkts * nr * nt          # all ranks together
@@ -351,6 +372,8 @@ def main():
                        'operands, 3 MFMA per product - error vs the fp64 oracle in parity_check (contract 1e-5)') if split_engine else
                       ('fp32 MFMA' if args.dtype == 'f32' else 'bf16 operands, fp32 accumulate'),
         'data': 'synthetic',
+        'launch': ('one hipGraph per step, replayed (%d replays counted): LS kernel + range-guard memsets + magnitude sample + layer 0 + '
+                   'per-pair layers + regressor, both models, every packet chunk' % graph_replays) if args.graph else 'eager kernel launches',
         'input': ('structured sounding packets, %d at each of {-25,-20,-15,-10,-5,0,5,10} dB in one launch (synth.mixed_snr_batch)' % (npkt // 8)) if mixed
                  else 'i.i.d. CN(0,1) generated on the device (csi_synth_white)',
         'config': {'workload': '%sNt=%d Nr=%d, %d packets/step in total (%d on this rank)%s, LS + DNN(real) + DNN(imag), FC %s + BN, 234 bins' % (
