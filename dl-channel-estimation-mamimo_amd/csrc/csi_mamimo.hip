@@ -20,7 +20,7 @@ namespace {
 // Which LS kernel serves this context.  FFT-first (all Nt spectra in LDS) up to ls_fft_first_max
 // antennas, the chunked FFT-first kernel (accumulators persist over 16/32-symbol chunks) up to
 // Nt = 128, the despread-first kernel beyond (or when forced through the "ls_kernel" option).
-enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4 };
+enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5 };
 struct LsPlan {
     int mode;
     const void* fn;
@@ -32,13 +32,26 @@ LsPlan ls_plan(const csi_ctx* c) {
     const int nt = c->cfg.nt;
     int mode = c->ls_kernel;
     const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
-    if (mode == LS_FWHT && !fwht_ok) mode = LS_AUTO;
-    if (mode == LS_AUTO) mode = fwht_ok ? LS_FWHT : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST));
+    if ((mode == LS_FWHT || mode == LS_FWHT2) && !fwht_ok) mode = LS_AUTO;
+    if (mode == LS_AUTO) mode = fwht_ok ? (nt >= 32 ? LS_FWHT2 : LS_FWHT) : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST));
     if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
     if (mode == LS_CHUNKED && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
     LsPlan p{};
     p.mode = mode;
-    if (mode == LS_FWHT) {
+    if (mode == LS_FWHT2) {
+        // shape per Nt as measured (profiles/r02_ls_probe.txt); "ls_v2" = 1 selects the runner-up for A/B runs
+        const int v = c->ls_v2;
+        int split = 1, ch = 16, nstg = 1;
+#define LS_V2(NTV, SP, CHV, NS) { p.fn = (const void*)ls_estimate_fwht2_kernel<NTV, SP, CHV, NS>; split = SP; ch = CHV; nstg = NS; }
+        if (nt == 16) { if (v == 1) LS_V2(16, 1, 8, 3) else LS_V2(16, 1, 16, 1) }
+        else if (nt == 32) { if (v == 1) LS_V2(32, 1, 8, 3) else LS_V2(32, 1, 16, 1) }
+        else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1) else LS_V2(64, 1, 8, 3) }
+        else { if (v == 1) LS_V2(128, 2, 8, 4) else LS_V2(128, 2, 16, 3) }
+#undef LS_V2
+        p.lds = (size_t)(ch * 2 * LS_PLANE + 2 * LS_FFT + nstg * ch * 2 * LS_FFT) * sizeof(float);
+        p.threads = 256 * split;
+        p.per_cu = std::max(1, std::min(split == 1 ? 2 : 1, (int)((160 * 1024) / p.lds)));
+    } else if (mode == LS_FWHT) {
         p.fn = nt == 16 ? (const void*)ls_estimate_fwht_kernel<16> : nt == 32 ? (const void*)ls_estimate_fwht_kernel<32>
                : nt == 64 ? (const void*)ls_estimate_fwht_kernel<64> : (const void*)ls_estimate_fwht_kernel<128, 2>;
         p.lds = (size_t)(16 * 2 * LS_PLANE + 2 * LS_FFT) * sizeof(float);
@@ -187,7 +200,8 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
-    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(4, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(5, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_V2")) c->ls_v2 = std::atoi(e);
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);
@@ -770,6 +784,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
     else if (n == "host_threads") *value = c->host_threads;
     else if (n == "ls_kernel") *value = c->ls_kernel;
+    else if (n == "ls_v2") *value = c->ls_v2;
     else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
     else if (n == "hs_launches") *value = c->hs_launches;
     else if (n == "hs_range_fallbacks") *value = c->hs_range_fallbacks;
@@ -823,10 +838,13 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 64");
         if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
         c->host_threads = (int)value;
+    } else if (n == "ls_v2") {
+        c->ls_v2 = (int)value;
+        return ls_prepare(c);
     } else if (n == "ls_debug") {
         c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
     } else if (n == "ls_kernel") {
-        if (value < 0 || value > 4) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first) or 4 (Walsh-Hadamard)");
+        if (value < 0 || value > 5) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first), 4 (Walsh-Hadamard) or 5 (Walsh-Hadamard, LDS-DMA fed)");
         c->ls_kernel = (int)value;
         return ls_prepare(c);
     } else {

@@ -53,10 +53,10 @@ __device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
 // interleaved in one instruction stream (independent chains hide the LDS round-trip latency of
 // each stage).  Inputs sit at base-4 digit-reversed positions, outputs are in natural bin order.
 // lane = one radix-4 butterfly per stage.  Positions go through ls_phys() (4 pad floats per 32).
-template <int NS>
+template <int NS, int ST_BEGIN = 0>
 __device__ __forceinline__ void ls_fft256_wave(float* const (&fr)[NS], const float* tw_re, const float* tw_im, int lane) {
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = ST_BEGIN; st < 4; ++st) {
         const int L = 1 << (2 * st);
         const int j = lane & (L - 1);
         const int base = (lane >> (2 * st)) * 4 * L + j;
@@ -543,6 +543,200 @@ __global__ __launch_bounds__(256 * SPLIT, 2) void ls_estimate_fwht_kernel(const 
             for (int j = 0; j < NOWN * CH; ++j) {
                 pre[j * LS_NDATA] = hre[j] / den;
                 pim[j * LS_NDATA] = him[j] / den;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Walsh-Hadamard kernel, second generation: the same arithmetic as ls_estimate_fwht_kernel, fed by
+// LDS-DMA instead of register prefetch.
+//   * every LTF symbol plane (1 KiB) goes HBM -> LDS by one global_load_lds_dwordx4 per wave into a
+//     ring of NSTG raw chunk slots [CH][re|im][256] (natural sample order, unpadded).  No VGPRs carry
+//     samples, so NSTG - 1 whole chunks stay in flight behind the one being transformed however many
+//     accumulators the despread owns (Nt = 64 / 128: 128 per thread).
+//   * the base-4 digit reversal of the DIT transform is folded into stage 0: butterfly `lane` of that
+//     stage needs elements rev3(lane) + 64 m of the natural-order row - across the wave a permutation
+//     of 64 consecutive floats, conflict-free - and writes its four outputs as one ds_write_b128 into
+//     the padded image F.  Stages 1-3 run in F as before.  The separate scatter pass is gone.
+//   * a wave transforms exactly the rows it fetched, so a slot row is recycled (next DMA issued) as
+//     soon as that wave's stage-0 reads have returned: no workgroup barrier on the load path, two
+//     per chunk on the spectrum path (spectra complete / spectra consumed).
+//   * the DMA is inline asm: hipcc would put s_waitcnt vmcnt(0) in front of every ds_write that follows a
+//     builtin LDS-DMA.  Landing is awaited with a counted s_waitcnt vmcnt(younger chunks * R); stores
+//     issued in between only make that wait conservative (loads complete in order among themselves).
+__device__ __forceinline__ void ls_dma16(const float* g_lane_src, uint32_t lds_byte_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_lane_src), "s"(lds_byte_off) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ls_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ls_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NT, int SPLIT, int CH, int NSTG>
+__global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
+    static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
+    static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
+    constexpr int NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, NOWN = NCH / SPLIT, R = 2 * SPW;
+    static_assert(SPW >= 1 && NOWN >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw_re = smem;
+    float* tw_im = smem + LS_FFT;
+    float* F = smem + 2 * LS_FFT;              // [CH][2][LS_PLANE] padded spectra image
+    float* S = F + CH * 2 * LS_PLANE;          // [NSTG][CH][2][256] raw samples, LDS-DMA target
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+    for (int i = tid; i < LS_FFT; i += 256 * SPLIT) {
+        tw_re[i] = a.tw[i];
+        tw_im[i] = a.tw[LS_FFT + i];
+    }
+    const int q = tid & 255;                    // this thread's data bin
+    const int own = (tid >> 8) * NOWN;          // first output block (of CH antennas) this thread accumulates
+    const bool qok = q < LS_NDATA;
+    const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
+    const float rden = 1.0f / a.denom[qok ? q : 0];          // +-1/NT, exact
+    __syncthreads();                            // tables visible; drains the table loads before any DMA is counted
+
+    const uint32_t s_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)S);
+    const int nitems = blockIdx.x < (unsigned)nblk ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = nitems * NCH;                 // chunks this workgroup walks
+    int ti = 0, ich = 0;                        // next chunk to request
+    size_t iblk = blockIdx.x;
+    auto issue_next = [&]() {
+        if (ti >= T) return;
+        const size_t o = iblk * a.len_ltf + (size_t)(ich * CH + wave) * LS_SYM + LS_CP + 4 * lane;
+        const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            ls_dma16(a.ltf_re + o + (size_t)u * NW * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+            ls_dma16(a.ltf_im + o + (size_t)u * NW * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+        }
+        ++ti;
+        if (++ich == NCH) { ich = 0; iblk += gridDim.x; }
+    };
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) issue_next();
+
+    int t = 0;
+    for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
+        float hre[NOWN * CH], him[NOWN * CH];
+#pragma unroll
+        for (int j = 0; j < NOWN * CH; ++j) { hre[j] = 0.f; him[j] = 0.f; }
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch, ++t) {
+            // ---- this wave's rows of chunk t have landed?
+            const int younger = ti - t - 1;
+            if (NSTG == 1 || younger <= 0) ls_wait_vm<0>();
+            else if (NSTG == 2 || younger == 1) ls_wait_vm<R>();
+            else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
+            else ls_wait_vm<3 * R>();
+            // ---- stage 0 (radix-4 butterflies without twiddles) straight from the raw rows
+            const float* srow = S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT;
+            f32x4 yr[SPW], yi[SPW];
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) {
+                const float* sr = srow + (size_t)u * NW * 2 * LS_FFT + rev3;
+                float xr[4], xi[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { xr[m] = sr[64 * m]; xi[m] = sr[LS_FFT + 64 * m]; }
+                if (a.dbg & 8) continue;
+                const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
+                const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
+                const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
+                const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
+                yr[u][0] = ar + cr; yi[u][0] = ai + ci;
+                yr[u][1] = br + di; yi[u][1] = bi - dr;
+                yr[u][2] = ar - cr; yi[u][2] = ai - ci;
+                yr[u][3] = br - di; yi[u][3] = bi + dr;
+            }
+            // slot rows consumed -> their successors (chunk t + NSTG) start streaming
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_next();
+            if (t > 0) ls_lds_barrier();          // spectra of chunk t - 1 consumed by every thread
+            {
+                const int p0 = 4 * lane + 4 * (lane >> 3);           // ls_phys(4 lane), 16-byte aligned
+#pragma unroll
+                for (int u = 0; u < SPW; ++u) {
+                    float* fr = F + (size_t)(wave + NW * u) * 2 * LS_PLANE;
+                    *reinterpret_cast<f32x4*>(fr + p0) = yr[u];
+                    *reinterpret_cast<f32x4*>(fr + LS_PLANE + p0) = yi[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // ---- stages 1-3 in F, two rows interleaved where the wave has them
+            if (!(a.dbg & 1)) {
+                if (SPW >= 2) {
+#pragma unroll
+                    for (int u = 0; u + 1 < SPW; u += 2) {
+                        float* const pr[2] = {F + (size_t)(wave + NW * u) * 2 * LS_PLANE, F + (size_t)(wave + NW * (u + 1)) * 2 * LS_PLANE};
+                        ls_fft256_wave<2, 1>(pr, tw_re, tw_im, lane);
+                    }
+                } else {
+                    float* const pr[1] = {F + (size_t)wave * 2 * LS_PLANE};
+                    ls_fft256_wave<1, 1>(pr, tw_re, tw_im, lane);
+                }
+            }
+            ls_lds_barrier();                     // spectra complete
+            // ---- this bin's CH spectra -> registers, FWHT per plane, signed add into the owned blocks
+            if (!(a.dbg & 2)) {
+                float wr[CH], wi[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    wr[r] = F[(size_t)r * 2 * LS_PLANE + pos];
+                    wi[r] = F[(size_t)r * 2 * LS_PLANE + LS_PLANE + pos];
+                }
+#pragma unroll
+                for (int h = 1; h < CH; h <<= 1)
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (!(i & h)) {
+                            const float xr = wr[i], yr2 = wr[i + h], xi = wi[i], yi2 = wi[i + h];
+                            wr[i] = xr + yr2; wr[i + h] = xr - yr2;
+                            wi[i] = xi + yi2; wi[i + h] = xi - yi2;
+                        }
+#pragma unroll
+                for (int ab = 0; ab < NOWN; ++ab) {
+                    const float sgn = (__builtin_popcount((own + ab) & ch) & 1) ? -1.f : 1.f;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        hre[ab * CH + j] = fmaf(sgn, wr[j], hre[ab * CH + j]);
+                        him[ab * CH + j] = fmaf(sgn, wi[j], him[ab * CH + j]);
+                    }
+                }
+            }
+        }
+        if (a.dbg & 32) {                          // store-pattern experiment: the item as flat float4 rows (values meaningless)
+            f32x4* pre = reinterpret_cast<f32x4*>(a.h_re + blk * NT * LS_NDATA);
+            f32x4* pim = reinterpret_cast<f32x4*>(a.h_im + blk * NT * LS_NDATA);
+            int jj = 0;
+            for (int f = tid; f < NT * LS_NDATA / 4; f += 256 * SPLIT, ++jj) {
+                const f32x4 vr = {hre[0] * rden, hre[1], hre[2], (float)jj}, vi = {him[0] * rden, him[1], him[2], (float)jj};
+                pre[f] = vr;
+                pim[f] = vi;
+            }
+        } else if (a.dbg & 16) {                   // store-pattern experiment: row pitch 256 floats (needs the larger buffer)
+            float* pre = a.h_re + (blk * NT + own * CH) * 256 + q;
+            float* pim = a.h_im + (blk * NT + own * CH) * 256 + q;
+#pragma unroll
+            for (int j = 0; j < NOWN * CH; ++j) {
+                pre[j * 256] = hre[j] * rden;
+                pim[j * 256] = him[j] * rden;
+            }
+        } else if (qok && !(a.dbg & 4)) {
+            float* pre = a.h_re + (blk * NT + own * CH) * LS_NDATA + q;
+            float* pim = a.h_im + (blk * NT + own * CH) * LS_NDATA + q;
+#pragma unroll
+            for (int j = 0; j < NOWN * CH; ++j) {
+                pre[j * LS_NDATA] = hre[j] * rden;
+                pim[j * LS_NDATA] = him[j] * rden;
             }
         }
     }

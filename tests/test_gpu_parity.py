@@ -132,7 +132,7 @@ def test_ls_all_kernels_agree(pkg, oracle, kernel):
             assert np.array_equal(h, e.ls_estimate(ltf))
 
 
-@pytest.mark.parametrize('nt,nr,npkt', [(16, 2, 5), (32, 3, 300), (64, 2, 7), (128, 2, 3)])
+@pytest.mark.parametrize('nt,nr,npkt', [(16, 2, 5), (32, 3, 300), (64, 2, 7), (128, 2, 3), (16, 4, 400), (64, 4, 300), (128, 2, 200)])
 def test_ls_walsh_hadamard_despread(pkg, oracle, nt, nr, npkt):
     """With the Sylvester Hadamard pilot matrix the LS despread is a fast Walsh-Hadamard transform
     (chosen automatically): same answer as the oracle and as the MFMA despread (ls_kernel 2) up to the
@@ -152,6 +152,15 @@ def test_ls_walsh_hadamard_despread(pkg, oracle, nt, nr, npkt):
     assert rel_rows(np.concatenate([h.real, h.imag], -1).reshape(-1, 468), np.concatenate([h2.real, h2.imag], -1).reshape(-1, 468)) < 2e-6
     e.set_option('ls_kernel', 0)
     assert np.array_equal(h, e.ls_estimate(ltf))                 # deterministic
+    # the two generations of the kernel (4: register prefetch, 5 = automatic: LDS-DMA ring) and both shapes of the
+    # second (16- and 8-symbol chunks group the additions differently) agree to rounding; every item is written
+    for opt, val in (('ls_kernel', 4), ('ls_v2', 1)):
+        e.set_option('ls_kernel', 0)
+        e.set_option(opt, val)
+        h4 = e.ls_estimate(ltf)
+        assert rel_rows(np.concatenate([h.real, h.imag], -1).reshape(-1, 468), np.concatenate([h4.real, h4.imag], -1).reshape(-1, 468)) < 1e-6, (opt, val)
+    e.set_option('ls_v2', 0)
+    e.set_option('ls_kernel', 0)
     # a pilot matrix that differs from the Sylvester matrix in one sign: generic path, still right
     P2 = P.copy()
     P2[3, 5] = -P2[3, 5]
