@@ -161,9 +161,9 @@ struct csi_ctx {
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
-    int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first (tests)
+    int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first, 4 / 5 Walsh-Hadamard (register prefetch / LDS-DMA ring), 6 generic P on the ring (tests, A/B runs)
     int ls_v2 = 0;               // CSI_LS_V2: shape variant of the LDS-DMA fed Walsh-Hadamard kernel (experiments)
-    int ls_fft_first_max = 31;   // FFT-first LS kernel up to this Nt; from 32 on the chunked kernel is faster (0.64 vs 0.67 ms at 32, 2.1 vs 3.9 ms at 64); debug knob CSI_LS_FFT_FIRST_MAX
+    int ls_fft_first_max = 15;   // FFT-first LS kernel (all Nt spectra in LDS) up to this Nt; from 16 on the ring kernel is faster (Nt = 16: 0.47 vs 0.72 ms); debug knob CSI_LS_FFT_FIRST_MAX
     int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)
     // profiling
     bool prof_on = false;

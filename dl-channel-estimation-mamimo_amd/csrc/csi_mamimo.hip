@@ -17,10 +17,11 @@
 
 namespace {
 
-// Which LS kernel serves this context.  FFT-first (all Nt spectra in LDS) up to ls_fft_first_max
-// antennas, the chunked FFT-first kernel (accumulators persist over 16/32-symbol chunks) up to
-// Nt = 128, the despread-first kernel beyond (or when forced through the "ls_kernel" option).
-enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5 };
+// Which LS kernel serves this context.  With the Sylvester Hadamard pilot matrix the Walsh-Hadamard kernels
+// (LDS-DMA ring from Nt = 32).  Any other P: FFT-first (all Nt spectra in LDS) up to ls_fft_first_max antennas, the
+// ring kernel with the matrix-core despread up to Nt = 128, the despread-first kernel beyond.  The older chunked
+// kernel stays selectable through the "ls_kernel" option (tests, A/B runs).
+enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5, LS_RING = 6 };
 struct LsPlan {
     int mode;
     const void* fn;
@@ -33,9 +34,9 @@ LsPlan ls_plan(const csi_ctx* c) {
     int mode = c->ls_kernel;
     const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
     if ((mode == LS_FWHT || mode == LS_FWHT2) && !fwht_ok) mode = LS_AUTO;
-    if (mode == LS_AUTO) mode = fwht_ok ? (nt >= 32 ? LS_FWHT2 : LS_FWHT) : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_CHUNKED : LS_DESPREAD_FIRST));
+    if (mode == LS_AUTO) mode = fwht_ok ? (nt >= 32 ? LS_FWHT2 : LS_FWHT) : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_RING : LS_DESPREAD_FIRST));
     if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
-    if (mode == LS_CHUNKED && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
+    if ((mode == LS_CHUNKED || mode == LS_RING) && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
     LsPlan p{};
     p.mode = mode;
     if (mode == LS_FWHT2) {
@@ -48,9 +49,25 @@ LsPlan ls_plan(const csi_ctx* c) {
         else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1) else LS_V2(64, 1, 8, 3) }
         else { if (v == 1) LS_V2(128, 2, 8, 4) else LS_V2(128, 2, 16, 3) }
 #undef LS_V2
-        p.lds = (size_t)(ch * 2 * LS_PLANE + 2 * LS_FFT + nstg * ch * 2 * LS_FFT) * sizeof(float);
+        p.lds = (size_t)(2 * LSC_NTW + ch * 2 * LSC_ROW + nstg * ch * 2 * LS_FFT) * sizeof(float);
         p.threads = 256 * split;
         p.per_cu = std::max(1, std::min(split == 1 ? 2 : 1, (int)((160 * 1024) / p.lds)));
+    } else if (mode == LS_RING) {
+        const int jt = (nt + 31) / 32, ldp = jt * 32;
+        int nw = 4, nstg = 1, chs = 16;
+#define LS_RING_K(J, W, C, NS) { p.fn = (const void*)ls_estimate_ring_kernel<J, W, C, NS>; nw = W; nstg = NS; chs = C; }
+        // 8-symbol chunks where they waste fewer padded symbols (Nt = 24, 40, ...) and for two antenna tiles, where they let
+        // two workgroups share a CU (measured: profiles/r02_ls_probe.txt); "ls_v2" = 1 flips the choice for A/B runs
+        bool ch8 = jt == 2 || (jt == 1 && (nt + 7) / 8 * 8 < (nt + 15) / 16 * 16);
+        if (c->ls_v2 == 1) ch8 = !ch8;
+        if (jt == 1) { if (ch8) LS_RING_K(1, 4, 8, 3) else LS_RING_K(1, 4, 16, 1) }
+        else if (jt == 2) { if (ch8) LS_RING_K(2, 4, 8, 2) else LS_RING_K(2, 8, 16, 3) }
+        else if (jt == 3) LS_RING_K(3, 8, 16, 2)
+        else LS_RING_K(4, 8, 16, 1)
+#undef LS_RING_K
+        p.lds = (size_t)(2 * LSC_NTW + chs * 2 * LSC_ROW + nstg * chs * 2 * LS_FFT + 32 * jt * (ldp + 1)) * sizeof(float);
+        p.threads = 64 * nw;
+        p.per_cu = std::max(1, std::min(nw == 4 ? 2 : 1, (int)((160 * 1024) / p.lds)));
     } else if (mode == LS_FWHT) {
         p.fn = nt == 16 ? (const void*)ls_estimate_fwht_kernel<16> : nt == 32 ? (const void*)ls_estimate_fwht_kernel<32>
                : nt == 64 ? (const void*)ls_estimate_fwht_kernel<64> : (const void*)ls_estimate_fwht_kernel<128, 2>;
@@ -200,7 +217,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
-    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(5, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(6, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_V2")) c->ls_v2 = std::atoi(e);
     auto bail = [&](int code) {
         g_create_error = c->err;
@@ -844,7 +861,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "ls_debug") {
         c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
     } else if (n == "ls_kernel") {
-        if (value < 0 || value > 5) return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first), 4 (Walsh-Hadamard) or 5 (Walsh-Hadamard, LDS-DMA fed)");
+        if (value < 0 || value > 6)
+            return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first), 4 (Walsh-Hadamard), "
+                                                "5 (Walsh-Hadamard, LDS-DMA fed) or 6 (generic P, LDS-DMA fed)");
         c->ls_kernel = (int)value;
         return ls_prepare(c);
     } else {

@@ -20,6 +20,7 @@
 
 namespace csi {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -576,30 +577,160 @@ __device__ __forceinline__ void ls_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+
+// ---- complex-interleaved spectra image of the two ring kernels: rows of 256 (re, im) pairs, 4 pad elements per 16
+// (stage-1 butterflies of 16 lanes then fall on 16 distinct 8-byte bank pairs; stages 2-3 and the per-bin gathers
+// read consecutive elements).  Every LDS access of stages 1-3 is one ds_*_b64 per complex value and the arithmetic
+// runs on the packed-fp32 pipe: v_pk_add_f32 for the butterflies (the +-i rotations are op_sel / neg modifiers),
+// v_pk_mul_f32 + v_pk_fma_f32 per twiddle product - half the VALU and LDS instructions of the planar transform
+// (ls_fft256_wave), which is what these kernels are bound by once the ring hides the HBM latency.
+constexpr int LSC_ROW = LS_FFT + LS_FFT / 4;            // 320 complex elements per padded row
+constexpr int LSC_NTW = 256;                            // twiddle table: stage 1 [3][4], stage 2 [3][16], stage 3 [3][64] (252 used)
+__device__ __forceinline__ int lsc_phys(int e) { return e + ((e >> 4) << 2); }
+
+// a - i b  and  a + i b
+__device__ __forceinline__ f32x2 pk_add_mi(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add_pi(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// x * w for w = (c, s):  (xr c - xi s, xi c + xr s)
+__device__ __forceinline__ f32x2 pk_cmul(f32x2 x, f32x2 w) {
+    f32x2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(t));
+    return d;
+}
+
+// twc[off(st) + (m - 1) L + j] = exp(-2 pi i j m / (4 L)),  L = 4^st, off = 0 / 12 / 60: the three twiddles of butterfly
+// j of stage st, contiguous in j (conflict-free, and no index arithmetic in the transform)
+__device__ __forceinline__ void lsc_build_twiddles(f32x2* twc, const float* tw, int tid, int nthreads) {
+    for (int i = tid; i < 252; i += nthreads) {
+        const int st = i < 12 ? 1 : (i < 60 ? 2 : 3);
+        const int r = i - (st == 1 ? 0 : (st == 2 ? 12 : 60));
+        const int L = 1 << (2 * st), m = r / L + 1, j = r % L;
+        const int u = (j * m * (64 >> (2 * st))) & 255;
+        twc[i] = f32x2{tw[u], tw[LS_FFT + u]};
+    }
+}
+
+// stage 0 of the DIT transform for this wave's SPW rows of a raw (planar, natural-order) chunk slot: butterfly `lane`
+// takes samples rev3(lane) + 64 m; no twiddles
+template <int SPW, int NW>
+__device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32x2 (&y)[SPW][4]) {
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+        const float* sr = srow + (size_t)u * NW * 2 * LS_FFT + rev3;
+        f32x2 x[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) x[m] = f32x2{sr[64 * m], sr[LS_FFT + 64 * m]};
+        const f32x2 a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = x[1] - x[3];
+        y[u][0] = a + c;
+        y[u][1] = pk_add_mi(b, d);
+        y[u][2] = a - c;
+        y[u][3] = pk_add_pi(b, d);
+    }
+}
+template <int SPW, int NW>
+__device__ __forceinline__ void lsc_stage0_write(f32x2* Fc, int wave, int lane, const f32x2 (&y)[SPW][4]) {
+    const int p0 = 4 * lane + 4 * (lane >> 2);           // lsc_phys(4 lane): elements 4 lane .. 4 lane + 3, 32-byte aligned
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+        f32x2* fc = Fc + (size_t)(wave + NW * u) * LSC_ROW + p0;
+        *reinterpret_cast<f32x4*>(fc) = f32x4{y[u][0][0], y[u][0][1], y[u][1][0], y[u][1][1]};
+        *reinterpret_cast<f32x4*>(fc + 2) = f32x4{y[u][2][0], y[u][2][1], y[u][3][0], y[u][3][1]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// stages 1-3, NS rows interleaved in one instruction stream
+template <int NS>
+__device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32x2* twc, int lane) {
+#pragma unroll
+    for (int st = 1; st < 4; ++st) {
+        const int L = 1 << (2 * st);
+        const int j = lane & (L - 1);
+        const int base = (lane >> (2 * st)) * 4 * L + j;
+        const f32x2* tws = twc + (st == 1 ? 0 : (st == 2 ? 12 : 60)) + j;
+        int p[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) p[m] = lsc_phys(base + m * L);
+        f32x2 x[NS][4], y[NS][4], w[4];
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) x[n][m] = fr[n][p[m]];
+#pragma unroll
+        for (int m = 1; m < 4; ++m) w[m] = tws[(m - 1) * L];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+#pragma unroll
+            for (int m = 1; m < 4; ++m) x[n][m] = pk_cmul(x[n][m], w[m]);
+            const f32x2 a = x[n][0] + x[n][2], b = x[n][0] - x[n][2], c = x[n][1] + x[n][3], d = x[n][1] - x[n][3];
+            y[n][0] = a + c;
+            y[n][1] = pk_add_mi(b, d);
+            y[n][2] = a - c;
+            y[n][3] = pk_add_pi(b, d);
+        }
+        __builtin_amdgcn_wave_barrier();          // every lane has read before anyone overwrites
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fr[n][p[m]] = y[n][m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+// stages 1-3 of this wave's rows wave, wave + NW, ...: pairs interleaved when PAIR
+template <int SPW, int NW, bool PAIR>
+__device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* twc, int lane) {
+    if (PAIR && SPW >= 2) {
+#pragma unroll
+        for (int u = 0; u + 1 < SPW; u += 2) {
+            f32x2* const pr[2] = {Fc + (size_t)(wave + NW * u) * LSC_ROW, Fc + (size_t)(wave + NW * (u + 1)) * LSC_ROW};
+            lsc_fft_stages<2>(pr, twc, lane);
+        }
+        if (SPW & 1) {
+            f32x2* const pr[1] = {Fc + (size_t)(wave + NW * (SPW - 1)) * LSC_ROW};
+            lsc_fft_stages<1>(pr, twc, lane);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            f32x2* const pr[1] = {Fc + (size_t)(wave + NW * u) * LSC_ROW};
+            lsc_fft_stages<1>(pr, twc, lane);
+        }
+    }
+}
+
 template <int NT, int SPLIT, int CH, int NSTG>
 __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
     static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
     static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
+    static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning half of the output blocks)");
     constexpr int NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, NOWN = NCH / SPLIT, R = 2 * SPW;
     static_assert(SPW >= 1 && NOWN >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tw_re = smem;
-    float* tw_im = smem + LS_FFT;
-    float* F = smem + 2 * LS_FFT;              // [CH][2][LS_PLANE] padded spectra image
-    float* S = F + CH * 2 * LS_PLANE;          // [NSTG][CH][2][256] raw samples, LDS-DMA target
+    f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW] per-stage twiddles
+    f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW] spectra image (re, im)
+    float* S = reinterpret_cast<float*>(Fc + CH * LSC_ROW);           // [NSTG][CH][2][256] raw samples, LDS-DMA target
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
-    for (int i = tid; i < LS_FFT; i += 256 * SPLIT) {
-        tw_re[i] = a.tw[i];
-        tw_im[i] = a.tw[LS_FFT + i];
-    }
+    lsc_build_twiddles(twc, a.tw, tid, 256 * SPLIT);
     const int q = tid & 255;                    // this thread's data bin
     const int own = (tid >> 8) * NOWN;          // first output block (of CH antennas) this thread accumulates
     const bool qok = q < LS_NDATA;
-    const int pos = ls_phys(a.bin_pos[qok ? q : 0]);
+    const int pos = lsc_phys(a.bin_pos[qok ? q : 0]);
     const float rden = 1.0f / a.denom[qok ? q : 0];          // +-1/NT, exact
     __syncthreads();                            // tables visible; drains the table loads before any DMA is counted
 
@@ -623,11 +754,27 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) issue_next();
 
+    // The finished item is stored one step late: after the next chunk's samples are in registers and the ring slot
+    // is refilled (vmcnt counts stores too: a landing wait right behind the stores would drain them with the ring idle).
+    f32x2 h[NOWN * CH];                         // (re, im) of the owned antennas
+    auto store_item = [&](size_t blk) {
+        if (qok && !(a.dbg & 4)) {
+            float* pre = a.h_re + (blk * NT + own * CH) * LS_NDATA + q;
+            float* pim = a.h_im + (blk * NT + own * CH) * LS_NDATA + q;
+#pragma unroll
+            for (int j = 0; j < NOWN * CH; ++j) {
+                pre[j * LS_NDATA] = h[j][0] * rden;
+                pim[j * LS_NDATA] = h[j][1] * rden;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NOWN * CH; ++j) h[j] = f32x2{0.f, 0.f};
+    };
+#pragma unroll
+    for (int j = 0; j < NOWN * CH; ++j) h[j] = f32x2{0.f, 0.f};
+
     int t = 0;
     for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
-        float hre[NOWN * CH], him[NOWN * CH];
-#pragma unroll
-        for (int j = 0; j < NOWN * CH; ++j) { hre[j] = 0.f; him[j] = 0.f; }
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch, ++t) {
             // ---- this wave's rows of chunk t have landed?
@@ -636,110 +783,204 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
             else if (NSTG == 2 || younger == 1) ls_wait_vm<R>();
             else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
             else ls_wait_vm<3 * R>();
-            // ---- stage 0 (radix-4 butterflies without twiddles) straight from the raw rows
-            const float* srow = S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT;
-            f32x4 yr[SPW], yi[SPW];
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) {
-                const float* sr = srow + (size_t)u * NW * 2 * LS_FFT + rev3;
-                float xr[4], xi[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { xr[m] = sr[64 * m]; xi[m] = sr[LS_FFT + 64 * m]; }
-                if (a.dbg & 8) continue;
-                const float ar = xr[0] + xr[2], ai = xi[0] + xi[2];
-                const float br = xr[0] - xr[2], bi = xi[0] - xi[2];
-                const float cr = xr[1] + xr[3], ci = xi[1] + xi[3];
-                const float dr = xr[1] - xr[3], di = xi[1] - xi[3];
-                yr[u][0] = ar + cr; yi[u][0] = ai + ci;
-                yr[u][1] = br + di; yi[u][1] = bi - dr;
-                yr[u][2] = ar - cr; yi[u][2] = ai - ci;
-                yr[u][3] = br - di; yi[u][3] = bi + dr;
-            }
+            // ---- stage 0 straight from the raw rows
+            f32x2 y0[SPW][4];
+            lsc_stage0_read<SPW, NW>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
             // slot rows consumed -> their successors (chunk t + NSTG) start streaming
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_next();
+            if (ch == 0 && t > 0) store_item(blk - gridDim.x);
             if (t > 0) ls_lds_barrier();          // spectra of chunk t - 1 consumed by every thread
-            {
-                const int p0 = 4 * lane + 4 * (lane >> 3);           // ls_phys(4 lane), 16-byte aligned
-#pragma unroll
-                for (int u = 0; u < SPW; ++u) {
-                    float* fr = F + (size_t)(wave + NW * u) * 2 * LS_PLANE;
-                    *reinterpret_cast<f32x4*>(fr + p0) = yr[u];
-                    *reinterpret_cast<f32x4*>(fr + LS_PLANE + p0) = yi[u];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            // ---- stages 1-3 in F, two rows interleaved where the wave has them
-            if (!(a.dbg & 1)) {
-                if (SPW >= 2) {
-#pragma unroll
-                    for (int u = 0; u + 1 < SPW; u += 2) {
-                        float* const pr[2] = {F + (size_t)(wave + NW * u) * 2 * LS_PLANE, F + (size_t)(wave + NW * (u + 1)) * 2 * LS_PLANE};
-                        ls_fft256_wave<2, 1>(pr, tw_re, tw_im, lane);
-                    }
-                } else {
-                    float* const pr[1] = {F + (size_t)wave * 2 * LS_PLANE};
-                    ls_fft256_wave<1, 1>(pr, tw_re, tw_im, lane);
-                }
-            }
+            lsc_stage0_write<SPW, NW>(Fc, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, true>(Fc, wave, twc, lane);
             ls_lds_barrier();                     // spectra complete
-            // ---- this bin's CH spectra -> registers, FWHT per plane, signed add into the owned blocks
+            // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
             if (!(a.dbg & 2)) {
-                float wr[CH], wi[CH];
+                f32x2 w[CH];
 #pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    wr[r] = F[(size_t)r * 2 * LS_PLANE + pos];
-                    wi[r] = F[(size_t)r * 2 * LS_PLANE + LS_PLANE + pos];
-                }
+                for (int r = 0; r < CH; ++r) w[r] = Fc[(size_t)r * LSC_ROW + pos];
 #pragma unroll
-                for (int h = 1; h < CH; h <<= 1)
+                for (int hh = 1; hh < CH; hh <<= 1)
 #pragma unroll
                     for (int i = 0; i < CH; ++i)
-                        if (!(i & h)) {
-                            const float xr = wr[i], yr2 = wr[i + h], xi = wi[i], yi2 = wi[i + h];
-                            wr[i] = xr + yr2; wr[i + h] = xr - yr2;
-                            wi[i] = xi + yi2; wi[i + h] = xi - yi2;
+                        if (!(i & hh)) {
+                            const f32x2 x = w[i], y = w[i + hh];
+                            w[i] = x + y;
+                            w[i + hh] = x - y;
                         }
+                // cross-chunk stages: output block ab takes +-w by the sign of H_{NT/CH}[ab][ch]
 #pragma unroll
                 for (int ab = 0; ab < NOWN; ++ab) {
-                    const float sgn = (__builtin_popcount((own + ab) & ch) & 1) ? -1.f : 1.f;
+                    const float sg = (__builtin_popcount((own + ab) & ch) & 1) ? -1.f : 1.f;
+                    const f32x2 sgn = {sg, sg};
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        hre[ab * CH + j] = fmaf(sgn, wr[j], hre[ab * CH + j]);
-                        him[ab * CH + j] = fmaf(sgn, wi[j], him[ab * CH + j]);
-                    }
+                    for (int j = 0; j < CH; ++j) h[ab * CH + j] = __builtin_elementwise_fma(sgn, w[j], h[ab * CH + j]);
                 }
-            }
-        }
-        if (a.dbg & 32) {                          // store-pattern experiment: the item as flat float4 rows (values meaningless)
-            f32x4* pre = reinterpret_cast<f32x4*>(a.h_re + blk * NT * LS_NDATA);
-            f32x4* pim = reinterpret_cast<f32x4*>(a.h_im + blk * NT * LS_NDATA);
-            int jj = 0;
-            for (int f = tid; f < NT * LS_NDATA / 4; f += 256 * SPLIT, ++jj) {
-                const f32x4 vr = {hre[0] * rden, hre[1], hre[2], (float)jj}, vi = {him[0] * rden, him[1], him[2], (float)jj};
-                pre[f] = vr;
-                pim[f] = vi;
-            }
-        } else if (a.dbg & 16) {                   // store-pattern experiment: row pitch 256 floats (needs the larger buffer)
-            float* pre = a.h_re + (blk * NT + own * CH) * 256 + q;
-            float* pim = a.h_im + (blk * NT + own * CH) * 256 + q;
-#pragma unroll
-            for (int j = 0; j < NOWN * CH; ++j) {
-                pre[j * 256] = hre[j] * rden;
-                pim[j * 256] = him[j] * rden;
-            }
-        } else if (qok && !(a.dbg & 4)) {
-            float* pre = a.h_re + (blk * NT + own * CH) * LS_NDATA + q;
-            float* pim = a.h_im + (blk * NT + own * CH) * LS_NDATA + q;
-#pragma unroll
-            for (int j = 0; j < NOWN * CH; ++j) {
-                pre[j * LS_NDATA] = hre[j] * rden;
-                pim[j * LS_NDATA] = him[j] * rden;
             }
         }
     }
+    if (nitems > 0) store_item(blockIdx.x + (size_t)(nitems - 1) * gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic-P kernel on the same LDS-DMA ring: the front end of ls_estimate_fwht2_kernel (ring of raw chunk slots,
+// digit reversal folded into stage 0, a wave transforms the rows it fetched) with the matrix-core despread of
+// ls_estimate_chunked_kernel behind it (D[j][q] += sum_{s in chunk} P[j][s] F[s][f(q)] on v_mfma_f32_32x32x2_f32,
+// accumulators persist over the chunks).  Any real P, any Nt from 16 to 32 JT: symbols beyond Nt in the last chunk
+// are fetched clamped (a valid symbol again) and meet the zero columns of the padded P (kept in LDS).
+template <int JT, int NW, int CH, int NSTG>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void ls_estimate_ring_kernel(const LsArgs a, int nblk) {
+    constexpr int SPW = CH / NW, QW = 8 / NW, R = 2 * SPW;
+    static_assert(SPW >= 1 && QW >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW]
+    f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW]
+    float* S = reinterpret_cast<float*>(Fc + CH * LSC_ROW);           // [NSTG][CH][2][256]
+    float* Pl = S + NSTG * CH * 2 * LS_FFT;    // [32 JT][ldp + 1] the padded pilot matrix: no global load may sit in the
+                                               // steady-state loop (loads return in order - it would wait for the ring)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = a.nt;
+    const int nchunk = (nt + CH - 1) / CH;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+    lsc_build_twiddles(twc, a.tw, tid, 64 * NW);
+    const int ldl = a.ldp + 1;
+    for (int i = tid; i < 32 * JT * a.ldp; i += 64 * NW) Pl[(i / a.ldp) * ldl + (i % a.ldp)] = a.Ppad[i];
+    int pos[QW];
+    float rden[QW];
+    bool qok[QW];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        const int q = (wave + NW * qi) * 32 + l31;
+        qok[qi] = q < LS_NDATA;
+        pos[qi] = lsc_phys(a.bin_pos[qok[qi] ? q : 0]);
+        rden[qi] = 1.0f / a.denom[qok[qi] ? q : 0];
+    }
+    __syncthreads();
+
+    const uint32_t s_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)S);
+    const int nitems = blockIdx.x < (unsigned)nblk ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = nitems * nchunk;
+    int ti = 0, ich = 0;
+    size_t iblk = blockIdx.x;
+    auto issue_next = [&]() {
+        if (ti >= T) return;
+        const size_t o = iblk * a.len_ltf + LS_CP + 4 * lane;
+        const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            const int sidx = min(ich * CH + wave + NW * u, nt - 1);
+            ls_dma16(a.ltf_re + o + (size_t)sidx * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+            ls_dma16(a.ltf_im + o + (size_t)sidx * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+        }
+        ++ti;
+        if (++ich == nchunk) { ich = 0; iblk += gridDim.x; }
+    };
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) issue_next();
+
+    f32x16 acc[QW][JT][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[qi][jt][0][e] = 0.f; acc[qi][jt][1][e] = 0.f; }
+    };
+    // scale and store: rows j = jt*32 + (r&3) + 8*(r>>2) + 4*hi, bins coalesced over the lanes (as in the chunked kernel)
+    auto store_item = [&](size_t blk) {
+        const bool full = (nt & 31) == 0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            if (!qok[qi] || (a.dbg & 4)) continue;
+            const size_t o = (blk * nt + 4 * hi) * LS_NDATA + (size_t)((wave + NW * qi) * 32 + l31);
+            float* pre = a.h_re + o;
+            float* pim = a.h_im + o;
+            const float inv = rden[qi];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if (jt * 32 >= nt) break;
+                if (full || (jt + 1) * 32 <= nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        pre[jo * LS_NDATA] = acc[qi][jt][0][r] * inv;
+                        pim[jo * LS_NDATA] = acc[qi][jt][1][r] * inv;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        if (jo + 4 * hi < nt) {
+                            pre[jo * LS_NDATA] = acc[qi][jt][0][r] * inv;
+                            pim[jo * LS_NDATA] = acc[qi][jt][1][r] * inv;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        zero_acc();
+    };
+    zero_acc();
+
+    int t = 0;
+    for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch, ++t) {
+            const int ns = min(CH, nt - ch * CH);                 // symbols in this chunk
+            const int younger = ti - t - 1;
+            if (NSTG == 1 || younger <= 0) ls_wait_vm<0>();
+            else if (NSTG == 2 || younger == 1) ls_wait_vm<R>();
+            else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
+            else ls_wait_vm<3 * R>();
+            f32x2 y0[SPW][4];
+            lsc_stage0_read<SPW, NW>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_next();
+            if (ch == 0 && t > 0) store_item(blk - gridDim.x);
+            if (t > 0) ls_lds_barrier();          // spectra of chunk t - 1 consumed
+            lsc_stage0_write<SPW, NW>(Fc, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1)>(Fc, wave, twc, lane);
+            ls_lds_barrier();                     // spectra complete
+
+            // ---- despread on the matrix core (operands of step ks + 1 requested before the MFMAs of step ks)
+            const int ksteps = (a.dbg & 2) ? 0 : (ns + 1) >> 1;
+            const float* prow = Pl + (size_t)l31 * ldl + ch * CH + hi;
+            const f32x2* frow = Fc + (size_t)hi * LSC_ROW;
+            float pvn[JT];
+            f32x2 bn[QW];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) pvn[jt] = prow[(size_t)jt * 32 * ldl];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) bn[qi] = frow[pos[qi]];
+            for (int ks = 0; ks < ksteps; ++ks) {
+                float pv[JT];
+                f32x2 bc[QW];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) pv[jt] = pvn[jt];
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) bc[qi] = bn[qi];
+                const int kn = min(ks + 1, CH / 2 - 1);
+                const f32x2* fn = frow + (size_t)kn * 2 * LSC_ROW;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) pvn[jt] = prow[(size_t)jt * 32 * ldl + 2 * kn];
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) bn[qi] = fn[pos[qi]];
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        acc[qi][jt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bc[qi][0], acc[qi][jt][0], 0, 0, 0);
+                        acc[qi][jt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bc[qi][1], acc[qi][jt][1], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (nitems > 0) store_item(blockIdx.x + (size_t)(nitems - 1) * gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------

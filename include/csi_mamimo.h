@@ -214,7 +214,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "force_tile"       128 | 256: row-tile height of every GEMM (0 = chosen by grid size)
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
- *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 31, max 64)
+ *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 15, max 64)
  *   "small_call_overlap" 1 (default): calls of at most 64 rx preambles run the real and the imag model on
  *                         two streams side by side (they are launch-latency bound); 0: one after the other
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
@@ -243,9 +243,12 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned
  *                         slots of the host-buffer entry points (0 = automatic: cores / 8, between 2 and 24)
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
- *                         FFT-first (32 < Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
- *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix - chosen
- *                         automatically then); a choice the kernel cannot serve falls back */
+ *                         FFT-first (16 <= Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
+ *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix), 5: the same
+ *                         fed by an LDS-DMA ring (chosen automatically for that P from Nt = 32), 6: generic P on
+ *                         the LDS-DMA ring (chosen automatically for any other P, 16 <= Nt <= 128); a choice the
+ *                         kernel cannot serve falls back
+ *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
 /* Current value of an option, or of the read-only counters "hs_launches" (split-engine GEMMs launched)
  * and "hs_range_fallbacks" (csi_predict calls repeated on the fp32 MFMA kernels). */

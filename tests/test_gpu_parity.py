@@ -105,15 +105,18 @@ def test_ls_non_power_of_two_nt_generic_pilot(pkg, oracle, nt):
     assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 6])
 def test_ls_all_kernels_agree(pkg, oracle, kernel):
-    """The three LS kernels (1 FFT-first, 2 chunked FFT-first, 3 despread-first) against the oracle on
+    """The generic LS kernels (1 FFT-first, 2 chunked FFT-first, 3 despread-first, 6 LDS-DMA ring) against the oracle on
     every Nt each of them serves, incl. partial MFMA tiles and partial symbol chunks (Nt = 40, 72, 100)
     and many more items than resident workgroups (persistent loops)."""
     rng = np.random.default_rng(kernel + 3)
     cases = {1: ((8, 2, 3), (32, 3, 3), (64, 2, 3), (40, 1, 2)),
              2: ((40, 2, 3), (64, 2, 3), (72, 1, 2), (96, 2, 2), (100, 1, 2), (128, 2, 2), (64, 4, 300)),
-             3: ((8, 2, 3), (64, 2, 3), (72, 1, 2), (128, 2, 2), (160, 1, 1))}[kernel]
+             3: ((8, 2, 3), (64, 2, 3), (72, 1, 2), (128, 2, 2), (160, 1, 1)),
+             # 6 = the chunked kernel's successor on the LDS-DMA ring (generic P): every antenna-tile count, partial last chunks
+             6: ((16, 2, 5), (24, 2, 3), (32, 3, 300), (40, 2, 3), (64, 2, 3), (72, 1, 2), (96, 2, 2), (100, 1, 2), (128, 2, 2),
+                 (64, 4, 300), (128, 3, 100))}[kernel]
     for nt, nr, npkt in cases:
         P = _pilot(rng, nt) if nt & (nt - 1) == 0 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
         if npkt > 10:

@@ -30,8 +30,9 @@ def _rows(d, first, cnt, nr, nt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--shapes', default='32x4x4000,64x4x5000,128x16x2000')
-    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--warm', type=int, default=10)
+    ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--variants', default='4:0,5:0,5:1,5:2,5:3,2:0')
     ap.add_argument('--dbg', default='0')
     ap.add_argument('--generic', action='store_true', help='non-Hadamard pilot matrix (only the generic kernels apply)')
@@ -39,8 +40,9 @@ def main():
     for shape in args.shapes.split(','):
         nt, nr, npkt = (int(v) for v in shape.split('x'))
         eng = CsiEngine(nt, nr, hidden=(32,), n_out=234)
-        P = hadamard(nt).astype(np.float32)
-        if args.generic:
+        if not args.generic:
+            P = hadamard(nt).astype(np.float32)
+        else:
             rng = np.random.default_rng(1)
             P = np.linalg.qr(rng.standard_normal((nt, nt)))[0].astype(np.float32) * np.sqrt(nt)
         eng.set_pilot(P)
@@ -49,15 +51,19 @@ def main():
         d_hr, d_hi = eng.empty((npkt, nr, nt, 256)), eng.empty((npkt, nr, nt, 256))       # 256: room for the pitch experiment (ls_debug 16)
         pairs = npkt * nr * nt
         ref = None
+        cases = []
         for kv in args.variants.split(','):
             k, v = (int(x) for x in kv.split(':'))
-            if k == 5 and v == 3 and nt != 128:
-                continue
             for dbg in (int(x) for x in args.dbg.split(',')):
+                cases.append((k, v, dbg))
+        times = {c: [] for c in cases}
+        errs = {}
+        for rnd in range(args.rounds):                     # variants interleaved: box drift hits all of them alike
+            for (k, v, dbg) in cases:
                 eng.set_option('ls_v2', v)
                 eng.set_option('ls_kernel', k)
                 eng.set_option('ls_debug', dbg)
-                for _ in range(args.warm):
+                for _ in range(args.warm if rnd == 0 else 2):
                     eng.ls_estimate_device(d_re, d_im, npkt, d_hr, d_hi)
                 eng.synchronize()
                 eng.profile_enable(True)
@@ -67,21 +73,23 @@ def main():
                 eng.synchronize()
                 pr = eng.profile()['ls_estimate']
                 eng.profile_enable(False)
-                ms = pr['ms'] / pr['launches']
-                err = ''
-                if dbg == 0:
+                times[(k, v, dbg)].append(pr['ms'] / pr['launches'])
+                if dbg == 0 and rnd == 0:
                     n = min(npkt, 64)
                     h = _rows(d_hr, 0, n, nr, nt) + 1j * _rows(d_hi, 0, n, nr, nt)
                     tail = _rows(d_hr, npkt - 1, 1, nr, nt)
                     if ref is None:
                         ref = (h, tail)
-                        err = 'reference'
+                        errs[(k, v, dbg)] = 'reference'
                     else:
-                        err = 'max rel diff %.2e' % max(float(np.max(np.abs(h - ref[0])) / np.max(np.abs(ref[0]))),
-                                                         float(np.max(np.abs(tail - ref[1])) / np.max(np.abs(ref[1]))))
-                tbs = pairs * (2560 + 1872) / (ms * 1e-3) / 1e12
-                print('Nt=%3d Nr=%2d pkts=%5d  kernel %d v%d dbg %2d : %7.3f ms  %5.2f TB/s  %.3f of 8 TB/s   %s'
-                      % (nt, nr, npkt, k, v, dbg, ms, tbs, tbs / 8, err), flush=True)
+                        errs[(k, v, dbg)] = 'max rel diff %.2e' % max(float(np.max(np.abs(h - ref[0])) / np.max(np.abs(ref[0]))),
+                                                                       float(np.max(np.abs(tail - ref[1])) / np.max(np.abs(ref[1]))))
+        for (k, v, dbg) in cases:
+            ts = sorted(times[(k, v, dbg)])
+            ms = ts[len(ts) // 2]
+            tbs = pairs * (2560 + 1872) / (ms * 1e-3) / 1e12
+            print('Nt=%3d Nr=%2d pkts=%5d  kernel %d v%d dbg %2d : median %7.3f ms (min %7.3f)  %5.2f TB/s  %.3f of 8 TB/s   %s'
+                  % (nt, nr, npkt, k, v, dbg, ms, ts[0], tbs, tbs / 8, errs.get((k, v, dbg), '')), flush=True)
         eng.close()
 
 
