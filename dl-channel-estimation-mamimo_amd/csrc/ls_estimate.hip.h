@@ -710,17 +710,21 @@ __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* t
     }
 }
 
-template <int NT, int SPLIT, int CH, int NSTG>
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false>
 __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
     static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
     static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
-    static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning half of the output blocks)");
-    constexpr int NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, NOWN = NCH / SPLIT, R = 2 * SPW;
-    static_assert(SPW >= 1 && NOWN >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
+    static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning one half of every output block)");
+    constexpr int NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, R = 2 * SPW;
+    // SPLIT = 2: thread half g owns antennas g CH/2 .. of every block of CH.  H_CH = H_2 (x) H_{CH/2} in the Sylvester
+    // order, so its CH/2 transform outputs are the FWHT_{CH/2} of x[s] + (-1)^g x[s + CH/2]: half the butterflies of
+    // the full transform instead of all of them in both threads.
+    constexpr int CHH = CH / SPLIT;
+    static_assert(SPW >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW] per-stage twiddles
     f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW] spectra image (re, im)
-    float* S = reinterpret_cast<float*>(Fc + CH * LSC_ROW);           // [NSTG][CH][2][256] raw samples, LDS-DMA target
+    float* S = reinterpret_cast<float*>(Fc + (DBF ? 2 : 1) * CH * LSC_ROW);   // [NSTG][CH][2][256] raw samples, LDS-DMA target
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
     const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
     lsc_build_twiddles(twc, a.tw, tid, 256 * SPLIT);
     const int q = tid & 255;                    // this thread's data bin
-    const int own = (tid >> 8) * NOWN;          // first output block (of CH antennas) this thread accumulates
+    const int g = SPLIT == 2 ? (tid >> 8) : 0;  // which half of every output block this thread accumulates
     const bool qok = q < LS_NDATA;
     const int pos = lsc_phys(a.bin_pos[qok ? q : 0]);
     const float rden = 1.0f / a.denom[qok ? q : 0];          // +-1/NT, exact
@@ -756,22 +760,24 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
 
     // The finished item is stored one step late: after the next chunk's samples are in registers and the ring slot
     // is refilled (vmcnt counts stores too: a landing wait right behind the stores would drain them with the ring idle).
-    f32x2 h[NOWN * CH];                         // (re, im) of the owned antennas
+    f32x2 h[NCH * CHH];                         // (re, im) of the owned antennas: block ab, antenna ab CH + g CHH + j
     auto store_item = [&](size_t blk) {
         if (qok && !(a.dbg & 4)) {
-            float* pre = a.h_re + (blk * NT + own * CH) * LS_NDATA + q;
-            float* pim = a.h_im + (blk * NT + own * CH) * LS_NDATA + q;
+            float* pre = a.h_re + (blk * NT + g * CHH) * LS_NDATA + q;
+            float* pim = a.h_im + (blk * NT + g * CHH) * LS_NDATA + q;
 #pragma unroll
-            for (int j = 0; j < NOWN * CH; ++j) {
-                pre[j * LS_NDATA] = h[j][0] * rden;
-                pim[j * LS_NDATA] = h[j][1] * rden;
-            }
+            for (int ab = 0; ab < NCH; ++ab)
+#pragma unroll
+                for (int j = 0; j < CHH; ++j) {
+                    pre[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][0] * rden;
+                    pim[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][1] * rden;
+                }
         }
 #pragma unroll
-        for (int j = 0; j < NOWN * CH; ++j) h[j] = f32x2{0.f, 0.f};
+        for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
     };
 #pragma unroll
-    for (int j = 0; j < NOWN * CH; ++j) h[j] = f32x2{0.f, 0.f};
+    for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
 
     int t = 0;
     for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
@@ -790,19 +796,30 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_next();
             if (ch == 0 && t > 0) store_item(blk - gridDim.x);
-            if (t > 0) ls_lds_barrier();          // spectra of chunk t - 1 consumed by every thread
-            lsc_stage0_write<SPW, NW>(Fc, wave, lane, y0);
-            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, true>(Fc, wave, twc, lane);
+            // DBF: two spectra images alternate, so the image written now was last read two chunks ago - every wave
+            // finished that despread before it arrived at the previous "spectra complete" barrier
+            f32x2* Fb = Fc + (DBF ? (t & 1) * CH * LSC_ROW : 0);
+            if (!DBF && t > 0) ls_lds_barrier();  // spectra of chunk t - 1 consumed by every thread
+            lsc_stage0_write<SPW, NW>(Fb, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, true>(Fb, wave, twc, lane);
             ls_lds_barrier();                     // spectra complete
             // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
             if (!(a.dbg & 2)) {
-                f32x2 w[CH];
+                f32x2 w[CHH];
+                if (SPLIT == 2) {
+                    const float gs = g ? -1.f : 1.f;
+                    const f32x2 gs2 = {gs, gs};
 #pragma unroll
-                for (int r = 0; r < CH; ++r) w[r] = Fc[(size_t)r * LSC_ROW + pos];
+                    for (int r = 0; r < CHH; ++r)
+                        w[r] = __builtin_elementwise_fma(gs2, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
+                } else {
 #pragma unroll
-                for (int hh = 1; hh < CH; hh <<= 1)
+                    for (int r = 0; r < CHH; ++r) w[r] = Fb[(size_t)r * LSC_ROW + pos];
+                }
 #pragma unroll
-                    for (int i = 0; i < CH; ++i)
+                for (int hh = 1; hh < CHH; hh <<= 1)
+#pragma unroll
+                    for (int i = 0; i < CHH; ++i)
                         if (!(i & hh)) {
                             const f32x2 x = w[i], y = w[i + hh];
                             w[i] = x + y;
@@ -810,11 +827,11 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
                         }
                 // cross-chunk stages: output block ab takes +-w by the sign of H_{NT/CH}[ab][ch]
 #pragma unroll
-                for (int ab = 0; ab < NOWN; ++ab) {
-                    const float sg = (__builtin_popcount((own + ab) & ch) & 1) ? -1.f : 1.f;
+                for (int ab = 0; ab < NCH; ++ab) {
+                    const float sg = (__builtin_popcount(ab & ch) & 1) ? -1.f : 1.f;
                     const f32x2 sgn = {sg, sg};
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) h[ab * CH + j] = __builtin_elementwise_fma(sgn, w[j], h[ab * CH + j]);
+                    for (int j = 0; j < CHH; ++j) h[ab * CHH + j] = __builtin_elementwise_fma(sgn, w[j], h[ab * CHH + j]);
                 }
             }
         }
