@@ -72,7 +72,7 @@ int launch_pair_bf16(csi_ctx* c, int kid, GemmBf16Args g, const PairSrc& ps) {
     ProfScope psc(c, kid, flops, bytes);
     g.tiles_n = (g.N + PP_BN - 1) / PP_BN;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
-    const size_t lds = (size_t)(PPP_RING_FLOATS + 2 * g.K) * sizeof(float);
+    const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
     auto kern = gemm_bf16_pp_pair_kernel<EPI, OUT_BF16>;
     static thread_local size_t attr_set = 0;       // per instantiation
     if (attr_set < lds) {
@@ -98,7 +98,7 @@ int launch_layer0_cast_bf16(csi_ctx* c, GemmBf16Args g, const float* x, int ldx,
         HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
+    PairSrc src{x, nullptr, ldx, 1};
     hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
@@ -203,7 +203,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, c->stream, l0, l0sum, n4, S);
                 HIP_TRY(c, hipGetLastError());
             }
-            PairSrc src{l0sum, m.T, m.layers[0].scale, m.layers[0].shift, h1, nt};
+            PairSrc src{l0sum, m.T, h1, nt};
             rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
         } else {
             {

@@ -114,7 +114,7 @@ int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1
     const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
     int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[0]);
     if (rc) return rc;
-    PairSrc src{x, nullptr, nullptr, nullptr, ldx, 1};
+    PairSrc src{x, nullptr, ldx, 1};
     const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
     hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
                        std::ldexp(1.f, in_shift), PairRegArgs{});
@@ -186,7 +186,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         HIP_TRY(c, hipGetLastError());
         m.T_hs_shift = s0;
     }
-    PairSrc src{l0sum, m.T_hs, nullptr, nullptr, h1, cf.nt};
+    PairSrc src{l0sum, m.T_hs, h1, cf.nt};
     GemmHsArgs p{};
     p.Bt = l1.Wh; p.ldb = l1.ldwh;
     p.M = M2; p.N = l1.out; p.K = h1;

@@ -365,8 +365,16 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
         if (bf16) {
             L.ldwb = (fan_in + B_BK - 1) / B_BK * B_BK;
             std::vector<uint16_t> wb((size_t)out * L.ldwb, 0);
+            // bf16 mode: the BatchNormalization of the previous layer lives in THIS layer's operands,
+            //     (relu(z) sc + sh) W + b  =  relu(z) (diag(sc) W) + (b + sh W),
+            // scaled rows rounded once, the shift product kept in fp32 in the bias below - so every hidden activation is
+            // bf16(relu(z)) and the kernels that build or read it carry no per-column affine (the fused first per-pair
+            // layer generated its A operand slower than the matrix cores consumed it)
             for (int o = 0; o < out; ++o)
-                for (int i = 0; i < fan_in; ++i) wb[(size_t)o * L.ldwb + i] = rne(wt[(size_t)o * L.ldw + i]);
+                for (int i = 0; i < fan_in; ++i) {
+                    const float w = wt[(size_t)o * L.ldw + i];
+                    wb[(size_t)o * L.ldwb + i] = rne(prev_scale.empty() ? w : (float)((double)w * (double)prev_scale[i]));
+                }
             const size_t bytes = wb.size() * 2 + 256;
             if (hipMalloc((void**)&L.Wb, bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
             HIP_TRY(c, hipMemset(L.Wb, 0, bytes));
@@ -434,7 +442,17 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 HIP_TRY(c, hipMemcpy(L.Wh_f, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
             }
         }
-        rc = upload(c, &L.bias, b->data, out);
+        if (bf16 && li >= 1 && !prev_shift.empty()) {
+            std::vector<float> bf(out);
+            for (int o = 0; o < out; ++o) {
+                double acc = b->data[o];
+                for (int i = 0; i < fan_in; ++i) acc += (double)prev_shift[i] * (double)k->data[(size_t)i * out + o];
+                bf[o] = (float)acc;
+            }
+            rc = upload(c, &L.bias, bf.data(), out);
+        } else {
+            rc = upload(c, &L.bias, b->data, out);
+        }
         if (rc) return rc;
         if (!bf16 && li >= 1) {
             // split engine: the previous layer's BatchNormalization shift moves into this layer's bias,
@@ -490,9 +508,11 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             L.ashift_pre = shift_for(amax_pre, L.ashift_pre);
         }
         if (!reg) {
-            rc = upload(c, &L.scale, sc.data(), out);
+            // bf16 mode: identity here, the real vectors went into the next layer (above)
+            const std::vector<float> one(out, 1.f), zero(out, 0.f);
+            rc = upload(c, &L.scale, bf16 ? one.data() : sc.data(), out);
             if (rc) return rc;
-            rc = upload(c, &L.shift, sh.data(), out);
+            rc = upload(c, &L.shift, bf16 ? zero.data() : sh.data(), out);
             if (rc) return rc;
         }
         if (li == 0 && cf.nt > 0) {

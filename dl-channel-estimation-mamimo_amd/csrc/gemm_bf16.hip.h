@@ -494,7 +494,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmB
 
 // ---------------------------------------------------------------------------------------------
 // Ping-pong kernel of the FIRST per-pair layer with the A operand generated in the kernel:
-//     A[(pr,t)][k] = bf16( bn0( relu( L0[pr][k] + T[t][k] ) ) )        (fp32 in, rounded once)
+//     A[(pr,t)][k] = bf16( relu( L0[pr][k] + T[t][k] ) )        (fp32 in, rounded once; bn0 sits in the weights)
 // so h1 never exists in HBM (pair_h1_bf16_kernel wrote 2.6 GB per launch at config 3 and this
 // kernel read it back).  Same phase structure as gemm_bf16_pp_kernel; differences:
 //   * every wave owns two A pieces and two B pieces of a sub-tile.  B pieces are LDS-DMA'd 3
@@ -505,17 +505,39 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_kernel(const GemmB
 //   * one vmcnt per sub-tile: vmcnt(1) in front of the generation (the loads it needs are older
 //     than the single DMA issued behind them).  Memory operations retire in order, so that wait
 //     also retires every older B piece - which is what the hand-over of B sub-tile u+1 needs.
-//   * bn0 scale / shift live in LDS (8 * K bytes behind the ring).
 // RAW: the A image of sub-tile u+2 is written (lgkmcnt(0), barrier) in load segment (u,1) and first
 // read in MFMA segment (u+1,1) - four barriers later for either group.  WAR: its slot last held
 // sub-tile u-2, whose final reads were retired two sub-tiles ago.
+// Vector-memory operations of the fused kernel are inline asm, counted by hand.  hipcc puts an s_waitcnt vmcnt in front
+// of every ds_write (and every asm statement) that follows a BUILTIN LDS-DMA still in flight - it cannot prove the two
+// do not alias - which made every phase wait for the B piece issued one phase earlier: the three-sub-tile prefetch
+// distance did not exist and a phase lasted one L2 round trip (0.65 us against 0.15 us of MFMA work).  With the DMA
+// hidden from the compiler its own count for the A-side loads would be short by the hidden pieces (an s_waitcnt is a
+// threshold on ONE counter), so those loads are asm as well and every use is preceded by a counted wait that names the
+// registers it releases ("+v": the compiler cannot move the use in front of it).
+__device__ __forceinline__ f32x4 pp_gload16(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+    return v;
+}
+__device__ __forceinline__ void pp_gdma16(const void* g_lane_src, uint32_t lds_byte_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_lane_src), "s"(lds_byte_off) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pp_wait_vm_dep(f32x4& a, f32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void pp_wait_vm_dep(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+__device__ __forceinline__ void pp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 constexpr int PPP_RING_FLOATS = 4 * PP_SUBF;           // LDS ring of the fused kernel (4 sub-tiles)
 
 struct PairSrc {
     const float* L0;       // [M / nt][ldl] fp32 (single slab)
     const float* T;        // [nt][ldl] fp32 pilot table incl. bias
-    const float* s0;       // [K] bn0 scale (1 without BN)
-    const float* t0;       // [K] bn0 shift
     int ldl, nt;
 };
 
@@ -525,9 +547,7 @@ struct PairSrc {
 template <int EPI, bool OUT_BF16, bool CAST = false>
 __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const GemmBf16Args g, const PairSrc ps) {
     constexpr int NSUB = 4, D = 3;
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring + 2 * K floats (s0 | t0)
-    float* sv_l = lds + NSUB * PP_SUBF;
-    float* hv_l = sv_l + g.K;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -547,15 +567,9 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     const int kend = CAST ? min(g.K, kbeg + g.k_per_split) : g.K;
     const int nsub = (kend - kbeg + PP_BK - 1) / PP_BK;
 
-    if (!CAST)
-        for (int i = tid; i < g.K; i += PP_THREADS) {
-            sv_l[i] = ps.s0[i];
-            hv_l[i] = ps.t0[i];
-        }
-
     // ---- B side: pieces 2w, 2w+1 of the 16 B pieces of a sub-tile
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.Bt + (size_t)n0 * g.ldb + kbeg), 0, 0x7fffffff, 0x00020000);
-    int voff[2];
+    const bf16_t* bsrc[2];                              // this lane's 16 bytes of B piece u, sub-tile 0
+    const uint32_t lds_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds);
     // ---- A side: pieces 2w, 2w+1 of the 16 A pieces; this lane's row and 8-column group
     const float* lrow[2];
     const float* trow[2];
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int row = 16 * (2 * wave + u) + (lane >> 2);
-        voff[u] = (min(row, g.N - 1 - n0) * g.ldb + clog * 8) * 2;
+        bsrc[u] = g.Bt + (size_t)(n0 + min(row, g.N - 1 - n0)) * g.ldb + kbeg + clog * 8;
         const int m = min(m0 + row, g.M - 1);
         if (CAST) {
             lrow[u] = ps.L0 + (size_t)m * ps.ldl + kbeg + clog * 8;
@@ -575,16 +589,20 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
         }
     }
     auto issue_b = [&](int sub, int slot, int u) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
-                                                 16, voff[u], sub * (PP_BK * 2), 0, 0);
+        pp_gdma16(bsrc[u] + sub * PP_BK, lds_off + (uint32_t)(slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256) * 4u);
     };
     f32x4 lv[2][2], tv[2][2];
     auto load_a = [&](int sub, int u) {                 // L0 / T values of A piece u of sub-tile sub
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            lv[u][h] = *reinterpret_cast<const f32x4*>(lrow[u] + sub * PP_BK + 4 * h);
-            if (!CAST) tv[u][h] = *reinterpret_cast<const f32x4*>(trow[u] + sub * PP_BK + 4 * h);
+            lv[u][h] = pp_gload16(lrow[u] + sub * PP_BK + 4 * h);
+            if (!CAST) tv[u][h] = pp_gload16(trow[u] + sub * PP_BK + 4 * h);
         }
+    };
+    auto wait_a = [&](int u, auto n_tag) {              // at most N younger operations stay in flight; releases piece u's values
+        constexpr int N = decltype(n_tag)::value;
+        if (CAST) pp_wait_vm_dep<N>(lv[u][0], lv[u][1]);
+        else pp_wait_vm_dep<N>(lv[u][0], lv[u][1], tv[u][0], tv[u][1]);
     };
     auto gen_a = [&](int sub, int slot, int u) {        // -> 16 B of bf16 per lane, lane-linear in the A image
         if (CAST) {
@@ -596,19 +614,13 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
             *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + (2 * wave + u) * 256 + lane * 4) = o;
             return;
         }
-        const int k = sub * PP_BK + clog * 8;
-        const f32x4 s_lo = *reinterpret_cast<const f32x4*>(sv_l + k), s_hi = *reinterpret_cast<const f32x4*>(sv_l + k + 4);
-        const f32x4 h_lo = *reinterpret_cast<const f32x4*>(hv_l + k), h_hi = *reinterpret_cast<const f32x4*>(hv_l + k + 4);
+        // bn0 is folded into the next layer's weights at load time (csi_load_weights): A = bf16(relu(L0 + T))
+        const f32x4 a0 = lv[u][0] + tv[u][0], a1 = lv[u][1] + tv[u][1];
         uint4 o;
-        f32x2 v;
-        v = f32x2{fmaf(fmaxf(lv[u][0][0] + tv[u][0][0], 0.f), s_lo[0], h_lo[0]), fmaf(fmaxf(lv[u][0][1] + tv[u][0][1], 0.f), s_lo[1], h_lo[1])};
-        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        v = f32x2{fmaf(fmaxf(lv[u][0][2] + tv[u][0][2], 0.f), s_lo[2], h_lo[2]), fmaf(fmaxf(lv[u][0][3] + tv[u][0][3], 0.f), s_lo[3], h_lo[3])};
-        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        v = f32x2{fmaf(fmaxf(lv[u][1][0] + tv[u][1][0], 0.f), s_hi[0], h_hi[0]), fmaf(fmaxf(lv[u][1][1] + tv[u][1][1], 0.f), s_hi[1], h_hi[1])};
-        o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        v = f32x2{fmaf(fmaxf(lv[u][1][2] + tv[u][1][2], 0.f), s_hi[2], h_hi[2]), fmaf(fmaxf(lv[u][1][3] + tv[u][1][3], 0.f), s_hi[3], h_hi[3])};
-        o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{fmaxf(a0[0], 0.f), fmaxf(a0[1], 0.f)}), bf16x2));
+        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{fmaxf(a0[2], 0.f), fmaxf(a0[3], 0.f)}), bf16x2));
+        o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f)}), bf16x2));
+        o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{fmaxf(a1[2], 0.f), fmaxf(a1[3], 0.f)}), bf16x2));
         *reinterpret_cast<uint4*>(lds + slot * PP_SUBF + (2 * wave + u) * 256 + lane * 4) = o;
     };
 
@@ -661,16 +673,17 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     };
 
     // ---- prologue: B sub-tiles 0..2 in flight, A sub-tiles 0 and 1 generated synchronously
-    __syncthreads();                    // s0 / t0 staged
     const int npro = min(nsub, D);
     for (int t = 0; t < npro; ++t) { issue_b(t, t, 0); issue_b(t, t, 1); }
     for (int t = 0; t < min(nsub, 2); ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             load_a(t, p);
-            gen_a(t, t, p);             // the compiler waits for the loads it just issued
+            wait_a(p, std::integral_constant<int, 0>{});
+            gen_a(t, t, p);
         }
-    pp_wait_vm_lgkm<0>();
+    pp_wait_vm0();
+    pp_wait_lgkm();
     if (nsub > 2) { load_a(2, 0); load_a(2, 1); }      // consumed in the two load segments of sub-tile 0
     pp_barrier();
     read_frags(0, 0, fa[0], fb[0]);
@@ -691,11 +704,17 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (has_a) {
-                if (STEADY) pp_wait_vm_lgkm<(CAST ? 4 : 6)>(); else pp_wait_vm_lgkm<0>();
+                // operations younger than this piece's loads: one DMA + the other piece's loads + one DMA (4 loads per
+                // piece, 2 when CAST); in the first sub-tile only what the prologue and phase 0 issued behind them
+                if (!STEADY) wait_a(p, std::integral_constant<int, 0>{});
+                else if (u == 0) wait_a(p, std::integral_constant<int, (CAST ? 2 : 4)>{});
+                else wait_a(p, std::integral_constant<int, (CAST ? 4 : 6)>{});
+                pp_wait_lgkm();
                 gen_a(u + 2, (slot + 2) & 3, p);
                 if (nxt_a) load_a(u + 3, p);
             } else if (p == 1) {
-                pp_wait_vm_lgkm<0>();   // tail: every outstanding B piece has landed
+                pp_wait_vm0();          // tail: every outstanding B piece has landed
+                pp_wait_lgkm();
             }
             if (has_b) issue_b(u + D, (slot + D) & 3, p);
             pp_wait_lgkm();             // the A image is written before the barrier publishes it

@@ -234,7 +234,8 @@ def predict_packets(ltf, P, w_real, w_imag, dtype=np.float64, pkt_batch=None):
 # bf16-operand emulation (BASELINE.json config 3).  Not a reference behaviour: the reference
 # runs fp32.  It defines what the CSI_DTYPE_BF16 kernels are expected to compute - operands
 # (inputs, weights, hidden activations) rounded to bfloat16 round-to-nearest-even, exact
-# products, wide accumulation, fp32 bias / relu / BN epilogue - so that their error against the
+# products, wide accumulation, fp32 bias / relu epilogue, BatchNormalization folded into the next layer's
+# operands before they are rounded - so that their error against the
 # fp64 oracle can be split into 'format' and 'implementation' parts.
 # ---------------------------------------------------------------------------
 def bf16_round(x):
@@ -245,19 +246,33 @@ def bf16_round(x):
 
 
 def fc_forward_bf16(x, w):
-    """Literal network with bf16 operands.  x [B, lenLTF+Nt] float."""
+    """Literal network with bf16 operands.  x [B, lenLTF+Nt] float.
+
+    The BatchNormalization behind a hidden layer is carried by the NEXT layer's operands, as csi_load_weights does
+    in bf16 mode:  (relu(z) sc + sh) W + b = relu(z) (diag(sc) W) + (b + sh W)  - the scaled kernel rows are rounded
+    to bf16 once, the shift product stays wide - so every hidden activation is bf16(relu(z))."""
     eps = float(w.get('bn_eps', BN_EPS))
     h = bf16_round(x).astype(np.float64)
+    sc = sh = None
     i = 0
-    while f'fc_dense{i}.kernel' in w:
-        z = h @ bf16_round(w[f'fc_dense{i}.kernel']).astype(np.float64) + w[f'fc_dense{i}.bias'].astype(np.float64)
+    while True:
+        name = f'fc_dense{i}' if f'fc_dense{i}.kernel' in w else 'fc_regressor'
+        k = w[name + '.kernel'].astype(np.float64)
+        b = w[name + '.bias'].astype(np.float64)
+        if sc is not None:
+            b = b + sh @ k
+            k = k * sc[:, None]
+        z = h @ bf16_round(k.astype(np.float32)).astype(np.float64) + b.astype(np.float32).astype(np.float64)
+        if name == 'fc_regressor':
+            return z.astype(np.float32)
         z = np.maximum(z.astype(np.float32), np.float32(0))
+        sc = sh = None
         if f'bn{i}.gamma' in w:
-            z = bn_inference(z, w[f'bn{i}.gamma'].astype(np.float32), w[f'bn{i}.beta'].astype(np.float32),
-                             w[f'bn{i}.moving_mean'].astype(np.float32), w[f'bn{i}.moving_variance'].astype(np.float32), eps)
+            inv = (np.float32(1) / np.sqrt(w[f'bn{i}.moving_variance'].astype(np.float32) + np.float32(eps))) * w[f'bn{i}.gamma'].astype(np.float32)
+            sc = inv.astype(np.float64)
+            sh = (w[f'bn{i}.beta'].astype(np.float32) - w[f'bn{i}.moving_mean'].astype(np.float32) * inv).astype(np.float64)
         h = bf16_round(z).astype(np.float64)
         i += 1
-    return (h @ bf16_round(w['fc_regressor.kernel']).astype(np.float64) + w['fc_regressor.bias'].astype(np.float64)).astype(np.float32)
 
 
 def predict_packets_bf16(ltf, P, w_real, w_imag):
