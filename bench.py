@@ -98,6 +98,7 @@ def main():
     ap.add_argument('--engine', default='auto', choices=['auto', 'native', 'split'],
                     help='fp32 contexts: auto = split-f16 engine for GEMMs that fill the chip (library default), '
                          'native = fp32 MFMA kernels only, split = split engine wherever the shapes allow')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE', help='csi_set_option before the timed region (A/B runs), repeatable')
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
     ap.add_argument('--host-path', type=int, default=4000,
                     help='also time the host-buffer (PCIe-inclusive) entry points on this many packets (0 = skip; rank 0, N = 1)')
@@ -168,6 +169,9 @@ def main():
 
     if args.dtype == 'f32':
         eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
+    for kv in args.option:
+        name, value = kv.split('=')
+        eng.set_option(name, int(value))
 
     def step():
         if args.graph:
