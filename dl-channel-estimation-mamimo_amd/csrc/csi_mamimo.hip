@@ -45,9 +45,9 @@ LsPlan ls_plan(const csi_ctx* c) {
         int split = 1, ch = 16, nstg = 1, nf = 1;
 #define LS_V2(NTV, SP, CHV, NS, DB) { p.fn = (const void*)ls_estimate_fwht2_kernel<NTV, SP, CHV, NS, DB>; split = SP; ch = CHV; nstg = NS; nf = DB ? 2 : 1; }
         if (nt == 16) { if (v == 1) LS_V2(16, 1, 8, 3, false) else LS_V2(16, 1, 16, 1, false) }
-        else if (nt == 32) { if (v == 1) LS_V2(32, 1, 8, 3, false) else if (v == 2) LS_V2(32, 1, 8, 2, true) else LS_V2(32, 1, 16, 1, false) }
-        else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1, false) else if (v == 2) LS_V2(64, 1, 8, 2, true) else LS_V2(64, 1, 8, 3, false) }
-        else { if (v == 1) LS_V2(128, 2, 8, 4, false) else if (v == 2) LS_V2(128, 2, 16, 3, false) else LS_V2(128, 2, 16, 2, true) }
+        else if (nt == 32) { if (v == 1) LS_V2(32, 1, 8, 3, false) else LS_V2(32, 1, 16, 1, false) }
+        else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1, false) else LS_V2(64, 1, 8, 3, false) }
+        else { if (v == 1) LS_V2(128, 2, 16, 3, false) else LS_V2(128, 2, 16, 2, true) }      // two spectra images: -6 %
 #undef LS_V2
         p.lds = (size_t)(2 * LSC_NTW + nf * ch * 2 * LSC_ROW + nstg * ch * 2 * LS_FFT) * sizeof(float);
         p.threads = 256 * split;
