@@ -162,14 +162,14 @@ int main(int argc, char** argv) {
     dim3 gridr(pp_grid(tiles_m, 1));
     GemmHsArgs gp = gh;                                   // pair kernel: A generated from L0 / T
     gp.Bt = Wfh; gp.ldb = ldbf; gp.acc_scale = std::ldexp(1.f, -(sa + swf));
-    PairSrc ps{L0, Ts, nullptr, nullptr, K, nt};
+    PairSrc ps{L0, Ts, K, nt};
     const size_t lds_pair = (size_t)PPP_RING_FLOATS * 4;
     auto kpair = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false>;
     auto kcast = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
     CK(hipFuncSetAttribute((const void*)kpair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
     CK(hipFuncSetAttribute((const void*)kcast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PPP_RING_FLOATS * 4)));
     GemmHsArgs gc = g; gc.C = C; gc.ldc = N;              // CAST: A = fp32 rows, raw output
-    PairSrc pc{A, nullptr, nullptr, nullptr, K, 1};
+    PairSrc pc{A, nullptr, K, 1};
 
     // ---- fused pair + regressor (hs_fused_regressor): W2 rows scaled by the pair layer's BN scale, its shift in the bias
     std::vector<float> hW2f(hW2.size()), hb2f(NO);
