@@ -552,3 +552,17 @@ def test_fit_callback_schedules_follow_keras_defaults(pkg):
     eng = _FakeTrainEngine([1.0] * 40)
     h = pkg.trainer.fit(eng, 'real', gen, gen, epochs=40, lr=1e-3, method='default', es_patience=100, rlr_patience=2, verbose=False)
     assert [round(l, 9) for _, l in eng.lr_calls] == [1e-4, 1e-5]
+
+
+@pytest.mark.parametrize('src', ['hs_probe.hip', 'gemm_probe.hip'])
+def test_probe_tools_still_compile(src, tmp_path):
+    """tools/*.hip include the product's kernel headers directly; a changed kernel argument struct must not leave
+    them behind (they produce the ablation evidence under profiles/).  Device code only, syntax + codegen."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-Wno-unused-value', '--cuda-device-only', '-c',
+                          os.path.join(root, 'tools', src), '-o', str(tmp_path / 'probe.o')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
