@@ -17,8 +17,8 @@
 
 namespace {
 
-// Which LS kernel serves this context.  With the Sylvester Hadamard pilot matrix the Walsh-Hadamard kernels
-// (LDS-DMA ring from Nt = 32).  Any other P: FFT-first (all Nt spectra in LDS) up to ls_fft_first_max antennas, the
+// Which LS kernel serves this context.  With the Sylvester Hadamard pilot matrix the Walsh-Hadamard kernel on the
+// LDS-DMA ring.  Any other P: FFT-first (all Nt spectra in LDS) up to ls_fft_first_max antennas, the
 // ring kernel with the matrix-core despread up to Nt = 128, the despread-first kernel beyond.  The older chunked
 // kernel stays selectable through the "ls_kernel" option (tests, A/B runs).
 enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5, LS_RING = 6 };
@@ -34,7 +34,7 @@ LsPlan ls_plan(const csi_ctx* c) {
     int mode = c->ls_kernel;
     const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
     if ((mode == LS_FWHT || mode == LS_FWHT2) && !fwht_ok) mode = LS_AUTO;
-    if (mode == LS_AUTO) mode = fwht_ok ? (nt >= 32 ? LS_FWHT2 : LS_FWHT) : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_RING : LS_DESPREAD_FIRST));
+    if (mode == LS_AUTO) mode = fwht_ok ? LS_FWHT2 : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_RING : LS_DESPREAD_FIRST));
     if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
     if ((mode == LS_CHUNKED || mode == LS_RING) && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
     LsPlan p{};
@@ -42,32 +42,40 @@ LsPlan ls_plan(const csi_ctx* c) {
     if (mode == LS_FWHT2) {
         // shape per Nt as measured (profiles/r02_ls_probe.txt); "ls_v2" = 1 selects the runner-up for A/B runs
         const int v = c->ls_v2;
-        int split = 1, ch = 16, nstg = 1, nf = 1;
+        int split = 1, ch = 16, nstg = 1, nf = 1, maxcu = 2;
 #define LS_V2(NTV, SP, CHV, NS, DB) { p.fn = (const void*)ls_estimate_fwht2_kernel<NTV, SP, CHV, NS, DB>; split = SP; ch = CHV; nstg = NS; nf = DB ? 2 : 1; }
-        if (nt == 16) { if (v == 1) LS_V2(16, 1, 8, 3, false) else LS_V2(16, 1, 16, 1, false) }
-        else if (nt == 32) { if (v == 1) LS_V2(32, 1, 8, 3, false) else LS_V2(32, 1, 16, 1, false) }
+        if (nt == 16) {
+            if (v == 1) LS_V2(16, 1, 16, 1, false)
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+        }
+        else if (nt == 32) {       // 8-symbol chunks, one slot: 38 KiB of LDS and 122 VGPRs - four workgroups per CU (0.379 ms; two with 16-symbol chunks: 0.402)
+            if (v == 1) LS_V2(32, 1, 16, 1, false)
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+        }
         else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1, false) else LS_V2(64, 1, 8, 3, false) }
         else { if (v == 1) LS_V2(128, 2, 16, 3, false) else LS_V2(128, 2, 16, 2, true) }      // two spectra images: -6 %
 #undef LS_V2
         p.lds = (size_t)(2 * LSC_NTW + nf * ch * 2 * LSC_ROW + nstg * ch * 2 * LS_FFT) * sizeof(float);
         p.threads = 256 * split;
-        p.per_cu = std::max(1, std::min(split == 1 ? 2 : 1, (int)((160 * 1024) / p.lds)));
+        p.per_cu = std::max(1, std::min(split == 1 ? maxcu : 1, (int)((160 * 1024) / p.lds)));
     } else if (mode == LS_RING) {
         const int jt = (nt + 31) / 32, ldp = jt * 32;
-        int nw = 4, nstg = 1, chs = 16;
+        int nw = 4, nstg = 1, chs = 16, ringcu = 2;
 #define LS_RING_K(J, W, C, NS) { p.fn = (const void*)ls_estimate_ring_kernel<J, W, C, NS>; nw = W; nstg = NS; chs = C; }
         // 8-symbol chunks where they waste fewer padded symbols (Nt = 24, 40, ...) and for two antenna tiles, where they let
         // two workgroups share a CU (measured: profiles/r02_ls_probe.txt); "ls_v2" = 1 flips the choice for A/B runs
         bool ch8 = jt == 2 || (jt == 1 && (nt + 7) / 8 * 8 < (nt + 15) / 16 * 16);
         if (c->ls_v2 == 1) ch8 = !ch8;
-        if (jt == 1) { if (ch8) LS_RING_K(1, 4, 8, 3) else LS_RING_K(1, 4, 16, 1) }
+        // one antenna tile: 8-symbol chunks and one slot leave room for three workgroups per CU (Nt = 32: 0.438 against 0.470 ms)
+        if (jt == 1 && c->ls_v2 == 0) { p.fn = (const void*)ls_estimate_ring_kernel<1, 4, 8, 1, 3>; nw = 4; nstg = 1; chs = 8; ringcu = 3; }
+        else if (jt == 1) { if (c->ls_v2 == 2) LS_RING_K(1, 4, 8, 3) else LS_RING_K(1, 4, 16, 1) }
         else if (jt == 2) { if (ch8) LS_RING_K(2, 4, 8, 2) else LS_RING_K(2, 8, 16, 3) }
         else if (jt == 3) LS_RING_K(3, 8, 16, 2)
         else LS_RING_K(4, 8, 16, 1)
 #undef LS_RING_K
         p.lds = (size_t)(2 * LSC_NTW + chs * 2 * LSC_ROW + nstg * chs * 2 * LS_FFT + 32 * jt * (ldp + 1)) * sizeof(float);
         p.threads = 64 * nw;
-        p.per_cu = std::max(1, std::min(nw == 4 ? 2 : 1, (int)((160 * 1024) / p.lds)));
+        p.per_cu = std::max(1, std::min(nw == 4 ? ringcu : 1, (int)((160 * 1024) / p.lds)));
     } else if (mode == LS_FWHT) {
         p.fn = nt == 16 ? (const void*)ls_estimate_fwht_kernel<16> : nt == 32 ? (const void*)ls_estimate_fwht_kernel<32>
                : nt == 64 ? (const void*)ls_estimate_fwht_kernel<64> : (const void*)ls_estimate_fwht_kernel<128, 2>;

@@ -710,8 +710,8 @@ __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* t
     }
 }
 
-template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false>
-__global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1)>
+__global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
     static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
     static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
     static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning one half of every output block)");
@@ -845,8 +845,8 @@ __global__ __launch_bounds__(256 * SPLIT, (SPLIT == 1 ? 2 : 1)) void ls_estimate
 // ls_estimate_chunked_kernel behind it (D[j][q] += sum_{s in chunk} P[j][s] F[s][f(q)] on v_mfma_f32_32x32x2_f32,
 // accumulators persist over the chunks).  Any real P, any Nt from 16 to 32 JT: symbols beyond Nt in the last chunk
 // are fetched clamped (a valid symbol again) and meet the zero columns of the padded P (kept in LDS).
-template <int JT, int NW, int CH, int NSTG>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void ls_estimate_ring_kernel(const LsArgs a, int nblk) {
+template <int JT, int NW, int CH, int NSTG, int MINB = (NW == 4 ? 2 : 1)>
+__global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ring_kernel(const LsArgs a, int nblk) {
     constexpr int SPW = CH / NW, QW = 8 / NW, R = 2 * SPW;
     static_assert(SPW >= 1 && QW >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
