@@ -245,7 +245,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "ls_kernel"        0: automatic, 1: FFT-first (all Nt spectra in LDS, Nt <= 64), 2: chunked
  *                         FFT-first (16 <= Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
  *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix), 5: the same
- *                         fed by an LDS-DMA ring (chosen automatically for that P from Nt = 32), 6: generic P on
+ *                         fed by an LDS-DMA ring (chosen automatically for that P), 6: generic P on
  *                         the LDS-DMA ring (chosen automatically for any other P, 16 <= Nt <= 128); a choice the
  *                         kernel cannot serve falls back
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs */
