@@ -145,7 +145,7 @@ struct csi_ctx {
     int hs_act_shift = HS_SHIFT_AUTO;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
     float* hs_zero = nullptr;    // zeros, widest hidden layer: the BN shift the split-engine kernels see (it lives in the next layer's bias)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
-    size_t hs_lds_attr[4] = {0, 0, 0, 0};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out) / pair + fused regressor
+    size_t hs_lds_attr[14] = {};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out) / pair + fused regressor
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
@@ -162,6 +162,7 @@ struct csi_ctx {
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
     int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first, 4 / 5 Walsh-Hadamard (register prefetch / LDS-DMA ring), 6 generic P on the ring (tests, A/B runs)
+    int hs_vm_cast = 2, hs_vm_pair = 3;   // "hs_vm_cast" / "hs_vm_pair": vector-memory schedule of the layer-0 / pair kernel (gemm_hs.hip.h): 0 builtin LDS-DMA + one drain per sub-tile, 1 hand-counted, 2 + one more sub-tile of look-ahead, 3 + one load and one 24-MFMA segment per sub-tile
     int ls_v2 = 0;               // CSI_LS_V2: shape variant of the LDS-DMA fed Walsh-Hadamard kernel (experiments)
     int ls_fft_first_max = 15;   // FFT-first LS kernel (all Nt spectra in LDS) up to this Nt; from 16 on the ring kernel is faster (Nt = 16: 0.47 vs 0.72 ms); debug knob CSI_LS_FFT_FIRST_MAX
     int force_pair_tile = 0;     // debug knob CSI_FORCE_PAIR_TILE=128|256: forces the row-tile height of every GEMM (tests)

@@ -110,16 +110,31 @@ int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1
     const double flops = 2.0 * (double)M1 * h1 * K;
     const double bytes = 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits);
     ProfScope ps(c, K_LAYER0_LTF, flops, bytes);
-    auto kern = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
     const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
-    int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[0]);
-    if (rc) return rc;
     PairSrc src{x, nullptr, ldx, 1};
     const int tiles_m = (M1 + PP_BM - 1) / PP_BM;
-    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
-                       std::ldexp(1.f, in_shift), PairRegArgs{});
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
+    auto go = [&](auto kern, size_t* attr) {
+        int rc = hs_dynamic_lds(c, kern, lds, attr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds, c->stream, g, src,
+                           std::ldexp(1.f, in_shift), PairRegArgs{});
+        HIP_TRY(c, hipGetLastError());
+        return (int)CSI_OK;
+    };
+    // "hs_vm": hand-counted vector-memory operations (gemm_hs.hip.h) - 2 = with the extra sub-tile of look-ahead for the fp32 rows
+    if (c->hs_vm_cast == 3) {
+        const size_t lds5 = (size_t)5 * PP_SUBF * sizeof(float);
+        auto kern = gemm_hs_pp_pair_kernel<EPI_RAW, false, true, 0, false, 3>;
+        int rc = hs_dynamic_lds(c, kern, lds5, &c->hs_lds_attr[11]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n), 1, (unsigned)splits), dim3(PP_THREADS), lds5, c->stream, g, src,
+                           std::ldexp(1.f, in_shift), PairRegArgs{});
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
+    }
+    if (c->hs_vm_cast == 2) return go(gemm_hs_pp_pair_kernel<EPI_RAW, false, true, 0, false, 2>, &c->hs_lds_attr[5]);
+    if (c->hs_vm_cast == 1) return go(gemm_hs_pp_pair_kernel<EPI_RAW, false, true, 0, false, 1>, &c->hs_lds_attr[6]);
+    return go(gemm_hs_pp_pair_kernel<EPI_RAW, false, true>, &c->hs_lds_attr[0]);
 }
 
 // first per-pair layer: A generated from (L0, T, bn0); hs output (a hidden layer follows) or fp32
@@ -139,14 +154,27 @@ int hs_launch_pair(csi_ctx* c, int kid, GemmHsArgs g, const PairSrc& src, int in
     const double flops = 2.0 * (double)g.M * g.N * g.K;
     const double bytes = 4.0 * ((double)g.M / src.nt * g.K + (double)src.nt * g.K + (double)g.N * g.K + (double)g.M * g.N);
     ProfScope ps(c, kid, flops, bytes);
-    auto kern = gemm_hs_pp_pair_kernel<EPI, OUT_HS, false>;
     const size_t lds = (size_t)PPP_RING_FLOATS * sizeof(float);
-    int rc = hs_dynamic_lds(c, kern, lds, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
-    if (rc) return rc;
     const int tiles_m = (g.M + PP_BM - 1) / PP_BM;
-    hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, in_shift), PairRegArgs{});
-    HIP_TRY(c, hipGetLastError());
-    return CSI_OK;
+    auto go = [&](auto kern, size_t* attr) {
+        int rc = hs_dynamic_lds(c, kern, lds, attr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds, c->stream, g, src, std::ldexp(1.f, in_shift), PairRegArgs{});
+        HIP_TRY(c, hipGetLastError());
+        return (int)CSI_OK;
+    };
+    if (c->hs_vm_pair == 3) {
+        const size_t lds5 = (size_t)5 * PP_SUBF * sizeof(float);
+        auto kern = gemm_hs_pp_pair_kernel<EPI, OUT_HS, false, 0, false, 3>;
+        int rc = hs_dynamic_lds(c, kern, lds5, &c->hs_lds_attr[OUT_HS ? 12 : 13]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp_grid(tiles_m, g.tiles_n)), dim3(PP_THREADS), lds5, c->stream, g, src, std::ldexp(1.f, in_shift), PairRegArgs{});
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
+    }
+    if (c->hs_vm_pair == 2) return go(gemm_hs_pp_pair_kernel<EPI, OUT_HS, false, 0, false, 2>, &c->hs_lds_attr[OUT_HS ? 7 : 8]);
+    if (c->hs_vm_pair == 1) return go(gemm_hs_pp_pair_kernel<EPI, OUT_HS, false, 0, false, 1>, &c->hs_lds_attr[OUT_HS ? 9 : 10]);
+    return go(gemm_hs_pp_pair_kernel<EPI, OUT_HS, false>, &c->hs_lds_attr[OUT_HS ? 1 : 2]);
 }
 
 template <int EPI, bool OUT_HS>

@@ -227,6 +227,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(6, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_V2")) c->ls_v2 = std::atoi(e);
+    if (const char* e = std::getenv("CSI_HS_VM")) c->hs_vm_cast = c->hs_vm_pair = std::min(3, std::max(0, std::atoi(e)));
     auto bail = [&](int code) {
         g_create_error = c->err;
         csi_destroy(c);
@@ -830,6 +831,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "host_threads") *value = c->host_threads;
     else if (n == "ls_kernel") *value = c->ls_kernel;
     else if (n == "ls_v2") *value = c->ls_v2;
+    else if (n == "hs_vm_cast") *value = c->hs_vm_cast;
+    else if (n == "hs_vm_pair") *value = c->hs_vm_pair;
     else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
     else if (n == "hs_launches") *value = c->hs_launches;
     else if (n == "hs_range_fallbacks") *value = c->hs_range_fallbacks;
@@ -883,6 +886,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 64");
         if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
         c->host_threads = (int)value;
+    } else if (n == "hs_vm_cast" || n == "hs_vm_pair") {
+        if (value < 0 || value > 3) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 ... 3", name);
+        drop_graphs(c);
+        (n == "hs_vm_cast" ? c->hs_vm_cast : c->hs_vm_pair) = (int)value;
     } else if (n == "ls_v2") {
         c->ls_v2 = (int)value;
         return ls_prepare(c);

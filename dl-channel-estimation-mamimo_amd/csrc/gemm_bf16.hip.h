@@ -521,6 +521,7 @@ __device__ __forceinline__ f32x4 pp_gload16(const float* p) {
     return v;
 }
 __device__ __forceinline__ void pp_gdma16(const void* g_lane_src, uint32_t lds_byte_off) {
+    lds_byte_off = __builtin_amdgcn_readfirstlane(lds_byte_off);       // wave-uniform by construction; the "s" operand needs an SGPR
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_lane_src), "s"(lds_byte_off) : "memory");
 }
 template <int N>

@@ -692,9 +692,22 @@ __device__ __forceinline__ void hs_fused_regressor(f32x16 (&acc)[4][2], const Ge
 // chunk written in front of it.  WAR: B slot of sub-tile u+3 = slot of u-1, last read in P0(u-1).
 // DBG (timing probes of tools/hs_probe.hip, results invalid): 1 = no L0 / T / X requests, 2 = no conversion (VALU, ds_write)
 // FUSE: the regressor runs behind this layer inside the kernel (hs_fused_regressor above; EPI / OUT_HS are then unused)
-template <int EPI, bool OUT_HS, bool CAST = false, int DBG = 0, bool FUSE = false>
+// VM (round 2): 0 = the schedule above (builtin LDS-DMA, one vmcnt(0) per sub-tile).  1 / 2 = every vector-memory
+// operation as inline asm counted by hand (helpers of gemm_bf16.hip.h): the B pieces then stay in flight across the
+// conversion's ds_writes and the A-side values are awaited with a counted vmcnt that names their registers; 2 also requests
+// the A-side values one sub-tile earlier (two register sets), which is what the fp32 rows of layer 0 need - they come
+// from HBM, and two segments of look-ahead are shorter than that latency.
+template <int EPI, bool OUT_HS, bool CAST = false, int DBG = 0, bool FUSE = false, int VM = 0>
 __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const GemmHsArgs g, const PairSrc ps, const float in_scale, const PairRegArgs rg) {
-    constexpr int NSUB = 4, D = 3;
+    // VM 3: VM 2 with ONE load segment and ONE 24-MFMA segment per sub-tile instead of three of each (two barriers per
+    // sub-tile and wave instead of six: an 8-MFMA segment is 256 cycles of the matrix pipe, and the skew of a barrier is
+    // a fair fraction of that).  The load segment then overlaps the partner group's whole previous MFMA segment, so the
+    // B pieces go into a fifth ring slot (the slot of sub-tile u - 2, which the partner has left a segment ago).
+    constexpr bool MERGE = VM == 3;
+    constexpr int NSUB = MERGE ? 5 : 4, D = 3;
+    constexpr int LA = VM >= 2 ? 4 : 3;            // sub-tiles between the request of A-side values and the sub-tile they belong to
+    constexpr bool TWOSETS = VM >= 2;
+    constexpr int NAL = CAST ? 2 : 4;               // A-side loads per sub-tile and wave
     extern __shared__ __attribute__((aligned(16))) float lds[];      // NSUB * PP_SUBF ring
 
     const int tid = threadIdx.x;
@@ -732,9 +745,16 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         const int clog = (lane & 3) ^ ((row >> 2) & 3);
         voff[u] = (min(row, g.N - 1 - n0) * g.ldb + clog * 8) * 2;
     }
+    const uint16_t* bsrc[2];                         // VM: this lane's 16 bytes of B piece u, sub-tile 0
+#pragma unroll
+    for (int u = 0; u < 2; ++u) bsrc[u] = g.Bt + (size_t)n0 * g.ldb + 2 * kbeg + voff[u] / 2;
+    const uint32_t lds_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds);
     auto issue_b = [&](int sub, int slot, int u) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
-                                                 16, voff[u], sub * 64, 0, 0);
+        if (VM)
+            pp_gdma16(bsrc[u] + sub * 32, lds_off + (uint32_t)(slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256) * 4u);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * PP_SUBF + (PP_BM / 16 + 2 * wave + u) * 256),
+                                                     16, voff[u], sub * 64, 0, 0);
     };
     // ---- A side: row 32w + perm(lane >> 1), k half lane & 1.  ds_write_b128 is serviced in groups of 8
     // CONTIGUOUS lanes against 32 banks ((a / 4) mod 32, MI355X_MICROARCH.md "LDS"): the 8 lanes of a group
@@ -761,29 +781,42 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
             trow = ps.T + (size_t)t * ps.ldl + 8 * kh;
         }
     }
-    f32x4 lv[2] = {}, tv[2] = {};
+    f32x4 lvs[2][2] = {}, tvs[2][2] = {};            // two register sets (sub-tile parity); VM 0 / 1 use set 0 only
     float apk = 0.f;
     u16x2 apk16 = {0, 0};              // pair mode: running maximum of the hi halves (bit patterns)                    // largest |scaled A operand| this lane converted
-    auto load_a = [&](int sub) {
+    auto load_a = [&](int sub, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         if (DBG & 1) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            lv[h] = *reinterpret_cast<const f32x4*>(lrow + sub * HS_G + 4 * h);
-            if (!CAST) tv[h] = *reinterpret_cast<const f32x4*>(trow + sub * HS_G + 4 * h);
+            if (VM) {
+                lvs[SET][h] = pp_gload16(lrow + sub * HS_G + 4 * h);
+                if (!CAST) tvs[SET][h] = pp_gload16(trow + sub * HS_G + 4 * h);
+            } else {
+                lvs[SET][h] = *reinterpret_cast<const f32x4*>(lrow + sub * HS_G + 4 * h);
+                if (!CAST) tvs[SET][h] = *reinterpret_cast<const f32x4*>(trow + sub * HS_G + 4 * h);
+            }
         }
+    };
+    // VM: at most N younger operations stay in flight; releases the values of register set SET
+    auto wait_a = [&](auto set_tag, auto n_tag) {
+        constexpr int SET = decltype(set_tag)::value, N = decltype(n_tag)::value;
+        if (CAST) pp_wait_vm_dep<N>(lvs[SET][0], lvs[SET][1]);
+        else pp_wait_vm_dep<N>(lvs[SET][0], lvs[SET][1], tvs[SET][0], tvs[SET][1]);
     };
     f32x4 gv[2];                        // the 8 scaled A values of the sub-tile in conversion (P0 -> P1)
     uint4 gh;                           // ... and their packed hi halves
-    auto gen_hi = [&](int sub, int slot) {
+    auto gen_hi = [&](int sub, int slot, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         if (DBG & 2) return;
         if (CAST) {
-            gv[0] = lv[0] * a_scale;
-            gv[1] = lv[1] * a_scale;
+            gv[0] = lvs[SET][0] * a_scale;
+            gv[1] = lvs[SET][1] * a_scale;
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gv[h][e] = fmaxf(fmaf(lv[h][e], in_scale, tv[h][e]), 0.f);
+                for (int e = 0; e < 4; ++e) gv[h][e] = fmaxf(fmaf(lvs[SET][h][e], in_scale, tvs[SET][h][e]), 0.f);
         }
         gh.x = hs_hi_pair(gv[0][0], gv[0][1]);
         gh.y = hs_hi_pair(gv[0][2], gv[0][3]);
@@ -836,15 +869,21 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
     HsFrags f;
 
     // ---- prologue: B sub-tiles 0..2 in flight, A sub-tiles 0 and 1 generated synchronously
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using N0 = std::integral_constant<int, 0>;
     const int npro = min(nsub, D);
     for (int t = 0; t < npro; ++t) { issue_b(t, t, 0); issue_b(t, t, 1); }
     for (int t = 0; t < min(nsub, 2); ++t) {
-        load_a(t);
-        gen_hi(t, t);                   // the compiler waits for the loads it just issued
+        load_a(t, S0{});
+        if (VM) wait_a(S0{}, N0{});     // VM 0: the compiler waits for the loads it just issued
+        gen_hi(t, t, S0{});
         gen_lo(t);
     }
+    if (VM) pp_wait_vm0();
     pp_wait_vm_lgkm<0>();
-    if (nsub > 2) load_a(2);            // consumed in P0 of sub-tile 0
+    if (nsub > 2) load_a(2, S0{});      // consumed in P0 of sub-tile 0
+    if (TWOSETS && nsub > 3) load_a(3, S1{});
     pp_barrier();
     read_a(0, 0, f.a_hi);
     read_b(0, 1, f.b_lo);
@@ -853,29 +892,62 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
 
     hs_stamp(g.stamps, 1);
     int slot = 0;
-    auto subtile = [&](int u, auto steady_tag) {
+    // PAR = parity of u + 2, the sub-tile whose A image this sub-tile generates (VM 2: its register set)
+    auto subtile = [&](int u, auto steady_tag, auto par_tag) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const int nslot = (slot + 1) & 3;
-        const bool has_a = STEADY || u + 2 < nsub, nxt_a = STEADY || u + 3 < nsub, has_b = STEADY || u + D < nsub;
+        constexpr int GS = TWOSETS ? decltype(par_tag)::value : 0;                 // set holding the values of sub-tile u + 2
+        constexpr int LS = TWOSETS ? (decltype(par_tag)::value ^ (LA & 1)) : 0;    // set receiving the values of sub-tile u + LA
+        using GST = std::integral_constant<int, GS>;
+        using LST = std::integral_constant<int, LS>;
+        const int nslot = (slot + 1) % NSUB;
+        const bool has_a = STEADY || u + 2 < nsub, nxt_a = STEADY || u + LA < nsub, has_b = STEADY || u + D < nsub;
         const bool last = !STEADY && u == nsub - 1;
-        // P0: every memory operation of this wave has landed (the values requested in P1 of the previous
-        // sub-tile, and behind them its two B pieces); no new one is issued before the lo chunk is written -
-        // hipcc puts s_waitcnt vmcnt(0) in front of a ds_write that follows an LDS-DMA still in flight
-        pp_wait_vm_lgkm<0>();
-        if (has_a) gen_hi(u + 2, (slot + 2) & 3);       // its ds_write retires with the lgkmcnt(0) that closes the MFMA segment
+        if (VM == 0) {
+            // P0: every memory operation of this wave has landed (the values requested in P1 of the previous
+            // sub-tile, and behind them its two B pieces); no new one is issued before the lo chunk is written -
+            // hipcc puts s_waitcnt vmcnt(0) in front of a ds_write that follows an LDS-DMA still in flight
+            pp_wait_vm_lgkm<0>();
+        } else if (STEADY) {
+            // the values of sub-tile u + 2 and the B pieces of sub-tile u + 1 (first read in P2 below) have landed; younger
+            // and still in flight: the two B pieces of P2(u - 1), and with VM 2 the values and pieces behind them
+            // MERGE issues the B pieces in front of the value requests and leaves only the youngest requests in flight: a piece
+            // must have landed a whole segment before the partner group reads it (the groups are one segment apart and
+            // synchronise only at segment boundaries)
+            wait_a(GST{}, std::integral_constant<int, (MERGE ? NAL : (TWOSETS ? NAL + 2 : 2))>{});
+            pp_wait_lgkm();
+        } else {
+            if (has_a) wait_a(GST{}, N0{}); else pp_wait_vm0();
+            pp_wait_lgkm();
+        }
+        if (has_a) gen_hi(u + 2, (slot + 2) % NSUB, GST{});     // its ds_write retires with the lgkmcnt(0) that closes the MFMA segment
+        if (MERGE) {
+            if (has_a) gen_lo((slot + 2) % NSUB);
+            if (has_b) {
+                issue_b(u + D, (slot + D) % NSUB, 0);
+                issue_b(u + D, (slot + D) % NSUB, 1);
+            }
+            if (nxt_a) load_a(u + LA, LST{});
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            hs_mfma_seg<0, FUSE>(acc, f, read_a, read_b, true, slot, nslot, false);
+            hs_mfma_seg<1, FUSE>(acc, f, read_a, read_b, true, slot, nslot, false);
+            hs_mfma_seg<2, FUSE>(acc, f, read_a, read_b, !last, slot, nslot, !(wm == 1 && last));
+            slot = nslot;
+            return;
+        }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         hs_mfma_seg<0, FUSE>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P1
-        if (has_a) gen_lo((slot + 2) & 3);
-        if (nxt_a) load_a(u + 3);
+        if (has_a) gen_lo((slot + 2) % NSUB);
+        if (nxt_a) load_a(u + LA, LST{});
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         hs_mfma_seg<1, FUSE>(acc, f, read_a, read_b, true, slot, nslot, true);
         // P2
         if (has_b) {
-            issue_b(u + D, (slot + D) & 3, 0);
-            issue_b(u + D, (slot + D) & 3, 1);
+            issue_b(u + D, (slot + D) % NSUB, 0);
+            issue_b(u + D, (slot + D) % NSUB, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
@@ -883,8 +955,27 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_hs_pp_pair_kernel(const Ge
         slot = nslot;
     };
     int u = 0;
-    for (; u + D < nsub; ++u) subtile(u, std::true_type{});
-    for (; u < nsub; ++u) subtile(u, std::false_type{});
+    if (VM) {
+        // the counted waits assume the issue pattern of the steady state behind them: the first two sub-tiles drain instead
+        if (nsub > 0) subtile(0, std::false_type{}, S0{});
+        if (nsub > 1) subtile(1, std::false_type{}, S1{});
+        u = min(2, nsub);
+    }
+    if (TWOSETS) {
+        // two sub-tiles per trip: the register set of a sub-tile's values is its parity, a compile-time constant here
+        for (; u + LA + 1 < nsub; u += 2) {
+            subtile(u, std::true_type{}, S0{});
+            subtile(u + 1, std::true_type{}, S1{});
+        }
+        for (; u < nsub; u += 2) {
+            subtile(u, std::false_type{}, S0{});
+            if (u + 1 < nsub) subtile(u + 1, std::false_type{}, S1{});
+        }
+    } else {
+        for (; u + LA < nsub; ++u) subtile(u, std::true_type{}, S0{});
+        for (; u < nsub; ++u) subtile(u, std::false_type{}, S0{});
+    }
+    if (VM) pp_wait_vm0();
 
     hs_stamp(g.stamps, 2);
     if (!CAST) {
