@@ -163,9 +163,15 @@ int main(int argc, char** argv) {
     GemmHsArgs gp = gh;                                   // pair kernel: A generated from L0 / T
     gp.Bt = Wfh; gp.ldb = ldbf; gp.acc_scale = std::ldexp(1.f, -(sa + swf));
     PairSrc ps{L0, Ts, K, nt};
-    const size_t lds_pair = (size_t)PPP_RING_FLOATS * 4;
-    auto kpair = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false>;
-    auto kcast = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
+    // the library's defaults: pair layer with hand-counted memory operations and merged segments (VM 3, five ring slots),
+    // layer 0 with the extra look-ahead (VM 2); kpair0 / kcast0 = the round-1/2 schedule (builtin LDS-DMA, drain per sub-tile)
+    const size_t lds_pair = (size_t)5 * PP_SUBF * 4;
+    auto kpair = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false, 0, false, 3>;
+    auto kpair0 = gemm_hs_pp_pair_kernel<EPI_BIAS_RELU_AFFINE, true, false>;
+    CK(hipFuncSetAttribute((const void*)kpair0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PPP_RING_FLOATS * 4)));
+    auto kcast = gemm_hs_pp_pair_kernel<EPI_RAW, false, true, 0, false, 2>;
+    auto kcast0 = gemm_hs_pp_pair_kernel<EPI_RAW, false, true>;
+    CK(hipFuncSetAttribute((const void*)kcast0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PPP_RING_FLOATS * 4)));
     CK(hipFuncSetAttribute((const void*)kpair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
     CK(hipFuncSetAttribute((const void*)kcast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PPP_RING_FLOATS * 4)));
     GemmHsArgs gc = g; gc.C = C; gc.ldc = N;              // CAST: A = fp32 rows, raw output
@@ -380,8 +386,10 @@ int main(int argc, char** argv) {
         report("generic hs->fp32", [&] { hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), grid, dim3(PP_THREADS), 0, 0, a); }, grid.x);
         a = gp; a.stamps = st;
         report("pair (fused A)", [&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, a, ps, std::ldexp(1.f, sa), PairRegArgs{}); }, grid.x);
+        report("pair, old schedule", [&] { hipLaunchKernelGGL(kpair0, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, ps, std::ldexp(1.f, sa), PairRegArgs{}); }, grid.x);
         a = gc; a.stamps = st;
         report("cast (A fp32)", [&] { hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, pc, 16.f, PairRegArgs{}); }, grid.x);
+        report("cast, old schedule", [&] { hipLaunchKernelGGL(kcast0, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, a, pc, 16.f, PairRegArgs{}); }, grid.x);
         {   // fused kernel: main loop -> [both halves of the regressor stage] -> [flag wait] -> [output] per column-tile class
             GemmHsArgs af = gf; af.stamps = st;
             auto lf = [&] { hipMemsetAsync(fflags, 0, (size_t)tiles_m * 4, 0); hipLaunchKernelGGL(kfuse, grid, dim3(PP_THREADS), PR_LDS_FLOATS * 4, 0, af, ps, std::ldexp(1.f, sa), rg); };
