@@ -248,7 +248,11 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         fed by an LDS-DMA ring (chosen automatically for that P), 6: generic P on
  *                         the LDS-DMA ring (chosen automatically for any other P, 16 <= Nt <= 128); a choice the
  *                         kernel cannot serve falls back
- *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs */
+ *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
+ *   "hs_vm_cast", "hs_vm_pair"  vector-memory schedule of the split-f16 layer-0 / first per-pair kernel: 0 builtin LDS-DMA
+ *                         with one drain per sub-tile, 1 hand-counted waits, 2 + one more sub-tile of look-ahead (default for
+ *                         layer 0), 3 + one load and one 24-MFMA segment per sub-tile (default for the pair layer); same
+ *                         results bit for bit, for A/B runs (tools/vm_ab.sh) */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
 /* Current value of an option, or of the read-only counters "hs_launches" (split-engine GEMMs launched)
  * and "hs_range_fallbacks" (csi_predict calls repeated on the fp32 MFMA kernels). */
