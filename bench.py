@@ -102,6 +102,9 @@ def main():
     ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
     ap.add_argument('--host-path', type=int, default=4000,
                     help='also time the host-buffer (PCIe-inclusive) entry points on this many packets (0 = skip; rank 0, N = 1)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='the default N = 1 run also measures BASELINE configs[2] and one GPU\'s share of configs[3] / configs[4] in fresh '
+                         'processes after its own timed region and reports them under "other_configs" (never part of "value"); this skips them')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()
@@ -121,10 +124,13 @@ def main():
         lo, hi = pkg.dist.shard_range(args.packets, rank, world) if args.scaling == 'strong' else (rank * args.packets, (rank + 1) * args.packets)
         seen = pkg.dist.all_reduce_sum(1.0)
         pkts = pkg.dist.all_reduce_sum(float(hi - lo))
+        infos = pkg.dist.gather_objects({'rank': rank, 'local_rank': local, 'pid': os.getpid(), 'packets': hi - lo, 'ms_per_step': None,
+                                         'device': {'ordinal': None, 'name': 'none (rendezvous only)', 'pci': None, 'arch': None}})
         pkg.dist.barrier()
         if rank == 0:
             print(json.dumps({'rendezvous_only': True, 'n_gpus': n_gpus, 'ranks_seen': int(seen), 'requested': args.gpus,
-                              'packets_per_step': int(pkts), 'scaling': args.scaling, 'backend': backend if world > 1 else None}))
+                              'packets_per_step': int(pkts), 'scaling': args.scaling, 'backend': backend if world > 1 else None,
+                              'ranks_ms': [i['ms_per_step'] for i in infos], 'devices': [i['device'] for i in infos], 'ranks': infos}))
         return
 
     nt, nr, hidden = args.nt, args.nr, tuple(args.hidden)
@@ -201,9 +207,19 @@ def main():
     for _ in range(args.steps):
         step()
     eng.synchronize()
+    dt_rank = time.perf_counter() - t0            # this rank's own steps (before waiting for the others)
     pkg.dist.barrier()
     dt = time.perf_counter() - t0
     dt = pkg.dist.all_reduce_max(dt)
+    # per-rank evidence for the N > 1 line: who ran, on which device, how long its own steps took, and that its split
+    # engine's range guard stayed silent
+    infos = pkg.dist.gather_objects({'rank': rank, 'local_rank': local, 'pid': os.getpid(), 'packets': npkt,
+                                     'ms_per_step': dt_rank / args.steps * 1e3, 'device': pkg.dist.device_identity(local % ndev),
+                                     'hs_range_fallbacks': eng.get_option('hs_range_fallbacks') if args.dtype == 'f32' else None})
+    if world > 1 and backend == 'nccl':
+        ords = sorted(i['device']['ordinal'] for i in infos)
+        assert pkg.dist.world_size() == world == len(infos), (pkg.dist.world_size(), world, len(infos))
+        assert ords == list(range(world)), 'ranks did not land on %d distinct devices: %s' % (world, ords)
 
     graph_replays = eng.get_option('graph_replays') if args.graph else 0
     if args.graph:                                 # kernel breakdown: one eager step with events, outside the timed region
@@ -227,7 +243,7 @@ def main():
     # (--no-cpu-baseline skips the timing) and compared with what the GPU produced for them (--check 0
     # skips the comparison).  The oracle is the checker / the baseline here, never the thing measured.
     check, cpu_baseline = {}, None
-    if rank == 0 and world == 1 and args.check > 0:
+    if rank == 0 and args.check > 0:               # N > 1: rank 0 checks packets of ITS shard
         from oracle import csi_oracle as o
         k = min(args.check, npkt)
         # first and last packets of the batch: with the mixed-SNR input these are the -25 dB and the +10 dB level
@@ -277,7 +293,6 @@ def main():
                   'pair_dense_gemm_tflops': ntf, 'frac_of_fp32_mfma_peak': ntf / FP32_MATRIX_PEAK_TFLOPS,
                   'what': "same steps with f32_engine = 0 (v_mfma_f32_32x32x2_f32 kernels)"}
         if args.check > 0:
-            from oracle import csi_oracle as o
             native['dnn_rel_err'] = max(o.row_rel_err(take(d_ore), r_re), o.row_rel_err(take(d_oim), r_im))
         eng.set_option('f32_engine', {'auto': -1, 'native': 0, 'split': 1}[args.engine])
 
@@ -388,6 +403,7 @@ def main():
                        nt, nr, total_pkts, npkt, ' (8 SNR x %d)' % (npkt // 8) if mixed else '', 'x'.join(map(str, hidden))),
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'ranks': world, 'devices_visible_per_rank': ndev, 'dist_backend': backend if world > 1 else None,
+                   'world_size_checked': pkg.dist.world_size(),
                    'sharding': ('contiguous packet ranges per rank (%s scaling), weights broadcast once over %s, no collective in the step'
                                 % (args.scaling, 'RCCL' if backend == 'nccl' else backend)) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,
@@ -400,6 +416,9 @@ def main():
         'kernels': kernels,
         'parity_check': check,
         'latency': latency,
+        'ranks_ms': [round(i['ms_per_step'], 4) for i in infos],
+        'devices': [i['device'] for i in infos],
+        'ranks': infos,
     }
     if guard:
         out['split_engine_range_guard'] = guard
@@ -418,7 +437,50 @@ def main():
 
     if cpu_baseline:
         out['cpu_baseline'] = cpu_baseline
+    default_run = (nt, nr, args.packets, args.dtype, tuple(hidden), args.engine) == (32, 4, 4000, 'f32', (1024, 1024), 'auto')
+    if world == 1 and default_run and not args.no_other_configs and not args.graph and not args.option:
+        del d_re, d_im, d_ore, d_oim, d_hre, d_him
+        out['other_configs'] = other_configs()
     print(json.dumps(out))
+
+
+OTHER_CONFIGS = [
+    ('configs[2]', 'Nt=64 Nr=4, 5000 packets, bf16 MFMA, 1 GPU',
+     ['--dtype', 'bf16', '--nt', '64', '--nr', '4', '--packets', '5000', '--steps', '3', '--warmup', '2']),
+    ('configs[3] share', 'Nt=64 Nr=8: one GPU\'s share (6250 packets) of the 50000 packets sharded over 8 GPUs, fp32',
+     ['--nt', '64', '--nr', '8', '--packets', '6250', '--steps', '3', '--warmup', '2']),
+    ('configs[4] share', 'Nt=128 Nr=16: one GPU\'s share (12500 packets) of the 100000 packets over 8 GPUs, fp32, one hipGraph per step',
+     ['--nt', '128', '--nr', '16', '--packets', '12500', '--steps', '3', '--warmup', '4', '--graph']),
+]
+
+
+def other_configs():
+    """BASELINE.json configs[2..4] as far as one GPU can run them, each in a FRESH process of this script (its own engine,
+    weights and buffers) after the headline's timed region: ms/step, pairs/s, the dominant kernel's roofline fraction and a
+    2-packet check against the fp64 oracle.  Reported beside the headline, never part of it."""
+    import subprocess
+    res = []
+    for name, what, flags in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-other-configs', '--no-cpu-baseline', '--no-latency',
+               '--host-path', '0', '--check', '2'] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not lines:
+                res.append({'config': name, 'workload': what, 'error': 'rc %d: %s' % (r.returncode, r.stderr[-400:])})
+                continue
+            j = json.loads(lines[-1])
+            res.append({'config': name, 'workload': what, 'flags': ' '.join(flags), 'value': j['value'], 'unit': j['unit'],
+                        'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'dtype': j['dtype'], 'launch': j['launch'],
+                        'pairs_per_step': j['config']['pairs_per_step'], 'input': j['input'],
+                        'roofline': {k: j['roofline'][k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms')},
+                        'roofline_ls_frac': (j.get('roofline_ls') or {}).get('frac'),
+                        'parity_check': j['parity_check'], 'split_engine_range_guard': j.get('split_engine_range_guard'),
+                        'wall_s': round(time.perf_counter() - t0, 1)})
+        except Exception as e:                      # a failed side measurement must never take the headline line down
+            res.append({'config': name, 'workload': what, 'error': repr(e)})
+    return res
 
 
 if __name__ == '__main__':

@@ -115,9 +115,9 @@ def build_library(force=False, verbose=False):
         if all(os.path.getmtime(s) <= so_m for s in srcs if os.path.exists(s)):
             return _SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    # host side: AVX2 (x86-64-v3) for the staging loops of the host pipeline - every host of an MI355X has it
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
-           '-Xarch_host', '-march=x86-64-v3', _SRC, '-o', _SO]
+    # host side: baseline x86-64; the three AVX2 staging loops of the host pipeline carry their own target attribute and a
+    # run-time CPU check (csi_hostpipe.hpp)
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', _SRC, '-o', _SO]
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

@@ -50,12 +50,15 @@ def build_parser():
 
 def _find_weights(modeldir, d):
     from .model import WEIGHT_FILE
-    for cand in (os.path.join(modeldir, d + '_keras_model', WEIGHT_FILE),
-                 os.path.join(modeldir, d + '_weights-improvement.hdf5'),             # the reference's own checkpoint name, DNN.py:279-281
+    # the checkpoint of the last fit comes first, as in the reference's test branch (DNN.py:279-281,334 always loads
+    # <d>_weights-improvement.hdf5): a <d>_keras_model/ folder in the same directory is what an EARLIER --test run
+    # saved (DNN.py:411) and may be stale after a re-train
+    for cand in (os.path.join(modeldir, d + '_weights-improvement.hdf5'),             # the reference's own checkpoint name
                  os.path.join(modeldir, d + '_weights-improvement.h5'),
                  os.path.join(modeldir, d + '_weights-improvement.safetensors'),
                  os.path.join(modeldir, d + '_weights-improvement.pt'),
                  os.path.join(modeldir, d + '_weights-improvement.npz'),
+                 os.path.join(modeldir, d + '_keras_model', WEIGHT_FILE),
                  os.path.join(modeldir, d + '_keras_model')):                         # a TF SavedModel directory (DNN.py:411)
         if os.path.exists(cand):
             return cand

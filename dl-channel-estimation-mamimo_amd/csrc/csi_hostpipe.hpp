@@ -24,12 +24,60 @@
 
 #include "csi_context.hpp"
 
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
+// AVX2 only inside the three staging loops below, each compiled for that ISA by a target attribute and entered behind a
+// run-time CPU check - the rest of the host code is built for the baseline x86-64 ISA (a host or VM without AVX2 would
+// otherwise die with SIGILL anywhere in the library, not only here: round-2 advice).
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
 #define CSI_HOST_AVX2 1
+#define CSI_AVX2_FN __attribute__((target("avx2")))
 #endif
 
 namespace {
+
+#ifdef CSI_HOST_AVX2
+inline bool hp_have_avx2() {
+    static const bool have = __builtin_cpu_supports("avx2");
+    return have;
+}
+// each returns the first element it did not handle
+CSI_AVX2_FN inline size_t hp_split_c128_avx2(const double* __restrict__ src, float* __restrict__ re, float* __restrict__ im, size_t j, size_t e) {
+    for (; j + 8 <= e; j += 8) {
+        const double* s = src + 2 * j;
+        const __m128 c0 = _mm256_cvtpd_ps(_mm256_loadu_pd(s)), c1 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 4));
+        const __m128 c2 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 8)), c3 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 12));
+        const __m256 v01 = _mm256_set_m128(c1, c0), v23 = _mm256_set_m128(c3, c2);       // [re0 im0 re1 im1 | re2 im2 re3 im3], [4 5 | 6 7]
+        const __m256 r = _mm256_shuffle_ps(v01, v23, 0x88), m = _mm256_shuffle_ps(v01, v23, 0xDD);   // [0 1 4 5 | 2 3 6 7]
+        _mm256_stream_ps(re + j, _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(r), 0xD8)));
+        _mm256_stream_ps(im + j, _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(m), 0xD8)));
+    }
+    _mm_sfence();
+    return j;
+}
+CSI_AVX2_FN inline size_t hp_weave_c64_avx2(const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ dst, size_t j, size_t e) {
+    for (; j + 8 <= e; j += 8) {
+        const __m256 r = _mm256_loadu_ps(re + j), m = _mm256_loadu_ps(im + j);
+        const __m256 lo = _mm256_unpacklo_ps(r, m), hi = _mm256_unpackhi_ps(r, m);      // [r0 m0 r1 m1 | r4 m4 r5 m5], [r2 m2 r3 m3 | r6 m6 r7 m7]
+        _mm256_stream_ps(dst + 2 * j, _mm256_permute2f128_ps(lo, hi, 0x20));
+        _mm256_stream_ps(dst + 2 * j + 8, _mm256_permute2f128_ps(lo, hi, 0x31));
+    }
+    _mm_sfence();
+    return j;
+}
+CSI_AVX2_FN inline size_t hp_stream_copy_avx2(char* __restrict__ d, const char* __restrict__ s, size_t bytes) {
+    size_t i = 0;
+    for (; i + 128 <= bytes; i += 128) {
+        const __m256 a = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i)), b = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 32));
+        const __m256 c = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 64)), e = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 96));
+        _mm256_stream_ps(reinterpret_cast<float*>(d + i), a);
+        _mm256_stream_ps(reinterpret_cast<float*>(d + i + 32), b);
+        _mm256_stream_ps(reinterpret_cast<float*>(d + i + 64), c);
+        _mm256_stream_ps(reinterpret_cast<float*>(d + i + 96), e);
+    }
+    _mm_sfence();
+    return i;
+}
+#endif
 
 // complex128 (re, im doubles interleaved) -> two float32 planes, elements [b, e).  The planes live in pinned staging
 // memory that this core never reads again (the DMA engine does): streaming stores spare the read-for-ownership of
@@ -37,22 +85,13 @@ namespace {
 inline void hp_split_c128(const double* __restrict__ src, float* __restrict__ re, float* __restrict__ im, size_t b, size_t e) {
     size_t j = b;
 #ifdef CSI_HOST_AVX2
-    while (j < e && ((reinterpret_cast<uintptr_t>(re + j) | reinterpret_cast<uintptr_t>(im + j)) & 31)) {
-        re[j] = (float)src[2 * j];
-        im[j] = (float)src[2 * j + 1];
-        ++j;
-    }
-    if (!((reinterpret_cast<uintptr_t>(re + j) | reinterpret_cast<uintptr_t>(im + j)) & 31)) {
-        for (; j + 8 <= e; j += 8) {
-            const double* s = src + 2 * j;
-            const __m128 c0 = _mm256_cvtpd_ps(_mm256_loadu_pd(s)), c1 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 4));
-            const __m128 c2 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 8)), c3 = _mm256_cvtpd_ps(_mm256_loadu_pd(s + 12));
-            const __m256 v01 = _mm256_set_m128(c1, c0), v23 = _mm256_set_m128(c3, c2);       // [re0 im0 re1 im1 | re2 im2 re3 im3], [4 5 | 6 7]
-            const __m256 r = _mm256_shuffle_ps(v01, v23, 0x88), m = _mm256_shuffle_ps(v01, v23, 0xDD);   // [0 1 4 5 | 2 3 6 7]
-            _mm256_stream_ps(re + j, _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(r), 0xD8)));
-            _mm256_stream_ps(im + j, _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(m), 0xD8)));
+    if (hp_have_avx2()) {
+        while (j < e && ((reinterpret_cast<uintptr_t>(re + j) | reinterpret_cast<uintptr_t>(im + j)) & 31)) {
+            re[j] = (float)src[2 * j];
+            im[j] = (float)src[2 * j + 1];
+            ++j;
         }
-        _mm_sfence();
+        if (!((reinterpret_cast<uintptr_t>(re + j) | reinterpret_cast<uintptr_t>(im + j)) & 31)) j = hp_split_c128_avx2(src, re, im, j, e);
     }
 #endif
     for (; j < e; ++j) {
@@ -65,19 +104,13 @@ inline void hp_split_c128(const double* __restrict__ src, float* __restrict__ re
 inline void hp_weave_c64(const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ dst, size_t b, size_t e) {
     size_t j = b;
 #ifdef CSI_HOST_AVX2
-    while (j < e && (reinterpret_cast<uintptr_t>(dst + 2 * j) & 31)) {
-        dst[2 * j] = re[j];
-        dst[2 * j + 1] = im[j];
-        ++j;
-    }
-    if (!(reinterpret_cast<uintptr_t>(dst + 2 * j) & 31)) {
-        for (; j + 8 <= e; j += 8) {
-            const __m256 r = _mm256_loadu_ps(re + j), m = _mm256_loadu_ps(im + j);
-            const __m256 lo = _mm256_unpacklo_ps(r, m), hi = _mm256_unpackhi_ps(r, m);      // [r0 m0 r1 m1 | r4 m4 r5 m5], [r2 m2 r3 m3 | r6 m6 r7 m7]
-            _mm256_stream_ps(dst + 2 * j, _mm256_permute2f128_ps(lo, hi, 0x20));
-            _mm256_stream_ps(dst + 2 * j + 8, _mm256_permute2f128_ps(lo, hi, 0x31));
+    if (hp_have_avx2()) {
+        while (j < e && (reinterpret_cast<uintptr_t>(dst + 2 * j) & 31)) {
+            dst[2 * j] = re[j];
+            dst[2 * j + 1] = im[j];
+            ++j;
         }
-        _mm_sfence();
+        if (!(reinterpret_cast<uintptr_t>(dst + 2 * j) & 31)) j = hp_weave_c64_avx2(re, im, dst, j, e);
     }
 #endif
     for (; j < e; ++j) {
@@ -93,19 +126,10 @@ inline void hp_stream_copy(void* __restrict__ dst, const void* __restrict__ src,
     char* d = static_cast<char*>(dst);
     const char* s = static_cast<const char*>(src);
     const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;
-    if (bytes >= 4096 + head) {
+    if (bytes >= 4096 + head && hp_have_avx2()) {
         std::memcpy(d, s, head);
         d += head; s += head; bytes -= head;
-        size_t i = 0;
-        for (; i + 128 <= bytes; i += 128) {
-            const __m256 a = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i)), b = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 32));
-            const __m256 c = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 64)), e = _mm256_loadu_ps(reinterpret_cast<const float*>(s + i + 96));
-            _mm256_stream_ps(reinterpret_cast<float*>(d + i), a);
-            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 32), b);
-            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 64), c);
-            _mm256_stream_ps(reinterpret_cast<float*>(d + i + 96), e);
-        }
-        _mm_sfence();
+        const size_t i = hp_stream_copy_avx2(d, s, bytes);
         std::memcpy(d + i, s + i, bytes - i);
         return;
     }

@@ -1081,6 +1081,33 @@ int csi_synchronize(csi_ctx* c) {
     return CSI_OK;
 }
 
+// Range guard of the split-f16 engine behind a host-buffer entry point (the stream is synchronised, the caller's buffers
+// are still here): if an operand left the f16 range, or a row sat in its denormals, run `again` on the fp32 MFMA kernels.
+// The retry must not replay a hipGraph captured with the split-engine kernels (the host pipeline calls the device
+// entry points with recurring buffers and chunk sizes, i.e. recurring graph keys): graphs are dropped and graph use is
+// off for its duration; and the guard is read once more behind it - nothing of the split engine may have run.
+static int range_guard_retry(csi_ctx* c, const std::function<int()>& again) {
+    float hit = 0.f;
+    bool low = false;
+    int rc = hs_range_check(c, &hit, &low);
+    if (rc || (hit == 0.f && !low)) return rc;
+    ++c->hs_range_fallbacks;
+    const int engine = c->f32_engine;
+    const bool graph = c->use_graph;
+    drop_graphs(c);
+    c->f32_engine = 0;
+    c->use_graph = false;
+    const int64_t launches = c->hs_launches;
+    rc = again();
+    c->f32_engine = engine;
+    c->use_graph = graph;
+    drop_graphs(c);
+    if (rc) return rc;
+    if (c->hs_launches != launches)
+        return fail(c, CSI_ERR_RANGE, "range-guard retry: the split-f16 engine ran again although f32_engine was 0");
+    return CSI_OK;
+}
+
 // ---- host-buffer entry points: two-slot pipeline of csi_hostpipe.hpp
 static int host_packets(csi_ctx* c, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im,
                         int n_out, bool ls) {
@@ -1102,16 +1129,7 @@ int csi_predict(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t np
     // range guard of the split-f16 engine: an operand beyond the f16 range, or a row of operands deep in
     // its denormal range -> the same call again on the
     // fp32 MFMA kernels (the caller's buffers are still here), so that this entry point never returns inf
-    float hit = 0.f;
-    bool low = false;
-    rc = hs_range_check(c, &hit, &low);
-    if (rc || (hit == 0.f && !low)) return rc;
-    ++c->hs_range_fallbacks;
-    const int engine = c->f32_engine;
-    c->f32_engine = 0;
-    rc = host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false);
-    c->f32_engine = engine;
-    return rc;
+    return range_guard_retry(c, [&] { return host_packets(c, ltf_re, ltf_im, npkt, out_re, out_im, c->cfg.n_out, false); });
 }
 
 int csi_estimate_c128(csi_ctx* c, const double* ltf_c128, int64_t npkt, float* dnn_c64, float* ls_c64) {
@@ -1124,16 +1142,7 @@ int csi_estimate_c128(csi_ctx* c, const double* ltf_c128, int64_t npkt, float* d
     rc = hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, ls_c64);
     if (rc || !dnn_c64) return rc;
     // range guard of the split-f16 engine, as in csi_predict: repeat the DNN on the fp32 MFMA kernels
-    float hit = 0.f;
-    bool low = false;
-    rc = hs_range_check(c, &hit, &low);
-    if (rc || (hit == 0.f && !low)) return rc;
-    ++c->hs_range_fallbacks;
-    const int engine = c->f32_engine;
-    c->f32_engine = 0;
-    rc = hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, nullptr);
-    c->f32_engine = engine;
-    return rc;
+    return range_guard_retry(c, [&] { return hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, nullptr); });
 }
 
 int csi_ls_estimate(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* h_re, float* h_im) {

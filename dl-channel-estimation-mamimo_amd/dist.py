@@ -90,6 +90,30 @@ def barrier():
         dist.barrier()
 
 
+def gather_objects(obj):
+    """Every rank's (small, picklable) object, in rank order, on every rank."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def device_identity(ordinal=None):
+    """What tells two GPUs apart in a bench line: ordinal used by this rank, marketing name, PCI address (when torch
+    exposes it) and the gfx architecture."""
+    import torch
+    if not torch.cuda.is_available():
+        return {'ordinal': None, 'name': 'cpu', 'pci': None, 'arch': None}
+    d = torch.cuda.current_device() if ordinal is None else int(ordinal)
+    pr = torch.cuda.get_device_properties(d)
+    pci = None
+    if hasattr(pr, 'pci_bus_id'):
+        pci = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+    return {'ordinal': d, 'name': pr.name, 'pci': pci, 'arch': getattr(pr, 'gcnArchName', None)}
+
+
 def all_reduce_max(value, device=None):
     """max over ranks of a python float (used for the max-over-ranks step time)."""
     import torch

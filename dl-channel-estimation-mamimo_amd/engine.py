@@ -407,14 +407,46 @@ class CsiEngine:
         return y
 
     # ------------------------------------------------------------------ device-resident calls
-    def predict_device(self, d_re, d_im, npkt, d_out_re, d_out_im):
-        """Asynchronous.  On the split-f16 engine a range-guard hit is reported by the NEXT ``synchronize()`` (CsiError
-        code -6): outputs must not be consumed before it returned cleanly (the host-buffer calls repeat by themselves)."""
-        self._check(self._lib.csi_predict_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr))
+    def _checked(self, launch):
+        """Run ``launch()`` (device-pointer calls), synchronise, and - if the split-f16 engine's range guard reports
+        (CsiError code -6: an operand left the f16 range after scaling, or a whole row sat in its denormals) - run it
+        again on the fp32 MFMA kernels, as the host-buffer entry points do by themselves.  Returns 'split', or 'fp32' when
+        the repeat served the call; the option is put back either way (changing it drops cached hipGraphs)."""
+        launch()
+        try:
+            self.synchronize()
+            return 'split'
+        except CsiError as err:
+            if err.code != -6:
+                raise
+        engine = self.get_option('f32_engine')
+        self.set_option('f32_engine', 0)
+        try:
+            launch()
+            self.synchronize()
+        finally:
+            self.set_option('f32_engine', engine)
+        self.range_recoveries = getattr(self, 'range_recoveries', 0) + 1
+        return 'fp32'
 
-    def estimate_device(self, d_re, d_im, npkt, d_out_re, d_out_im, d_h_re, d_h_im):
-        """LS + DNN of device-resident packets as one call (one hipGraph under 'use_graph')."""
-        self._check(self._lib.csi_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr, d_h_re.ptr, d_h_im.ptr))
+    def predict_device(self, d_re, d_im, npkt, d_out_re, d_out_im, checked=False):
+        """Asynchronous.  On the split-f16 engine a range-guard hit is reported by the NEXT ``synchronize()`` (CsiError
+        code -6): outputs must not be consumed before it returned cleanly (the host-buffer calls repeat by themselves).
+        ``checked=True`` does that for the caller: synchronises, repeats the call on the fp32 MFMA kernels if the guard
+        reported, and returns which engine served it ('split' / 'fp32')."""
+        def launch():
+            self._check(self._lib.csi_predict_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr))
+        if checked:
+            return self._checked(launch)
+        launch()
+
+    def estimate_device(self, d_re, d_im, npkt, d_out_re, d_out_im, d_h_re, d_h_im, checked=False):
+        """LS + DNN of device-resident packets as one call (one hipGraph under 'use_graph'); ``checked`` as in predict_device."""
+        def launch():
+            self._check(self._lib.csi_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_out_re.ptr, d_out_im.ptr, d_h_re.ptr, d_h_im.ptr))
+        if checked:
+            return self._checked(launch)
+        launch()
 
     def ls_estimate_device(self, d_re, d_im, npkt, d_h_re, d_h_im):
         self._check(self._lib.csi_ls_estimate_device(self._ctx, d_re.ptr, d_im.ptr, int(npkt), d_h_re.ptr, d_h_im.ptr))

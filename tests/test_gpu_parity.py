@@ -860,6 +860,23 @@ def test_cli_test_run_end_to_end(pkg, oracle, tmp_path, capsys):
     m = loadmat(str(work2 / 'test_csi_predictions_real_1.mat'))['all_pkts_csi_nn_out'][0, 0]
     assert rel_rows(m['y'], r_re[npkt - 1].reshape(nr * nt, 234)) < TOL
     np.testing.assert_array_equal(m['true_y'], y.real.reshape(npkt, nr * nt, 234)[npkt - 1])
+    # train -> test -> re-train -> test in ONE work directory (round-2 advice): the second test run must evaluate the
+    # new checkpoint, not the <d>_keras_model/ folder the first test run left there (DNN.py:279-281,334 always loads
+    # <d>_weights-improvement.hdf5)
+    work3 = tmp_path / 'out3'
+    work3.mkdir()
+    pkg.save_weight_file(str(work3 / 'real_weights-improvement.safetensors'), w_re)
+    pkg.save_weight_file(str(work3 / 'imag_weights-improvement.safetensors'), w_im)
+    args3 = ['--test', '-x', str(tmp_path / 'test.b'), '-d', str(work3), '--nn', '64', '32', '--useBN', '--datasource', 'matlab_maMimo', '--valSameTrain']
+    assert cli.main(args3) == 0 and os.path.isdir(work3 / 'real_keras_model')
+    w_re2, w_im2 = _weights(oracle, 4, nt, hidden)
+    pkg.save_weight_file(str(work3 / 'real_weights-improvement.safetensors'), w_re2)
+    pkg.save_weight_file(str(work3 / 'imag_weights-improvement.safetensors'), w_im2)
+    assert cli.main(args3) == 0
+    capsys.readouterr()
+    n_re, n_im = oracle.predict_packets(ltf.astype(np.complex64), P_rows, w_re2, w_im2, np.float64, pkt_batch=npkt)
+    m = loadmat(str(work3 / 'test_csi_predictions_real_2.mat'))['all_pkts_csi_nn_out'][0, 0]
+    assert rel_rows(m['y'], n_re[1].reshape(nr * nt, 234)) < TOL
 
 
 def test_host_pipeline_many_chunks_pinned_and_pageable(pkg, oracle):

@@ -442,6 +442,9 @@ def test_bench_gpus_n_starts_n_ranks():
     that answered, and strong scaling shards a fixed total."""
     line = _bench(['--gpus', '2', '--rendezvous-only', '--scaling', 'strong', '--packets', '50001'], {'CSI_DIST_BACKEND': 'gloo'})
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['packets_per_step'] == 50001 and line['scaling'] == 'strong'
+    # per-rank evidence (round-2 verdict): one entry per rank that ran, distinct processes, the shard each one held
+    assert len(line['ranks_ms']) == 2 and len(line['devices']) == 2 and [r['rank'] for r in line['ranks']] == [0, 1]
+    assert len({r['pid'] for r in line['ranks']}) == 2 and [r['packets'] for r in line['ranks']] == [25001, 25000]
     line = _bench(['--gpus', '3', '--rendezvous-only', '--packets', '4000'], {'CSI_DIST_BACKEND': 'gloo'})
     assert line['n_gpus'] == 3 and line['ranks_seen'] == 3 and line['packets_per_step'] == 12000 and line['scaling'] == 'weak'
     line = _bench(['--gpus', '1', '--rendezvous-only'], {})
@@ -459,6 +462,7 @@ def test_bench_under_torchrun_env_uses_the_given_ranks():
     import json
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['ranks_seen'] == 2
+    assert len(lines[0]['ranks_ms']) == 2 and len(lines[0]['devices']) == 2 and len({r['pid'] for r in lines[0]['ranks']}) == 2
 
 
 def test_mixed_snr_batch_generator(pkg, oracle):
@@ -566,3 +570,18 @@ def test_probe_tools_still_compile(src, tmp_path):
                           os.path.join(root, 'tools', src), '-o', str(tmp_path / 'probe.o')],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_cli_prefers_the_checkpoint_over_a_stale_model_folder(pkg, tmp_path):
+    """cli._find_weights: <d>_weights-improvement.* (what a fit writes, DNN.py:279-281,319) wins over the <d>_keras_model/
+    folder an earlier --test run left in the same directory (DNN.py:411); the folder is still found when it is all there is."""
+    from dl_channel_estimation_mamimo_amd import cli
+    from dl_channel_estimation_mamimo_amd.model import WEIGHT_FILE
+    d = tmp_path / 'w'
+    (d / 'real_keras_model').mkdir(parents=True)
+    (d / 'real_keras_model' / WEIGHT_FILE).write_bytes(b'old')
+    assert cli._find_weights(str(d), 'real') == str(d / 'real_keras_model' / WEIGHT_FILE)
+    (d / 'real_weights-improvement.safetensors').write_bytes(b'new')
+    assert cli._find_weights(str(d), 'real') == str(d / 'real_weights-improvement.safetensors')
+    (d / 'real_weights-improvement.hdf5').write_bytes(b'newer')
+    assert cli._find_weights(str(d), 'real') == str(d / 'real_weights-improvement.hdf5')
