@@ -105,6 +105,10 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true',
                     help='the default N = 1 run also measures BASELINE configs[2] and one GPU\'s share of configs[3] / configs[4] in fresh '
                          'processes after its own timed region and reports them under "other_configs" (never part of "value"); this skips them')
+    ap.add_argument('--weights-via', default='rccl', choices=['rccl', 'torch'],
+                    help='N > 1: rccl = rank 0 loads the weights into its context and the library broadcasts its device buffers '
+                         '(csi_comm_init / csi_broadcast_weights: ncclBroadcast inside the C-ABI); torch = dist.broadcast_weights '
+                         '(torch.distributed, host round trip).  CSI_DIST_BACKEND=gloo implies torch.')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()
@@ -153,18 +157,34 @@ def main():
         rng = np.random.default_rng(1234)
         wts = {'real': pkg.synth.make_weights(rng, nt, hidden), 'imag': pkg.synth.make_weights(rng, nt, hidden),
                'P': {'pilot': pkg.synth.hadamard(nt)}}
-    if world > 1:
-        wts = {k: pkg.dist.broadcast_weights(wts[k] if rank == 0 else None, src=0) for k in ('real', 'imag', 'P')}
-    eng.load_weights('real', wts['real'])
-    eng.load_weights('imag', wts['imag'])
-    eng.set_pilot(wts['P']['pilot'])
+    via = 'single GPU'
+    if world > 1 and args.weights_via == 'rccl' and backend == 'nccl':
+        # the library's own communicator: rank 0 loads, every context receives the device buffers over RCCL
+        t_b = time.perf_counter()
+        eng.comm_init(rank, world, pkg.dist.exchange_unique_id(rank, world))
+        if rank == 0:
+            eng.load_weights('real', wts['real'])
+            eng.load_weights('imag', wts['imag'])
+            eng.set_pilot(wts['P']['pilot'])
+        moved = eng.broadcast_weights(0)
+        via = 'csi_broadcast_weights: ncclBroadcast of %d device buffers, %.1f MB, %.0f ms incl. communicator setup and rank 0 load' % (
+            eng.get_option('comm_blobs'), moved / 1e6, (time.perf_counter() - t_b) * 1e3)
+        P_host = pkg.synth.hadamard(nt)             # the pilot matrix is a constant of the configuration (input synthesis below)
+    else:
+        if world > 1:
+            wts = {k: pkg.dist.broadcast_weights(wts[k] if rank == 0 else None, src=0) for k in ('real', 'imag', 'P')}
+            via = 'dist.broadcast_weights (torch.distributed, %s)' % backend
+        eng.load_weights('real', wts['real'])
+        eng.load_weights('imag', wts['imag'])
+        eng.set_pilot(wts['P']['pilot'])
+        P_host = wts['P']['pilot']
 
     # this rank's packet shard, resident in HBM before the timed region
     d_re, d_im = eng.empty((npkt, nr, eng.len_ltf)), eng.empty((npkt, nr, eng.len_ltf))
     mixed = args.input == 'mixed-snr' or (args.input == 'auto' and npkt <= 8000 and npkt % 8 == 0)
     if mixed:
         assert npkt % 8 == 0, 'mixed-snr input needs a multiple of 8 packets per rank'
-        for p0, snr, blk in pkg.synth.mixed_snr_batch(2024 + 1 + 1000 * rank, nr, wts['P']['pilot'], per_level=npkt // 8):
+        for p0, snr, blk in pkg.synth.mixed_snr_batch(2024 + 1 + 1000 * rank, nr, P_host, per_level=npkt // 8):
             d_re.upload(np.ascontiguousarray(blk.real), first=p0)
             d_im.upload(np.ascontiguousarray(blk.imag), first=p0)
     else:
@@ -403,7 +423,7 @@ def main():
                        nt, nr, total_pkts, npkt, ' (8 SNR x %d)' % (npkt // 8) if mixed else '', 'x'.join(map(str, hidden))),
                    'pairs_per_step': pairs_per_step, 'packets_per_s': value / (nr * nt), 'ls_included': not args.no_ls,
                    'ranks': world, 'devices_visible_per_rank': ndev, 'dist_backend': backend if world > 1 else None,
-                   'world_size_checked': pkg.dist.world_size(),
+                   'world_size_checked': pkg.dist.world_size(), 'weights_via': via,
                    'sharding': ('contiguous packet ranges per rank (%s scaling), weights broadcast once over %s, no collective in the step'
                                 % (args.scaling, 'RCCL' if backend == 'nccl' else backend)) if world > 1 else 'single GPU'},
         'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,

@@ -5,6 +5,7 @@ copied from the header.  ``load_library()`` raises ``CsiError`` when the shared 
 been built - the product path never falls back to a CPU implementation."""
 import ctypes
 import os
+import sys
 import subprocess
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -92,6 +93,10 @@ SYMBOLS = {
     'csi_profile_enable': (ctypes.c_int, [_ctx, ctypes.c_int]),
     'csi_profile_reset': (ctypes.c_int, [_ctx]),
     'csi_profile_num_kernels': (ctypes.c_int, []),
+    'csi_get_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
+    'csi_comm_init': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    'csi_comm_destroy': (ctypes.c_int, [_ctx]),
+    'csi_broadcast_weights': (ctypes.c_int, [_ctx, ctypes.c_int]),
     'csi_profile_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
     'csi_profile_query': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
@@ -105,9 +110,40 @@ def library_path():
     return _SO
 
 
+def build_band_kernel(verbose=False):
+    """csrc/band_kernel_gen.py -> gfx950 assembly -> code object -> csrc/band8_hsaco.inc (a C array the library embeds and
+    loads with hipModuleLoadData on first use).  clang / ld.lld of the ROCm LLVM; no GPU needed."""
+    import tempfile
+    csrc = os.path.join(_PKG_DIR, 'csrc')
+    gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
+    if os.path.exists(inc) and os.path.getmtime(inc) >= os.path.getmtime(gen):
+        return inc
+    llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+    with tempfile.TemporaryDirectory() as tmp:
+        asm, obj, co = (os.path.join(tmp, 'band8.' + e) for e in ('s', 'o', 'hsaco'))
+        cmds = [[sys.executable, gen, asm, 'csi_band8'],
+                [os.path.join(llvm, 'clang'), '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', asm, '-o', obj],
+                [os.path.join(llvm, 'ld.lld'), '-shared', obj, '-o', co]]
+        for cmd in cmds:
+            if verbose:
+                print(' '.join(cmd))
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+            if res.returncode != 0:
+                raise RuntimeError('band kernel build failed:\n' + res.stdout)
+        with open(co, 'rb') as f:
+            blob = f.read()
+    rows = [', '.join('0x%02x' % b for b in blob[i:i + 24]) for i in range(0, len(blob), 24)]
+    with open(inc + '.tmp', 'w') as f:
+        f.write('// generated by _lib.build_band_kernel from band_kernel_gen.py - gfx950 code object of csi_band8 (%d bytes)\n' % len(blob))
+        f.write('alignas(4096) static const unsigned char band8_hsaco[] = {\n' + ',\n'.join(rows) + '};\n')
+    os.replace(inc + '.tmp', inc)
+    return inc
+
+
 def build_library(force=False, verbose=False):
     """Compile csrc/csi_mamimo.hip for gfx950 into the in-tree shared object (hipcc
-    cross-compiles without a GPU).  Returns the path."""
+    cross-compiles without a GPU); the assembly band kernel is generated, assembled and embedded first.  Returns the path."""
+    build_band_kernel(verbose)
     srcs = [_SRC] + [os.path.join(_PKG_DIR, 'csrc', f) for f in os.listdir(os.path.join(_PKG_DIR, 'csrc'))]
     srcs.append(os.path.join(_REPO, 'include', 'csi_mamimo.h'))
     if not force and os.path.exists(_SO):

@@ -1,0 +1,723 @@
+#!/usr/bin/env python3
+"""band_kernel_gen.py - writes the gfx950 assembly of the fused pair-layer + regressor kernel ("band8").
+
+What the kernel computes (massiveMIMO_CSI_prediction_DNN.py:211-227, the shipped 2-hidden-layer network on the shared
+layer-0 path; operands as csi_load_weights prepares them for the split-f16 engine, gemm_hs.hip.h):
+
+    h1[m][k]   = relu(in_scale * L0[m / nt][k] + Ts[m % nt][k])                        (bn0 folded into W1 / bias1)
+    h2[m][n]   = out_scale * relu(acc_scale1 * sum_k split(h1)[m][k] * W1[n][k] + bias1[n])      (bn1 folded into W2 / bias2)
+    out[m][o]  = acc_scale2 * sum_n split(h2)[m][n] * W2[o][n] + bias2[o]
+
+with every product a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16.  h2 never leaves the registers.
+
+Why assembly.  The C++ form of the same idea (gemm_hs_band.hip.h, 4 waves x 512 registers) is correct but (a) hipcc
+copies / spills whole accumulator sets once both fill the AGPR file, and (b) measured (profiles/r03_band_probe_4wave.txt):
+a wave that is ALONE on its SIMD pays for every VALU instruction in matrix-pipe time - the MFMA + weight-stream skeleton
+runs 1.19 ms per 262144 rows, the full kernel 1.9-2.0, the difference being the operand conversion.  So this kernel keeps
+TWO waves per SIMD that share their 32 activation rows and split the output features:
+
+  workgroup = 8 waves = one band of 128 pair rows.  wave w: row group rg = w & 3 (rows 32 rg .. +31), half h = w >> 2.
+  Waves w and w + 4 sit on the same SIMD.  In a column step of 256 features half h owns feature tiles 4h .. 4h+3 of stage 1
+  (64 accumulator registers) and output tiles 4h .. 4h+3 of stage 2 (64 more, alive across the column steps): 128 AGPRs,
+  and < 128 VGPRs for fragments, look-ahead values and addresses - 256 registers per wave, two waves per SIMD.
+
+  MFMA operands are swapped (A = weight fragment, B = activation fragment), so lane = activation row and a lane's 8
+  accumulator registers of 16 consecutive features are - after bias / relu / split - the B operand of the regressor
+  product in the k order {0-3, 8-11 | 4-7, 12-15}; the regressor weights are stored in that order (hs_band_kperm).
+  The activation fragment of a sub-step (32 rows x 16 k, hi + lo = 8 registers) is needed by BOTH waves of a pair: one
+  of them produces it (VALU, while the partner's MFMAs keep the SIMD's matrix pipe busy), leaves a copy in a 2 KiB LDS
+  slot, and the partner reads it behind the sub-step's barrier.  Producers alternate: stage-1 fragment u by half u & 1,
+  stage-2 fragment q by the half that owns its accumulator tile.
+
+  The LDS carries the weight stream (ring of 4 sub-tiles of 16 KiB = [256 rows][16 k as hi | lo], 4 sub-steps ahead,
+  2 LDS-DMA pieces per wave and sub-step), the fragment exchange (16 KiB) and the two bias tables.
+
+Every vector-memory wait is a counted s_waitcnt vmcnt(N); N comes from a simulation of each role's in-order queue over
+every control-flow path (the minimum over the paths is taken, which is always safe).
+
+Usage: band_kernel_gen.py out.s            (then: clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c; ld.lld -shared)
+"""
+import re
+import sys
+
+# ----------------------------------------------------------------------------------------------- layout constants
+RING_SLOT = 16384
+AX_OFF = 4 * RING_SLOT            # fragment exchange: [rg][parity][hi | lo][64 lanes x 16 B]
+BIAS1_OFF = AX_OFF + 16384        # out_scale * bias1 [N1], then bias2 [256]
+KARG_BYTES = 128
+MAX_N1 = 4096                     # static LDS: ring + exchange + bias tables for up to this many hidden features
+LDS_BYTES = BIAS1_OFF + 4 * MAX_N1 + 1024
+
+# scalar registers
+S_L0, S_TS, S_W1, S_B1, S_W2, S_B2, S_OUT, S_PEAK = 4, 6, 8, 10, 12, 14, 16, 18
+S_STAMPS, S_LDL, S_NT, S_LDB1, S_M, S_K1, S_N1, S_LDB2, S_N2, S_LDO = 20, 22, 23, 24, 25, 26, 27, 28, 29, 30
+S_INSC, S_AS1OS, S_OUTSC, S_AS2, S_MAGIC = 31, 32, 33, 34, 35
+S_WAVE, S_RG, S_H, S_M0 = 36, 37, 38, 39
+S_W1P, S_W2P, S_L0P, S_TSP = 40, 42, 44, 46
+S_TRIP, S_COL, S_NCOL, S_NSUB1, S_DMA = 48, 49, 50, 51, 52
+S_T = 54                          # s54..s63 scratch
+S_ROWMASK, S_SAVE = 64, 66
+S_COLBYTES, S_BIAS2OFF, S_DMA2 = 68, 69, 70
+
+# vector registers (arch half: v0..v127)
+V_TID, V_LANE = 0, 1
+V_WHI, V_WLO = 2, 18
+V_AHI, V_ALO = (34, 42), (38, 46)
+V_LV, V_TV, V_GV, V_BQ = 50, 58, 66, 74
+V_RDHI, V_RDLO, V_AX, V_LOFF, V_TOFF, V_PK1, V_PK2, V_BADDR = 82, 83, 84, 85, 86, 91, 92, 93
+V_VO1, V_VO2 = 117, 121           # LDS-DMA offsets: [own piece 0, own piece 1, partner's piece 0, partner's piece 1]
+V_T = 94                          # v94..v109 scratch
+V_OUTOFF, V_M, V_4HI, V_B2ADDR, V_HI, V_L31 = 110, 112, 113, 114, 115, 116
+ACC1, ACC2 = 0, 64                # AGPR bases
+
+
+def sreg(i, n=1):
+    return 's%d' % i if n == 1 else 's[%d:%d]' % (i, i + n - 1)
+
+
+def vreg(i, n=1):
+    return 'v%d' % i if n == 1 else 'v[%d:%d]' % (i, i + n - 1)
+
+
+def areg(i, n=1):
+    return 'a%d' % i if n == 1 else 'a[%d:%d]' % (i, i + n - 1)
+
+
+class Wait:
+    """placeholder of a counted vmcnt wait; `needs` = tags whose last issued operation must have completed"""
+
+    def __init__(self, needs):
+        self.needs = set(needs)
+        self.n = None              # min over the simulated paths
+
+    def text(self):
+        return '  s_waitcnt vmcnt(%d)' % min(self.n if self.n is not None else 0, 63)
+
+
+class Block:
+    def __init__(self, name):
+        self.name = name
+        self.items = []            # str | Wait | ('vm', tag)
+
+    def e(self, s):
+        self.items.append('  ' + s)
+
+    def label(self, s):
+        self.items.append(s + ':')
+
+    def vm(self, s, tag):
+        self.items.append('  ' + s)
+        self.items.append(('vm', tag))
+
+    def wait_vm(self, needs):
+        w = Wait(needs)
+        self.items.append(w)
+        return w
+
+
+def simulate(blocks_in_order, queue=None):
+    """walk the blocks in execution order; every Wait gets n = min(n, operations younger than its newest needed one)"""
+    q = list(queue or [])
+    for b in blocks_in_order:
+        for it in b.items:
+            if isinstance(it, tuple):
+                q.append(it[1])
+            elif isinstance(it, Wait):
+                pos = -1
+                for i, t in enumerate(q):
+                    if t in it.needs:
+                        pos = i
+                if pos >= 0:
+                    n = len(q) - 1 - pos
+                    it.n = n if it.n is None else min(it.n, n)
+                    q = q[pos + 1:]
+                elif it.n is None:
+                    it.n = 63      # nothing of it in flight on this path
+    return q
+
+
+class Role:
+    """straight-line program of one wave half (h = 0 / 1)"""
+
+    def __init__(self, h, dbg):
+        self.h = h
+        self.dbg = dbg
+        self.uid = 0
+
+    # ---------------------------------------------------------------- pieces of code
+    def mfma(self, b, acc, w, a, zero_c=False):
+        b.e('v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (areg(acc, 16), vreg(w, 4), vreg(a, 4), '0' if zero_c else areg(acc, 16)))
+
+    def read_w(self, b, plane, slot):
+        base, addr = (V_WLO, V_RDLO) if plane else (V_WHI, V_RDHI)
+        if 'noread' in self.dbg:
+            return
+        for jj in range(4):
+            b.e('ds_read_b128 %s, %s offset:%d' % (vreg(base + 4 * jj, 4), vreg(addr), slot * RING_SLOT + jj * 2048))
+
+    def request(self, b, mode):
+        """4 x 16 B per lane of L0 / Ts for this role's next stage-1 fragment; mode 'reset': first of a column"""
+        if mode == 'reset':
+            for p, src in ((S_L0P, S_L0), (S_TSP, S_TS)):
+                b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), 64 * self.h))
+                b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(src + 1)))
+        if 'noreq' not in self.dbg:
+            b.vm('global_load_dwordx4 %s, %s, %s' % (vreg(V_LV, 4), vreg(V_LOFF), sreg(S_L0P, 2)), 'V')
+            b.vm('global_load_dwordx4 %s, %s, %s offset:16' % (vreg(V_LV + 4, 4), vreg(V_LOFF), sreg(S_L0P, 2)), 'V')
+            b.vm('global_load_dwordx4 %s, %s, %s' % (vreg(V_TV, 4), vreg(V_TOFF), sreg(S_TSP, 2)), 'V')
+            b.vm('global_load_dwordx4 %s, %s, %s offset:16' % (vreg(V_TV + 4, 4), vreg(V_TOFF), sreg(S_TSP, 2)), 'V')
+        for p in (S_L0P, S_TSP):
+            b.e('s_add_u32 %s, %s, 128' % (sreg(p), sreg(p)))
+            b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(p + 1)))
+
+    def pieces(self, b, kind, slot, who='own'):
+        """LDS-DMA pieces of the next sub-tile of the stream (kind 's1' / 's2') into ring slot `slot`: who = 'own' (this
+        wave's 2), 'all' (its own and its partner's: the wave that does not convert in this sub-step takes both), 'none'"""
+        ptr, vo = (S_W1P, V_VO1) if kind == 's1' else (S_W2P, V_VO2)
+        if 'nodma' not in self.dbg and who != 'none':
+            for p in range(4 if who == 'all' else 2):
+                b.e('s_add_u32 m0, %s, %d' % (sreg(S_DMA if p < 2 else S_DMA2), slot * RING_SLOT + (p & 1) * 1024))
+                b.e('s_nop 0')
+                b.vm('global_load_lds_dwordx4 %s, %s' % (vreg(vo + p), sreg(ptr, 2)), 'P%d' % slot)
+        b.e('s_add_u32 %s, %s, 64' % (sreg(ptr), sreg(ptr)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1)))
+
+    def convert(self, b, kind, par_next, jj=0, g=0):
+        """fragment of the NEXT sub-step into a_hi / a_lo [par_next] and the exchange slot.  kind 't1': from the requested
+        L0 / Ts values; 't2': from stage-1 accumulator tile jj, registers 8 g .. 8 g + 7"""
+        ahi, alo = V_AHI[par_next], V_ALO[par_next]
+        pk = V_PK1 if kind == 't1' else V_PK2
+        if 'noconv' not in self.dbg:
+            if kind == 't1':
+                b.wait_vm({'V'})
+                for e in range(8):
+                    b.e('v_fma_f32 %s, %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + e), sreg(S_INSC), vreg(V_TV + e)))
+            else:
+                imm = (128 * self.h + 32 * jj + 16 * g) * 4
+                b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ, 4), vreg(V_BADDR), imm))
+                b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ + 4, 4), vreg(V_BADDR), imm + 32))
+                for e in range(8):
+                    b.e('v_accvgpr_read_b32 %s, %s' % (vreg(V_GV + e), areg(ACC1 + 16 * jj + 8 * g + e)))
+                b.e('s_waitcnt lgkmcnt(0)')
+                for e in range(8):
+                    b.e('v_fma_f32 %s, %s, %s, %s' % (vreg(V_GV + e), vreg(V_GV + e), sreg(S_AS1OS), vreg(V_BQ + e)))
+            for e in range(8):
+                b.e('v_max_f32_e32 %s, 0, %s' % (vreg(V_GV + e), vreg(V_GV + e)))
+            for p in range(4):
+                b.e('v_cvt_pk_f16_f32 %s, %s, %s' % (vreg(ahi + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
+            # lo halves: f16(x - hi) through v_fma_mix (hs_lo_pair); dependent op_sel / packed operations are never adjacent
+            for p in range(4):
+                b.e('v_fma_mixlo_f16 %s, %s, -1.0, %s op_sel_hi:[1,0,0]' % (vreg(alo + p), vreg(ahi + p), vreg(V_GV + 2 * p)))
+                b.e('v_pk_max_u16 %s, %s, %s' % (vreg(pk), vreg(pk), vreg(ahi + p)))
+            for p in range(4):
+                b.e('v_fma_mixhi_f16 %s, %s, -1.0, %s op_sel:[1,0,0] op_sel_hi:[1,0,0]' % (vreg(alo + p), vreg(ahi + p), vreg(V_GV + 2 * p + 1)))
+        b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(ahi, 4), par_next * 2048))
+        b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(alo, 4), par_next * 2048 + 1024))
+
+    def read_frag(self, b, par_next):
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_AHI[par_next], 4), vreg(V_AX), par_next * 2048))
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_ALO[par_next], 4), vreg(V_AX), par_next * 2048 + 1024))
+
+    def barrier(self, b):
+        if 'nobarrier' not in self.dbg:
+            b.e('s_barrier')
+
+    def substep(self, b, kind, slot, par, first=False, produce=None, consume=False, request=None, piece='s1', pre_piece=None, who='own'):
+        """kind 1 / 2: which accumulator set this sub-step's 12 MFMAs feed"""
+        acc = ACC1 if kind == 1 else ACC2
+        nslot = (slot + 1) & 3
+        b.e('s_waitcnt lgkmcnt(0)')                       # w_lo of this sub-tile, the fragment read behind the last barrier
+        self.read_w(b, 0, slot)                           # w_hi: the sub-tile is visible since the last barrier
+        if produce is not None:
+            self.convert(b, produce[0], par ^ 1, *produce[1:])
+        if request is not None:
+            self.request(b, request)
+        def P(ph):
+            for jj in range(4):
+                if ph == 0:                               # P0: w_lo x a_hi
+                    self.mfma(b, acc + 16 * jj, V_WLO + 4 * jj, V_AHI[par], zero_c=first)
+                elif ph == 1:                             # P1: w_hi x a_hi
+                    self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_AHI[par])
+                else:                                     # P2: w_hi x a_lo
+                    self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_ALO[par])
+
+        def sync():
+            b.e('s_waitcnt lgkmcnt(0)')                   # w_hi in registers (the slot may be refilled), exchange slot written
+            b.wait_vm({'P%d' % nslot})                    # this wave's pieces of the next sub-tile have landed
+            self.barrier(b)                               # -> sub-tile s + 1 and fragment s + 1 visible, slot s free
+
+        def after():
+            if pre_piece:
+                for ln in pre_piece:
+                    b.e(ln)
+            self.pieces(b, piece, slot, who)
+            self.read_w(b, 1, nslot)
+            if consume:
+                self.read_frag(b, par ^ 1)
+
+        # The two waves of a SIMD (half 0 / half 1 of a row group) meet at ONE barrier per sub-step but sit at different
+        # places of their MFMA sequence when they do: half 0 has 8 of its 12 MFMAs in front of it, half 1 four - so one
+        # wave's reads / LDS-DMA / conversion run beside the other's MFMAs instead of beside its reads.
+        if self.h == 0 or 'nostagger' in self.dbg:
+            P(0)
+            b.e('s_waitcnt lgkmcnt(0)')
+            P(1)
+            sync()
+            after()
+            P(2)
+        else:
+            P(0)
+            sync()
+            P(1)
+            after()
+            P(2)
+
+    # ---------------------------------------------------------------- the role's program
+    def build(self):
+        h = self.h
+        L = lambda s: 'L_r%d_%s' % (h, s)
+        pro, head, loop, last, bub, st2, tail = (Block(n) for n in ('pro', 'head', 'loop', 'last', 'bub', 'st2', 'tail'))
+
+        # ---- prologue: the state a column step starts from
+        b = pro
+        b.label(L('start'))
+        for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
+            b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
+            b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
+        for t in range(4):
+            self.pieces(b, 's1', t)
+        if h == 0:
+            self.request(b, 'reset')
+            self.convert(b, 't1', 0)
+            self.request(b, 'advance')
+        else:
+            self.request(b, 'reset')
+        b.wait_vm({'P0'})
+        b.e('s_waitcnt lgkmcnt(0)')
+        self.barrier(b)
+        if h == 1:
+            self.read_frag(b, 0)
+        self.read_w(b, 1, 0)
+        b.e('s_mov_b32 %s, 0' % sreg(S_COL))
+
+        # ---- stage 1.  Fragment u + 1 is produced during sub-step u by half (u + 1) & 1; its producer then requests the
+        # values of fragment u + 3.  u_rel = position inside a trip of four, flags say what still exists near the column end.
+        def s1_substep(b, i, first=False, produce_ok=True, request_ok=True, piece='s1'):
+            prod = ((i + 1) & 1) == h and produce_ok
+            cons = ((i + 1) & 1) != h and produce_ok
+            who = 'none' if prod else ('all' if cons else 'own')       # the converting wave leaves the LDS-DMA to its partner
+            if 'ownpieces' in self.dbg:
+                who = 'own'
+            self.substep(b, 1, i & 3, i & 1, first=first, produce=('t1',) if prod else None, consume=cons,
+                         request='advance' if (prod and request_ok) else None, piece=piece, who=who)
+
+        head.label(L('col'))
+        for i in range(4):
+            s1_substep(head, i, first=(i == 0))
+        head.e('s_lshr_b32 %s, %s, 2' % (sreg(S_TRIP), sreg(S_NSUB1)))
+        head.e('s_sub_u32 %s, %s, 2' % (sreg(S_TRIP), sreg(S_TRIP)))
+        head.e('s_cmp_eq_u32 %s, 0' % sreg(S_TRIP))
+        head.e('s_cbranch_scc1 %s' % L('last'))
+        loop.items.append('  .p2align 6')
+        loop.label(L('loop'))
+        for i in range(4):
+            s1_substep(loop, i)
+        loop.e('s_sub_u32 %s, %s, 1' % (sreg(S_TRIP), sreg(S_TRIP)))
+        loop.e('s_cmp_lg_u32 %s, 0' % sreg(S_TRIP))
+        loop.e('s_cbranch_scc1 %s' % L('loop'))
+        last.label(L('last'))
+        for i in range(4):
+            s1_substep(last, i, produce_ok=(i < 3), request_ok=(i == 0), piece='s2')
+
+        # ---- first fragment of stage 2 (features 0..15 of the column step, tile 0 of half 0) needs the finished accumulators
+        if h == 0:
+            bub.e('s_nop 15')
+            bub.e('s_nop 15')
+            self.convert(bub, 't2', 0, 0, 0)
+            bub.e('s_waitcnt lgkmcnt(0)')
+            self.barrier(bub)
+        else:
+            self.barrier(bub)
+            self.read_frag(bub, 0)
+
+        # ---- stage 2: sub-step q consumes fragment q (tile q >> 1, half q & 1 of its 16-feature groups)
+        for q in range(16):
+            nq = q + 1
+            produce, consume, request, pre = None, False, None, None
+            if nq <= 15:
+                owner = 0 if nq <= 7 else 1
+                if owner == h:
+                    produce = ('t2', (nq >> 1) - 4 * h, nq & 1)
+                else:
+                    consume = True
+            else:                                          # fragment 0 of the next column step (stage-1 kind), by half 0
+                if h == 0:
+                    produce, request = ('t1',), 'advance'
+                else:
+                    consume = True
+            if q == 13 and h == 0:
+                request = 'reset'
+            if q == 14 and h == 1:
+                request = 'reset'
+            piece = 's2' if q < 12 else 's1'
+            if q == 12:                                    # weight pointer of stage 1 moves to the next column step (wraps at the end)
+                pre = ['s_add_u32 %s, %s, 1' % (sreg(S_T), sreg(S_COL)),
+                       's_cmp_ge_u32 %s, %s' % (sreg(S_T), sreg(S_NCOL)),
+                       's_cselect_b32 %s, 0, %s' % (sreg(S_T), sreg(S_T)),
+                       's_mul_i32 %s, %s, %s' % (sreg(S_T + 1), sreg(S_T), sreg(S_COLBYTES)),
+                       's_add_u32 %s, %s, %s' % (sreg(S_W1P), sreg(S_W1), sreg(S_T + 1)),
+                       's_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1 + 1))]
+            who = 'none' if produce is not None else ('all' if consume else 'own')
+            if 'ownpieces' in self.dbg:
+                who = 'own'
+            self.substep(st2, 2, q & 3, q & 1, produce=produce, consume=consume, request=request, piece=piece, pre_piece=pre, who=who)
+        tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
+        tail.e('s_add_u32 %s, %s, 1' % (sreg(S_COL), sreg(S_COL)))
+        tail.e('s_cmp_lt_u32 %s, %s' % (sreg(S_COL), sreg(S_NCOL)))
+        tail.e('s_cbranch_scc1 %s' % L('col'))
+        tail.e('s_branch L_epilogue_%d' % h)
+
+        # ---- counted waits: every path through the loops
+        col0 = [head, last, bub, st2, tail]
+        col1 = [head, loop, last, bub, st2, tail]
+        col2 = [head, loop, loop, last, bub, st2, tail]
+        for first_col in (col0, col1, col2):
+            for second_col in (col0, col1, col2):
+                simulate([pro] + first_col + second_col + second_col)
+        return [pro, head, loop, last, bub, st2, tail]
+
+
+def stamp(b, i, uid):
+    """wave 0, lane 0: (shader cycles, wall ticks) into stamps[(workgroup * 6 + i) * 2 ..]"""
+    skip = 'L_stamp_skip_%d' % uid
+    b.e('s_cmp_eq_u64 %s, 0' % sreg(S_STAMPS, 2))
+    b.e('s_cbranch_scc1 %s' % skip)
+    b.e('s_cmp_lg_u32 %s, 0' % sreg(S_WAVE))
+    b.e('s_cbranch_scc1 %s' % skip)
+    b.e('s_memtime %s' % sreg(S_T, 2))
+    b.e('s_memrealtime %s' % sreg(S_T + 2, 2))
+    b.e('s_mul_i32 %s, s2, 96' % sreg(S_T + 4))
+    b.e('s_waitcnt lgkmcnt(0)')
+    b.e('s_mov_b64 %s, exec' % sreg(S_SAVE, 2))
+    b.e('s_mov_b64 exec, 1')
+    for k in range(4):
+        b.e('v_mov_b32_e32 %s, %s' % (vreg(V_T + k), sreg(S_T + k)))
+    b.e('v_mov_b32_e32 %s, %s' % (vreg(V_T + 4), sreg(S_T + 4)))
+    b.e('global_store_dwordx4 %s, %s, %s offset:%d' % (vreg(V_T + 4), vreg(V_T, 4), sreg(S_STAMPS, 2), 16 * i))
+    b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+    b.label(skip)
+
+
+def common_prologue(b, dbg=()):
+    b.e('s_load_dwordx16 %s, s[0:1], 0x0' % sreg(4, 16))
+    b.e('s_load_dwordx16 %s, s[0:1], 0x40' % sreg(20, 16))
+    b.e('s_waitcnt lgkmcnt(0)')
+    b.e('v_and_b32_e32 %s, 63, v0' % vreg(V_LANE))
+    b.e('v_readfirstlane_b32 %s, v0' % sreg(S_WAVE))
+    b.e('s_nop 4')
+    b.e('s_lshr_b32 %s, %s, 6' % (sreg(S_WAVE), sreg(S_WAVE)))
+    b.e('s_and_b32 %s, %s, 3' % (sreg(S_RG), sreg(S_WAVE)))
+    b.e('s_lshr_b32 %s, %s, 2' % (sreg(S_H), sreg(S_WAVE)))
+    b.e('s_lshl_b32 %s, s2, 7' % sreg(S_M0))
+    if 'dump0' in dbg:         # bring-up: count the waves that arrive, leave a few raw registers
+        b.e('s_mov_b64 exec, 1')
+        b.e('v_mov_b32_e32 %s, 0' % vreg(V_T))
+        b.e('v_mov_b32_e32 %s, 1' % vreg(V_T + 1))
+        b.e('global_atomic_add %s, %s, %s' % (vreg(V_T), vreg(V_T + 1), sreg(S_PEAK, 2)))
+        for k, src in enumerate(('s2', 's3', sreg(S_M), sreg(S_WAVE), sreg(S_RG), sreg(S_H), sreg(S_M0), sreg(S_MAGIC))):
+            b.e('v_mov_b32_e32 %s, %s' % (vreg(V_T + 1), src))
+            b.e('global_store_dword %s, %s, %s offset:%d' % (vreg(V_T), vreg(V_T + 1), sreg(S_PEAK, 2), 4 + 4 * k))
+        b.e('global_store_dword %s, v0, %s offset:%d' % (vreg(V_T), sreg(S_PEAK, 2), 40))
+        b.e('s_waitcnt vmcnt(0)')
+        b.e('s_endpgm')
+    b.e('s_cmp_ge_i32 %s, %s' % (sreg(S_M0), sreg(S_M)))
+    b.e('s_cbranch_scc1 L_end')
+    if 'exit0' in dbg:
+        b.e('s_branch L_end')
+    stamp(b, 0, 0)
+    b.e('s_lshr_b32 %s, %s, 4' % (sreg(S_NSUB1), sreg(S_K1)))
+    b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_NCOL), sreg(S_N1)))
+    b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_COLBYTES), sreg(S_LDB1)))        # 256 rows x ldb1 halves x 2 B
+    b.e('s_lshl_b32 %s, %s, 11' % (sreg(S_DMA), sreg(S_WAVE)))            # this wave's 2 pieces: image rows 32 w ..
+    # ---- bias tables: bias1s[i] = out_scale * bias1[i] (i < N1), bias2s[i] = bias2[i] (i < n2, else 0; 256 entries)
+    b.e('s_mov_b32 %s, 0' % sreg(S_T))
+    b.label('L_b1')
+    b.e('v_add_u32_e32 %s, %s, v0' % (vreg(V_T), sreg(S_T)))
+    b.e('v_cmp_gt_u32_e32 vcc, %s, %s' % (sreg(S_N1), vreg(V_T)))
+    b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+    b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 1), vreg(V_T)))
+    b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B1, 2)))
+    b.e('s_waitcnt vmcnt(0)')
+    b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_OUTSC), vreg(V_T + 2)))
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 1), BIAS1_OFF, vreg(V_T + 1)))
+    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 1), vreg(V_T + 2)))
+    b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+    b.e('s_add_u32 %s, %s, 512' % (sreg(S_T), sreg(S_T)))
+    b.e('s_cmp_lt_u32 %s, %s' % (sreg(S_T), sreg(S_N1)))
+    b.e('s_cbranch_scc1 L_b1')
+    b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_BIAS2OFF), sreg(S_N1)))
+    b.e('s_add_u32 %s, %s, %d' % (sreg(S_BIAS2OFF), sreg(S_BIAS2OFF), BIAS1_OFF))
+    b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
+    b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))
+    b.e('v_cmp_gt_u32_e32 vcc, %s, v0' % sreg(S_N2))
+    b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+    b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B2, 2)))
+    b.e('s_waitcnt vmcnt(0)')
+    b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+    b.e('v_cmp_gt_u32_e32 vcc, 256, v0')
+    b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), sreg(S_BIAS2OFF), vreg(V_T + 1)))
+    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 1), vreg(V_T + 2)))
+    b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+    # ---- this lane's row: m = m0 + 32 rg + l31 (clamped for the loads), pr = m / nt, t = m - pr * nt
+    b.e('v_and_b32_e32 %s, 31, %s' % (vreg(V_L31), vreg(V_LANE)))
+    b.e('v_lshrrev_b32_e32 %s, 5, %s' % (vreg(V_HI), vreg(V_LANE)))
+    b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T), sreg(S_RG)))
+    b.e('s_add_u32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_M0)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_M), sreg(S_T), vreg(V_L31)))
+    b.e('v_cmp_gt_i32_e32 vcc, %s, %s' % (sreg(S_M), vreg(V_M)))
+    b.e('s_mov_b64 %s, vcc' % sreg(S_ROWMASK, 2))
+    b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_M)))
+    b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(V_M)))
+    b.e('v_mul_hi_u32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T), sreg(S_MAGIC)))          # q <= m / nt <= q + 1
+    b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_NT)))
+    b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T), vreg(V_T + 2)))          # r = m - q nt
+    b.e('v_cmp_le_u32_e32 vcc, %s, %s' % (sreg(S_NT), vreg(V_T + 3)))
+    b.e('v_cndmask_b32_e64 %s, 0, 1, vcc' % vreg(V_T + 4))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 4)))
+    b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 4), vreg(V_T + 4), sreg(S_NT)))
+    b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T + 3), vreg(V_T + 4)))
+    for dst, idx in ((V_LOFF, V_T + 1), (V_TOFF, V_T + 3)):
+        b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 5), vreg(idx), sreg(S_LDL)))
+        b.e('v_lshl_add_u32 %s, %s, 3, %s' % (vreg(V_T + 5), vreg(V_HI), vreg(V_T + 5)))
+        b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(dst), vreg(V_T + 5)))
+    # ---- weight fragment reads: row (128 h + 32 jj + l31) of the image, 16-byte chunk ((2 plane + hi) ^ ((l31 >> 2) & 3))
+    b.e('v_bfe_u32 %s, %s, 2, 2' % (vreg(V_T), vreg(V_L31)))
+    b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_HI), vreg(V_T)))
+    b.e('v_or_b32_e32 %s, 2, %s' % (vreg(V_T + 2), vreg(V_HI)))
+    b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 2), vreg(V_T)))
+    b.e('v_lshlrev_b32_e32 %s, 6, %s' % (vreg(V_T + 3), vreg(V_L31)))
+    b.e('s_lshl_b32 %s, %s, 13' % (sreg(S_T), sreg(S_H)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 3), sreg(S_T), vreg(V_T + 3)))
+    b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_RDHI), vreg(V_T + 1), vreg(V_T + 3)))
+    b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_RDLO), vreg(V_T + 2), vreg(V_T + 3)))
+    # ---- fragment exchange slot of this row group: lane-linear 16 B
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_AX), vreg(V_LANE)))
+    b.e('s_lshl_b32 %s, %s, 12' % (sreg(S_T), sreg(S_RG)))
+    b.e('s_add_u32 %s, %s, %d' % (sreg(S_T), sreg(S_T), AX_OFF))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_AX), sreg(S_T), vreg(V_AX)))
+    # ---- LDS-DMA pieces: image row 32 w + 16 p + (lane >> 2), chunk (lane & 3) ^ ((lane >> 4) & 3); for this wave (w) and
+    # for its partner on the SIMD (w ^ 4), whose pieces it issues in the sub-steps in which the partner converts
+    b.e('v_and_b32_e32 %s, 3, %s' % (vreg(V_T + 1), vreg(V_LANE)))
+    b.e('v_bfe_u32 %s, %s, 4, 2' % (vreg(V_T + 2), vreg(V_LANE)))
+    b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 2)))
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_T + 1), vreg(V_T + 1)))
+    b.e('s_xor_b32 %s, %s, 4' % (sreg(S_T + 1), sreg(S_WAVE)))
+    b.e('s_lshl_b32 %s, %s, 11' % (sreg(S_DMA2), sreg(S_T + 1)))
+    for k, wv in ((0, S_WAVE), (2, S_T + 1)):
+        b.e('v_lshrrev_b32_e32 %s, 2, %s' % (vreg(V_T), vreg(V_LANE)))
+        b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T), sreg(wv)))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(V_T)))
+        for vo, ld in ((V_VO1, S_LDB1), (V_VO2, S_LDB2)):
+            b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T), sreg(ld)))
+            b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(vo + k), vreg(V_T + 3), vreg(V_T + 1)))
+            b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T), sreg(ld)))
+            b.e('v_add_u32_e32 %s, %s, %s' % (vreg(vo + k + 1), sreg(S_T), vreg(vo + k)))
+    # ---- bias reads, output addressing, guards
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_BADDR), vreg(V_HI)))
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_BADDR), BIAS1_OFF, vreg(V_BADDR)))
+    b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_4HI), vreg(V_HI)))
+    b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_T), sreg(S_H)))                                 # 128 h floats = 512 h bytes
+    b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_B2ADDR), vreg(V_HI), sreg(S_BIAS2OFF)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_B2ADDR), sreg(S_T), vreg(V_B2ADDR)))
+    b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_OUTOFF), vreg(V_M), sreg(S_LDO)))
+    b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_OUTOFF), vreg(V_OUTOFF)))
+    b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_OUTOFF), vreg(V_HI), vreg(V_OUTOFF)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_OUTOFF), sreg(S_T), vreg(V_OUTOFF)))
+    b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK1))
+    b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK2))
+    for i in range(64):
+        b.e('v_accvgpr_write_b32 %s, 0' % areg(ACC2 + i))
+    b.e('s_waitcnt lgkmcnt(0)')
+    stamp(b, 1, 1)
+    if 'exit1' in dbg:
+        b.e('s_branch L_end')
+    if 'dump' in dbg:          # bring-up: workgroup 0, wave 0, lane 0 writes a few registers to the range-guard words
+        b.e('s_cmp_lg_u32 s2, 0')
+        b.e('s_cbranch_scc1 L_end')
+        b.e('s_cmp_lg_u32 %s, 0' % sreg(S_WAVE))
+        b.e('s_cbranch_scc1 L_end')
+        b.e('s_mov_b64 exec, 1')
+        b.e('v_mov_b32_e32 %s, 0' % vreg(V_T))
+        for k, src in enumerate((sreg(S_OUT), sreg(S_OUT + 1), sreg(S_LDO), sreg(S_M), sreg(S_N2), sreg(S_PEAK), sreg(S_PEAK + 1), sreg(S_STAMPS))):
+            b.e('v_mov_b32_e32 %s, %s' % (vreg(V_T + 1), src))
+            b.e('global_store_dword %s, %s, %s offset:%d' % (vreg(V_T), vreg(V_T + 1), sreg(S_PEAK, 2), 4 * k))
+        for k, src in enumerate((V_OUTOFF, V_M, V_B2ADDR, V_LOFF, V_TOFF, V_VO1, V_VO2, V_RDHI)):
+            b.e('global_store_dword %s, %s, %s offset:%d' % (vreg(V_T), vreg(src), sreg(S_PEAK, 2), 32 + 4 * k))
+        b.e('s_waitcnt vmcnt(0)')
+        b.e('s_branch L_end')
+    if 'exit2' in dbg:
+        b.e('s_cmp_eq_u32 %s, 0' % sreg(S_H))
+        b.e('s_cbranch_scc1 L_epilogue_0')
+        b.e('s_branch L_epilogue_1')
+    b.e('s_cmp_eq_u32 %s, 0' % sreg(S_H))
+    b.e('s_cbranch_scc0 L_r1_start')
+
+
+def epilogue(b, h, dbg=()):
+    b.label('L_epilogue_%d' % h)
+    b.e('s_waitcnt vmcnt(0)')                 # the re-fetched head of the stream has landed: the ring may go
+    b.e('s_nop 15')
+    b.e('s_nop 15')
+    stamp(b, 2, 10 + h)
+    # ---- range guard (hs_report_peak): pk1 = this lane's row maximum of |h1| hi halves, pk2 = of |h2| hi halves
+    b.e('s_cmp_eq_u64 %s, 0' % sreg(S_PEAK, 2))
+    b.e('s_cbranch_scc1 L_noguard_%d' % h)
+    if 'noguard' in dbg:
+        b.e('s_branch L_noguard_%d' % h)
+    for pk, row_max in ((V_PK1, True), (V_PK2, False)):
+        b.e('v_lshrrev_b32_e32 %s, 16, %s' % (vreg(V_T), vreg(pk)))
+        b.e('v_and_b32_e32 %s, 0xffff, %s' % (vreg(V_T + 1), vreg(pk)))
+        b.e('v_max_u32_e32 %s, %s, %s' % (vreg(V_T), vreg(V_T), vreg(V_T + 1)))
+        b.e('v_min_u32_e32 %s, 0x7c00, %s' % (vreg(V_T), vreg(V_T)))
+        b.e('v_cvt_f32_f16_e32 %s, %s' % (vreg(V_T + 1), vreg(V_T)))
+        b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
+        b.e('v_cmp_lt_f32_e32 vcc, 0x476a6000, %s' % vreg(V_T + 1))                 # 60000.0 < m
+        b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+        b.e('global_atomic_umax %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_PEAK, 2)))
+        b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+        if row_max:
+            b.e('v_cmp_lt_f32_e32 vcc, 0, %s' % vreg(V_T + 1))
+            b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+            b.e('v_cmp_gt_f32_e32 vcc, 0x3d800000, %s' % vreg(V_T + 1))              # m < 0.0625
+            b.e('s_and_b64 exec, exec, vcc')
+            b.e('v_mov_b32_e32 %s, 1' % vreg(V_T + 3))
+            b.e('global_atomic_or %s, %s, %s offset:4' % (vreg(V_T + 2), vreg(V_T + 3), sreg(S_PEAK, 2)))
+            b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+    b.label('L_noguard_%d' % h)
+    if 'nostore' in dbg:
+        b.e('s_branch L_end')
+    # ---- output: lane = row, register quad = 4 consecutive outputs (columns 128 h + 32 jj + 8 rq + 4 hi + e)
+    b.e('s_mov_b64 exec, %s' % sreg(S_ROWMASK, 2))
+    for jj in range(4):
+        for rq in range(4):
+            c0 = 128 * h + 32 * jj + 8 * rq                 # + 4 hi + e
+            imm = (32 * jj + 8 * rq) * 4
+            uid = 'L_o%d_%d_%d' % (h, jj, rq)
+            b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_T + 4, 4), vreg(V_B2ADDR), imm))
+            for e in range(4):
+                b.e('v_accvgpr_read_b32 %s, %s' % (vreg(V_T + e), areg(ACC2 + 16 * jj + 4 * rq + e)))
+            b.e('s_waitcnt lgkmcnt(0)')
+            for e in range(4):
+                b.e('v_fma_f32 %s, %s, %s, %s' % (vreg(V_T + e), vreg(V_T + e), sreg(S_AS2), vreg(V_T + 4 + e)))
+            # whole chunk (both hi halves) inside n2 ?
+            b.e('s_cmp_ge_u32 %s, %d' % (sreg(S_N2), c0 + 8))
+            b.e('s_cbranch_scc0 %s_m' % uid)
+            b.e('global_store_dwordx2 %s, %s, %s offset:%d' % (vreg(V_OUTOFF), vreg(V_T, 2), sreg(S_OUT, 2), imm))
+            b.e('global_store_dwordx2 %s, %s, %s offset:%d' % (vreg(V_OUTOFF), vreg(V_T + 2, 2), sreg(S_OUT, 2), imm + 8))
+            b.e('s_branch %s_d' % uid)
+            b.label('%s_m' % uid)
+            for e in range(4):
+                b.e('s_sub_i32 %s, %s, %d' % (sreg(S_T), sreg(S_N2), c0 + e))          # column valid <=> 4 hi < n2 - c0 - e
+                b.e('v_cmp_gt_i32_e32 vcc, %s, %s' % (sreg(S_T), vreg(V_4HI)))
+                b.e('s_and_b64 exec, vcc, %s' % sreg(S_ROWMASK, 2))
+                b.e('global_store_dword %s, %s, %s offset:%d' % (vreg(V_OUTOFF), vreg(V_T + e), sreg(S_OUT, 2), imm + 4 * e))
+            b.e('s_mov_b64 exec, %s' % sreg(S_ROWMASK, 2))
+            b.label('%s_d' % uid)
+    b.e('s_mov_b64 exec, -1')
+    stamp(b, 3, 20 + h)
+    b.e('s_branch L_end')
+
+
+def kernel(name, dbg=()):
+    out = ['.globl %s' % name, '.p2align 8', '.type %s,@function' % name, '%s:' % name]
+    pre = Block('common')
+    common_prologue(pre, dbg)
+    blocks = [pre]
+    r0 = Role(0, dbg).build()
+    r1 = Role(1, dbg).build()
+    e0, e1 = Block('ep0'), Block('ep1')
+    epilogue(e0, 0, dbg)
+    epilogue(e1, 1, dbg)
+    blocks += r0 + [e0] + r1 + [e1]
+    end = Block('end')
+    end.label('L_end')
+    end.e('s_endpgm')
+    blocks.append(end)
+    for b in blocks:
+        for it in b.items:
+            if isinstance(it, tuple):
+                continue
+            out.append(it.text() if isinstance(it, Wait) else it)
+    text = '\n'.join(out)
+    return re.sub(r'\bL_\w+', lambda m: name + '_' + m.group(0), text)      # labels are per kernel
+
+
+DESCRIPTOR = '''
+.rodata
+.p2align 6
+.amdhsa_kernel {name}
+  .amdhsa_group_segment_fixed_size {lds}
+  .amdhsa_private_segment_fixed_size 0
+  .amdhsa_kernarg_size {karg}
+  .amdhsa_user_sgpr_count 2
+  .amdhsa_user_sgpr_kernarg_segment_ptr 1
+  .amdhsa_system_sgpr_workgroup_id_x 1
+  .amdhsa_system_vgpr_workitem_id 0
+  .amdhsa_next_free_vgpr 256
+  .amdhsa_next_free_sgpr 96
+  .amdhsa_accum_offset 128
+  .amdhsa_reserve_vcc 1
+  .amdhsa_float_round_mode_32 0
+  .amdhsa_float_round_mode_16_64 0
+  .amdhsa_float_denorm_mode_32 3
+  .amdhsa_float_denorm_mode_16_64 3
+  .amdhsa_dx10_clamp 1
+  .amdhsa_ieee_mode 1
+  .amdhsa_tg_split 0
+.end_amdhsa_kernel
+.text
+'''
+
+META_KERNEL = '''  - .name: {name}
+    .symbol: {name}.kd
+    .kernarg_segment_size: {karg}
+    .kernarg_segment_align: 8
+    .group_segment_fixed_size: {lds}
+    .private_segment_fixed_size: 0
+    .wavefront_size: 64
+    .sgpr_count: 102
+    .vgpr_count: 256
+    .agpr_count: 128
+    .max_flat_workgroup_size: 512
+    .args:
+      - .offset: 0
+        .size: {karg}
+        .value_kind: by_value
+'''
+
+VARIANTS = [('csi_band8', ()), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
+            ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
+            ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
+            ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
+            ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else 'gemm_hs_band8_gfx950.s'
+    only = sys.argv[2:] or None
+    parts = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', '.text']
+    meta = []
+    for name, dbg in VARIANTS:
+        if only and name not in only:
+            continue
+        parts.append(kernel(name, dbg))
+        parts.append(DESCRIPTOR.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
+        meta.append(META_KERNEL.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
+    parts.append('.amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.target: amdgcn-amd-amdhsa--gfx950\namdhsa.kernels:\n' + ''.join(meta) + '...\n.end_amdgpu_metadata\n')
+    with open(path, 'w') as f:
+        f.write('\n'.join(parts))
+
+
+if __name__ == '__main__':
+    main()

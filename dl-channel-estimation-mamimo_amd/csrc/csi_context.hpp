@@ -15,6 +15,7 @@
 #include "gemm_f32.hip.h"
 #include "gemm_bf16.hip.h"
 #include "gemm_hs.hip.h"
+#include "gemm_hs_band.hip.h"
 #include "ls_estimate.hip.h"
 #include "lmmse.hip.h"
 #include "metrics.hip.h"
@@ -57,6 +58,8 @@ struct Layer {
     int ldwb = 0;
     uint16_t* Wh_f = nullptr; // regressor behind ONE per-pair layer: Wh with that layer's BN scale folded into its rows (fused kernel)
     int wshift_f = 0;
+    uint16_t* Wh_p = nullptr; // the same folded regressor weights, 256 rows (rows >= out zero), k permuted inside every group of 16
+                              // (hs_band_kperm): the fused band kernel (gemm_hs_band.hip.h / band_kernel_gen.py)
     int ashift_pre = 4;       // like ashift for this layer's relu output BEFORE BatchNormalization (its scale lives in the next weights)
     uint16_t* Wh = nullptr;   // [out][ldwh] split-f16 ("hs", gemm_hs.hip.h) copy of Wt * 2^wshift; layer 0: LTF columns only
     int ldwh = 0;             // halves per row = 2 * (in rounded up to 16)
@@ -99,6 +102,7 @@ struct ProfSpan {
 
 struct csi_trainer;          // csi_train.hpp
 struct csi_hostpipe;         // csi_hostpipe.hpp
+struct csi_comm;             // csi_comm.hpp
 
 struct csi_ctx {
     csi_config cfg;
@@ -108,6 +112,7 @@ struct csi_ctx {
     Model model[2];
     csi_trainer* trainer[2] = {nullptr, nullptr};   // on-box fine-tuning state per component model
     csi_hostpipe* hostpipe = nullptr;               // streams / pinned slots / host threads of the host-buffer entry points
+    csi_comm* comm = nullptr;                       // RCCL communicator of csi_comm_init (weight broadcast)
     int host_threads = 0;                           // "host_threads" option: threads of the user <-> pinned copies (0 = automatic)
     float* P = nullptr;          // device [nt][nt]
     float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)
@@ -155,6 +160,13 @@ struct csi_ctx {
                                  // partial sums the four column tiles exchange cost what the h2 round trip cost
     char* fuse_ws = nullptr;     // its partial-sum slabs + row-tile flags
     size_t fuse_ws_bytes = 0;
+    int hs_band = 1;             // "hs_band": two hidden layers -> first per-pair layer + regressor as ONE kernel, the assembly "band8"
+                                 // kernel of band_kernel_gen.py (h2 stays in registers; measured -4 .. -7 % against the two kernels,
+                                 // profiles/r03_band_probe.txt); 0 = the separate pair and regressor kernels
+    hipModule_t band_mod = nullptr;          // its code object (embedded in the library, loaded on first use)
+    hipFunction_t band_fn = nullptr;
+    bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
+    int64_t band_launches = 0;
     int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024: 40 packets); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
@@ -282,6 +294,7 @@ void free_layer(Layer& l) {
     if (l.Wb) hipFree(l.Wb);
     if (l.Wh) hipFree(l.Wh);
     if (l.Wh_f) hipFree(l.Wh_f);
+    if (l.Wh_p) hipFree(l.Wh_p);
     if (l.bias) hipFree(l.bias);
     if (l.bias_hs) hipFree(l.bias_hs);
     if (l.scale) hipFree(l.scale);

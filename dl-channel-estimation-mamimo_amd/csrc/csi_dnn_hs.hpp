@@ -192,6 +192,29 @@ int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
     return CSI_OK;
 }
 
+// ---- the fused band kernel (gemm_hs_band.hip.h, band_kernel_gen.py): code object embedded at build time
+#if __has_include("band8_hsaco.inc")
+#include "band8_hsaco.inc"
+#define CSI_HAVE_BAND8 1
+#endif
+
+int band8_function(csi_ctx* c, hipFunction_t* fn) {
+    *fn = nullptr;
+#ifdef CSI_HAVE_BAND8
+    if (c->band_failed) return CSI_OK;
+    if (!c->band_fn) {
+        if (hipModuleLoadData(&c->band_mod, band8_hsaco) != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, "csi_band8") != hipSuccess) {
+            (void)hipGetLastError();
+            c->band_failed = true;       // not fatal: the separate kernels serve the call
+            c->band_fn = nullptr;
+            return CSI_OK;
+        }
+    }
+    *fn = c->band_fn;
+#endif
+    return CSI_OK;
+}
+
 // the per-pair layers of one chunk: l0sum [M1][h1] fp32 -> out [M2][n_out] fp32; hbuf0 / hbuf1 are the
 // ping-pong activation buffers of the fp32 path re-used as hs matrices (same 4 bytes per element)
 int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, float* hbuf1, float* out) {
@@ -225,6 +248,33 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         return hs_launch_pair<EPI_BIAS, false>(c, K_REGRESSOR, p, src, s0);
     }
     const Layer& lr = m.layers[nh];
+    if (nh == 2 && c->hs_band && !c->hs_fuse_regressor && lr.Wh_p) {
+        // first per-pair layer + regressor in one kernel, h2 in registers: the assembly band kernel (8 waves per 128-row band)
+        const int s1 = hs_act_shift_of(c, m, 1, true);
+        BandArgs ba{};
+        ba.L0 = l0sum; ba.Ts = m.T_hs; ba.ldl = h1; ba.nt = cf.nt; ba.in_scale = std::ldexp(1.f, s0);
+        ba.W1 = l1.Wh; ba.ldb1 = l1.ldwh; ba.bias1 = l1.bias_hs; ba.M = M2; ba.K1 = h1; ba.N1 = l1.out;
+        ba.acc_scale1 = std::ldexp(1.f, -(s0 + l1.wshift)); ba.out_scale = std::ldexp(1.f, s1);
+        ba.W2p = lr.Wh_p; ba.ldb2 = lr.ldwh; ba.bias2 = lr.bias_hs; ba.n2 = cf.n_out; ba.acc_scale2 = std::ldexp(1.f, -(s1 + lr.wshift_f));
+        ba.out = out; ba.ldo = cf.n_out; ba.peak = c->hs_peak;
+        hipFunction_t fn = nullptr;
+        if (band8_serves(ba) && h1 == l1.in && lr.in == l1.out) {
+            int rc = band8_function(c, &fn);
+            if (rc) return rc;
+        }
+        if (fn) {
+            ++c->hs_launches;
+            ++c->band_launches;
+            const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
+            const double bytes = 4.0 * ((double)M2 / cf.nt * h1 + (double)cf.nt * h1 + (double)l1.out * h1 + (double)cf.n_out * l1.out + (double)M2 * cf.n_out);
+            ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
+            Band8Args a8 = band8_args(ba);
+            size_t sz = sizeof(a8);
+            void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((M2 + BAND_ROWS - 1) / BAND_ROWS), 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+            return CSI_OK;
+        }
+    }
     if (nh == 2 && c->hs_fuse_regressor && lr.Wh_f && cf.n_out <= PP_BN && l1.out % PP_BN == 0) {
         // regressor inside the pair kernel: h2 never leaves the CU (hs_fused_regressor)
         const int tiles_m = (M2 + PP_BM - 1) / PP_BM, tiles_n = l1.out / PP_BN;

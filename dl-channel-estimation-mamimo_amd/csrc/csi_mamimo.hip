@@ -14,6 +14,7 @@
 #include "csi_dnn_bf16.hpp"
 #include "csi_train.hpp"
 #include "csi_hostpipe.hpp"
+#include "csi_comm.hpp"
 
 namespace {
 
@@ -305,6 +306,8 @@ void csi_destroy(csi_ctx* c) {
     free_model(c->model[1]);
     for (int d = 0; d < 2; ++d) tr_free(c->trainer[d]);
     delete c->hostpipe;
+    comm_free(c);
+    if (c->band_mod) hipModuleUnload(c->band_mod);
     if (c->P) hipFree(c->P);
     if (c->hs_peak) hipFree(c->hs_peak);
     if (c->hs_zero) hipFree(c->hs_zero);
@@ -449,6 +452,23 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 if (hipMalloc((void**)&L.Wh_f, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
                 HIP_TRY(c, hipMemset(L.Wh_f, 0, hbytes));
                 HIP_TRY(c, hipMemcpy(L.Wh_f, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+                if (out <= 256) {
+                    // ... and the form the fused band kernel reads: 256 rows, k permuted inside every group of 16 so that a
+                    // lane's stage-1 accumulator registers are its stage-2 operand (gemm_hs_band.hip.h)
+                    std::vector<uint16_t> wp((size_t)256 * L.ldwh, 0);
+                    for (int o = 0; o < out; ++o)
+                        for (int g16 = 0; g16 < L.ldwh / 32; ++g16)
+                            for (int pos = 0; pos < 16; ++pos) {
+                                const size_t src = (size_t)o * L.ldwh + (size_t)g16 * 32 + hs_band_kperm(pos);
+                                const size_t dst = (size_t)o * L.ldwh + (size_t)g16 * 32 + pos;
+                                wp[dst] = wh[src];
+                                wp[dst + 16] = wh[src + 16];
+                            }
+                    const size_t pbytes = wp.size() * 2 + 4096;
+                    if (hipMalloc((void**)&L.Wh_p, pbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
+                    HIP_TRY(c, hipMemset(L.Wh_p, 0, pbytes));
+                    HIP_TRY(c, hipMemcpy(L.Wh_p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+                }
             }
         }
         if (bf16 && li >= 1 && !prev_shift.empty()) {
@@ -822,6 +842,12 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "ls_fft_first_max") *value = c->ls_fft_first_max;
     else if (n == "small_call_overlap") *value = c->small_call_overlap;
     else if (n == "f32_engine") *value = c->f32_engine;
+    else if (n == "hs_band") *value = c->hs_band;
+    else if (n == "band_launches") *value = c->band_launches;
+    else if (n == "comm_bytes") *value = c->comm ? c->comm->bytes_broadcast : 0;
+    else if (n == "comm_blobs") *value = c->comm ? c->comm->blobs_broadcast : 0;
+    else if (n == "comm_world") *value = c->comm ? c->comm->world : 0;
+    else if (n == "comm_rank") *value = c->comm ? c->comm->rank : -1;
     else if (n == "hs_act_shift") *value = c->hs_act_shift;
     else if (n == "hs_min_blocks") *value = c->hs_min_blocks;
     else if (n == "hs_fuse_regressor") *value = c->hs_fuse_regressor;
@@ -871,6 +897,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "hs_fuse_regressor") {
         drop_graphs(c);
         c->hs_fuse_regressor = value != 0;
+    } else if (n == "hs_band") {
+        drop_graphs(c);
+        c->hs_band = value != 0;
     } else if (n == "hs_min_blocks") {
         if (value < 1 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "hs_min_blocks must be 1..65536");
         drop_graphs(c);
@@ -1063,6 +1092,147 @@ int csi_train_end(csi_ctx* c, int model, int commit) {
     tr_free(t);
     c->trainer[model] = nullptr;
     return rc;
+}
+
+// ---- multi-GPU: RCCL weight broadcast inside the C-ABI (csi_comm.hpp)
+int csi_get_unique_id(char id[CSI_UNIQUE_ID_BYTES]) {
+    if (!id) return fail(nullptr, CSI_ERR_INVALID_ARG, "csi_get_unique_id: null buffer");
+    RcclApi& r = rccl();
+    if (!r.lib) return fail(nullptr, CSI_ERR_HIP, "%s", r.why.c_str());
+    nccl_uid u;
+    NCCL_TRY(nullptr, r.GetUniqueId(&u));
+    std::memcpy(id, u.internal, CSI_UNIQUE_ID_BYTES);
+    return CSI_OK;
+}
+
+int csi_comm_init(csi_ctx* c, int rank, int world, const char id[CSI_UNIQUE_ID_BYTES]) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, CSI_ERR_INVALID_ARG, "csi_comm_init: bad rank %d / world %d", rank, world);
+    RcclApi& r = rccl();
+    if (!r.lib) return fail(c, CSI_ERR_HIP, "%s", r.why.c_str());
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    comm_free(c);
+    c->comm = new csi_comm;
+    c->comm->rank = rank;
+    c->comm->world = world;
+    nccl_uid u;
+    std::memcpy(u.internal, id, CSI_UNIQUE_ID_BYTES);
+    NCCL_TRY(c, r.CommInitRank(&c->comm->comm, world, u, rank));
+    HIP_TRY(c, hipMalloc(&c->comm->wire, sizeof(WireMeta)));
+    return CSI_OK;
+}
+
+int csi_comm_destroy(csi_ctx* c) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    comm_free(c);
+    return CSI_OK;
+}
+
+int csi_broadcast_weights(csi_ctx* c, int root) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (!c->comm || !c->comm->comm) return fail(c, CSI_ERR_NOT_READY, "csi_broadcast_weights: csi_comm_init has not been called");
+    csi_comm& cm = *c->comm;
+    if (root < 0 || root >= cm.world) return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: root %d of %d ranks", root, cm.world);
+    RcclApi& r = rccl();
+    const csi_config& cf = c->cfg;
+    HIP_TRY(c, hipSetDevice(cf.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graphs(c);
+    const bool is_root = cm.rank == root;
+    // 1. the host-side scalars that belong to the device blobs
+    WireMeta w;
+    std::memset(&w, 0, sizeof w);
+    if (is_root) {
+        w.magic = WIRE_MAGIC;
+        w.n_layers = cf.n_hidden + 1;
+        w.pilot_ok = c->pilot_ok;
+        w.p_sylvester = c->p_sylvester;
+        for (int d = 0; d < 2; ++d) {
+            const Model& m = c->model[d];
+            w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
+            if (!w.loaded[d]) continue;
+            w.has_W0p[d] = m.W0p != nullptr;
+            w.has_W0rm[d] = m.W0rm != nullptr;
+            for (int i = 0; i <= cf.n_hidden; ++i) {
+                const Layer& L = m.layers[i];
+                WireLayer& x = w.layer[d][i];
+                x.in = L.in; x.out = L.out; x.ldw = L.ldw; x.ldwb = L.ldwb; x.ldwh = L.ldwh;
+                x.wshift = L.wshift; x.wshift_f = L.wshift_f; x.ashift = L.ashift; x.ashift_pre = L.ashift_pre;
+                x.has_Wt = L.Wt != nullptr; x.has_Wb = L.Wb != nullptr; x.has_Wh = L.Wh != nullptr; x.has_Wh_f = L.Wh_f != nullptr;
+                x.has_Wh_p = L.Wh_p != nullptr; x.has_bias = L.bias != nullptr; x.has_bias_hs = L.bias_hs != nullptr;
+                x.has_scale = L.scale != nullptr; x.has_shift = L.shift != nullptr;
+            }
+        }
+        HIP_TRY(c, hipMemcpyAsync(cm.wire, &w, sizeof w, hipMemcpyHostToDevice, c->stream));
+    }
+    NCCL_TRY(c, r.Broadcast(cm.wire, cm.wire, sizeof w, NCCL_CHAR, root, cm.comm, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&w, cm.wire, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (w.magic != WIRE_MAGIC || w.n_layers != cf.n_hidden + 1)
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: the root's record does not match this context (layers %d vs %d)", w.n_layers, cf.n_hidden + 1);
+    // 2. receivers: buffers of the root's sizes
+    std::vector<WBlob> blobs;
+    for (int d = 0; d < 2; ++d) {
+        Model& m = c->model[d];
+        if (!is_root) {
+            free_model(m);
+            if (w.loaded[d]) {
+                m.layers.resize(cf.n_hidden + 1);
+                for (int i = 0; i <= cf.n_hidden; ++i) {
+                    Layer& L = m.layers[i];
+                    const WireLayer& x = w.layer[d][i];
+                    const int want_out = i == cf.n_hidden ? cf.n_out : cf.hidden[i];
+                    if (x.out != want_out) return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: layer %d is %d wide on the root, %d here", i, x.out, want_out);
+                    L.in = x.in; L.out = x.out; L.ldw = x.ldw; L.ldwb = x.ldwb; L.ldwh = x.ldwh;
+                    L.wshift = x.wshift; L.wshift_f = x.wshift_f; L.ashift = x.ashift; L.ashift_pre = x.ashift_pre;
+                }
+            }
+        }
+        if (w.loaded[d]) model_blobs(cf, m, w.layer[d], w.has_W0p[d], w.has_W0rm[d], blobs);
+    }
+    if (w.pilot_ok && cf.nt > 0) {
+        const size_t ldp = (size_t)(cf.nt + 31) / 32 * 32, slack = G_SLACK_FLOATS * sizeof(float);
+        blobs.push_back({(void**)&c->P, (size_t)cf.nt * cf.nt * 4 + slack});
+        blobs.push_back({(void**)&c->Ppad, ldp * ldp * 4 + slack});
+    }
+    if (!is_root) {
+        if (c->P) { hipFree(c->P); c->P = nullptr; }
+        if (c->Ppad) { hipFree(c->Ppad); c->Ppad = nullptr; }
+        for (WBlob& b : blobs) {
+            if (hipMalloc(b.p, b.bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "csi_broadcast_weights: device allocation of %zu bytes failed", b.bytes);
+        }
+    }
+    // 3. the blobs themselves, device to device, one group
+    cm.bytes_broadcast = 0;
+    cm.blobs_broadcast = (int64_t)blobs.size();
+    NCCL_TRY(c, r.GroupStart());
+    for (WBlob& b : blobs) {
+        NCCL_TRY(c, r.Broadcast(*b.p, *b.p, b.bytes, NCCL_CHAR, root, cm.comm, c->stream));
+        cm.bytes_broadcast += (int64_t)b.bytes;
+    }
+    NCCL_TRY(c, r.GroupEnd());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // 4. what is derived locally
+    if (!is_root) {
+        c->pilot_ok = w.pilot_ok != 0;
+        c->p_sylvester = w.p_sylvester != 0;
+        if (c->pilot_ok) {
+            int rc = ls_prepare(c);
+            if (rc) return rc;
+        }
+        for (int d = 0; d < 2; ++d) {
+            Model& m = c->model[d];
+            m.loaded = w.loaded[d] != 0;
+            m.table_ok = false;
+            if (m.loaded && c->pilot_ok) {
+                int rc = build_pilot_table(c, m);
+                if (rc) return rc;
+            }
+        }
+    }
+    return CSI_OK;
 }
 
 int csi_synchronize(csi_ctx* c) {

@@ -73,6 +73,42 @@ struct BandArgs {
     const unsigned long long* stamps;   // timing probe, null in the library
 };
 
+// Kernel arguments of the assembly form (band_kernel_gen.py: "csi_band8", 8 waves, two per SIMD): 128 bytes, loaded with two
+// s_load_dwordx16 - the layout is part of that kernel.
+struct Band8Args {
+    const float* L0;
+    const float* Ts;
+    const uint16_t* W1;
+    const float* bias1;
+    const uint16_t* W2p;
+    const float* bias2;
+    float* out;
+    unsigned* peak;
+    const unsigned long long* stamps;
+    int ldl, nt, ldb1, M, K1, N1, ldb2, n2, ldo;
+    float in_scale, as1os, out_scale, acc_scale2;
+    unsigned nt_magic;           // floor(2^32 / nt): row -> (pair row, tx antenna) by multiplication
+};
+static_assert(sizeof(Band8Args) == 128, "Band8Args is read by s_load_dwordx16 x 2");
+constexpr int BAND8_THREADS = 512;
+constexpr int BAND8_MAX_N1 = 4096;
+
+inline Band8Args band8_args(const BandArgs& g) {
+    Band8Args a{};
+    a.L0 = g.L0; a.Ts = g.Ts; a.W1 = g.W1; a.bias1 = g.bias1; a.W2p = g.W2p; a.bias2 = g.bias2; a.out = g.out; a.peak = g.peak;
+    a.stamps = g.stamps;
+    a.ldl = g.ldl; a.nt = g.nt; a.ldb1 = g.ldb1; a.M = g.M; a.K1 = g.K1; a.N1 = g.N1; a.ldb2 = g.ldb2; a.n2 = g.n2; a.ldo = g.ldo;
+    a.in_scale = g.in_scale; a.as1os = g.acc_scale1 * g.out_scale; a.out_scale = g.out_scale; a.acc_scale2 = g.acc_scale2;
+    a.nt_magic = g.nt <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)g.nt);
+    return a;
+}
+// shapes the assembly kernel serves (the caller falls back to the separate kernels otherwise)
+inline bool band8_serves(const BandArgs& g) {
+    return g.K1 >= 128 && (g.K1 % 64) == 0 && g.N1 >= 256 && (g.N1 % 256) == 0 && g.N1 <= BAND8_MAX_N1 && g.n2 >= 1 && g.n2 <= 256 &&
+           g.nt >= 1 && (unsigned long long)g.M * (unsigned long long)g.nt < 0xffffffffull && (unsigned long long)g.M * g.ldo * 4ull < 0xffffffffull &&
+           (unsigned long long)((g.M + g.nt - 1) / g.nt) * g.ldl * 4ull < 0x7fffffffull;
+}
+
 // position p of a 16-k group of the permuted regressor weights holds original k-column hs_band_kperm(p)
 __host__ __device__ __forceinline__ constexpr int hs_band_kperm(int p) { return (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1); }
 

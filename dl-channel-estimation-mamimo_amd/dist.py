@@ -73,6 +73,46 @@ def broadcast_weights(weights, src=0, device=None):
     return out
 
 
+def exchange_unique_id(rank, world, timeout_s=120.0):
+    """The RCCL unique id of the library's own communicator (engine.get_unique_id) from rank 0 to every rank.  With
+    ``torch.distributed`` initialised it rides on its object broadcast; without it, through a file next to the
+    rendezvous (``CSI_RCCL_ID_FILE``, default /tmp/csi_rccl_id_<MASTER_ADDR>_<MASTER_PORT>_<WORLD_SIZE>) that rank 0 writes
+    atomically and removes at exit - no torch in the process at all."""
+    import time
+    from .engine import get_unique_id
+    try:
+        import torch.distributed as tdist
+        have_pg = tdist.is_available() and tdist.is_initialized()
+    except Exception:
+        have_pg = False
+    if have_pg:
+        box = [get_unique_id() if rank == 0 else None]
+        tdist.broadcast_object_list(box, src=0)
+        return box[0]
+    path = os.environ.get('CSI_RCCL_ID_FILE') or '/tmp/csi_rccl_id_%s_%s_%d' % (
+        os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world)
+    if rank == 0:
+        uid = get_unique_id()
+        tmp = '%s.%d' % (path, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        import atexit
+        atexit.register(lambda: os.path.exists(path) and os.remove(path))
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            st = os.stat(path)
+            if st.st_size == 128 and st.st_mtime >= t0 - 30.0:         # a file of THIS launch, not a leftover
+                with open(path, 'rb') as f:
+                    return f.read()
+        except FileNotFoundError:
+            pass
+        time.sleep(0.05)
+    raise RuntimeError('no RCCL unique id at %s after %.0f s' % (path, timeout_s))
+
+
 def local_device_count():
     """GPUs visible to this process (ranks are mapped onto them round-robin)."""
     import torch

@@ -61,6 +61,16 @@ class DeviceArray:
             pass
 
 
+def get_unique_id():
+    """128-byte RCCL unique id (ncclGetUniqueId through the C-ABI) - create on ONE rank, hand to all."""
+    lib = _lib.load_library()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.csi_get_unique_id(buf)
+    if rc != 0:
+        raise CsiError(rc, (lib.csi_last_error(None) or b'').decode())
+    return buf.raw
+
+
 class CsiEngine:
     """Owns a ``csi_ctx``.  Shapes follow the reference: nt tx antennas, nr rx antennas,
     len_ltf = 320*nt samples per rx preamble, FC hidden widths ``hidden`` (--nn), n_out outputs
@@ -405,6 +415,24 @@ class CsiEngine:
         y = np.empty((x.shape[0], self.n_out), dtype=np.float32)
         self._check(self._lib.csi_predict_samples(self._ctx, int(idx), _fp(x), x.shape[0], _fp(y)))
         return y
+
+    # ------------------------------------------------------------------ multi-GPU: RCCL inside the library
+    def comm_init(self, rank, world, unique_id):
+        """ncclCommInitRank on this engine's GPU (collective over the ranks); ``unique_id`` = the 128 bytes
+        ``get_unique_id()`` produced on one rank (see ``dist.exchange_unique_id``)."""
+        uid = bytes(unique_id)
+        if len(uid) != 128:
+            raise CsiError(-1, 'unique id must be 128 bytes')
+        self._check(self._lib.csi_comm_init(self._ctx, int(rank), int(world), uid))
+
+    def broadcast_weights(self, root=0):
+        """Both component models and the pilot matrix as they sit on ``root``'s GPU -> every rank's GPU (ncclBroadcast of the
+        device buffers, no host copy); afterwards every engine is loaded.  Returns the bytes moved."""
+        self._check(self._lib.csi_broadcast_weights(self._ctx, int(root)))
+        return self.get_option('comm_bytes')
+
+    def comm_destroy(self):
+        self._check(self._lib.csi_comm_destroy(self._ctx))
 
     # ------------------------------------------------------------------ device-resident calls
     def _checked(self, launch):

@@ -272,6 +272,27 @@ int  csi_memcpy_d2h(csi_ctx* ctx, void* dst_host, const void* src_dev, int64_t b
 int  csi_synth_white(csi_ctx* ctx, uint64_t seed, int64_t first_pkt, int64_t npkt,
                      float* d_ltf_re, float* d_ltf_im);
 
+/* ---- multi-GPU: packets shard over the GPUs of a node (one process and one context per GPU), the weights are shared and
+ * read-only, outputs stay sharded.  The single collective of the path is the load-time broadcast of the
+ * weights, here inside the library on RCCL (ncclBroadcast over xGMI), device to device on the context's stream.  The
+ * reference has no multi-device code; this replaces what `Model.load_weights` (DNN.py:334) would otherwise do once per GPU.
+ * RCCL (librccl.so.1) is dlopen'ed by csi_comm_init; nothing else in the library needs it.
+ *
+ *   rank 0:      csi_get_unique_id(id);  -> hand the 128 bytes to the other ranks (file, environment, socket, MPI ...)
+ *   every rank:  csi_create(...);  csi_comm_init(ctx, rank, world, id);
+ *   rank root:   csi_load_weights(ctx, 0, ...);  csi_load_weights(ctx, 1, ...);  csi_set_pilot(ctx, P);
+ *   every rank:  csi_broadcast_weights(ctx, root);      -> every context is loaded; no host copy of the weights elsewhere
+ *   every rank:  csi_predict[_device] / csi_ls_estimate[_device] on its own packet range  */
+#define CSI_UNIQUE_ID_BYTES 128
+int  csi_get_unique_id(char id[CSI_UNIQUE_ID_BYTES]);            /* ncclGetUniqueId; errors: csi_last_error(NULL) */
+int  csi_comm_init(csi_ctx* ctx, int rank, int world, const char id[CSI_UNIQUE_ID_BYTES]);   /* ncclCommInitRank on the context's device (collective) */
+int  csi_comm_destroy(csi_ctx* ctx);
+/* Both component models and the pilot matrix as csi_load_weights / csi_set_pilot left them on `root`: the re-laid-out fp32
+ * matrices, their split-f16 / bf16 forms, bias and BatchNormalization vectors, P - ncclBroadcast of the device buffers
+ * themselves, then the pilot tables are rebuilt locally.  Collective; synchronous at return.  Contexts must share one csi_config
+ * (shape and dtype).  "comm_bytes" / "comm_blobs" (csi_get_option) report what the last call moved. */
+int  csi_broadcast_weights(csi_ctx* ctx, int root);
+
 /* Per-kernel HIP-event timing on the context's stream (the reference's --execTime). */
 int  csi_profile_enable(csi_ctx* ctx, int on);
 int  csi_profile_reset(csi_ctx* ctx);

@@ -224,3 +224,135 @@ def test_fuzz_shape_cases(seed, cases):
     log = []
     bad = [i for i in range(cases) if not fuzz_shapes.run_case(rng, i, log.append)]
     assert not bad, '\n'.join(log[i] for i in bad)
+
+
+# ------------------------------------------------------------------------------------ fused band kernel (assembly)
+BAND_CASES = [
+    (32, 4, 24, (1024, 1024)),      # the shipped network; 3072 rows = 24 bands
+    (8, 2, 70, (128, 256)),         # K1 = 128: no trip of the stage-1 loop; one column step; ragged last band (1120 rows)
+    (4, 1, 131, (192, 512)),        # K1 = 192: one loop trip; two column steps; 524 rows
+    (12, 2, 21, (256, 768)),        # Nt that does not divide the band: rows of one band span several (packet, rx) items
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', BAND_CASES)
+def test_band_kernel_matches_oracle_and_separate_kernels(pkg, oracle, nt, nr, npkt, hidden):
+    """First per-pair layer + regressor as ONE kernel (band_kernel_gen.py, option hs_band): against the fp64 oracle, against
+    the two kernels it replaces, run-to-run identical, and really launched."""
+    rng = np.random.default_rng(nt * 1000 + npkt)
+    w_re, w_im = _weights(oracle, 5 + nt, nt, hidden)
+    P = oracle.hadamard(nt) if nt & (nt - 1) == 0 else rng.integers(-2, 3, (nt, nt)).astype(np.float64)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, oracle.hadamard(nt), snr_db=5.0)[0] if nt & (nt - 1) == 0 else \
+        (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    e.set_option('f32_engine', 1)
+    assert e.get_option('hs_band') == 1                       # the default
+    n0 = e.get_option('band_launches')
+    b_re, b_im = e.predict(ltf)
+    assert e.get_option('band_launches') == n0 + 2, 'the band kernel did not serve the call'
+    assert e.get_option('hs_range_fallbacks') == 0
+    k = min(npkt, 6)
+    sel = np.r_[0:k // 2, npkt - (k - k // 2):npkt]
+    r_re, r_im = oracle.predict_packets(ltf[sel].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    assert rel_rows(b_re[sel], r_re) < TOL and rel_rows(b_im[sel], r_im) < TOL
+    b2_re, _ = e.predict(ltf)
+    assert np.array_equal(b_re, b2_re)
+    e.set_option('hs_band', 0)
+    s_re, s_im = e.predict(ltf)
+    assert e.get_option('band_launches') == n0 + 4
+    assert rel_rows(b_re, s_re) < 5e-6 and rel_rows(b_im, s_im) < 5e-6
+
+
+def test_band_kernel_range_guard_and_graph(pkg, oracle):
+    """The band kernel carries the split engine's range guard (both words) and is capturable: data that overflows the hidden
+    activations makes csi_predict repeat on the fp32 MFMA kernels; a hipGraph of the device call replays bit-identically."""
+    rng = np.random.default_rng(9)
+    nt, nr, npkt, hidden = 8, 2, 40, (128, 256)
+    w_re, w_im = _weights(oracle, 3, nt, hidden)
+    P = oracle.hadamard(nt)
+    base = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=10.0)[0]
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    e.set_option('f32_engine', 1)
+    for gain, fallbacks in ((1.0, 0), (3.0e4, 1)):
+        ltf = (gain * base).astype(np.complex64)
+        fb, bl = e.get_option('hs_range_fallbacks'), e.get_option('band_launches')
+        o_re, o_im = e.predict(ltf)
+        assert e.get_option('band_launches') == bl + 2 and e.get_option('hs_range_fallbacks') == fb + fallbacks, gain
+        r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+        assert np.isfinite(o_re).all() and rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL, gain
+    d_re, d_im = e.to_device(np.ascontiguousarray(base.real, np.float32)), e.to_device(np.ascontiguousarray(base.imag, np.float32))
+    o1, o2 = e.empty((npkt, nr, nt, 234)), e.empty((npkt, nr, nt, 234))
+    e.predict_device(d_re, d_im, npkt, o1, o2)
+    e.synchronize()
+    eager = o1.download().copy()
+    e.set_option('use_graph', 1)
+    for _ in range(4):
+        o1.upload(np.zeros((npkt, nr, nt, 234), np.float32))
+        e.predict_device(d_re, d_im, npkt, o1, o2)
+        e.synchronize()
+        assert np.array_equal(o1.download(), eager)
+    assert e.get_option('graph_replays') >= 1
+
+
+def test_full_size_config2_band_vs_separate(pkg, oracle, config2):
+    """BASELINE configs[1] size (512 000 pair rows per component model): the band kernel against the separate kernels on
+    every 97th packet, and against the oracle on a handful."""
+    c = config2
+    e, npkt = c['e'], c['npkt']
+    o_re, o_im, s_re, s_im = c['outs']
+    e.set_option('f32_engine', -1)
+    e.set_option('hs_band', 1)
+    bl = e.get_option('band_launches')
+    assert e.predict_device(c['d_re'], c['d_im'], npkt, o_re, o_im, checked=True) == 'split'
+    assert e.get_option('band_launches') == bl + 2
+    e.set_option('hs_band', 0)
+    assert e.predict_device(c['d_re'], c['d_im'], npkt, s_re, s_im, checked=True) == 'split'
+    e.set_option('hs_band', 1)
+    pick = list(range(0, npkt, 97)) + [npkt - 1]
+    a = np.concatenate([o_re.download(p, 1) for p in pick])
+    b = np.concatenate([s_re.download(p, 1) for p in pick])
+    assert np.isfinite(a).all() and rel_rows(a, b) < 5e-6
+    few = [0, 1234, npkt - 1]
+    ltf = np.concatenate([c['d_re'].download(p, 1) + 1j * c['d_im'].download(p, 1) for p in few])
+    r_re, r_im = oracle.predict_packets_shared(ltf, c['P'], c['w_re'], c['w_im'])
+    assert rel_rows(np.concatenate([o_re.download(p, 1) for p in few]), r_re) < TOL
+    assert rel_rows(np.concatenate([o_im.download(p, 1) for p in few]), r_im) < TOL
+
+
+# ------------------------------------------------------------------------------------ RCCL inside the C-ABI
+def test_rccl_self_broadcast_world1(pkg, oracle):
+    """csi_get_unique_id / csi_comm_init / csi_broadcast_weights with one rank: the communicator comes up on RCCL, the
+    broadcast walks every device buffer of both models and P (root = the only rank), and the context answers as before.
+    (Two ranks on ONE GPU are refused by RCCL; the N > 1 path runs in the driver's scaling bench.)"""
+    from dl_channel_estimation_mamimo_amd.engine import get_unique_id
+    rng = np.random.default_rng(4)
+    nt, nr, npkt, hidden = 8, 2, 6, (64, 48)
+    w_re, w_im = _weights(oracle, 21, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=10.0)[0]
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    uid = get_unique_id()
+    assert len(uid) == 128 and any(uid)
+    e.comm_init(0, 1, uid)
+    assert e.get_option('comm_world') == 1 and e.get_option('comm_rank') == 0
+    with pytest.raises(pkg.CsiError):
+        e.broadcast_weights(3)                                 # no such root
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    before = e.predict(ltf)
+    moved = e.broadcast_weights(0)
+    n_params = sum(int(np.prod(v.shape)) for v in w_re.values()) * 2
+    assert moved > 4 * n_params and e.get_option('comm_blobs') >= 2 * (3 * 3 + 2) + 2       # fp32 + split forms of every matrix, vectors, P
+    after = e.predict(ltf)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    r_re, r_im = oracle.predict_packets(ltf.astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(after[0], r_re) < TOL and rel_rows(after[1], r_im) < TOL
+    e.comm_destroy()
+    assert e.get_option('comm_world') == 0

@@ -65,6 +65,7 @@ static double time_ms(F&& launch, int iters = 7) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const std::string mode = argc > 1 ? argv[1] : "check";
     const bool timing = mode == "time" || mode == "stamps";
     const int nt = argc > 2 ? atoi(argv[2]) : 32;
@@ -153,6 +154,42 @@ int main(int argc, char** argv) {
     };
     (void)W2fh;
 
+    // ---- the assembly form (8 waves, two per SIMD): code object built by csrc/band_kernel_gen.py
+    const char* hsaco = getenv("BAND8_HSACO");
+    hipModule_t mod8 = nullptr;
+    auto get8 = [&](const char* name) {
+        hipFunction_t f = nullptr;
+        if (mod8 && hipModuleGetFunction(&f, mod8, name) != hipSuccess) f = nullptr;
+        return f;
+    };
+    if (hsaco && hipModuleLoad(&mod8, hsaco) != hipSuccess) { printf("cannot load %s\n", hsaco); mod8 = nullptr; }
+    hipFunction_t k8 = get8("csi_band8");
+    Band8Args a8 = band8_args(ba);
+    auto launch8f = [&](hipFunction_t f, const Band8Args& args) {
+        Band8Args tmp = args;
+        size_t sz = sizeof(tmp);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tmp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        CK(hipModuleLaunchKernel(f, nbands, 1, 1, BAND8_THREADS, 1, 1, 0, 0, nullptr, extra));
+    };
+    auto launch_band8 = [&] { launch8f(k8, a8); };
+    if (k8) printf("band8 code object %s loaded; shapes served: %d\n", hsaco, (int)band8_serves(ba));
+    if (const char* only = getenv("BAND8_ONLY")) {      // bring-up: one launch of one variant, nothing else
+        hipFunction_t f = get8(only);
+        if (!f) { printf("no kernel %s\n", only); return 2; }
+        printf("launching %s once (M = %d, %d bands)...\n", only, M, nbands);
+        launch8f(f, a8);
+        const hipError_t e = hipDeviceSynchronize();
+        printf("   -> %s\n", hipGetErrorString(e));
+        std::vector<float> o8((size_t)4 * NO);
+        CK(hipMemcpy(o8.data(), O, o8.size() * 4, hipMemcpyDeviceToHost));
+        printf("   out[0][0..3] = %g %g %g %g\n", o8[0], o8[1], o8[2], o8[3]);
+        unsigned pw[16]; CK(hipMemcpy(pw, peak, 64, hipMemcpyDeviceToHost));
+        printf("   host: out %p peak %p ldo %d M %d n2 %d\n   guard words:", (void*)O, (void*)peak, NO, M, NO);
+        for (int i = 0; i < 16; ++i) printf(" %08x", pw[i]);
+        printf("\n");
+        return 0;
+    }
+
     if (!timing) {
         std::vector<double> reff((size_t)M * NO);
         {
@@ -200,7 +237,37 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(go2.data(), O2, go2.size() * 4, hipMemcpyDeviceToHost));
         printf("separate pair + regressor kernels           worst row rel err %.3g\n", rel_rows(reff, go2, M, NO));
-        return e1 > 1e-5;
+        double e8 = 0;
+        if (k8) {
+            CK(hipMemset(O, 0xff, (size_t)M * NO * 4));
+            CK(hipMemset(peak, 0, 64));
+            launch_band8();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(go.data(), O, go.size() * 4, hipMemcpyDeviceToHost));
+            e8 = rel_rows(reff, go, M, NO, &wr);
+            printf("band8 (assembly, 8 waves)                   worst row rel err %.3g (row %d)\n", e8, wr);
+            if (!(e8 <= 1e-5)) {
+                for (int n = 0; n < 8; ++n) printf("   row %d col %d: got %.6g ref %.6g\n", wr, n, go[(size_t)wr * NO + n], reff[(size_t)wr * NO + n]);
+                for (int m : {0, 1, 31, 32, 33, 64, 127, 128, 129, 1023, 1024, M - 1}) {
+                    double e = 0, r = 0;
+                    for (int n = 0; n < NO; ++n) { const double d = go[(size_t)m * NO + n] - reff[(size_t)m * NO + n]; e += d * d; r += reff[(size_t)m * NO + n] * reff[(size_t)m * NO + n]; }
+                    printf("   row %d rel err %.3g\n", m, std::sqrt(e / r));
+                }
+                for (int c0 = 0; c0 < NO; c0 += 16) {
+                    double e = 0, r = 0;
+                    for (int m = 0; m < 128; ++m) for (int n = c0; n < std::min(NO, c0 + 16); ++n) { const double d = go[(size_t)m * NO + n] - reff[(size_t)m * NO + n]; e += d * d; r += reff[(size_t)m * NO + n] * reff[(size_t)m * NO + n]; }
+                    printf("   band 0, columns %d..%d rel err %.3g\n", c0, c0 + 15, std::sqrt(e / r));
+                }
+            }
+            CK(hipMemset(O, 0, (size_t)M * NO * 4));
+            launch_band8();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(go2.data(), O, go2.size() * 4, hipMemcpyDeviceToHost));
+            printf("   second run bit-identical: %s\n", memcmp(go.data(), go2.data(), go.size() * 4) == 0 ? "yes" : "NO");
+            CK(hipMemcpy(pk, peak, 8, hipMemcpyDeviceToHost));
+            printf("   range guard words: %08x %08x\n", pk[0], pk[1]);
+        }
+        return e1 > 1e-5 || !(e8 <= 1e-5);
     }
     const double fl = 2.0 * M * N * K + 2.0 * M * N * NO;
     if (mode == "stamps") {
@@ -224,6 +291,25 @@ int main(int argc, char** argv) {
                n, cyc[0] / n, wall[0] / n / 100, cyc[1] / n, wall[1] / n / 100, cyc[2] / n, wall[2] / n / 100,
                (cyc[0] + cyc[1] + cyc[2]) / (wall[0] + wall[1] + wall[2]) / 10.0, (t_max - t_min) / 100.0);
         printf("(ideal band: 4 x (64 + 16) sub-steps x 24 MFMA x 32 cycles = 245760 cycles of the SIMD's matrix pipe)\n");
+        if (k8) {
+            Band8Args a = a8; a.stamps = st;
+            auto l8 = [&] { launch8f(k8, a); };
+            l8(); CK(hipDeviceSynchronize());
+            CK(hipMemset(st, 0, (size_t)nbands * 12 * 8));
+            l8(); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            double c2[3] = {0, 0, 0}, w2[3] = {0, 0, 0};
+            t_min = ~0ull; t_max = 0; n = 0;
+            for (int bnd = 0; bnd < nbands; ++bnd) {
+                const unsigned long long* p = &h[(size_t)bnd * 12];
+                if (!p[0] || !p[6]) continue;
+                for (int i = 0; i < 3; ++i) { c2[i] += (double)(p[2 * (i + 1)] - p[2 * i]); w2[i] += (double)(p[2 * (i + 1) + 1] - p[2 * i + 1]); }
+                t_min = std::min(t_min, p[1]); t_max = std::max(t_max, p[7]); ++n;
+            }
+            printf("band8 kernel %zu workgroups: head %.0f cyc (%.2f us)  band %.0f cyc (%.2f us)  output %.0f cyc (%.2f us)  | clock %.2f GHz | launch span %.1f us\n",
+                   n, c2[0] / n, w2[0] / n / 100, c2[1] / n, w2[1] / n / 100, c2[2] / n, w2[2] / n / 100,
+                   (c2[0] + c2[1] + c2[2]) / (w2[0] + w2[1] + w2[2]) / 10.0, (t_max - t_min) / 100.0);
+        }
         return 0;
     }
     auto kb1 = gemm_hs_band_kernel<1>; auto kb2 = gemm_hs_band_kernel<2>; auto kb3 = gemm_hs_band_kernel<3>;
@@ -233,6 +319,11 @@ int main(int argc, char** argv) {
         double ms = time_ms(launch_band);
         printf("band kernel (fused)          %.3f ms  %.0f TF fp32-equivalent (%.0f TF f16 executed incl. 256-column regressor tile)\n", ms, fl / ms / 1e9,
                3 * (2.0 * M * N * K + 2.0 * M * N * 256) / ms / 1e9);
+        if (k8) {
+            const double m8 = time_ms(launch_band8);
+            printf("band8 (assembly, fused)      %.3f ms  %.0f TF fp32-equivalent (%.0f TF f16 executed incl. 256-column regressor tile)\n", m8, fl / m8 / 1e9,
+                   3 * (2.0 * M * N * K + 2.0 * M * N * 256) / m8 / 1e9);
+        }
         double ms2 = time_ms(launch_sep);
         printf("pair + regressor (separate)  %.3f ms  %.0f TF fp32-equivalent\n", ms2, fl / ms2 / 1e9);
         double p1 = time_ms([&] { hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{}); });
@@ -250,6 +341,12 @@ int main(int argc, char** argv) {
             t(kb8, "full, no barriers (invalid)");
             t(kb16, "no A side, no DMA, no fragment reads (invalid)");
             t(kb31, "MFMA only (invalid)");
+            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_nostagger", "csi_band8_ownpieces", "csi_band8"}) {
+                hipFunction_t f = get8(nm);
+                if (!f) continue;
+                const double m = time_ms([&] { launch8f(f, a8); });
+                printf("   %-58s %.3f ms\n", nm, m);
+            }
         }
     }
     return 0;
