@@ -253,6 +253,7 @@ def main():
     pairs_per_step = total_pkts * nr * nt          # all ranks together
     value = pairs_per_step * args.steps / dt
     split_engine = args.dtype == 'f32' and eng.get_option('hs_launches') > 0
+    band_kernel = args.dtype == 'f32' and eng.get_option('band_launches') > 0      # first per-pair layer + regressor as one kernel (hs_band)
     # range guard of the split-f16 engine over the timed steps: a hit would have made eng.synchronize() raise
     # (CSI_ERR_RANGE) above; the counters go into the line
     guard = {'hs_launches': eng.get_option('hs_launches'), 'hs_range_fallbacks': eng.get_option('hs_range_fallbacks'),
@@ -426,11 +427,11 @@ def main():
                    'world_size_checked': pkg.dist.world_size(), 'weights_via': via,
                    'sharding': ('contiguous packet ranges per rank (%s scaling), weights broadcast once over %s, no collective in the step'
                                 % (args.scaling, 'RCCL' if backend == 'nccl' else backend)) if world > 1 else 'single GPU'},
-        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm', 'achieved': achieved, 'peak': mfma_peak,
+        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm' + (' (csi_band8: first per-pair layer + regressor fused, h2 in registers)' if band_kernel else ''), 'achieved': achieved, 'peak': mfma_peak,
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
-                     'traffic': hbm_per_launch('gemm_hs_pp_pair_kernel<2' if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
+                     'traffic': hbm_per_launch(('csi_band8' if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
         'kernels': kernels,

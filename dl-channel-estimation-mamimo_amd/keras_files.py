@@ -426,7 +426,9 @@ def read_keras_hdf5_weights(path):
 # TF SavedModel variables (TensorBundle): variables.index (SSTable) + variables.data-*
 # =====================================================================================================
 _TABLE_MAGIC = 0xdb4775248b80fb57
-_DT = {1: '<f4', 2: '<f8', 3: '<i4', 4: 'u1', 5: '<i2', 6: 'i1', 9: '<i8', 10: '?', 17: '<u2', 19: '<f2', 22: '<u4', 23: '<u8'}
+# tensorflow/core/framework/types.proto: DT_FLOAT 1, DT_DOUBLE 2, DT_INT32 3, DT_UINT8 4, DT_INT16 5, DT_INT8 6, DT_INT64 9, DT_BOOL 10,
+# DT_BFLOAT16 14 (widened to float32 below), DT_UINT16 17, DT_HALF 19, DT_UINT32 22, DT_UINT64 23
+_DT = {1: '<f4', 2: '<f8', 3: '<i4', 4: 'u1', 5: '<i2', 6: 'i1', 9: '<i8', 10: '?', 14: '<u2', 17: '<u2', 19: '<f2', 22: '<u4', 23: '<u8'}
 
 
 def _varint(b, p):
@@ -548,7 +550,7 @@ def _unmask_crc(masked):
     return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
 
 
-def read_tensor_bundle(prefix, verify_crc=False):
+def read_tensor_bundle(prefix, verify_crc=True):
     """{key: ndarray} of the tensor bundle ``<prefix>.index`` + ``<prefix>.data-xxxxx-of-yyyyy`` in key order
     (keys of object-based checkpoints look like ``layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE``)."""
     with open(prefix + '.index', 'rb') as fh:
@@ -572,7 +574,7 @@ def read_tensor_bundle(prefix, verify_crc=False):
             for fn, wt, v in _proto_fields(val):
                 if fn == 1:
                     num_shards = v
-                if fn == 2 and v != 0:
+                if fn == 2 and v != 0:                         # BundleHeaderProto.Endianness: LITTLE = 0, BIG = 1
                     raise KerasFileError(f'{prefix}.index: big-endian bundle')
             continue
         dtype = shard = offset = size = 0
@@ -601,7 +603,11 @@ def read_tensor_bundle(prefix, verify_crc=False):
         if sliced:
             raise KerasFileError(f'{prefix}.index: tensor {name} is stored in slices (partitioned variable)')
         if shard not in shards:
+            if not 0 <= shard < max(num_shards, 1):
+                raise KerasFileError(f'{prefix}.index: tensor {name} sits in shard {shard} of {num_shards}')
             fn_ = '%s.data-%05d-of-%05d' % (prefix, shard, num_shards)
+            if not os.path.exists(fn_):
+                raise KerasFileError(f'{fn_}: shard file of tensor {name} is missing')
             with open(fn_, 'rb') as fh:
                 shards[shard] = fh.read()
         raw = shards[shard][offset:offset + size]
@@ -611,14 +617,17 @@ def read_tensor_bundle(prefix, verify_crc=False):
             raise KerasFileError(f'{prefix}: tensor {name} has {size} bytes for shape {shape} of {dt}')
         if verify_crc and crc is not None and crc32c(raw) != _unmask_crc(crc):
             raise KerasFileError(f'{prefix}: checksum mismatch in tensor {name}')
-        out[name] = np.frombuffer(raw, dtype=dt).reshape(shape).copy()
+        arr = np.frombuffer(raw, dtype=dt).reshape(shape).copy()
+        if dtype == 14:                                          # DT_BFLOAT16: the upper half of a float32
+            arr = (arr.astype(np.uint32) << 16).view(np.float32)
+        out[name] = arr
     return out
 
 
 _BN_VARS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
 
 
-def read_savedmodel_variables(model_dir, verify_crc=False):
+def read_savedmodel_variables(model_dir, verify_crc=True):
     """Weights of a Keras model saved as a TF SavedModel directory (DNN.py:411), as keras-style paths in model
     order.  The object-based checkpoint names the tensors by position - ``layer_with_weights-<i>/<attribute>`` with i
     counting the layers that own weights, in model order - which is all load-by-topology needs: a layer with

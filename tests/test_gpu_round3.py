@@ -348,7 +348,7 @@ def test_rccl_self_broadcast_world1(pkg, oracle):
     e.set_pilot(P)
     before = e.predict(ltf)
     moved = e.broadcast_weights(0)
-    n_params = sum(int(np.prod(v.shape)) for v in w_re.values()) * 2
+    n_params = sum(int(np.prod(v.shape)) for v in w_re.values() if isinstance(v, np.ndarray)) * 2
     assert moved > 4 * n_params and e.get_option('comm_blobs') >= 2 * (3 * 3 + 2) + 2       # fp32 + split forms of every matrix, vectors, P
     after = e.predict(ltf)
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
