@@ -158,7 +158,18 @@ def main():
         wts = {'real': pkg.synth.make_weights(rng, nt, hidden), 'imag': pkg.synth.make_weights(rng, nt, hidden),
                'P': {'pilot': pkg.synth.hadamard(nt)}}
     via = 'single GPU'
-    if world > 1 and args.weights_via == 'rccl' and backend == 'nccl':
+    use_lib_rccl = world > 1 and args.weights_via == 'rccl' and backend == 'nccl'
+    if use_lib_rccl:
+        # can every rank load RCCL through the library at all?  (decided together: a rank that cannot must not leave the
+        # others waiting inside ncclCommInitRank - then everybody takes the torch.distributed path)
+        try:
+            pkg.engine.get_unique_id()
+            mine = 1.0
+        except Exception as err:                       # noqa: BLE001
+            print('bench.py: rank %d cannot use the library\'s RCCL path (%s)' % (rank, err), file=sys.stderr)
+            mine = 0.0
+        use_lib_rccl = pkg.dist.all_reduce_min(mine) > 0.5
+    if use_lib_rccl:
         # the library's own communicator: rank 0 loads, every context receives the device buffers over RCCL
         t_b = time.perf_counter()
         eng.comm_init(rank, world, pkg.dist.exchange_unique_id(rank, world))

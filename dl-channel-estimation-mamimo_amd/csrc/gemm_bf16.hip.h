@@ -51,7 +51,19 @@ struct GemmBf16Args {
     const float* bias;
     const float* scale;
     const float* shift;
+    const unsigned long long* stamps = nullptr;   // timing probe (tools/bf16_pair_probe.hip), null otherwise: pp_stamp
 };
+
+// Optional per-workgroup time stamps (timing probes; null in the library): wave 0 writes (shader cycles, 10-ns wall ticks)
+// at kernel entry, after the prologue, after the main loop and after the epilogue - slots 0..3 of 6 x 16 bytes per workgroup.
+__device__ __forceinline__ void pp_stamp(const unsigned long long* base, int i) {
+    if (!base) return;
+    if (threadIdx.x == 0) {
+        unsigned long long* p = const_cast<unsigned long long*>(base) + ((size_t)blockIdx.x * 6 + i) * 2;
+        p[0] = __builtin_readcyclecounter();
+        p[1] = wall_clock64();
+    }
+}
 
 template <int P, int NS>
 __device__ __forceinline__ void bring_handover(int groups) {
@@ -563,6 +575,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     const int tm = cols ? idx * (8 / g.tiles_n) + xcd / g.tiles_n : (idx / g.tiles_n) * 8 + xcd;
     const int tn = cols ? xcd % g.tiles_n : idx % g.tiles_n;
     if (tm * PP_BM >= g.M) return;
+    pp_stamp(g.stamps, 0);
     const int m0 = tm * PP_BM, n0 = tn * PP_BN;
     const int kbeg = CAST ? blockIdx.z * g.k_per_split : 0;
     const int kend = CAST ? min(g.K, kbeg + g.k_per_split) : g.K;
@@ -691,6 +704,7 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     pp_wait_lgkm();
     if (wm == 1) pp_barrier();          // group 1 runs one segment behind
 
+    pp_stamp(g.stamps, 1);
     int slot = 0;
     // one sub-tile (two phases).  STEADY: sub-tiles u+2 and u+3 exist and u is not the last one -
     // straight-line code, so that the MFMA / fragment-read interleave pattern applies
@@ -730,7 +744,9 @@ __global__ __launch_bounds__(PP_THREADS, 1) void gemm_bf16_pp_pair_kernel(const 
     for (; u + D < nsub; ++u) subtile(u, std::true_type{});
     for (; u < nsub; ++u) subtile(u, std::false_type{});
 
+    pp_stamp(g.stamps, 2);
     pp_epilogue<EPI, OUT_BF16>(acc, g, lds, m0, n0, wave, lane);
+    pp_stamp(g.stamps, 3);
 }
 
 // dst[i] = bf16(src[i]); n8 = number of 8-element groups

@@ -1035,7 +1035,7 @@ def test_hipgraph_config5_scale_multi_chunk(pkg, oracle):
     e.synchronize()
     eager = [o.download() for o in outs]
     n_eager = e.get_option('hs_launches')
-    assert n_eager >= 2 * 2 * 3                                          # two chunks x two models x (layer 0, pair, regressor)
+    assert n_eager >= 2 * 2 * 2                                          # two chunks x two models x (layer 0, pair layer + regressor [one band kernel])
     e.set_option('use_graph', 1)
     for it in range(4):                                                  # eager, capture, replay, replay
         for o in outs:
