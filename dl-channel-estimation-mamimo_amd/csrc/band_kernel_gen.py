@@ -66,7 +66,8 @@ V_AHI, V_ALO = (34, 42), (38, 46)
 V_LV, V_TV, V_GV, V_BQ = 50, 58, 66, 74
 V_RDHI, V_RDLO, V_AX, V_LOFF, V_TOFF, V_PK1, V_PK2, V_BADDR = 82, 83, 84, 85, 86, 91, 92, 93
 V_VO1, V_VO2 = 117, 121           # LDS-DMA offsets: [own piece 0, own piece 1, partner's piece 0, partner's piece 1]
-V_T = 94                          # v94..v109 scratch
+V_T = 94                          # v94..v109 scratch (prologue, epilogue, stamps); bf16 mode: also the 16 requested Ts values
+V_TV16 = 94
 V_OUTOFF, V_M, V_4HI, V_B2ADDR, V_HI, V_L31 = 110, 112, 113, 114, 115, 116
 ACC1, ACC2 = 0, 64                # AGPR bases
 
@@ -139,14 +140,18 @@ def simulate(blocks_in_order, queue=None):
 class Role:
     """straight-line program of one wave half (h = 0 / 1)"""
 
-    def __init__(self, h, dbg):
+    def __init__(self, h, dbg, mode='hs'):
         self.h = h
         self.dbg = dbg
+        self.mode = mode
+        self.bf = mode == 'bf16'
+        self.nq = 8 if self.bf else 16          # stage-2 sub-steps per column step (sub-tiles of 32 / 16 k)
+        self.tv = V_TV16 if self.bf else V_TV
         self.uid = 0
 
     # ---------------------------------------------------------------- pieces of code
     def mfma(self, b, acc, w, a, zero_c=False):
-        b.e('v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (areg(acc, 16), vreg(w, 4), vreg(a, 4), '0' if zero_c else areg(acc, 16)))
+        b.e('v_mfma_f32_32x32x16_%s %s, %s, %s, %s' % ('bf16' if self.bf else 'f16', areg(acc, 16), vreg(w, 4), vreg(a, 4), '0' if zero_c else areg(acc, 16)))
 
     def read_w(self, b, plane, slot):
         base, addr = (V_WLO, V_RDLO) if plane else (V_WHI, V_RDHI)
@@ -156,18 +161,20 @@ class Role:
             b.e('ds_read_b128 %s, %s offset:%d' % (vreg(base + 4 * jj, 4), vreg(addr), slot * RING_SLOT + jj * 2048))
 
     def request(self, b, mode):
-        """4 x 16 B per lane of L0 / Ts for this role's next stage-1 fragment; mode 'reset': first of a column"""
+        """L0 / Ts values of this role's next stage-1 fragment (hs: 16 k = 2 x 16 B per lane and array; bf16: 32 k = 4 x 16 B:
+        k 8 hi .. +7 of both 16-k MFMA steps); mode 'reset': first of a column"""
+        step = 128 if self.bf else 64           # bytes of one fragment's k range in a row
         if mode == 'reset':
             for p, src in ((S_L0P, S_L0), (S_TSP, S_TS)):
-                b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), 64 * self.h))
+                b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), step * self.h))
                 b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(src + 1)))
         if 'noreq' not in self.dbg:
-            b.vm('global_load_dwordx4 %s, %s, %s' % (vreg(V_LV, 4), vreg(V_LOFF), sreg(S_L0P, 2)), 'V')
-            b.vm('global_load_dwordx4 %s, %s, %s offset:16' % (vreg(V_LV + 4, 4), vreg(V_LOFF), sreg(S_L0P, 2)), 'V')
-            b.vm('global_load_dwordx4 %s, %s, %s' % (vreg(V_TV, 4), vreg(V_TOFF), sreg(S_TSP, 2)), 'V')
-            b.vm('global_load_dwordx4 %s, %s, %s offset:16' % (vreg(V_TV + 4, 4), vreg(V_TOFF), sreg(S_TSP, 2)), 'V')
+            offs = (0, 16, 64, 80) if self.bf else (0, 16)
+            for dst, voff, ptr in ((V_LV, V_LOFF, S_L0P), (self.tv, V_TOFF, S_TSP)):
+                for i, o in enumerate(offs):
+                    b.vm('global_load_dwordx4 %s, %s, %s%s' % (vreg(dst + 4 * i, 4), vreg(voff), sreg(ptr, 2), ' offset:%d' % o if o else ''), 'V')
         for p in (S_L0P, S_TSP):
-            b.e('s_add_u32 %s, %s, 128' % (sreg(p), sreg(p)))
+            b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(p), 2 * step))
             b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(p + 1)))
 
     def pieces(self, b, kind, slot, who='own'):
@@ -183,11 +190,32 @@ class Role:
         b.e('s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1)))
 
     def convert(self, b, kind, par_next, jj=0, g=0):
-        """fragment of the NEXT sub-step into a_hi / a_lo [par_next] and the exchange slot.  kind 't1': from the requested
-        L0 / Ts values; 't2': from stage-1 accumulator tile jj, registers 8 g .. 8 g + 7"""
+        """fragment of the NEXT sub-step into the two operand registers quads [par_next] and the exchange slot.
+        hs: (hi, lo) halves of 16 k.  kind 't1': from the requested L0 / Ts values; 't2': from stage-1 accumulator tile jj,
+        registers 8 g .. 8 g + 7.  bf16: (k-step 0, k-step 1) of 32 k; 't2' converts the whole tile jj (both halves)."""
         ahi, alo = V_AHI[par_next], V_ALO[par_next]
         pk = V_PK1 if kind == 't1' else V_PK2
-        if 'noconv' not in self.dbg:
+        if 'noconv' not in self.dbg and self.bf:
+            if kind == 't1':
+                b.wait_vm({'V'})
+            for half, dst in ((0, ahi), (1, alo)):
+                if kind == 't1':
+                    for e in range(8):
+                        b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + 8 * half + e), vreg(self.tv + 8 * half + e)))
+                else:
+                    imm = (128 * self.h + 32 * jj + 16 * half) * 4
+                    b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ, 4), vreg(V_BADDR), imm))
+                    b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ + 4, 4), vreg(V_BADDR), imm + 32))
+                    for e in range(8):
+                        b.e('v_accvgpr_read_b32 %s, %s' % (vreg(V_GV + e), areg(ACC1 + 16 * jj + 8 * half + e)))
+                    b.e('s_waitcnt lgkmcnt(0)')
+                    for e in range(8):
+                        b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_GV + e), vreg(V_BQ + e)))
+                for e in range(8):
+                    b.e('v_max_f32_e32 %s, 0, %s' % (vreg(V_GV + e), vreg(V_GV + e)))
+                for p in range(4):
+                    b.e('v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(dst + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
+        elif 'noconv' not in self.dbg:
             if kind == 't1':
                 b.wait_vm({'V'})
                 for e in range(8):
@@ -232,13 +260,20 @@ class Role:
             self.convert(b, produce[0], par ^ 1, *produce[1:])
         if request is not None:
             self.request(b, request)
+        # hs: P0 w_lo x a_hi, P1 w_hi x a_hi, P2 w_hi x a_lo (three products of the split operands).  bf16: the sub-tile is 32 k =
+        # two MFMA k-steps: P0 = k-step 1 (weight chunks 2, 3 = "plane 1", read behind the previous barrier), P1 = k-step 0
         def P(ph):
             for jj in range(4):
-                if ph == 0:                               # P0: w_lo x a_hi
+                if self.bf:
+                    if ph == 0:
+                        self.mfma(b, acc + 16 * jj, V_WLO + 4 * jj, V_ALO[par], zero_c=first)
+                    else:
+                        self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_AHI[par])
+                elif ph == 0:
                     self.mfma(b, acc + 16 * jj, V_WLO + 4 * jj, V_AHI[par], zero_c=first)
-                elif ph == 1:                             # P1: w_hi x a_hi
+                elif ph == 1:
                     self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_AHI[par])
-                else:                                     # P2: w_hi x a_lo
+                else:
                     self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_ALO[par])
 
         def sync():
@@ -258,7 +293,12 @@ class Role:
         # The two waves of a SIMD (half 0 / half 1 of a row group) meet at ONE barrier per sub-step but sit at different
         # places of their MFMA sequence when they do: half 0 has 8 of its 12 MFMAs in front of it, half 1 four - so one
         # wave's reads / LDS-DMA / conversion run beside the other's MFMAs instead of beside its reads.
-        if self.h == 0 or 'nostagger' in self.dbg:
+        if self.bf:
+            P(0)
+            sync()
+            after()
+            P(1)
+        elif self.h == 0 or 'nostagger' in self.dbg:
             P(0)
             b.e('s_waitcnt lgkmcnt(0)')
             P(1)
@@ -333,21 +373,22 @@ class Role:
         if h == 0:
             bub.e('s_nop 15')
             bub.e('s_nop 15')
-            self.convert(bub, 't2', 0, 0, 0)
+            self.convert(bub, 't2', 0, 0, 0)                # (bf16: the whole tile 0)
             bub.e('s_waitcnt lgkmcnt(0)')
             self.barrier(bub)
         else:
             self.barrier(bub)
             self.read_frag(bub, 0)
 
-        # ---- stage 2: sub-step q consumes fragment q (tile q >> 1, half q & 1 of its 16-feature groups)
-        for q in range(16):
+        # ---- stage 2: sub-step q consumes fragment q (hs: tile q >> 1, half q & 1 of its 16-feature groups; bf16: tile q)
+        NQ = self.nq
+        for q in range(NQ):
             nq = q + 1
             produce, consume, request, pre = None, False, None, None
-            if nq <= 15:
-                owner = 0 if nq <= 7 else 1
+            if nq <= NQ - 1:
+                owner = 0 if nq < NQ // 2 else 1
                 if owner == h:
-                    produce = ('t2', (nq >> 1) - 4 * h, nq & 1)
+                    produce = ('t2', nq - 4 * h) if self.bf else ('t2', (nq >> 1) - 4 * h, nq & 1)
                 else:
                     consume = True
             else:                                          # fragment 0 of the next column step (stage-1 kind), by half 0
@@ -355,12 +396,12 @@ class Role:
                     produce, request = ('t1',), 'advance'
                 else:
                     consume = True
-            if q == 13 and h == 0:
+            if q == NQ - 3 and h == 0:
                 request = 'reset'
-            if q == 14 and h == 1:
+            if q == NQ - 2 and h == 1:
                 request = 'reset'
-            piece = 's2' if q < 12 else 's1'
-            if q == 12:                                    # weight pointer of stage 1 moves to the next column step (wraps at the end)
+            piece = 's2' if q < NQ - 4 else 's1'
+            if q == NQ - 4:                                # weight pointer of stage 1 moves to the next column step (wraps at the end)
                 pre = ['s_add_u32 %s, %s, 1' % (sreg(S_T), sreg(S_COL)),
                        's_cmp_ge_u32 %s, %s' % (sreg(S_T), sreg(S_NCOL)),
                        's_cselect_b32 %s, 0, %s' % (sreg(S_T), sreg(S_T)),
@@ -408,7 +449,7 @@ def stamp(b, i, uid):
     b.label(skip)
 
 
-def common_prologue(b, dbg=()):
+def common_prologue(b, dbg=(), mode='hs'):
     b.e('s_load_dwordx16 %s, s[0:1], 0x0' % sreg(4, 16))
     b.e('s_load_dwordx16 %s, s[0:1], 0x40' % sreg(20, 16))
     b.e('s_waitcnt lgkmcnt(0)')
@@ -435,7 +476,7 @@ def common_prologue(b, dbg=()):
     if 'exit0' in dbg:
         b.e('s_branch L_end')
     stamp(b, 0, 0)
-    b.e('s_lshr_b32 %s, %s, 4' % (sreg(S_NSUB1), sreg(S_K1)))
+    b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_NSUB1), sreg(S_K1), 5 if mode == 'bf16' else 4))        # sub-tiles of 16 (hs) / 32 (bf16) k
     b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_NCOL), sreg(S_N1)))
     b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_COLBYTES), sreg(S_LDB1)))        # 256 rows x ldb1 halves x 2 B
     b.e('s_lshl_b32 %s, %s, 11' % (sreg(S_DMA), sreg(S_WAVE)))            # this wave's 2 pieces: image rows 32 w ..
@@ -629,13 +670,13 @@ def epilogue(b, h, dbg=()):
     b.e('s_branch L_end')
 
 
-def kernel(name, dbg=()):
+def kernel(name, dbg=(), mode='hs'):
     out = ['.globl %s' % name, '.p2align 8', '.type %s,@function' % name, '%s:' % name]
     pre = Block('common')
-    common_prologue(pre, dbg)
+    common_prologue(pre, dbg, mode)
     blocks = [pre]
-    r0 = Role(0, dbg).build()
-    r1 = Role(1, dbg).build()
+    r0 = Role(0, dbg, mode).build()
+    r1 = Role(1, dbg, mode).build()
     e0, e1 = Block('ep0'), Block('ep1')
     epilogue(e0, 0, dbg)
     epilogue(e1, 1, dbg)
@@ -696,7 +737,8 @@ META_KERNEL = '''  - .name: {name}
         .value_kind: by_value
 '''
 
-VARIANTS = [('csi_band8', ()), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
+VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
+            ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
@@ -711,7 +753,7 @@ def main():
     for name, dbg in VARIANTS:
         if only and name not in only:
             continue
-        parts.append(kernel(name, dbg))
+        parts.append(kernel(name, dbg, 'bf16' if 'bf16' in dbg else 'hs'))
         parts.append(DESCRIPTOR.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
         meta.append(META_KERNEL.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
     parts.append('.amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.target: amdgcn-amd-amdhsa--gfx950\namdhsa.kernels:\n' + ''.join(meta) + '...\n.end_amdgpu_metadata\n')

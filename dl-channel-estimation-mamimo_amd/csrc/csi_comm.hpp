@@ -66,7 +66,7 @@ RcclApi& rccl() {
 // host-side scalars of the device blobs, one record for both component models
 struct WireLayer {
     int32_t in, out, ldw, ldwb, ldwh, wshift, wshift_f, ashift, ashift_pre;
-    int32_t has_Wt, has_Wb, has_Wh, has_Wh_f, has_Wh_p, has_bias, has_bias_hs, has_scale, has_shift;
+    int32_t has_Wt, has_Wb, has_Wb_p, has_Wh, has_Wh_f, has_Wh_p, has_bias, has_bias_hs, has_scale, has_shift;
 };
 struct WireMeta {
     int32_t magic, n_layers;
@@ -89,6 +89,7 @@ void model_blobs(const csi_config& cf, Model& m, const WireLayer* wl, const int3
         const WireLayer& w = wl[i];
         if (w.has_Wt) v.push_back({(void**)&L.Wt, (size_t)L.out * L.ldw * 4 + slack});
         if (w.has_Wb) v.push_back({(void**)&L.Wb, (size_t)L.out * L.ldwb * 2 + 256});
+        if (w.has_Wb_p) v.push_back({(void**)&L.Wb_p, (size_t)256 * L.ldwb * 2 + 256});
         if (w.has_Wh) v.push_back({(void**)&L.Wh, (size_t)L.out * L.ldwh * 2 + 4096});
         if (w.has_Wh_f) v.push_back({(void**)&L.Wh_f, (size_t)L.out * L.ldwh * 2 + 4096});
         if (w.has_Wh_p) v.push_back({(void**)&L.Wh_p, (size_t)256 * L.ldwh * 2 + 4096});

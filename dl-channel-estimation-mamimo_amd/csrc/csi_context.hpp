@@ -56,6 +56,7 @@ struct Layer {
     int ldw = 0;
     bf16_t* Wb = nullptr;     // [out][ldwb] bf16 (K-major, ldwb = in rounded up to 64)          bf16 mode
     int ldwb = 0;
+    bf16_t* Wb_p = nullptr;   // regressor behind one per-pair layer, bf16 mode: 256 rows, k permuted inside every group of 16 (band kernel)
     uint16_t* Wh_f = nullptr; // regressor behind ONE per-pair layer: Wh with that layer's BN scale folded into its rows (fused kernel)
     int wshift_f = 0;
     uint16_t* Wh_p = nullptr; // the same folded regressor weights, 256 rows (rows >= out zero), k permuted inside every group of 16
@@ -165,6 +166,7 @@ struct csi_ctx {
                                  // profiles/r03_band_probe.txt); 0 = the separate pair and regressor kernels
     hipModule_t band_mod = nullptr;          // its code object (embedded in the library, loaded on first use)
     hipFunction_t band_fn = nullptr;
+    hipFunction_t band_fn_bf16 = nullptr;
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;
     int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
@@ -292,6 +294,7 @@ int upload(csi_ctx* c, float** dst, const float* src, size_t n) {
 void free_layer(Layer& l) {
     if (l.Wt) hipFree(l.Wt);
     if (l.Wb) hipFree(l.Wb);
+    if (l.Wb_p) hipFree(l.Wb_p);
     if (l.Wh) hipFree(l.Wh);
     if (l.Wh_f) hipFree(l.Wh_f);
     if (l.Wh_p) hipFree(l.Wh_p);

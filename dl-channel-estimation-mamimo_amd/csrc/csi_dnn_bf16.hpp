@@ -204,7 +204,30 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 HIP_TRY(c, hipGetLastError());
             }
             PairSrc src{l0sum, m.T, h1, nt};
-            rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
+            const Layer& lr = m.layers[nh];
+            hipFunction_t fn = nullptr;
+            BandArgs ba{};
+            if (nh == 2 && c->hs_band == 2 && lr.Wb_p) {
+                // first per-pair layer + regressor as one kernel, h2 in registers: the bf16 form of the assembly band kernel.  Only on
+                // request ("hs_band" = 2): measured SLOWER than the two bf16 kernels at config 3 (4.90 vs 3.37 + 0.99 ms,
+                // profiles/r03_bench_bf16_band_ab.txt) - with one MFMA per product its per-sub-step overheads are not covered
+                ba.L0 = l0sum; ba.Ts = m.T; ba.ldl = h1; ba.nt = nt; ba.in_scale = 1.f;
+                ba.W1 = reinterpret_cast<const uint16_t*>(l1.Wb); ba.ldb1 = l1.ldwb; ba.bias1 = l1.bias; ba.M = M2; ba.K1 = h1; ba.N1 = l1.out;
+                ba.acc_scale1 = 1.f; ba.out_scale = 1.f;
+                ba.W2p = reinterpret_cast<const uint16_t*>(lr.Wb_p); ba.ldb2 = lr.ldwb; ba.bias2 = lr.bias; ba.n2 = cf.n_out; ba.acc_scale2 = 1.f;
+                ba.out = d_out + (size_t)p0 * nr * nt * cf.n_out; ba.ldo = cf.n_out; ba.peak = nullptr;
+                if (band8_serves(ba, true) && l1.in == h1 && lr.in == l1.out && l1.ldwb == h1 && lr.ldwb == l1.out) {
+                    rc = band8_function(c, &fn, true);
+                    if (rc) return rc;
+                }
+            }
+            if (fn) {
+                const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
+                const double bytes = 4.0 * ((double)M2 / nt * h1 + (double)nt * h1) + 2.0 * ((double)l1.out * h1 + (double)cf.n_out * l1.out) + 4.0 * (double)M2 * cf.n_out;
+                rc = band8_launch(c, fn, ba, flops, bytes);
+            } else {
+                rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
+            }
         } else {
             {
                 ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);

@@ -198,20 +198,31 @@ int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
 #define CSI_HAVE_BAND8 1
 #endif
 
-int band8_function(csi_ctx* c, hipFunction_t* fn) {
+int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false) {
     *fn = nullptr;
 #ifdef CSI_HAVE_BAND8
     if (c->band_failed) return CSI_OK;
-    if (!c->band_fn) {
-        if (hipModuleLoadData(&c->band_mod, band8_hsaco) != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, "csi_band8") != hipSuccess) {
+    if (!c->band_mod) {
+        if (hipModuleLoadData(&c->band_mod, band8_hsaco) != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, "csi_band8") != hipSuccess ||
+            hipModuleGetFunction(&c->band_fn_bf16, c->band_mod, "csi_band8_bf16") != hipSuccess) {
             (void)hipGetLastError();
             c->band_failed = true;       // not fatal: the separate kernels serve the call
-            c->band_fn = nullptr;
+            c->band_fn = c->band_fn_bf16 = nullptr;
             return CSI_OK;
         }
     }
-    *fn = c->band_fn;
+    *fn = bf16 ? c->band_fn_bf16 : c->band_fn;
 #endif
+    return CSI_OK;
+}
+
+int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops, double bytes) {
+    ++c->band_launches;
+    ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
+    Band8Args a8 = band8_args(ba);
+    size_t sz = sizeof(a8);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
     return CSI_OK;
 }
 
@@ -264,15 +275,9 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         }
         if (fn) {
             ++c->hs_launches;
-            ++c->band_launches;
             const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
             const double bytes = 4.0 * ((double)M2 / cf.nt * h1 + (double)cf.nt * h1 + (double)l1.out * h1 + (double)cf.n_out * l1.out + (double)M2 * cf.n_out);
-            ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
-            Band8Args a8 = band8_args(ba);
-            size_t sz = sizeof(a8);
-            void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-            HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((M2 + BAND_ROWS - 1) / BAND_ROWS), 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
-            return CSI_OK;
+            return band8_launch(c, fn, ba, flops, bytes);
         }
     }
     if (nh == 2 && c->hs_fuse_regressor && lr.Wh_f && cf.n_out <= PP_BN && l1.out % PP_BN == 0) {

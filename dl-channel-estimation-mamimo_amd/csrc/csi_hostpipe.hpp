@@ -301,6 +301,22 @@ int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, b
     return CSI_OK;
 }
 
+// Packet ranges of the pipelined calls.  They are bound by the slower copy direction (the download: 1.92 GB for DNN + LS at config 2;
+// rocprofv3 --memory-copy-trace shows the D2H engine busy 88 % of the span at ~50 GB/s, profiles/r03_c128_copy_trace.txt), so what is left
+// to win is the head and the tail of that stream: a SHORT first chunk lets the first download start after ~1.5 ms instead of ~4.5, a short
+// last one leaves little to copy out behind the last download.  `chunk` stays the slot size; every host-buffer entry point uses the same
+// schedule (the plane calls and csi_estimate_c128 return identical bits for identical packets).
+void hp_schedule(int64_t npkt, int64_t chunk, std::vector<int64_t>& first_of, std::vector<int64_t>& size_of) {
+    const int64_t small = std::max<int64_t>(1, chunk / 4);
+    int64_t p = 0;
+    auto push = [&](int64_t n) { first_of.push_back(p); size_of.push_back(n); p += n; };
+    if (npkt > chunk) push(small);
+    while (npkt - p > chunk + small) push(chunk);
+    if (npkt - p > chunk) { push(npkt - p - small); push(small); }
+    else if (npkt - p > 2 * small && npkt > chunk) { push(npkt - p - small); push(small); }
+    else push(npkt - p);
+}
+
 // run(d_re, d_im, np, d_ore, d_oim) enqueues the kernels of np packets on c->stream
 int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
                     const std::function<int(const float*, const float*, int64_t, float*, float*)>& run);
@@ -339,7 +355,9 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
     rc = hp_reserve(c, h, 2 * in_pkt * chunk, 2 * out_pkt * chunk, !in_pinned, !out_pinned);
     if (rc) return rc;
 
-    const int64_t nchunks = (npkt + chunk - 1) / chunk;
+    std::vector<int64_t> first_of, size_of;
+    hp_schedule(npkt, chunk, first_of, size_of);
+    const int64_t nchunks = (int64_t)size_of.size();
     if (nchunks == 1 && 2 * (in_pkt + out_pkt) * (size_t)npkt <= ((size_t)8 << 20)) {
         // small call (the reference's per-packet loop): nothing to pipeline - one stream, no events, no
         // thread hand-over; the staging copies are a few hundred KB
@@ -370,13 +388,13 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
         }
         return CSI_OK;
     }
-    auto np_of = [&](int64_t i) { return std::min(chunk, npkt - i * chunk); };
+    auto np_of = [&](int64_t i) { return size_of[(size_t)i]; };
     auto drain = [&](int64_t i) -> int {                 // pinned[slot] -> user, after the D2H of chunk i
         const int s = (int)(i & 1);
         HIP_TRY(c, hipEventSynchronize(h->ev_out[s]));
         if (!out_pinned) {
             const int64_t np = np_of(i);
-            const size_t off = (size_t)i * chunk * cf.nr * cf.nt * n_out;
+            const size_t off = (size_t)first_of[(size_t)i] * cf.nr * cf.nt * n_out;
             h->copy(o_re + off, h->pin_out[s], out_pkt * np);
             h->copy(o_im + off, h->pin_out[s] + out_pkt * chunk, out_pkt * np);
         }
@@ -385,7 +403,7 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
     for (int64_t i = 0; i < nchunks; ++i) {
         const int s = (int)(i & 1);
         const int64_t np = np_of(i);
-        const size_t ioff = (size_t)i * chunk * cf.nr * cf.len_ltf;
+        const size_t ioff = (size_t)first_of[(size_t)i] * cf.nr * cf.len_ltf;
         float* d_re = reinterpret_cast<float*>(h->dev[s]);
         float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
         float* d_ore = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
@@ -412,7 +430,7 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
         // pinned_out[s] must have been drained to the user (chunk i-2) before it is overwritten
         if (i >= 2) { rc = drain(i - 2); if (rc) return rc; }
         HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
-        const size_t ooff = (size_t)i * chunk * cf.nr * cf.nt * n_out;
+        const size_t ooff = (size_t)first_of[(size_t)i] * cf.nr * cf.nt * n_out;
         if (out_pinned) {
             HIP_TRY(c, hipMemcpyAsync(o_re + ooff, d_ore, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
             HIP_TRY(c, hipMemcpyAsync(o_im + ooff, d_oim, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
@@ -449,11 +467,13 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     chunk = std::min(chunk, npkt);
     rc = hp_reserve(c, h, 2 * in_pkt * chunk, 2 * out_pkt * chunk, true, true);
     if (rc) return rc;
-    const int64_t nchunks = (npkt + chunk - 1) / chunk;
-    auto np_of = [&](int64_t i) { return std::min(chunk, npkt - i * chunk); };
+    std::vector<int64_t> first_of, size_of;
+    hp_schedule(npkt, chunk, first_of, size_of);
+    const int64_t nchunks = (int64_t)size_of.size();
+    auto np_of = [&](int64_t i) { return size_of[(size_t)i]; };
     auto stage_in = [&](int64_t i, int s) {                              // complex128 -> two float32 planes in pinned[s]
         const int64_t np = np_of(i);
-        const double* src = in + (size_t)i * chunk * in_n * 2;
+        const double* src = in + (size_t)first_of[(size_t)i] * in_n * 2;
         float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
         float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
         h->parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
@@ -467,8 +487,8 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
             h->parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
         };
         // pinned[s] layout = device[s] output layout: dnn re | dnn im | ls re | ls im, each sized for `chunk` packets
-        if (dnn_c64) weave(p, p + dnn_n * chunk, dnn_c64 + (size_t)i * chunk * dnn_n * 2, (size_t)np * dnn_n);
-        if (ls_c64) weave(p + 2 * dnn_n * chunk, p + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)i * chunk * ls_n * 2, (size_t)np * ls_n);
+        if (dnn_c64) weave(p, p + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
+        if (ls_c64) weave(p + 2 * dnn_n * chunk, p + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
         return CSI_OK;
     };
     for (int64_t i = 0; i < nchunks; ++i) {

@@ -391,6 +391,17 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             if (hipMalloc((void**)&L.Wb, bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
             HIP_TRY(c, hipMemset(L.Wb, 0, bytes));
             HIP_TRY(c, hipMemcpy(L.Wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+            if (reg && li == 2 && cf.nt > 0 && out <= 256) {
+                // the regressor behind ONE per-pair layer: a copy for the fused band kernel - 256 rows (rows >= out zero), k
+                // permuted inside every group of 16 so that a lane's stage-1 accumulators are its stage-2 operand
+                std::vector<uint16_t> wp((size_t)256 * L.ldwb, 0);
+                for (int o = 0; o < out; ++o)
+                    for (int i = 0; i < L.ldwb; ++i) wp[(size_t)o * L.ldwb + i] = wb[(size_t)o * L.ldwb + (i & ~15) + hs_band_kperm(i & 15)];
+                const size_t pbytes = wp.size() * 2 + 256;
+                if (hipMalloc((void**)&L.Wb_p, pbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
+                HIP_TRY(c, hipMemset(L.Wb_p, 0, pbytes));
+                HIP_TRY(c, hipMemcpy(L.Wb_p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+            }
         } else {
             rc = upload(c, &L.Wt, wt.data(), wt.size());
             if (rc) return rc;
@@ -898,8 +909,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         drop_graphs(c);
         c->hs_fuse_regressor = value != 0;
     } else if (n == "hs_band") {
+        if (value < 0 || value > 2) return fail(c, CSI_ERR_INVALID_ARG, "hs_band must be 0 (separate kernels), 1 (band kernel for fp32 contexts) or 2 (also for bf16 contexts)");
         drop_graphs(c);
-        c->hs_band = value != 0;
+        c->hs_band = (int)value;
     } else if (n == "hs_min_blocks") {
         if (value < 1 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "hs_min_blocks must be 1..65536");
         drop_graphs(c);
@@ -1160,7 +1172,7 @@ int csi_broadcast_weights(csi_ctx* c, int root) {
                 WireLayer& x = w.layer[d][i];
                 x.in = L.in; x.out = L.out; x.ldw = L.ldw; x.ldwb = L.ldwb; x.ldwh = L.ldwh;
                 x.wshift = L.wshift; x.wshift_f = L.wshift_f; x.ashift = L.ashift; x.ashift_pre = L.ashift_pre;
-                x.has_Wt = L.Wt != nullptr; x.has_Wb = L.Wb != nullptr; x.has_Wh = L.Wh != nullptr; x.has_Wh_f = L.Wh_f != nullptr;
+                x.has_Wt = L.Wt != nullptr; x.has_Wb = L.Wb != nullptr; x.has_Wb_p = L.Wb_p != nullptr; x.has_Wh = L.Wh != nullptr; x.has_Wh_f = L.Wh_f != nullptr;
                 x.has_Wh_p = L.Wh_p != nullptr; x.has_bias = L.bias != nullptr; x.has_bias_hs = L.bias_hs != nullptr;
                 x.has_scale = L.scale != nullptr; x.has_shift = L.shift != nullptr;
             }

@@ -102,9 +102,9 @@ inline Band8Args band8_args(const BandArgs& g) {
     a.nt_magic = g.nt <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)g.nt);
     return a;
 }
-// shapes the assembly kernel serves (the caller falls back to the separate kernels otherwise)
-inline bool band8_serves(const BandArgs& g) {
-    return g.K1 >= 128 && (g.K1 % 64) == 0 && g.N1 >= 256 && (g.N1 % 256) == 0 && g.N1 <= BAND8_MAX_N1 && g.n2 >= 1 && g.n2 <= 256 &&
+// shapes the assembly kernel serves (the caller falls back to the separate kernels otherwise); bf16: sub-tiles of 32 k
+inline bool band8_serves(const BandArgs& g, bool bf16 = false) {
+    return g.K1 >= (bf16 ? 256 : 128) && (g.K1 % (bf16 ? 128 : 64)) == 0 && g.N1 >= 256 && (g.N1 % 256) == 0 && g.N1 <= BAND8_MAX_N1 && g.n2 >= 1 && g.n2 <= 256 &&
            g.nt >= 1 && (unsigned long long)g.M * (unsigned long long)g.nt < 0xffffffffull && (unsigned long long)g.M * g.ldo * 4ull < 0xffffffffull &&
            (unsigned long long)((g.M + g.nt - 1) / g.nt) * g.ldl * 4ull < 0x7fffffffull;
 }

@@ -59,7 +59,10 @@ typedef enum {
 } csi_status;
 
 typedef enum {
-    CSI_DTYPE_F32 = 0,          /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out    */
+    CSI_DTYPE_F32 = 0,          /* fp32 in / accumulate / out.  GEMMs that fill the chip run on the split-f16 engine (every fp32
+                                 * operand as hi + lo f16 halves, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation; same
+                                 * 1e-5 contract, both f16 range ends guarded with an automatic repeat); smaller calls and
+                                 * "f32_engine" = 0 run v_mfma_f32_32x32x2_f32 (exact fp32 products)                    */
     CSI_DTYPE_BF16 = 1          /* bf16 operands, fp32 accumulate MFMA, fp32 out            */
 } csi_dtype;
 
@@ -249,6 +252,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         the LDS-DMA ring (chosen automatically for any other P, 16 <= Nt <= 128); a choice the
  *                         kernel cannot serve falls back
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
+ *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor of an fp32 context's split engine as ONE
+ *                         kernel, h2 in registers (generated gfx950 assembly, csrc/band_kernel_gen.py); 0: the two separate kernels
+ *                         (A/B runs); 2: also the bf16 form for bf16 contexts (measured slower).  Read-only: "band_launches".
  *   "hs_vm_cast", "hs_vm_pair"  vector-memory schedule of the split-f16 layer-0 / first per-pair kernel: 0 builtin LDS-DMA
  *                         with one drain per sub-tile, 1 hand-counted waits, 2 + one more sub-tile of look-ahead (default for
  *                         layer 0), 3 + one load and one 24-MFMA segment per sub-tile (default for the pair layer); same
