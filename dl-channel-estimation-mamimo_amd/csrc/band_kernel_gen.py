@@ -160,21 +160,24 @@ class Role:
         for jj in range(4):
             b.e('ds_read_b128 %s, %s offset:%d' % (vreg(base + 4 * jj, 4), vreg(addr), slot * RING_SLOT + jj * 2048))
 
-    def request(self, b, mode):
-        """L0 / Ts values of this role's next stage-1 fragment (hs: 16 k = 2 x 16 B per lane and array; bf16: 32 k = 4 x 16 B:
-        k 8 hi .. +7 of both 16-k MFMA steps); mode 'reset': first of a column"""
-        step = 128 if self.bf else 64           # bytes of one fragment's k range in a row
+    def request(self, b, mode, xset=0):
+        """L0 / Ts values of a stage-1 fragment.  hs: this role's next fragment (16 k = 2 x 16 B per lane and array), requested by
+        the half that will convert it.  bf16: BOTH halves convert every fragment, each its own 16-k MFMA step of the 32 (half 0:
+        k 8 hi .. +7, half 1: 16 + 8 hi ..), so each requests 2 x 16 B per array into register set `xset` (fragment parity).
+        mode 'reset': first of a column."""
         if mode == 'reset':
             for p, src in ((S_L0P, S_L0), (S_TSP, S_TS)):
-                b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), step * self.h))
+                b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), 0 if self.bf else 64 * self.h))
                 b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(src + 1)))
         if 'noreq' not in self.dbg:
-            offs = (0, 16, 64, 80) if self.bf else (0, 16)
+            offs = ((0, 16), (64, 80))[self.h] if self.bf else (0, 16)
+            base = 8 * xset if self.bf else 0
             for dst, voff, ptr in ((V_LV, V_LOFF, S_L0P), (self.tv, V_TOFF, S_TSP)):
                 for i, o in enumerate(offs):
-                    b.vm('global_load_dwordx4 %s, %s, %s%s' % (vreg(dst + 4 * i, 4), vreg(voff), sreg(ptr, 2), ' offset:%d' % o if o else ''), 'V')
+                    b.vm('global_load_dwordx4 %s, %s, %s%s' % (vreg(dst + base + 4 * i, 4), vreg(voff), sreg(ptr, 2), ' offset:%d' % o if o else ''),
+                         'V%d' % xset if self.bf else 'V')
         for p in (S_L0P, S_TSP):
-            b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(p), 2 * step))
+            b.e('s_add_u32 %s, %s, 128' % (sreg(p), sreg(p)))
             b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(p + 1)))
 
     def pieces(self, b, kind, slot, who='own'):
@@ -195,14 +198,23 @@ class Role:
         registers 8 g .. 8 g + 7.  bf16: (k-step 0, k-step 1) of 32 k; 't2' converts the whole tile jj (both halves)."""
         ahi, alo = V_AHI[par_next], V_ALO[par_next]
         pk = V_PK1 if kind == 't1' else V_PK2
+        if self.bf and kind == 't1':
+            # split production: this wave converts ITS k-step of the fragment (half 0: k-step 0 -> a0, half 1: k-step 1 -> a1),
+            # leaves it in the exchange slot and reads the partner's half behind the barrier
+            dst = ahi if self.h == 0 else alo
+            if 'noconv' not in self.dbg:
+                b.wait_vm({'V%d' % g})                 # g = register set of this fragment
+                for e in range(8):
+                    b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + 8 * g + e), vreg(self.tv + 8 * g + e)))
+                for e in range(8):
+                    b.e('v_max_f32_e32 %s, 0, %s' % (vreg(V_GV + e), vreg(V_GV + e)))
+                for p in range(4):
+                    b.e('v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(dst + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
+            b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(dst, 4), par_next * 2048 + 1024 * self.h))
+            return
         if 'noconv' not in self.dbg and self.bf:
-            if kind == 't1':
-                b.wait_vm({'V'})
             for half, dst in ((0, ahi), (1, alo)):
-                if kind == 't1':
-                    for e in range(8):
-                        b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + 8 * half + e), vreg(self.tv + 8 * half + e)))
-                else:
+                if True:
                     imm = (128 * self.h + 32 * jj + 16 * half) * 4
                     b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ, 4), vreg(V_BADDR), imm))
                     b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_BQ + 4, 4), vreg(V_BADDR), imm + 32))
@@ -242,9 +254,11 @@ class Role:
         b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(ahi, 4), par_next * 2048))
         b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(alo, 4), par_next * 2048 + 1024))
 
-    def read_frag(self, b, par_next):
-        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_AHI[par_next], 4), vreg(V_AX), par_next * 2048))
-        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_ALO[par_next], 4), vreg(V_AX), par_next * 2048 + 1024))
+    def read_frag(self, b, par_next, partner_half_only=False):
+        if not partner_half_only or self.h == 1:
+            b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_AHI[par_next], 4), vreg(V_AX), par_next * 2048))
+        if not partner_half_only or self.h == 0:
+            b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_ALO[par_next], 4), vreg(V_AX), par_next * 2048 + 1024))
 
     def barrier(self, b):
         if 'nobarrier' not in self.dbg:
@@ -259,7 +273,10 @@ class Role:
         if produce is not None:
             self.convert(b, produce[0], par ^ 1, *produce[1:])
         if request is not None:
-            self.request(b, request)
+            if isinstance(request, tuple):
+                self.request(b, request[0], request[1])
+            else:
+                self.request(b, request)
         # hs: P0 w_lo x a_hi, P1 w_hi x a_hi, P2 w_hi x a_lo (three products of the split operands).  bf16: the sub-tile is 32 k =
         # two MFMA k-steps: P0 = k-step 1 (weight chunks 2, 3 = "plane 1", read behind the previous barrier), P1 = k-step 0
         def P(ph):
@@ -288,14 +305,22 @@ class Role:
             self.pieces(b, piece, slot, who)
             self.read_w(b, 1, nslot)
             if consume:
-                self.read_frag(b, par ^ 1)
+                self.read_frag(b, par ^ 1, partner_half_only=(consume == 'half'))
 
         # The two waves of a SIMD (half 0 / half 1 of a row group) meet at ONE barrier per sub-step but sit at different
         # places of their MFMA sequence when they do: half 0 has 8 of its 12 MFMAs in front of it, half 1 four - so one
         # wave's reads / LDS-DMA / conversion run beside the other's MFMAs instead of beside its reads.
-        if self.bf:
+        if self.bf and (self.h == 0 or 'nostagger' in self.dbg):
             P(0)
             sync()
+            after()
+            P(1)
+        elif self.bf:
+            # half 1 meets the barrier BEFORE its first MFMA group: behind the barrier it runs P0 while half 0 issues its LDS-DMA and
+            # reads, then its own LDS-DMA / reads while half 0 runs P1, then P1 while half 0 converts - with 8 MFMAs per wave and
+            # barrier there is nothing else to hide a wave's non-MFMA work behind
+            sync()
+            P(0)
             after()
             P(1)
         elif self.h == 0 or 'nostagger' in self.dbg:
@@ -326,7 +351,12 @@ class Role:
             b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
         for t in range(4):
             self.pieces(b, 's1', t)
-        if h == 0:
+        if self.bf:                                         # split production: both halves convert their k-step of fragment 0
+            self.request(b, 'reset', 0)
+            self.request(b, 'advance', 1)
+            self.convert(b, 't1', 0, 0, 0)
+            self.request(b, 'advance', 0)
+        elif h == 0:
             self.request(b, 'reset')
             self.convert(b, 't1', 0)
             self.request(b, 'advance')
@@ -335,7 +365,9 @@ class Role:
         b.wait_vm({'P0'})
         b.e('s_waitcnt lgkmcnt(0)')
         self.barrier(b)
-        if h == 1:
+        if self.bf:
+            self.read_frag(b, 0, partner_half_only=True)
+        elif h == 1:
             self.read_frag(b, 0)
         self.read_w(b, 1, 0)
         b.e('s_mov_b32 %s, 0' % sreg(S_COL))
@@ -343,6 +375,12 @@ class Role:
         # ---- stage 1.  Fragment u + 1 is produced during sub-step u by half (u + 1) & 1; its producer then requests the
         # values of fragment u + 3.  u_rel = position inside a trip of four, flags say what still exists near the column end.
         def s1_substep(b, i, first=False, produce_ok=True, request_ok=True, piece='s1'):
+            if self.bf:
+                # fragment u + 1 (register set (i + 1) & 1): both halves convert their k-step; then the values of fragment u + 3
+                self.substep(b, 1, i & 3, i & 1, first=first, produce=('t1', 0, (i + 1) & 1) if produce_ok else None,
+                             consume='half' if produce_ok else False, request=('advance', (i + 1) & 1) if (produce_ok and request_ok) else None,
+                             piece=piece, who='own')
+                return
             prod = ((i + 1) & 1) == h and produce_ok
             cons = ((i + 1) & 1) != h and produce_ok
             who = 'none' if prod else ('all' if cons else 'own')       # the converting wave leaves the LDS-DMA to its partner
@@ -391,15 +429,23 @@ class Role:
                     produce = ('t2', nq - 4 * h) if self.bf else ('t2', (nq >> 1) - 4 * h, nq & 1)
                 else:
                     consume = True
+            elif self.bf:                                  # fragment 0 of the next column step: split production (register set 0)
+                produce, consume, request = ('t1', 0, 0), 'half', ('advance', 0)
             else:                                          # fragment 0 of the next column step (stage-1 kind), by half 0
                 if h == 0:
                     produce, request = ('t1',), 'advance'
                 else:
                     consume = True
-            if q == NQ - 3 and h == 0:
-                request = 'reset'
-            if q == NQ - 2 and h == 1:
-                request = 'reset'
+            if self.bf:
+                if q == NQ - 3:
+                    request = ('reset', 0)
+                if q == NQ - 2:
+                    request = ('advance', 1)
+            else:
+                if q == NQ - 3 and h == 0:
+                    request = 'reset'
+                if q == NQ - 2 and h == 1:
+                    request = 'reset'
             piece = 's2' if q < NQ - 4 else 's1'
             if q == NQ - 4:                                # weight pointer of stage 1 moves to the next column step (wraps at the end)
                 pre = ['s_add_u32 %s, %s, 1' % (sreg(S_T), sreg(S_COL)),
@@ -409,7 +455,7 @@ class Role:
                        's_add_u32 %s, %s, %s' % (sreg(S_W1P), sreg(S_W1), sreg(S_T + 1)),
                        's_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1 + 1))]
             who = 'none' if produce is not None else ('all' if consume else 'own')
-            if 'ownpieces' in self.dbg:
+            if 'ownpieces' in self.dbg or consume == 'half':      # split production: both halves convert, both issue their own pieces
                 who = 'own'
             self.substep(st2, 2, q & 3, q & 1, produce=produce, consume=consume, request=request, piece=piece, pre_piece=pre, who=who)
         tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
@@ -738,7 +784,7 @@ META_KERNEL = '''  - .name: {name}
 '''
 
 VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
-            ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
+            ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
