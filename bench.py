@@ -270,6 +270,40 @@ def main():
     guard = {'hs_launches': eng.get_option('hs_launches'), 'hs_range_fallbacks': eng.get_option('hs_range_fallbacks'),
              'csi_synchronize': 'clean'} if args.dtype == 'f32' else None
 
+    # ---- host-buffer (PCIe-inclusive) entry points: measured first, before the CPU legs below start their BLAS / OpenMP thread
+    # pools and fragment host memory (measured on one box: 50 ms here, 60 ms behind the oracle check)
+    host_path = None
+    if rank == 0 and world == 1 and args.host_path > 0:
+        k = min(args.host_path, npkt)
+        h_re, h_im = d_re.download(0, k), d_im.download(0, k)
+        o_ls = (np.zeros((k, nr, nt, 234), np.float32), np.zeros((k, nr, nt, 234), np.float32))
+        o_nn = (np.zeros((k, nr, nt, 234), np.float32), np.zeros((k, nr, nt, 234), np.float32))
+        eng.predict(h_re, h_im, out=o_nn); eng.ls_estimate(h_re, h_im, out=o_ls)          # warm-up (staging slots)
+        t0 = time.perf_counter()
+        eng.ls_estimate(h_re, h_im, out=o_ls)
+        eng.predict(h_re, h_im, out=o_nn)
+        t1 = time.perf_counter() - t0
+        host_path = {'packets': k, 'pairs_per_s': k * nr * nt / t1, 'ms': t1 * 1e3,
+                     'note': 'csi_ls_estimate + csi_predict on pre-allocated pageable host buffers: staging + H2D + kernels + D2H, pipelined over packet chunks'}
+        # the deployment surface (inference.py:24-32): complex128 batch in, complex64 estimates out, through the Python
+        # wrapper - csi_estimate_c128: ONE upload for both estimators, split / interleave inside the staging copies
+        x128 = np.empty(h_re.shape, np.complex128)
+        x128.real, x128.imag = h_re, h_im
+        bufs = (np.zeros((k, nr, nt, 234), np.complex64), np.zeros((k, nr, nt, 234), np.complex64))   # touched, like o_ls / o_nn above
+        eng.estimate(x128, out=bufs)                                                       # warm-up (staging slots)
+        t2s = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eng.estimate(x128, out=bufs)
+            t2s.append(time.perf_counter() - t0)
+        t2 = sorted(t2s)[1]
+        host_path['python_c128_to_c64'] = {'pairs_per_s': k * nr * nt / t2, 'ms': t2 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t2s],
+                                           'd2h_bytes': int(bufs[0].nbytes + bufs[1].nbytes),
+                                           'note': 'CsiEngine.estimate (LS + DNN) on a complex128 numpy batch, complex64 numpy results; median of 3 calls. '
+                                                   'Bound: the download of the two result arrays over one PCIe direction (~50 GB/s measured: '
+                                                   'profiles/r03_c128_copy_trace.txt)'}
+        del x128, bufs
+
     # ---- cpu_baseline leg (rank 0, N = 1, after the timed region): the only place that touches oracle/.
     # It runs the CPU restatement of the reference on a bounded sample of the very same packets - timed
     # (--no-cpu-baseline skips the timing) and compared with what the GPU produced for them (--check 0
@@ -341,38 +375,6 @@ def main():
             eng.synchronize()
             ts.append(time.perf_counter() - t1)
         latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6), 'what': 'LS + DNN(real) + DNN(imag) of one packet, device-resident, median of 30 calls'}
-
-    host_path = None
-    if rank == 0 and world == 1 and args.host_path > 0:
-        k = min(args.host_path, npkt)
-        h_re, h_im = d_re.download(0, k), d_im.download(0, k)
-        o_ls = (np.zeros((k, nr, nt, 234), np.float32), np.zeros((k, nr, nt, 234), np.float32))
-        o_nn = (np.zeros((k, nr, nt, 234), np.float32), np.zeros((k, nr, nt, 234), np.float32))
-        eng.predict(h_re, h_im, out=o_nn); eng.ls_estimate(h_re, h_im, out=o_ls)          # warm-up (staging slots)
-        t0 = time.perf_counter()
-        eng.ls_estimate(h_re, h_im, out=o_ls)
-        eng.predict(h_re, h_im, out=o_nn)
-        t1 = time.perf_counter() - t0
-        host_path = {'packets': k, 'pairs_per_s': k * nr * nt / t1, 'ms': t1 * 1e3,
-                     'note': 'csi_ls_estimate + csi_predict on pre-allocated pageable host buffers: staging + H2D + kernels + D2H, pipelined over packet chunks'}
-        # the deployment surface (inference.py:24-32): complex128 batch in, complex64 estimates out, through the Python
-        # wrapper - csi_estimate_c128: ONE upload for both estimators, split / interleave inside the staging copies
-        x128 = np.empty(h_re.shape, np.complex128)
-        x128.real, x128.imag = h_re, h_im
-        bufs = (np.zeros((k, nr, nt, 234), np.complex64), np.zeros((k, nr, nt, 234), np.complex64))   # touched, like o_ls / o_nn above
-        eng.estimate(x128, out=bufs)                                                       # warm-up (staging slots)
-        t2s = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            eng.estimate(x128, out=bufs)
-            t2s.append(time.perf_counter() - t0)
-        t2 = sorted(t2s)[1]
-        host_path['python_c128_to_c64'] = {'pairs_per_s': k * nr * nt / t2, 'ms': t2 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t2s],
-                                           'd2h_bytes': int(bufs[0].nbytes + bufs[1].nbytes),
-                                           'note': 'CsiEngine.estimate (LS + DNN) on a complex128 numpy batch, complex64 numpy results; median of 3 calls. '
-                                                   'Bound: the download of the two result arrays over one PCIe direction (~50 GB/s measured: '
-                                                   'profiles/r03_c128_copy_trace.txt)'}
-        del x128, bufs
 
     if rank != 0:
         return

@@ -270,17 +270,29 @@ class Role:
         nslot = (slot + 1) & 3
         b.e('s_waitcnt lgkmcnt(0)')                       # w_lo of this sub-tile, the fragment read behind the last barrier
         self.read_w(b, 0, slot)                           # w_hi: the sub-tile is visible since the last barrier
+        pending = []                                      # 'interleave' (experiment): conversion spread between this wave's own MFMAs
         if produce is not None:
-            self.convert(b, produce[0], par ^ 1, *produce[1:])
-        if request is not None:
+            if 'interleave' in self.dbg and not self.bf:
+                tmp = Block('conv')
+                self.convert(tmp, produce[0], par ^ 1, *produce[1:])
+                pending = list(tmp.items)
+            else:
+                self.convert(b, produce[0], par ^ 1, *produce[1:])
+        if request is not None and not pending:
             if isinstance(request, tuple):
                 self.request(b, request[0], request[1])
             else:
                 self.request(b, request)
         # hs: P0 w_lo x a_hi, P1 w_hi x a_hi, P2 w_hi x a_lo (three products of the split operands).  bf16: the sub-tile is 32 k =
         # two MFMA k-steps: P0 = k-step 1 (weight chunks 2, 3 = "plane 1", read behind the previous barrier), P1 = k-step 0
+        def drip(n):
+            for _ in range(n):
+                if pending:
+                    b.items.append(pending.pop(0))
+
         def P(ph):
             for jj in range(4):
+                drip((len(pending) + 3) // 4 if (self.h == 1 and ph == 0) else (len(pending) + (7 - 4 * ph - jj)) // max(8 - 4 * ph - jj, 1) if ph < 2 else 0)
                 if self.bf:
                     if ph == 0:
                         self.mfma(b, acc + 16 * jj, V_WLO + 4 * jj, V_ALO[par], zero_c=first)
@@ -294,6 +306,9 @@ class Role:
                     self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_ALO[par])
 
         def sync():
+            drip(len(pending))
+            if 'interleave' in self.dbg and request is not None and produce is not None and not self.bf:
+                self.request(b, request)
             b.e('s_waitcnt lgkmcnt(0)')                   # w_hi in registers (the slot may be refilled), exchange slot written
             b.wait_vm({'P%d' % nslot})                    # this wave's pieces of the next sub-tile have landed
             self.barrier(b)                               # -> sub-tile s + 1 and fragment s + 1 visible, slot s free
@@ -786,7 +801,7 @@ META_KERNEL = '''  - .name: {name}
 VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
-            ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
+            ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_interleave', ('interleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
 
