@@ -71,7 +71,7 @@ struct WireLayer {
 struct WireMeta {
     int32_t magic, n_layers;
     int32_t loaded[2], has_W0p[2], has_W0rm[2];
-    int32_t pilot_ok, p_sylvester;
+    int32_t pilot_ok, p_sylvester, p_pieces;
     WireLayer layer[2][CSI_MAX_HIDDEN + 1];
 };
 constexpr int32_t WIRE_MAGIC = 0x43534931;      // "CSI1"

@@ -116,6 +116,7 @@ struct csi_ctx {
     csi_comm* comm = nullptr;                       // RCCL communicator of csi_comm_init (weight broadcast)
     int host_threads = 0;                           // "host_threads" option: threads of the user <-> pinned copies (0 = automatic)
     float* P = nullptr;          // device [nt][nt]
+    float* Pbf = nullptr;        // device: bf16 pieces of P in MFMA operand order (ls_pilot layout of ls_estimate_ringb_kernel), 2 per float
     float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)
     bool pilot_ok = false;
     // LS constants
@@ -173,9 +174,11 @@ struct csi_ctx {
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024: 40 packets); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
+    int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats
+    int ls_ringb_min = 16;       // "ls_ringb_min": from this Nt on a non-Hadamard pilot takes the bf16-split despread (ls_estimate_ringb_kernel)
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
-    int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first, 4 / 5 Walsh-Hadamard (register prefetch / LDS-DMA ring), 6 generic P on the ring (tests, A/B runs)
+    int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first, 4 / 5 Walsh-Hadamard (register prefetch / LDS-DMA ring), 6 generic P on the ring (fp32 despread), 7 generic P, bf16-split despread (tests, A/B runs)
     int hs_vm_cast = 2, hs_vm_pair = 3;   // "hs_vm_cast" / "hs_vm_pair": vector-memory schedule of the layer-0 / pair kernel (gemm_hs.hip.h): 0 builtin LDS-DMA + one drain per sub-tile, 1 hand-counted, 2 + one more sub-tile of look-ahead, 3 + one load and one 24-MFMA segment per sub-tile
     int ls_v2 = 0;               // CSI_LS_V2: shape variant of the LDS-DMA fed Walsh-Hadamard kernel (experiments)
     int ls_fft_first_max = 15;   // FFT-first LS kernel (all Nt spectra in LDS) up to this Nt; from 16 on the ring kernel is faster (Nt = 16: 0.47 vs 0.72 ms); debug knob CSI_LS_FFT_FIRST_MAX

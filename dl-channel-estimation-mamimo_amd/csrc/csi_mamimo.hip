@@ -19,10 +19,12 @@
 namespace {
 
 // Which LS kernel serves this context.  With the Sylvester Hadamard pilot matrix the Walsh-Hadamard kernel on the
-// LDS-DMA ring.  Any other P: FFT-first (all Nt spectra in LDS) up to ls_fft_first_max antennas, the
-// ring kernel with the matrix-core despread up to Nt = 128, the despread-first kernel beyond.  The older chunked
+// LDS-DMA ring.  Any other P: FFT-first (all Nt spectra in LDS) up to ls_fft_first_max antennas, the ring kernels with
+// the matrix-core despread up to Nt = 128 - bf16-split (ls_estimate_ringb_kernel) except for a pilot matrix of arbitrary
+// floats at Nt <= 32, where the fp32 despread of ls_estimate_ring_kernel is as fast (profiles/r03_ls_probe_generic.txt) -
+// the despread-first kernel beyond.  The older chunked
 // kernel stays selectable through the "ls_kernel" option (tests, A/B runs).
-enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5, LS_RING = 6 };
+enum LsMode { LS_AUTO = 0, LS_FFT_FIRST = 1, LS_CHUNKED = 2, LS_DESPREAD_FIRST = 3, LS_FWHT = 4, LS_FWHT2 = 5, LS_RING = 6, LS_RINGB = 7 };
 struct LsPlan {
     int mode;
     const void* fn;
@@ -30,16 +32,47 @@ struct LsPlan {
     int threads;
     int per_cu;           // resident workgroups per CU (persistent grids)
 };
+// the bf16-split ring kernel (ls_estimate_ringb_kernel) for this Nt / pilot: its shape and LDS need; fn == nullptr when Nt is outside 16 ... 128
+struct LsRingB { const void* fn; size_t lds; int nw, per_cu; };
+LsRingB ls_ringb_shape(const csi_ctx* c) {
+    const int nt = c->cfg.nt, jt = (nt + 31) / 32, npp = std::min(3, std::max(1, c->p_pieces));
+    LsRingB r{nullptr, 0, 8, 1};
+    if (nt < 16 || nt > 128) return r;
+    int nstg = 1;
+#define LS_RB(J, W, NS, MB)                                                                                        \
+    {                                                                                                              \
+        r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 1, MB>                                   \
+               : (npp == 2 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 2, MB> : (const void*)ls_estimate_ringb_kernel<J, W, NS, 3, MB>); \
+        r.nw = W; nstg = NS; r.per_cu = MB;                                                                        \
+    }
+    // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the other ring depth for A/B runs
+    if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2) else LS_RB(1, 4, 1, 2) }
+    else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 2, 1) else LS_RB(2, 8, 1, 1) }
+    else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 1, 1) else LS_RB(3, 8, 2, 1) }
+    else { if (c->ls_v2 == 1) LS_RB(4, 8, 2, 1) else LS_RB(4, 8, 1, 1) }
+#undef LS_RB
+    r.lds = (size_t)(2 * LSC_NTW + 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
+    if (r.lds > 160 * 1024) r.fn = nullptr;
+    r.per_cu = std::max(1, std::min(r.per_cu, (int)((160 * 1024) / r.lds)));
+    return r;
+}
 LsPlan ls_plan(const csi_ctx* c) {
     const int nt = c->cfg.nt;
     int mode = c->ls_kernel;
     const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
     if ((mode == LS_FWHT || mode == LS_FWHT2) && !fwht_ok) mode = LS_AUTO;
-    if (mode == LS_AUTO) mode = fwht_ok ? LS_FWHT2 : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? LS_RING : LS_DESPREAD_FIRST));
+    const LsRingB rb = ls_ringb_shape(c);
+    if (mode == LS_RINGB && !rb.fn) mode = LS_AUTO;
+    if (mode == LS_AUTO)
+        mode = fwht_ok ? LS_FWHT2 : (nt <= c->ls_fft_first_max ? LS_FFT_FIRST : (nt <= 128 ? (rb.fn && nt >= c->ls_ringb_min && (c->p_pieces < 3 || nt > 32) ? LS_RINGB : LS_RING) : LS_DESPREAD_FIRST));
     if (mode == LS_FFT_FIRST && nt > 64) mode = LS_CHUNKED;
     if ((mode == LS_CHUNKED || mode == LS_RING) && (nt < 16 || nt > 128)) mode = nt < 16 ? LS_FFT_FIRST : LS_DESPREAD_FIRST;
     LsPlan p{};
     p.mode = mode;
+    if (mode == LS_RINGB) {
+        p.fn = rb.fn; p.lds = rb.lds; p.threads = 64 * rb.nw; p.per_cu = rb.per_cu;
+        return p;
+    }
     if (mode == LS_FWHT2) {
         // shape per Nt as measured (profiles/r02_ls_probe.txt); "ls_v2" = 1 selects the runner-up for A/B runs
         const int v = c->ls_v2;
@@ -226,7 +259,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
     if (const char* e = std::getenv("CSI_LS_FFT_FIRST_MAX")) c->ls_fft_first_max = std::min(64, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_DEBUG")) c->ls_debug = std::atoi(e);
-    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(6, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CSI_LS_KERNEL")) c->ls_kernel = std::min(7, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CSI_LS_V2")) c->ls_v2 = std::atoi(e);
     if (const char* e = std::getenv("CSI_HS_VM")) c->hs_vm_cast = c->hs_vm_pair = std::min(3, std::max(0, std::atoi(e)));
     auto bail = [&](int code) {
@@ -313,6 +346,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->hs_zero) hipFree(c->hs_zero);
     if (c->fuse_ws) hipFree(c->fuse_ws);
     if (c->Ppad) hipFree(c->Ppad);
+    if (c->Pbf) hipFree(c->Pbf);
     if (c->tw) hipFree(c->tw);
     if (c->bin_pos) hipFree(c->bin_pos);
     if (c->denom) hipFree(c->denom);
@@ -592,6 +626,36 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
             for (int q = 0; q < nt; ++q)
                 if (P[(size_t)j * nt + q] != ((__builtin_popcount(j & q) & 1) ? -1.0f : 1.0f)) { syl = false; break; }
         c->p_sylvester = syl;
+        // how many bf16 pieces (8 significand bits each, truncation) the entries need: the bf16-split LS despread keeps that many
+        int pieces = 1;
+        for (size_t i = 0; i < (size_t)nt * nt && pieces < 3; ++i) {
+            uint32_t u; std::memcpy(&u, &P[i], 4);
+            uint32_t t = u & 0xffff0000u; float f1; std::memcpy(&f1, &t, 4);
+            const float r1 = P[i] - f1;
+            if (r1 != 0.f) {
+                std::memcpy(&u, &r1, 4); t = u & 0xffff0000u; float f2; std::memcpy(&f2, &t, 4);
+                pieces = std::max(pieces, r1 - f2 != 0.f ? 3 : 2);
+            }
+        }
+        c->p_pieces = pieces;
+        // the pieces in the operand order of v_mfma_f32_32x32x16_bf16: block (chunk of 16 symbols, piece, antenna tile) =
+        // [k half][row 32][8 symbols], what lane (row + 32 half) of a wave reads as one 16-byte LDS word
+        const int jt = (nt + 31) / 32, nch = (nt + 15) / 16;
+        std::vector<uint16_t> pb((size_t)nch * 3 * jt * LSB_BLOCK, 0);
+        for (int j = 0; j < nt; ++j)
+            for (int s = 0; s < nt; ++s) {
+                float x = P[(size_t)j * nt + s];
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t u; std::memcpy(&u, &x, 4);
+                    const uint32_t t = u & 0xffff0000u; float f; std::memcpy(&f, &t, 4);
+                    pb[(((size_t)(s >> 4) * 3 + k) * jt + (j >> 5)) * LSB_BLOCK + (((s >> 3) & 1) * 32 + (j & 31)) * 8 + (s & 7)] = (uint16_t)(t >> 16);
+                    x -= f;
+                }
+            }
+        std::vector<float> pbf((pb.size() + 1) / 2);
+        std::memcpy(pbf.data(), pb.data(), pb.size() * 2);
+        rc = upload(c, &c->Pbf, pbf.data(), pbf.size());
+        if (rc) return rc;
     }
     {   // zero-padded copy for the chunked LS kernel (rows / columns up to the next multiple of 32)
         const int nt = c->cfg.nt, ldp = (nt + 31) / 32 * 32;
@@ -696,7 +760,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
     HIP_TRY(c, hipSetDevice(cf.device));
     const int64_t nblk = npkt * cf.nr;
     LsArgs a{};
-    a.P = c->P; a.Ppad = c->Ppad; a.ldp = (cf.nt + 31) / 32 * 32; a.dbg = c->ls_debug;
+    a.P = c->P; a.Ppad = c->Ppad; a.Pbf = reinterpret_cast<const uint16_t*>(c->Pbf); a.ldp = (cf.nt + 31) / 32 * 32; a.dbg = c->ls_debug;
     a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
     a.nt = cf.nt; a.len_ltf = cf.len_ltf;
     const int64_t max_grid = ((int64_t)1 << 30) / n_jc;      // also keeps nb inside an int
@@ -868,6 +932,9 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "host_threads") *value = c->host_threads;
     else if (n == "ls_kernel") *value = c->ls_kernel;
     else if (n == "ls_v2") *value = c->ls_v2;
+    else if (n == "ls_ringb_min") *value = c->ls_ringb_min;
+    else if (n == "ls_pilot_pieces") *value = c->p_pieces;
+    else if (n == "ls_mode") *value = ls_plan(c).mode;
     else if (n == "hs_vm_cast") *value = c->hs_vm_cast;
     else if (n == "hs_vm_pair") *value = c->hs_vm_pair;
     else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
@@ -895,6 +962,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "ls_fft_first_max") {
         if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "ls_fft_first_max must be 0..64");
         c->ls_fft_first_max = (int)value;
+        return ls_prepare(c);
+    } else if (n == "ls_ringb_min") {
+        if (value < 0 || value > 1024) return fail(c, CSI_ERR_INVALID_ARG, "ls_ringb_min must be 0..1024");
+        c->ls_ringb_min = (int)value;
         return ls_prepare(c);
     } else if (n == "small_call_overlap") {
         c->small_call_overlap = value == 2 ? 2 : (value != 0);
@@ -937,9 +1008,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "ls_debug") {
         c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
     } else if (n == "ls_kernel") {
-        if (value < 0 || value > 6)
+        if (value < 0 || value > 7)
             return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first), 4 (Walsh-Hadamard), "
-                                                "5 (Walsh-Hadamard, LDS-DMA fed) or 6 (generic P, LDS-DMA fed)");
+                                                "5 (Walsh-Hadamard, LDS-DMA fed), 6 (generic P, LDS-DMA fed, fp32 despread) or 7 (generic P, bf16-split despread)");
         c->ls_kernel = (int)value;
         return ls_prepare(c);
     } else {
@@ -1161,6 +1232,7 @@ int csi_broadcast_weights(csi_ctx* c, int root) {
         w.n_layers = cf.n_hidden + 1;
         w.pilot_ok = c->pilot_ok;
         w.p_sylvester = c->p_sylvester;
+        w.p_pieces = c->p_pieces;
         for (int d = 0; d < 2; ++d) {
             const Model& m = c->model[d];
             w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
@@ -1208,10 +1280,12 @@ int csi_broadcast_weights(csi_ctx* c, int root) {
         const size_t ldp = (size_t)(cf.nt + 31) / 32 * 32, slack = G_SLACK_FLOATS * sizeof(float);
         blobs.push_back({(void**)&c->P, (size_t)cf.nt * cf.nt * 4 + slack});
         blobs.push_back({(void**)&c->Ppad, ldp * ldp * 4 + slack});
+        blobs.push_back({(void**)&c->Pbf, (size_t)((cf.nt + 15) / 16) * 3 * ((cf.nt + 31) / 32) * LSB_BLOCK * 2 + slack});
     }
     if (!is_root) {
         if (c->P) { hipFree(c->P); c->P = nullptr; }
         if (c->Ppad) { hipFree(c->Ppad); c->Ppad = nullptr; }
+        if (c->Pbf) { hipFree(c->Pbf); c->Pbf = nullptr; }
         for (WBlob& b : blobs) {
             if (hipMalloc(b.p, b.bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "csi_broadcast_weights: device allocation of %zu bytes failed", b.bytes);
         }
@@ -1230,6 +1304,7 @@ int csi_broadcast_weights(csi_ctx* c, int root) {
     if (!is_root) {
         c->pilot_ok = w.pilot_ok != 0;
         c->p_sylvester = w.p_sylvester != 0;
+        c->p_pieces = w.p_pieces;
         if (c->pilot_ok) {
             int rc = ls_prepare(c);
             if (rc) return rc;

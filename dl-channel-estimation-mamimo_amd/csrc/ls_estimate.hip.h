@@ -36,8 +36,9 @@ struct LsArgs {
     const float* ltf_im;
     const float* P;          // [nt][nt] row j = pilot sequence of tx j
     const float* Ppad;       // [ceil32(nt)][ldp] zero-padded copy of P (chunked kernel)
+    const uint16_t* Pbf;     // [ceil16(nt)/16][3 pieces][ceil32(nt)/32][2][32][8] bf16 pieces of P in MFMA operand order (ls_estimate_ringb_kernel)
     int ldp;                 // ceil32(nt)
-    int dbg;                 // timing experiments only ("ls_debug" option): 1 skip FFT, 2 skip despread, 4 skip stores, 8 skip scatter
+    int dbg;                 // timing experiments only ("ls_debug" option): 1 skip FFT, 2 skip despread, 4 skip stores, 8 skip scatter, 64 no MFMA drain (ringb)
     const float* tw;         // [2][256] cos / -sin table, exp(-2 pi i u / 256)
     const int* bin_pos;      // [234] natural-order FFT index f(q) of data bin q
     const float* denom;      // [234] nt * ltf[q]
@@ -994,6 +995,244 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ring_kernel(const L
                         acc[qi][jt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bc[qi][0], acc[qi][jt][0], 0, 0, 0);
                         acc[qi][jt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[jt], bc[qi][1], acc[qi][jt][1], 0, 0, 0);
                     }
+            }
+        }
+    }
+    if (nitems > 0) store_item(blockIdx.x + (size_t)(nitems - 1) * gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic-P kernel, bf16-split despread: the ring kernel above with the despread moved from v_mfma_f32_32x32x2_f32
+// (64 cycles per 2 symbols) to v_mfma_f32_32x32x16_bf16 (32 cycles per 16 symbols).  Every fp32 value is cut EXACTLY
+// into three bf16 pieces (8 significand bits each: x = b1 + b2 + b3, truncation, each residual is exact), bf16 has
+// fp32's exponent range - no scaling, no range guard - and the products kept are the pairs (P piece i, F piece j)
+// with i + j <= 4: what is dropped is below 2^-24 of |P||F|, accumulation is fp32 in the matrix core.
+// NPP = how many pieces the pilot matrix needs (found on the host when it is set): 1 for +-1 / small-integer
+// pilots (3 MFMAs per product), 2 for 16-bit entries (5), 3 for arbitrary floats (6): 6, 10 and 12 cycles per symbol
+// and 32x32 tile against 32.  A chunk is one K = 16 MFMA step.  The P pieces of a chunk - [piece][antenna tile] blocks
+// of 1 KiB, cut and laid out on the host in MFMA operand order (ls_pilot_pieces_layout) - ride the ring with the samples:
+// one more LDS-DMA per block and chunk, from L2, into a ring of NSTG + 1 slots (the slot refilled during chunk t held the
+// pieces of chunk t - 1, and the refill is issued behind the barrier that ends that chunk's despread).  The spectra are
+// gathered per bin from the fp32 image and cut in registers.
+typedef __bf16 ls_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t ls_bf_top(float x) { return __builtin_bit_cast(uint32_t, x) & 0xffff0000u; }
+// the three bf16 pieces of two floats, packed (low half = x0)
+__device__ __forceinline__ void ls_bf_split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t a0 = ls_bf_top(x0), a1 = ls_bf_top(x1);
+    const float r0 = x0 - __builtin_bit_cast(float, a0), r1 = x1 - __builtin_bit_cast(float, a1);
+    const uint32_t b0 = ls_bf_top(r0), b1 = ls_bf_top(r1);
+    const float q0 = r0 - __builtin_bit_cast(float, b0), q1 = r1 - __builtin_bit_cast(float, b1);
+    p1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q1), __builtin_bit_cast(uint32_t, q0), 0x07060302u);
+}
+
+constexpr int LSB_BLOCK = 512;      // bf16 elements of one (chunk, piece, antenna tile) block: [2 k-halves][32 rows][8 symbols]
+
+template <int JT, int NW, int NSTG, int NPP, int MINB = 1>
+__global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const LsArgs a, int nblk) {
+    constexpr int CH = 16, SPW = CH / NW, QW = 8 / NW;
+    constexpr int NB = NPP * JT, NPD = (NB + NW - 1) / NW;      // P blocks per chunk, LDS-DMAs per wave for them
+    constexpr int R = 2 * SPW + NPD, NPS = NSTG + 1;
+    static_assert(SPW >= 1 && QW >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63 && NPP >= 1 && NPP <= 3, "shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW]
+    f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW]
+    float* S = reinterpret_cast<float*>(Fc + CH * LSC_ROW);           // [NSTG][CH][2][256]
+    uint16_t* Pb = reinterpret_cast<uint16_t*>(S + NSTG * CH * 2 * LS_FFT);   // [NPS][NB][LSB_BLOCK] bf16
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nt = a.nt;
+    const int nchunk = (nt + CH - 1) / CH;
+    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+    lsc_build_twiddles(twc, a.tw, tid, 64 * NW);
+    int pos[QW];
+    float rden[QW];
+    bool qok[QW];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        const int q = (wave + NW * qi) * 32 + l31;
+        qok[qi] = q < LS_NDATA;
+        pos[qi] = lsc_phys(a.bin_pos[qok[qi] ? q : 0]);
+        rden[qi] = 1.0f / a.denom[qok[qi] ? q : 0];
+    }
+    __syncthreads();
+
+    const uint32_t s_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)S);
+    const uint32_t p_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Pb);
+    const int nitems = blockIdx.x < (unsigned)nblk ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = nitems * nchunk;
+    int ti = 0, ich = 0;
+    size_t iblk = blockIdx.x;
+    auto issue_next = [&]() {                   // the samples of chunk ti
+        if (ti >= T) return;
+        const size_t o = iblk * a.len_ltf + LS_CP + 4 * lane;
+        const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+            const int sidx = min(ich * CH + wave + NW * u, nt - 1);
+            ls_dma16(a.ltf_re + o + (size_t)sidx * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+            ls_dma16(a.ltf_im + o + (size_t)sidx * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+        }
+        ++ti;
+        if (++ich == nchunk) { ich = 0; iblk += gridDim.x; }
+    };
+    int tp = 0, ichp = 0;
+    auto issue_pieces = [&]() {                 // the P pieces of chunk tp: block x by wave x mod NW (the last one again where NB is no multiple of NW)
+        if (tp >= T) return;
+        const float* src = reinterpret_cast<const float*>(a.Pbf + (size_t)ichp * 3 * JT * LSB_BLOCK) + 4 * lane;
+        const uint32_t d = p_off + (uint32_t)((tp % NPS) * NB * LSB_BLOCK * 2);
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int x = min(wave + NW * u, NB - 1);
+            ls_dma16(src + (size_t)x * (LSB_BLOCK / 2), d + (uint32_t)x * LSB_BLOCK * 2);
+        }
+        ++tp;
+        if (++ichp == nchunk) ichp = 0;
+    };
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) { issue_next(); issue_pieces(); }
+
+    f32x16 acc[QW][JT][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[qi][jt][0][e] = 0.f; acc[qi][jt][1][e] = 0.f; }
+    };
+    // rows j = jt*32 + (r&3) + 8*(r>>2) + 4*hi, bins coalesced over the lanes (the accumulator layout of the 32x32 MFMAs)
+    auto store_item = [&](size_t blk) {
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            if (!qok[qi] || (a.dbg & 4)) continue;
+            const size_t o = (blk * nt + 4 * hi) * LS_NDATA + (size_t)((wave + NW * qi) * 32 + l31);
+            float* pre = a.h_re + o;
+            float* pim = a.h_im + o;
+            const float inv = rden[qi];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if (jt * 32 >= nt) break;
+                if ((jt + 1) * 32 <= nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        pre[jo * LS_NDATA] = acc[qi][jt][0][r] * inv;
+                        pim[jo * LS_NDATA] = acc[qi][jt][1][r] * inv;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jo = jt * 32 + (r & 3) + 8 * (r >> 2);
+                        if (jo + 4 * hi < nt) {
+                            pre[jo * LS_NDATA] = acc[qi][jt][0][r] * inv;
+                            pim[jo * LS_NDATA] = acc[qi][jt][1][r] * inv;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        zero_acc();
+    };
+    zero_acc();
+
+    int t = 0;
+    for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch, ++t) {
+            // the DMAs of this wave for chunk t (its sample rows, its P blocks) have landed?  Younger chunks: R each.
+            const int younger = ti - t - 1;
+            if (NSTG == 1 || younger <= 0) ls_wait_vm<0>();
+            else if (NSTG == 2 || younger == 1) ls_wait_vm<R>();
+            else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
+            else ls_wait_vm<3 * R>();
+            f32x2 y0[SPW][4];
+            lsc_stage0_read<SPW, NW>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_next();
+            if (ch == 0 && t > 0) store_item(blk - gridDim.x);
+            if (t > 0) ls_lds_barrier();          // spectra and P pieces of chunk t - 1 consumed
+            issue_pieces();                       // ... so the slot of those pieces takes chunk t + NSTG
+            lsc_stage0_write<SPW, NW>(Fc, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1)>(Fc, wave, twc, lane);
+            ls_lds_barrier();                     // spectra complete; every wave has seen its P blocks of chunk t land
+
+            // ---- despread: one K = 16 step.  A = P pieces (row j = l31 of antenna tile jt, symbols 8 hi .. 8 hi + 7),
+            // B = this lane's bin of the same 8 symbols, cut into pieces here.
+            if (a.dbg & 2) continue;
+            const uint16_t* pbs = Pb + (size_t)(t % NPS) * NB * LSB_BLOCK + lane * 8;
+            ls_bf16x8 pa[JT][NPP];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int k = 0; k < NPP; ++k)
+                    pa[jt][k] = __builtin_bit_cast(ls_bf16x8, *reinterpret_cast<const ls_u32x4*>(pbs + (k * JT + jt) * LSB_BLOCK));
+            const f32x2* frow = Fc + (size_t)(8 * hi) * LSC_ROW;
+            ls_u32x4 fb[QW][2][3];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                f32x2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = frow[(size_t)i * LSC_ROW + pos[qi]];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t p1, p2, p3;
+                        ls_bf_split2(v[2 * i][c], v[2 * i + 1][c], p1, p2, p3);
+                        fb[qi][c][0][i] = p1; fb[qi][c][1][i] = p2; fb[qi][c][2][i] = p3;
+                    }
+            }
+            // every operand is in registers before the first MFMA; none of these registers may be written again until the
+            // MFMAs that read them have left the matrix pipe (see below)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        f32x16 d = acc[qi][jt][c];
+                        // small terms first
+                        if (NPP >= 3) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][NPP >= 3 ? 2 : 0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][0]), d, 0, 0, 0);
+                        if (NPP >= 2) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][NPP >= 2 ? 1 : 0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][1]), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][2]), d, 0, 0, 0);
+                        if (NPP >= 2) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][NPP >= 2 ? 1 : 0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][0]), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][1]), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][0]), d, 0, 0, 0);
+                        acc[qi][jt][c] = d;
+                    }
+            // Drain before leaving the block.  Measured (tools/ls_dbg.py, round 3): with a second wave on the SIMD feeding the
+            // same matrix pipe, LDS reads issued right behind the last MFMA - the stage-0 reads of the next chunk, which the
+            // register allocator had put into the registers of this chunk's A operand - corrupted one or two spectra of a few
+            // items per thousand; a dependent read of every accumulator (the MFMAs of a chain retire in order) followed by a
+            // use of every operand register closes it: nothing the MFMAs read is recycled before they have finished.
+            if (!(a.dbg & 64)) {
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float tmp;
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(tmp) : "v"(acc[qi][jt][c][15]));
+                        }
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int k = 0; k < NPP; ++k) asm volatile("" ::"v"(pa[jt][k]));
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) asm volatile("" ::"v"(fb[qi][c][k]));
             }
         }
     }

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Stress run of the generic-P LS kernels on one MI355X (not a pytest file; `python tests/stress_ls_generic.py [--reps 20]`).
+
+The bf16-split despread kernel (ls_kernel 7) is run `reps` times per (Nt, pilot kind, ring depth) over many more items than
+resident workgroups; EVERY item of every run is compared bit for bit with the first run and, to rounding, with the fp32
+matrix-core despread (ls_kernel 6).  Written after a race was found in the first version of the kernel (LDS reads of the next
+chunk issued while the last MFMAs of a chunk were still in the pipe: 1-5 wrong items per 4000, only with two waves per SIMD):
+`--no-drain` (ls_debug 64) runs the kernel without the drain that closes it."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dl_channel_estimation_mamimo_amd as pkg            # noqa: E402
+
+
+def pilot(rng, nt, kind):
+    if kind == 'pm1':
+        return rng.choice([-1.0, 1.0], (nt, nt))
+    P = np.linalg.qr(rng.standard_normal((nt, nt)))[0].astype(np.float32) * np.float32(np.sqrt(nt))
+    if kind == 'q16':
+        P = (P.view(np.uint32) & np.uint32(0xffffff00)).view(np.float32)
+    return P.astype(np.float64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--no-drain', action='store_true')
+    ap.add_argument('--shapes', default='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300')
+    args = ap.parse_args()
+    rng = np.random.default_rng(5)
+    total_bad = 0
+    for shape in args.shapes.split(','):
+        nt, nr, npkt = (int(v) for v in shape.split('x'))
+        ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+        for kind in ('pm1', 'q16', 'qr'):
+            e = pkg.CsiEngine(nt, nr, hidden=(8,))
+            e.set_pilot(pilot(rng, nt, kind))
+            e.set_option('ls_kernel', 6)
+            h6 = e.ls_estimate(ltf)
+            e.set_option('ls_kernel', 7)
+            for v in (0, 1):
+                e.set_option('ls_v2', v)
+                e.set_option('ls_debug', 64 if args.no_drain else 0)
+                first, bad_runs, bad_items = None, 0, 0
+                for _ in range(args.reps):
+                    h = e.ls_estimate(ltf)
+                    if first is None:
+                        first = h
+                        d = np.abs(h - h6).reshape(npkt * nr, -1).max(1) / np.abs(h6).reshape(npkt * nr, -1).max(1)
+                        n6 = int((d > 2e-6).sum())
+                    nb = int((h != first).reshape(npkt * nr, -1).any(1).sum())
+                    bad_runs += nb > 0
+                    bad_items += nb
+                total_bad += bad_items + n6
+                print(f'Nt={nt:3d} items={npkt * nr:5d} pilot={kind:3s} pieces={e.get_option("ls_pilot_pieces")} shape v{v}: '
+                      f'{args.reps} runs, {bad_runs} differ from the first ({bad_items} items), {n6} items off the fp32 despread', flush=True)
+            e.close() if hasattr(e, 'close') else None
+    print('TOTAL bad items:', total_bad)
+    return 1 if total_bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

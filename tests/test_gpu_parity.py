@@ -135,6 +135,50 @@ def test_ls_all_kernels_agree(pkg, oracle, kernel):
             assert np.array_equal(h, e.ls_estimate(ltf))
 
 
+@pytest.mark.parametrize('pieces', [1, 2, 3])
+def test_ls_bf16_split_despread(pkg, oracle, pieces):
+    """ls_kernel 7: the generic-P ring kernel with the despread on v_mfma_f32_32x32x16_bf16, fp32 values cut exactly into
+    three bf16 pieces.  Pilot matrices that need 1 (+-1 entries), 2 (16 significand bits) and 3 (arbitrary floats) pieces,
+    every antenna-tile count, partial last chunks (Nt = 24, 40, 72, 100), persistent walks, extreme amplitudes (bf16 has
+    fp32's exponent range: no scaling is involved), and the automatic choice for a non-Hadamard pilot."""
+    rng = np.random.default_rng(70 + pieces)
+    cases = ((16, 2, 5), (24, 2, 3), (32, 3, 300), (40, 2, 3), (64, 2, 3), (72, 1, 2), (96, 2, 2), (100, 1, 2), (128, 2, 2), (64, 4, 300), (128, 3, 100),
+             (32, 4, 1000), (24, 4, 700), (96, 4, 200))
+    for nt, nr, npkt in cases:
+        if pieces == 1:
+            P = rng.choice([-1.0, 1.0], (nt, nt))
+        else:
+            P = np.linalg.qr(rng.standard_normal((nt, nt)))[0].astype(np.float32) * np.float32(np.sqrt(nt))
+            if pieces == 2:
+                P = (P.view(np.uint32) & np.uint32(0xffffff00)).view(np.float32)
+            P = P.astype(np.float64)
+        if npkt > 10:
+            ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+        else:
+            ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+            ltf[0] *= 1e-18                      # far below / above anything an f16 scheme could hold
+            ltf[-1] *= 1e15
+        e = pkg.CsiEngine(nt, nr, hidden=(8,))
+        e.set_pilot(P)
+        assert e.get_option('ls_pilot_pieces') == pieces
+        assert e.get_option('ls_mode') == (6 if pieces == 3 and nt <= 32 else 7), (nt, pieces)   # the automatic choice
+        e.set_option('ls_kernel', 7)
+        h = e.ls_estimate(ltf)
+        ref = oracle.ls_estimate(np.asarray(ltf).astype(np.complex64), P)          # EVERY item against the oracle
+        assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL, (nt, nr, npkt)
+        e.set_option('ls_kernel', 6)             # the fp32 matrix-core despread: same answer to rounding
+        h6 = e.ls_estimate(ltf)
+        assert not np.array_equal(h, h6)
+        assert rel_rows(np.concatenate([h.real, h.imag], -1).reshape(-1, 468), np.concatenate([h6.real, h6.imag], -1).reshape(-1, 468)) < 2e-6
+        e.set_option('ls_kernel', 7)
+        e.set_option('ls_v2', 1)                 # the other ring depth of the same kernel: the same arithmetic per (bin, antenna)
+        assert np.array_equal(h, e.ls_estimate(ltf))
+        e.set_option('ls_v2', 0)
+        if npkt > 10:                            # persistent walk, repeated: a race shows up as a run that differs
+            for _ in range(4):
+                assert np.array_equal(h, e.ls_estimate(ltf))
+
+
 @pytest.mark.parametrize('nt,nr,npkt', [(16, 2, 5), (32, 3, 300), (64, 2, 7), (128, 2, 3), (16, 4, 400), (64, 4, 300), (128, 2, 200)])
 def test_ls_walsh_hadamard_despread(pkg, oracle, nt, nr, npkt):
     """With the Sylvester Hadamard pilot matrix the LS despread is a fast Walsh-Hadamard transform

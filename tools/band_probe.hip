@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
         return f;
     };
     if (hsaco && hipModuleLoad(&mod8, hsaco) != hipSuccess) { printf("cannot load %s\n", hsaco); mod8 = nullptr; }
-    hipFunction_t k8 = get8("csi_band8");
+    hipFunction_t k8 = get8(getenv("BAND8_NAME") ? getenv("BAND8_NAME") : "csi_band8");
     Band8Args a8 = band8_args(ba);
     auto launch8f = [&](hipFunction_t f, const Band8Args& args) {
         Band8Args tmp = args;

@@ -36,6 +36,8 @@ def main():
     ap.add_argument('--variants', default='4:0,5:0,5:1,5:2,5:3,2:0')
     ap.add_argument('--dbg', default='0')
     ap.add_argument('--generic', action='store_true', help='non-Hadamard pilot matrix (only the generic kernels apply)')
+    ap.add_argument('--pilot', default='qr', help="with --generic: 'qr' random orthogonal floats (3 bf16 pieces), 'q16' the same rounded "
+                    "to 16 significand bits (2 pieces), 'perm' random +-1 entries (1 piece)")
     args = ap.parse_args()
     for shape in args.shapes.split(','):
         nt, nr, npkt = (int(v) for v in shape.split('x'))
@@ -44,7 +46,11 @@ def main():
             P = hadamard(nt).astype(np.float32)
         else:
             rng = np.random.default_rng(1)
-            P = np.linalg.qr(rng.standard_normal((nt, nt)))[0].astype(np.float32) * np.sqrt(nt)
+            P = np.linalg.qr(rng.standard_normal((nt, nt)))[0].astype(np.float32) * np.float32(np.sqrt(nt))
+            if args.pilot == 'q16':
+                P = (P.view(np.uint32) & np.uint32(0xffffff00)).view(np.float32)
+            elif args.pilot == 'perm':
+                P = rng.choice([-1.0, 1.0], (nt, nt)).astype(np.float32)
         eng.set_pilot(P)
         d_re, d_im = eng.empty((npkt, nr, 320 * nt)), eng.empty((npkt, nr, 320 * nt))
         eng.synth_white(7, 0, npkt, d_re, d_im)
