@@ -249,8 +249,11 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         FFT-first (16 <= Nt <= 128), 3: despread-first (any Nt), 4: Walsh-Hadamard
  *                         despread (Nt = 16 / 32 / 64 / 128 and P the Sylvester Hadamard matrix), 5: the same
  *                         fed by an LDS-DMA ring (chosen automatically for that P), 6: generic P on
- *                         the LDS-DMA ring (chosen automatically for any other P, 16 <= Nt <= 128); a choice the
- *                         kernel cannot serve falls back
+ *                         the LDS-DMA ring, fp32 matrix-core despread, 7: generic P, despread on the bf16 matrix
+ *                         cores with every fp32 value cut exactly into three bf16 pieces (one of the two is chosen
+ *                         automatically for any other P, 16 <= Nt <= 128); a choice the kernel cannot serve falls back
+ *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 16)
+ *   get only: "ls_mode" (the kernel the next LS call runs), "ls_pilot_pieces" (bf16 pieces the entries of P need: 1 - 3)
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
  *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor of an fp32 context's split engine as ONE
  *                         kernel, h2 in registers (generated gfx950 assembly, csrc/band_kernel_gen.py); 0: the two separate kernels

@@ -59,6 +59,27 @@ def main():
                 print(f'Nt={nt:3d} items={npkt * nr:5d} pilot={kind:3s} pieces={e.get_option("ls_pilot_pieces")} shape v{v}: '
                       f'{args.reps} runs, {bad_runs} differ from the first ({bad_items} items), {n6} items off the fp32 despread', flush=True)
             e.close() if hasattr(e, 'close') else None
+    # the round-2 kernels the same way: Walsh-Hadamard ring kernel (the headline LS kernel) and the fp32 matrix-core ring kernel
+    for shape in args.shapes.split(','):
+        nt, nr, npkt = (int(v) for v in shape.split('x'))
+        ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
+        for kernel, P in ((5, pkg.synth.hadamard(nt) if nt & (nt - 1) == 0 else None), (6, pilot(rng, nt, 'qr'))):
+            if P is None:
+                continue
+            e = pkg.CsiEngine(nt, nr, hidden=(8,))
+            e.set_pilot(P)
+            e.set_option('ls_kernel', kernel)
+            for v in (0, 1):
+                e.set_option('ls_v2', v)
+                first, bad_runs, bad_items = None, 0, 0
+                for _ in range(args.reps):
+                    h = e.ls_estimate(ltf)
+                    first = h if first is None else first
+                    nb = int((h != first).reshape(npkt * nr, -1).any(1).sum())
+                    bad_runs += nb > 0
+                    bad_items += nb
+                total_bad += bad_items
+                print(f'Nt={nt:3d} items={npkt * nr:5d} kernel {kernel} (mode {e.get_option("ls_mode")}) shape v{v}: {args.reps} runs, {bad_runs} differ from the first ({bad_items} items)', flush=True)
     print('TOTAL bad items:', total_bad)
     return 1 if total_bad else 0
 
