@@ -270,9 +270,11 @@ class Role:
         nslot = (slot + 1) & 3
         b.e('s_waitcnt lgkmcnt(0)')                       # w_lo of this sub-tile, the fragment read behind the last barrier
         self.read_w(b, 0, slot)                           # w_hi: the sub-tile is visible since the last barrier
-        pending = []                                      # 'interleave' (experiment): conversion spread between this wave's own MFMAs
+        # hs: the producer's conversion is dripped between its own MFMAs of P0 (and P1 for half 0) instead of standing in front of
+        # them - measured 1.604 against 1.631 ms per 262144 rows, band stamps 355 k against 373 k cycles ('nointerleave' = the block form)
+        pending = []
         if produce is not None:
-            if 'interleave' in self.dbg and not self.bf:
+            if 'nointerleave' not in self.dbg and not self.bf:
                 tmp = Block('conv')
                 self.convert(tmp, produce[0], par ^ 1, *produce[1:])
                 pending = list(tmp.items)
@@ -307,7 +309,7 @@ class Role:
 
         def sync():
             drip(len(pending))
-            if 'interleave' in self.dbg and request is not None and produce is not None and not self.bf:
+            if 'nointerleave' not in self.dbg and request is not None and produce is not None and not self.bf:
                 self.request(b, request)
             b.e('s_waitcnt lgkmcnt(0)')                   # w_hi in registers (the slot may be refilled), exchange slot written
             b.wait_vm({'P%d' % nslot})                    # this wave's pieces of the next sub-tile have landed
@@ -801,7 +803,7 @@ META_KERNEL = '''  - .name: {name}
 VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
-            ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_interleave', ('interleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
+            ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
 

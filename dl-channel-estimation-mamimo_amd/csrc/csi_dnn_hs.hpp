@@ -298,6 +298,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         p.out_scale = std::ldexp(1.f, s1);
         p.tiles_n = tiles_n;
         p.peak = c->hs_peak;
+        p.xcd_cols = 0;                     // the kernel's flag wait relies on the plain blockIdx -> (row tile, column tile) order: never the XCD remap
         HIP_TRY(c, hipMemsetAsync(rg.flags, 0, (size_t)tiles_m * sizeof(unsigned), c->stream));
         ++c->hs_launches;
         const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
