@@ -264,7 +264,8 @@ def main():
     pairs_per_step = total_pkts * nr * nt          # all ranks together
     value = pairs_per_step * args.steps / dt
     split_engine = args.dtype == 'f32' and eng.get_option('hs_launches') > 0
-    band_kernel = args.dtype == 'f32' and eng.get_option('band_launches') > 0      # first per-pair layer + regressor as one kernel (hs_band)
+    band_any = eng.get_option('band_launches') > 0                                   # first per-pair layer + regressor as one kernel (hs_band)
+    band_kernel = args.dtype == 'f32' and band_any
     # range guard of the split-f16 engine over the timed steps: a hit would have made eng.synchronize() raise
     # (CSI_ERR_RANGE) above; the counters go into the line
     guard = {'hs_launches': eng.get_option('hs_launches'), 'hs_range_fallbacks': eng.get_option('hs_range_fallbacks'),
@@ -446,7 +447,7 @@ def main():
                    'world_size_checked': pkg.dist.world_size(), 'weights_via': via,
                    'sharding': ('contiguous packet ranges per rank (%s scaling), weights broadcast once over %s, no collective in the step'
                                 % (args.scaling, 'RCCL' if backend == 'nccl' else backend)) if world > 1 else 'single GPU'},
-        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm' + (' (csi_band8: first per-pair layer + regressor fused, h2 in registers)' if band_kernel else ''), 'achieved': achieved, 'peak': mfma_peak,
+        'roofline': {'bound': 'mfma', 'kernel': 'pair_dense_gemm' + ((' (csi_band8%s: first per-pair layer + regressor fused, h2 in registers)' % ('' if band_kernel else '_bf16')) if band_any else ''), 'achieved': achieved, 'peak': mfma_peak,
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,

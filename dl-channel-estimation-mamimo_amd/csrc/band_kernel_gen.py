@@ -46,7 +46,14 @@ AX_OFF = 4 * RING_SLOT            # fragment exchange: [rg][parity][hi | lo][64 
 BIAS1_OFF = AX_OFF + 16384        # out_scale * bias1 [N1], then bias2 [256]
 KARG_BYTES = 128
 MAX_N1 = 4096                     # static LDS: ring + exchange + bias tables for up to this many hidden features
-LDS_BYTES = BIAS1_OFF + 4 * MAX_N1 + 1024
+LDS_OLD = BIAS1_OFF + 4 * MAX_N1 + 1024
+# bf16 'staged' form: the L0 / T values of the stage-1 fragments come through LDS as well - per sub-step one slab of the pilot table
+# ([nt rows][32 k] fp32, 16-byte units XOR-swizzled by (row >> 1) & 7, laid out that way in HBM by band_tsw_kernel so that the
+# LDS-DMA is linear) and one of the band's L0 rows ([<= 8 rows][32 k]) - rings of 4 slabs, 5 sub-steps ahead
+TS_OFF = LDS_OLD                  # 4 x 8 KiB (nt <= 64)
+TSLAB = 8192
+L0S_OFF = TS_OFF + 4 * TSLAB      # 4 x 1 KiB
+LDS_BYTES = L0S_OFF + 4 * 1024
 
 # scalar registers
 S_L0, S_TS, S_W1, S_B1, S_W2, S_B2, S_OUT, S_PEAK = 4, 6, 8, 10, 12, 14, 16, 18
@@ -58,6 +65,7 @@ S_TRIP, S_COL, S_NCOL, S_NSUB1, S_DMA = 48, 49, 50, 51, 52
 S_T = 54                          # s54..s63 scratch
 S_ROWMASK, S_SAVE = 64, 66
 S_COLBYTES, S_BIAS2OFF, S_DMA2 = 68, 69, 70
+S_TSLABB, S_TCH = 72, 73        # staged bf16 form: bytes of a T slab (nt * 128), byte offset of this wave's 1-KiB chunk of it
 
 # vector registers (arch half: v0..v127)
 V_TID, V_LANE = 0, 1
@@ -68,6 +76,7 @@ V_RDHI, V_RDLO, V_AX, V_LOFF, V_TOFF, V_PK1, V_PK2, V_BADDR = 82, 83, 84, 85, 86
 V_VO1, V_VO2 = 117, 121           # LDS-DMA offsets: [own piece 0, own piece 1, partner's piece 0, partner's piece 1]
 V_T = 94                          # v94..v109 scratch (prologue, epilogue, stamps); bf16 mode: also the 16 requested Ts values
 V_TV16 = 94
+V_TL0, V_TL1, V_LL = 87, 88, 89    # staged bf16 form: LDS addresses of this lane's two T units and of its L0 units; V_LOFF / V_TOFF hold the DMA lane offsets
 V_OUTOFF, V_M, V_4HI, V_B2ADDR, V_HI, V_L31 = 110, 112, 113, 114, 115, 116
 ACC1, ACC2 = 0, 64                # AGPR bases
 
@@ -110,18 +119,25 @@ class Block:
         self.items.append('  ' + s)
         self.items.append(('vm', tag))
 
+    def vm_opt(self, s, tag):
+        """an operation only SOME waves of the role issue (behind a scalar branch): counted waits take the minimum of both cases"""
+        self.items.append('  ' + s)
+        self.items.append(('vmopt', tag))
+
     def wait_vm(self, needs):
         w = Wait(needs)
         self.items.append(w)
         return w
 
 
-def simulate(blocks_in_order, queue=None):
+def simulate(blocks_in_order, queue=None, with_opt=True):
     """walk the blocks in execution order; every Wait gets n = min(n, operations younger than its newest needed one)"""
     q = list(queue or [])
     for b in blocks_in_order:
         for it in b.items:
             if isinstance(it, tuple):
+                if it[0] == 'vmopt' and not with_opt:
+                    continue
                 q.append(it[1])
             elif isinstance(it, Wait):
                 pos = -1
@@ -147,6 +163,7 @@ class Role:
         self.bf = mode == 'bf16'
         self.nq = 8 if self.bf else 16          # stage-2 sub-steps per column step (sub-tiles of 32 / 16 k)
         self.tv = V_TV16 if self.bf else V_TV
+        self.staged = self.bf and 'nostage' not in dbg
         self.uid = 0
 
     # ---------------------------------------------------------------- pieces of code
@@ -165,6 +182,8 @@ class Role:
         the half that will convert it.  bf16: BOTH halves convert every fragment, each its own 16-k MFMA step of the 32 (half 0:
         k 8 hi .. +7, half 1: 16 + 8 hi ..), so each requests 2 x 16 B per array into register set `xset` (fragment parity).
         mode 'reset': first of a column."""
+        if self.staged:
+            return
         if mode == 'reset':
             for p, src in ((S_L0P, S_L0), (S_TSP, S_TS)):
                 b.e('s_add_u32 %s, %s, %d' % (sreg(p), sreg(src), 0 if self.bf else 64 * self.h))
@@ -179,6 +198,40 @@ class Role:
         for p in (S_L0P, S_TSP):
             b.e('s_add_u32 %s, %s, 128' % (sreg(p), sreg(p)))
             b.e('s_addc_u32 %s, %s, 0' % (sreg(p + 1), sreg(p + 1)))
+
+    def stage_issue(self, b, slot, reset=False):
+        """staged form: LDS-DMA of the next slab of the T / L0 streams into ring slot `slot` - every wave its 1-KiB chunk of the T
+        slab, wave 0 the L0 slab.  reset: the streams restart (slab 0 of a column step; the A operand does not depend on the column)"""
+        if reset:
+            for p, src in ((S_L0P, S_L0), (S_TSP, S_TS)):
+                b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
+                b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
+        if 'noreq' not in self.dbg:
+            b.e('s_add_u32 m0, %s, %d' % (sreg(S_TCH), TS_OFF + slot * TSLAB))
+            b.e('s_nop 0')
+            b.vm('global_load_lds_dwordx4 %s, %s' % (vreg(V_TOFF), sreg(S_TSP, 2)), 'T%d' % slot)
+            if self.h == 0:
+                self.uid += 1
+                skip = 'L_r0_l0skip_%d' % self.uid
+                b.e('s_cmp_lg_u32 %s, 0' % sreg(S_WAVE))
+                b.e('s_cbranch_scc1 %s' % skip)
+                b.e('s_mov_b32 m0, %d' % (L0S_OFF + slot * 1024))
+                b.e('s_nop 0')
+                b.vm_opt('global_load_lds_dwordx4 %s, %s' % (vreg(V_LOFF), sreg(S_L0P, 2)), 'L%d' % slot)
+                b.label(skip)
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_TSP), sreg(S_TSP), sreg(S_TSLABB)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_TSP + 1), sreg(S_TSP + 1)))
+        b.e('s_add_u32 %s, %s, 128' % (sreg(S_L0P), sreg(S_L0P)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_L0P + 1), sreg(S_L0P + 1)))
+
+    def stage_read(self, b, slot, xset):
+        """this lane's 8 L0 and 8 T values of its k-step of the fragment whose slab sits in `slot` -> register set xset"""
+        if 'noreq' in self.dbg:
+            return
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(self.tv + 8 * xset, 4), vreg(V_TL0), slot * TSLAB))
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(self.tv + 8 * xset + 4, 4), vreg(V_TL1), slot * TSLAB))
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_LV + 8 * xset, 4), vreg(V_LL), slot * 1024))
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_LV + 8 * xset + 4, 4), vreg(V_LL), slot * 1024 + 16))
 
     def pieces(self, b, kind, slot, who='own'):
         """LDS-DMA pieces of the next sub-tile of the stream (kind 's1' / 's2') into ring slot `slot`: who = 'own' (this
@@ -203,7 +256,8 @@ class Role:
             # leaves it in the exchange slot and reads the partner's half behind the barrier
             dst = ahi if self.h == 0 else alo
             if 'noconv' not in self.dbg:
-                b.wait_vm({'V%d' % g})                 # g = register set of this fragment
+                if not self.staged:
+                    b.wait_vm({'V%d' % g})             # g = register set of this fragment
                 for e in range(8):
                     b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + 8 * g + e), vreg(self.tv + 8 * g + e)))
                 for e in range(8):
@@ -264,7 +318,7 @@ class Role:
         if 'nobarrier' not in self.dbg:
             b.e('s_barrier')
 
-    def substep(self, b, kind, slot, par, first=False, produce=None, consume=False, request=None, piece='s1', pre_piece=None, who='own'):
+    def substep(self, b, kind, slot, par, first=False, produce=None, consume=False, request=None, piece='s1', pre_piece=None, who='own', stage=None):
         """kind 1 / 2: which accumulator set this sub-step's 12 MFMAs feed"""
         acc = ACC1 if kind == 1 else ACC2
         nslot = (slot + 1) & 3
@@ -312,7 +366,10 @@ class Role:
             if 'nointerleave' not in self.dbg and request is not None and produce is not None and not self.bf:
                 self.request(b, request)
             b.e('s_waitcnt lgkmcnt(0)')                   # w_hi in registers (the slot may be refilled), exchange slot written
-            b.wait_vm({'P%d' % nslot})                    # this wave's pieces of the next sub-tile have landed
+            needs = {'P%d' % nslot}
+            if stage and stage.get('read') is not None:   # ... and its chunk of the T / L0 slab that is read behind this barrier
+                needs |= {'T%d' % stage['read'][0], 'L%d' % stage['read'][0]}
+            b.wait_vm(needs)                              # this wave's pieces of the next sub-tile have landed
             self.barrier(b)                               # -> sub-tile s + 1 and fragment s + 1 visible, slot s free
 
         def after():
@@ -323,6 +380,10 @@ class Role:
             self.read_w(b, 1, nslot)
             if consume:
                 self.read_frag(b, par ^ 1, partner_half_only=(consume == 'half'))
+            if stage and stage.get('read') is not None:
+                self.stage_read(b, *stage['read'])
+            if stage and stage.get('issue') is not None:
+                self.stage_issue(b, stage['issue'][0], reset=stage['issue'][1])
 
         # The two waves of a SIMD (half 0 / half 1 of a row group) meet at ONE barrier per sub-step but sit at different
         # places of their MFMA sequence when they do: half 0 has 8 of its 12 MFMAs in front of it, half 1 four - so one
@@ -368,7 +429,16 @@ class Role:
             b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
         for t in range(4):
             self.pieces(b, 's1', t)
-        if self.bf:                                         # split production: both halves convert their k-step of fragment 0
+        if self.staged:                                     # slabs 0 .. 3 of the T / L0 streams; fragment 0 from slab 0
+            for t in range(4):
+                self.stage_issue(b, t, reset=(t == 0))
+            b.wait_vm({'T0', 'L0'})
+            b.e('s_waitcnt lgkmcnt(0)')
+            self.barrier(b)
+            self.stage_read(b, 0, 0)
+            b.e('s_waitcnt lgkmcnt(0)')
+            self.convert(b, 't1', 0, 0, 0)
+        elif self.bf:                                       # split production: both halves convert their k-step of fragment 0
             self.request(b, 'reset', 0)
             self.request(b, 'advance', 1)
             self.convert(b, 't1', 0, 0, 0)
@@ -379,7 +449,7 @@ class Role:
             self.request(b, 'advance')
         else:
             self.request(b, 'reset')
-        b.wait_vm({'P0'})
+        b.wait_vm({'P0', 'T1', 'L1'} if self.staged else {'P0'})
         b.e('s_waitcnt lgkmcnt(0)')
         self.barrier(b)
         if self.bf:
@@ -387,16 +457,23 @@ class Role:
         elif h == 1:
             self.read_frag(b, 0)
         self.read_w(b, 1, 0)
+        if self.staged:                                     # fragment 1 <- slab 1; slab 0 has been read by every wave: slab 4 takes its slot
+            self.stage_read(b, 1, 1)
+            self.stage_issue(b, 0)
         b.e('s_mov_b32 %s, 0' % sreg(S_COL))
 
         # ---- stage 1.  Fragment u + 1 is produced during sub-step u by half (u + 1) & 1; its producer then requests the
         # values of fragment u + 3.  u_rel = position inside a trip of four, flags say what still exists near the column end.
-        def s1_substep(b, i, first=False, produce_ok=True, request_ok=True, piece='s1'):
+        def s1_substep(b, i, first=False, produce_ok=True, request_ok=True, piece='s1', stage_ok=True, issue_ok=True):
             if self.bf:
                 # fragment u + 1 (register set (i + 1) & 1): both halves convert their k-step; then the values of fragment u + 3
+                # staged form: behind the barrier of sub-step u slab u + 2 is read (fragment u + 2, set u & 1) and slab u + 5 requested
+                stage = None
+                if self.staged:
+                    stage = {'read': ((i + 2) & 3, i & 1) if stage_ok else None, 'issue': ((i + 1) & 3, False) if issue_ok else None}
                 self.substep(b, 1, i & 3, i & 1, first=first, produce=('t1', 0, (i + 1) & 1) if produce_ok else None,
                              consume='half' if produce_ok else False, request=('advance', (i + 1) & 1) if (produce_ok and request_ok) else None,
-                             piece=piece, who='own')
+                             piece=piece, who='own', stage=stage)
                 return
             prod = ((i + 1) & 1) == h and produce_ok
             cons = ((i + 1) & 1) != h and produce_ok
@@ -422,7 +499,7 @@ class Role:
         loop.e('s_cbranch_scc1 %s' % L('loop'))
         last.label(L('last'))
         for i in range(4):
-            s1_substep(last, i, produce_ok=(i < 3), request_ok=(i == 0), piece='s2')
+            s1_substep(last, i, produce_ok=(i < 3), request_ok=(i == 0), piece='s2', stage_ok=(i < 2), issue_ok=False)
 
         # ---- first fragment of stage 2 (features 0..15 of the column step, tile 0 of half 0) needs the finished accumulators
         if h == 0:
@@ -474,7 +551,11 @@ class Role:
             who = 'none' if produce is not None else ('all' if consume else 'own')
             if 'ownpieces' in self.dbg or consume == 'half':      # split production: both halves convert, both issue their own pieces
                 who = 'own'
-            self.substep(st2, 2, q & 3, q & 1, produce=produce, consume=consume, request=request, piece=piece, pre_piece=pre, who=who)
+            stage = None
+            if self.staged:                                # the next column step's slabs 0 .. 4, fragments 0 and 1
+                stage = {NQ - 5: {'issue': (0, True)}, NQ - 4: {'issue': (1, False)}, NQ - 3: {'issue': (2, False)},
+                         NQ - 2: {'read': (0, 0), 'issue': (3, False)}, NQ - 1: {'read': (1, 1), 'issue': (0, False)}}.get(q)
+            self.substep(st2, 2, q & 3, q & 1, produce=produce, consume=consume, request=request, piece=piece, pre_piece=pre, who=who, stage=stage)
         tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
         tail.e('s_add_u32 %s, %s, 1' % (sreg(S_COL), sreg(S_COL)))
         tail.e('s_cmp_lt_u32 %s, %s' % (sreg(S_COL), sreg(S_NCOL)))
@@ -487,7 +568,8 @@ class Role:
         col2 = [head, loop, loop, last, bub, st2, tail]
         for first_col in (col0, col1, col2):
             for second_col in (col0, col1, col2):
-                simulate([pro] + first_col + second_col + second_col)
+                for with_opt in (True, False):
+                    simulate([pro] + first_col + second_col + second_col, with_opt=with_opt)
         return [pro, head, loop, last, bub, st2, tail]
 
 
@@ -591,10 +673,58 @@ def common_prologue(b, dbg=(), mode='hs'):
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 4)))
     b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 4), vreg(V_T + 4), sreg(S_NT)))
     b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T + 3), vreg(V_T + 4)))
-    for dst, idx in ((V_LOFF, V_T + 1), (V_TOFF, V_T + 3)):
-        b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 5), vreg(idx), sreg(S_LDL)))
-        b.e('v_lshl_add_u32 %s, %s, 3, %s' % (vreg(V_T + 5), vreg(V_HI), vreg(V_T + 5)))
-        b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(dst), vreg(V_T + 5)))
+    if mode == 'bf16' and 'nostage' not in dbg:
+        # staged form (pr = v[V_T+1], t = v[V_T+3]).  LDS read addresses: T unit u of row t sits at t * 128 + ((u ^ ((t >> 1) & 7)) << 4),
+        # this lane's k-step is units 4 h + 2 hi, + 1; the L0 rows of the band sit unswizzled, row pr - pr0
+        b.e('v_bfe_u32 %s, %s, 1, 3' % (vreg(V_T + 5), vreg(V_T + 3)))                       # (t >> 1) & 7
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_H)))
+        b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI), sreg(S_T)))         # 4 h + 2 hi
+        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 7), vreg(V_T + 3)))                  # t * 128
+        b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 7), TS_OFF, vreg(V_T + 7)))
+        b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 6), vreg(V_T + 5)))
+        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL0), vreg(V_T + 8), vreg(V_T + 7)))
+        b.e('v_or_b32_e32 %s, 1, %s' % (vreg(V_T + 8), vreg(V_T + 6)))
+        b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 5)))
+        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL1), vreg(V_T + 8), vreg(V_T + 7)))
+        # pr0 = m0 / nt and prmax = (M - 1) / nt: the same exact division on uniform values
+        for k, src in ((0, sreg(S_M0)), (1, None)):
+            if src is None:
+                b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_M)))
+                src = sreg(S_T)
+            b.e('v_mov_b32_e32 %s, %s' % (vreg(V_T + 8), src))
+            b.e('v_mul_hi_u32 %s, %s, %s' % (vreg(V_T + 9), vreg(V_T + 8), sreg(S_MAGIC)))
+            b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 10), vreg(V_T + 9), sreg(S_NT)))
+            b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 10), vreg(V_T + 8), vreg(V_T + 10)))
+            b.e('v_cmp_le_u32_e32 vcc, %s, %s' % (sreg(S_NT), vreg(V_T + 10)))
+            b.e('v_addc_co_u32_e32 %s, vcc, 0, %s, vcc' % (vreg(V_T + 11 + k), vreg(V_T + 9)))    # q + (r >= nt)
+        # L0 slab read: row pr - pr0, units 4 h + 2 hi, + 1 (contiguous)
+        b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 1), vreg(V_T + 11)))
+        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 8), vreg(V_T + 8)))
+        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_T + 8), vreg(V_T + 6), vreg(V_T + 8)))
+        b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_LL), L0S_OFF, vreg(V_T + 8)))
+        # L0 slab DMA (wave 0): lane -> row min(pr0 + (lane >> 3), prmax), 16-byte unit lane & 7
+        b.e('v_lshrrev_b32_e32 %s, 3, %s' % (vreg(V_T + 8), vreg(V_LANE)))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 11)))
+        b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 12)))
+        b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), sreg(S_LDL)))
+        b.e('v_and_b32_e32 %s, 7, %s' % (vreg(V_T + 9), vreg(V_LANE)))
+        b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 9), vreg(V_T + 9)))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 9)))
+        b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_LOFF), vreg(V_T + 8)))
+        # T slab DMA: this wave's 1-KiB chunk min(wave, nch - 1) of the nt * 128 bytes
+        b.e('s_lshl_b32 %s, %s, 7' % (sreg(S_TSLABB), sreg(S_NT)))
+        b.e('s_add_u32 %s, %s, 7' % (sreg(S_T), sreg(S_NT)))
+        b.e('s_lshr_b32 %s, %s, 3' % (sreg(S_T), sreg(S_T)))
+        b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_T)))
+        b.e('s_min_u32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_WAVE)))
+        b.e('s_lshl_b32 %s, %s, 10' % (sreg(S_TCH), sreg(S_T)))
+        b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_TOFF), vreg(V_LANE)))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_TOFF), sreg(S_TCH), vreg(V_TOFF)))
+    else:
+        for dst, idx in ((V_LOFF, V_T + 1), (V_TOFF, V_T + 3)):
+            b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 5), vreg(idx), sreg(S_LDL)))
+            b.e('v_lshl_add_u32 %s, %s, 3, %s' % (vreg(V_T + 5), vreg(V_HI), vreg(V_T + 5)))
+            b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(dst), vreg(V_T + 5)))
     # ---- weight fragment reads: row (128 h + 32 jj + l31) of the image, 16-byte chunk ((2 plane + hi) ^ ((l31 >> 2) & 3))
     b.e('v_bfe_u32 %s, %s, 2, 2' % (vreg(V_T), vreg(V_L31)))
     b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_HI), vreg(V_T)))
@@ -800,7 +930,7 @@ META_KERNEL = '''  - .name: {name}
         .value_kind: by_value
 '''
 
-VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
+VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),

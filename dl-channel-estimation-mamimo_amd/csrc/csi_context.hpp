@@ -81,6 +81,8 @@ struct Model {
     float* T = nullptr;          // [nt][H1] pilot table incl. bias
     float* T_hs = nullptr;       // [nt][H1] 2^T_hs_shift * T: what the split-f16 pair kernel adds (gemm_hs.hip.h)
     int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
+    float* T_sw = nullptr;       // T in the slab order of the staged bf16 band kernel (band_tsw_kernel); rebuilt with the table
+    bool T_sw_ok = false;
     bool loaded = false;
     bool table_ok = false;
 };
@@ -168,6 +170,7 @@ struct csi_ctx {
     hipModule_t band_mod = nullptr;          // its code object (embedded in the library, loaded on first use)
     hipFunction_t band_fn = nullptr;
     hipFunction_t band_fn_bf16 = nullptr;
+    hipFunction_t band_fn_bf16_ns = nullptr;   // bf16 form without the staged T / L0 streams (nt outside 32 .. 64)
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;
     int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
@@ -316,7 +319,9 @@ void free_model(Model& m) {
     m.W0rm = nullptr;
     if (m.T) hipFree(m.T);
     if (m.T_hs) hipFree(m.T_hs);
-    m.W0p = m.T = m.T_hs = nullptr;
+    if (m.T_sw) hipFree(m.T_sw);
+    m.W0p = m.T = m.T_hs = m.T_sw = nullptr;
+    m.T_sw_ok = false;
     m.T_hs_shift = HS_SHIFT_AUTO;
     m.loaded = m.table_ok = false;
 }

@@ -207,18 +207,30 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
             const Layer& lr = m.layers[nh];
             hipFunction_t fn = nullptr;
             BandArgs ba{};
-            if (nh == 2 && c->hs_band == 2 && lr.Wb_p) {
-                // first per-pair layer + regressor as one kernel, h2 in registers: the bf16 form of the assembly band kernel.  Only on
-                // request ("hs_band" = 2): measured SLOWER than the two bf16 kernels at config 3 (4.90 vs 3.37 + 0.99 ms,
-                // profiles/r03_bench_bf16_band_ab.txt) - with one MFMA per product its per-sub-step overheads are not covered
+            if (nh == 2 && c->hs_band && lr.Wb_p) {
+                // first per-pair layer + regressor as one kernel, h2 in registers: the bf16 form of the assembly band kernel.  With the
+                // L0 / T values of the fragments streamed through LDS (32 <= nt <= 64) it replaces the two bf16 kernels by default: 3.52
+                // against 3.37 + 0.99 ms per launch at configs[2]; the form with per-lane global loads of those values (any nt) is bound by
+                // the vector-memory path - 4.9 ms - and runs only on request ("hs_band" = 2): profiles/r03_bench_bf16_band_ab.txt
                 ba.L0 = l0sum; ba.Ts = m.T; ba.ldl = h1; ba.nt = nt; ba.in_scale = 1.f;
                 ba.W1 = reinterpret_cast<const uint16_t*>(l1.Wb); ba.ldb1 = l1.ldwb; ba.bias1 = l1.bias; ba.M = M2; ba.K1 = h1; ba.N1 = l1.out;
                 ba.acc_scale1 = 1.f; ba.out_scale = 1.f;
                 ba.W2p = reinterpret_cast<const uint16_t*>(lr.Wb_p); ba.ldb2 = lr.ldwb; ba.bias2 = lr.bias; ba.n2 = cf.n_out; ba.acc_scale2 = 1.f;
                 ba.out = d_out + (size_t)p0 * nr * nt * cf.n_out; ba.ldo = cf.n_out; ba.peak = nullptr;
-                if (band8_serves(ba, true) && l1.in == h1 && lr.in == l1.out && l1.ldwb == h1 && lr.ldwb == l1.out) {
-                    rc = band8_function(c, &fn, true);
+                if (band8_serves(ba, true) && (c->hs_band == 2 || band8_staged(ba)) && l1.in == h1 && lr.in == l1.out && l1.ldwb == h1 && lr.ldwb == l1.out) {
+                    rc = band8_function(c, &fn, true, band8_staged(ba));
                     if (rc) return rc;
+                }
+                if (fn && band8_staged(ba)) {       // the kernel streams the pilot table slab by slab through LDS: its slab-ordered copy
+                    if (!m.T_sw_ok) {
+                        const size_t floats = (size_t)(h1 / 32 + 1) * nt * 32;
+                        if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + G_SLACK_FLOATS) * sizeof(float)) != hipSuccess)
+                            return fail(c, CSI_ERR_NOMEM, "device allocation of the slab-ordered pilot table failed");
+                        hipLaunchKernelGGL(band_tsw_kernel, dim3(256), dim3(256), 0, c->stream, m.T, h1, nt, h1, m.T_sw);
+                        HIP_TRY(c, hipGetLastError());
+                        m.T_sw_ok = true;
+                    }
+                    ba.Ts = m.T_sw;
                 }
             }
             if (fn) {

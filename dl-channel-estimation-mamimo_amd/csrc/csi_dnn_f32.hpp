@@ -164,6 +164,7 @@ int build_pilot_table(csi_ctx* c, Model& m) {
     HIP_TRY(c, hipGetLastError());
     m.table_ok = true;
     m.T_hs_shift = HS_SHIFT_AUTO;       // the split engine's pre-scaled copy is rebuilt on its next use
+    m.T_sw_ok = false;                  // ... and the slab-ordered copy of the bf16 band kernel
     return CSI_OK;
 }
 

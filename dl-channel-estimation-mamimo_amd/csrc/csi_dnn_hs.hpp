@@ -198,20 +198,27 @@ int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
 #define CSI_HAVE_BAND8 1
 #endif
 
-int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false) {
+int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged = false) {
     *fn = nullptr;
 #ifdef CSI_HAVE_BAND8
     if (c->band_failed) return CSI_OK;
     if (!c->band_mod) {
-        if (hipModuleLoadData(&c->band_mod, band8_hsaco) != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, "csi_band8") != hipSuccess ||
-            hipModuleGetFunction(&c->band_fn_bf16, c->band_mod, "csi_band8_bf16") != hipSuccess) {
+        // timing experiments (tools/): CSI_BAND8_HSACO = a code object built by tools/build_band8.sh (every ablation variant of
+        // band_kernel_gen.py), CSI_BAND8_NAME / CSI_BAND8_BF16_NAME = the variants to run in place of the two product kernels
+        const char* ext = std::getenv("CSI_BAND8_HSACO");
+        const char* n_hs = std::getenv("CSI_BAND8_NAME");
+        const char* n_bf = std::getenv("CSI_BAND8_BF16_NAME");
+        const hipError_t le = ext && *ext ? hipModuleLoad(&c->band_mod, ext) : hipModuleLoadData(&c->band_mod, band8_hsaco);
+        if (le != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, ext && n_hs ? n_hs : "csi_band8") != hipSuccess ||
+            hipModuleGetFunction(&c->band_fn_bf16, c->band_mod, ext && n_bf ? n_bf : "csi_band8_bf16") != hipSuccess ||
+            hipModuleGetFunction(&c->band_fn_bf16_ns, c->band_mod, "csi_band8_bf16_nostage") != hipSuccess) {
             (void)hipGetLastError();
             c->band_failed = true;       // not fatal: the separate kernels serve the call
-            c->band_fn = c->band_fn_bf16 = nullptr;
+            c->band_fn = c->band_fn_bf16 = c->band_fn_bf16_ns = nullptr;
             return CSI_OK;
         }
     }
-    *fn = bf16 ? c->band_fn_bf16 : c->band_fn;
+    *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : c->band_fn;
 #endif
     return CSI_OK;
 }
