@@ -303,6 +303,16 @@ def main():
                                            'note': 'CsiEngine.estimate (LS + DNN) on a complex128 numpy batch, complex64 numpy results; median of 3 calls. '
                                                    'Bound: the download of the two result arrays over one PCIe direction (~50 GB/s measured: '
                                                    'profiles/r03_c128_copy_trace.txt)'}
+        # the reference's inference.py:24-32 returns the DNN estimate only: the same call without the LS array (half the download)
+        t3s = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eng.estimate(x128, ls=False, out=(bufs[0], None))
+            t3s.append(time.perf_counter() - t0)
+        t3 = sorted(t3s)[1]
+        host_path['python_c128_to_c64']['dnn_only'] = {'pairs_per_s': k * nr * nt / t3, 'ms': t3 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t3s],
+                                                       'd2h_bytes': int(bufs[0].nbytes),
+                                                       'note': 'CsiEngine.estimate(ls=False): what CSIPredictor.inference returns (model_real + 1j * model_imag)'}
         del x128, bufs
 
     # ---- cpu_baseline leg (rank 0, N = 1, after the timed region): the only place that touches oracle/.

@@ -121,7 +121,7 @@ def build_band_kernel(verbose=False):
     llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
     with tempfile.TemporaryDirectory() as tmp:
         asm, obj, co = (os.path.join(tmp, 'band8.' + e) for e in ('s', 'o', 'hsaco'))
-        cmds = [[sys.executable, gen, asm, 'csi_band8', 'csi_band8_bf16', 'csi_band8_bf16_nostage'],
+        cmds = [[sys.executable, gen, asm, 'csi_band8', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage'],
                 [os.path.join(llvm, 'clang'), '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', asm, '-o', obj],
                 [os.path.join(llvm, 'ld.lld'), '-shared', obj, '-o', co]]
         for cmd in cmds:

@@ -163,7 +163,8 @@ class Role:
         self.bf = mode == 'bf16'
         self.nq = 8 if self.bf else 16          # stage-2 sub-steps per column step (sub-tiles of 32 / 16 k)
         self.tv = V_TV16 if self.bf else V_TV
-        self.staged = self.bf and 'nostage' not in dbg
+        self.staged = 'nostage' not in dbg
+        self.slab_k = 32 if self.bf else 16       # k-columns of a T / L0 slab = of a sub-step
         self.uid = 0
 
     # ---------------------------------------------------------------- pieces of code
@@ -221,13 +222,15 @@ class Role:
                 b.label(skip)
         b.e('s_add_u32 %s, %s, %s' % (sreg(S_TSP), sreg(S_TSP), sreg(S_TSLABB)))
         b.e('s_addc_u32 %s, %s, 0' % (sreg(S_TSP + 1), sreg(S_TSP + 1)))
-        b.e('s_add_u32 %s, %s, 128' % (sreg(S_L0P), sreg(S_L0P)))
+        b.e('s_add_u32 %s, %s, %d' % (sreg(S_L0P), sreg(S_L0P), 4 * self.slab_k))
         b.e('s_addc_u32 %s, %s, 0' % (sreg(S_L0P + 1), sreg(S_L0P + 1)))
 
     def stage_read(self, b, slot, xset):
         """this lane's 8 L0 and 8 T values of its k-step of the fragment whose slab sits in `slot` -> register set xset"""
         if 'noreq' in self.dbg:
             return
+        if not self.bf:
+            xset = 0                                       # hs: one register set, the producer of a fragment reads it
         b.e('ds_read_b128 %s, %s offset:%d' % (vreg(self.tv + 8 * xset, 4), vreg(V_TL0), slot * TSLAB))
         b.e('ds_read_b128 %s, %s offset:%d' % (vreg(self.tv + 8 * xset + 4, 4), vreg(V_TL1), slot * TSLAB))
         b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_LV + 8 * xset, 4), vreg(V_LL), slot * 1024))
@@ -283,7 +286,8 @@ class Role:
                     b.e('v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(dst + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
         elif 'noconv' not in self.dbg:
             if kind == 't1':
-                b.wait_vm({'V'})
+                if not self.staged:
+                    b.wait_vm({'V'})
                 for e in range(8):
                     b.e('v_fma_f32 %s, %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + e), sreg(S_INSC), vreg(V_TV + e)))
             else:
@@ -380,8 +384,8 @@ class Role:
             self.read_w(b, 1, nslot)
             if consume:
                 self.read_frag(b, par ^ 1, partner_half_only=(consume == 'half'))
-            if stage and stage.get('read') is not None:
-                self.stage_read(b, *stage['read'])
+            if stage and stage.get('read') is not None and (len(stage['read']) < 3 or stage['read'][2] == self.h):
+                self.stage_read(b, stage['read'][0], stage['read'][1])
             if stage and stage.get('issue') is not None:
                 self.stage_issue(b, stage['issue'][0], reset=stage['issue'][1])
 
@@ -435,9 +439,13 @@ class Role:
             b.wait_vm({'T0', 'L0'})
             b.e('s_waitcnt lgkmcnt(0)')
             self.barrier(b)
-            self.stage_read(b, 0, 0)
-            b.e('s_waitcnt lgkmcnt(0)')
-            self.convert(b, 't1', 0, 0, 0)
+            if self.bf or h == 0:                           # (hs: half 0 produces fragment 0)
+                self.stage_read(b, 0, 0)
+                b.e('s_waitcnt lgkmcnt(0)')
+                if self.bf:
+                    self.convert(b, 't1', 0, 0, 0)
+                else:
+                    self.convert(b, 't1', 0)
         elif self.bf:                                       # split production: both halves convert their k-step of fragment 0
             self.request(b, 'reset', 0)
             self.request(b, 'advance', 1)
@@ -458,7 +466,8 @@ class Role:
             self.read_frag(b, 0)
         self.read_w(b, 1, 0)
         if self.staged:                                     # fragment 1 <- slab 1; slab 0 has been read by every wave: slab 4 takes its slot
-            self.stage_read(b, 1, 1)
+            if self.bf or h == 1:                           # (hs: half 1 produces fragment 1)
+                self.stage_read(b, 1, 1)
             self.stage_issue(b, 0)
         b.e('s_mov_b32 %s, 0' % sreg(S_COL))
 
@@ -480,8 +489,11 @@ class Role:
             who = 'none' if prod else ('all' if cons else 'own')       # the converting wave leaves the LDS-DMA to its partner
             if 'ownpieces' in self.dbg:
                 who = 'own'
+            stage = None
+            if self.staged:     # behind the barrier of sub-step u the producer of fragment u + 2 (half u & 1) reads slab u + 2; slab u + 5 is requested
+                stage = {'read': ((i + 2) & 3, 0, i & 1) if stage_ok else None, 'issue': ((i + 1) & 3, False) if issue_ok else None}
             self.substep(b, 1, i & 3, i & 1, first=first, produce=('t1',) if prod else None, consume=cons,
-                         request='advance' if (prod and request_ok) else None, piece=piece, who=who)
+                         request='advance' if (prod and request_ok) else None, piece=piece, who=who, stage=stage)
 
         head.label(L('col'))
         for i in range(4):
@@ -553,8 +565,9 @@ class Role:
                 who = 'own'
             stage = None
             if self.staged:                                # the next column step's slabs 0 .. 4, fragments 0 and 1
+                r0, r1 = ((0, 0), (1, 1)) if self.bf else ((0, 0, 0), (1, 0, 1))      # hs: fragment 0 by half 0, fragment 1 by half 1
                 stage = {NQ - 5: {'issue': (0, True)}, NQ - 4: {'issue': (1, False)}, NQ - 3: {'issue': (2, False)},
-                         NQ - 2: {'read': (0, 0), 'issue': (3, False)}, NQ - 1: {'read': (1, 1), 'issue': (0, False)}}.get(q)
+                         NQ - 2: {'read': r0, 'issue': (3, False)}, NQ - 1: {'read': r1, 'issue': (0, False)}}.get(q)
             self.substep(st2, 2, q & 3, q & 1, produce=produce, consume=consume, request=request, piece=piece, pre_piece=pre, who=who, stage=stage)
         tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
         tail.e('s_add_u32 %s, %s, 1' % (sreg(S_COL), sreg(S_COL)))
@@ -673,13 +686,19 @@ def common_prologue(b, dbg=(), mode='hs'):
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 4)))
     b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 4), vreg(V_T + 4), sreg(S_NT)))
     b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T + 3), vreg(V_T + 4)))
-    if mode == 'bf16' and 'nostage' not in dbg:
+    if 'nostage' not in dbg:
         # staged form (pr = v[V_T+1], t = v[V_T+3]).  LDS read addresses: T unit u of row t sits at t * 128 + ((u ^ ((t >> 1) & 7)) << 4),
         # this lane's k-step is units 4 h + 2 hi, + 1; the L0 rows of the band sit unswizzled, row pr - pr0
-        b.e('v_bfe_u32 %s, %s, 1, 3' % (vreg(V_T + 5), vreg(V_T + 3)))                       # (t >> 1) & 7
-        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_H)))
-        b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI), sreg(S_T)))         # 4 h + 2 hi
-        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 7), vreg(V_T + 3)))                  # t * 128
+        bf = mode == 'bf16'
+        rsh = 7 if bf else 6                      # log2 of the bytes of a slab row (32 / 16 k)
+        if bf:
+            b.e('v_bfe_u32 %s, %s, 1, 3' % (vreg(V_T + 5), vreg(V_T + 3)))                   # (t >> 1) & 7
+            b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_H)))
+            b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI), sreg(S_T)))     # unit 4 h + 2 hi: this half's k-step
+        else:                                     # hs: slab rows of 16 k = 4 units, swizzle (t >> 2) & 3; the producer converts units 2 hi, 2 hi + 1
+            b.e('v_bfe_u32 %s, %s, 2, 2' % (vreg(V_T + 5), vreg(V_T + 3)))
+            b.e('v_lshlrev_b32_e32 %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI)))
+        b.e('v_lshlrev_b32_e32 %s, %d, %s' % (vreg(V_T + 7), rsh, vreg(V_T + 3)))            # t * row bytes
         b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 7), TS_OFF, vreg(V_T + 7)))
         b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 6), vreg(V_T + 5)))
         b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL0), vreg(V_T + 8), vreg(V_T + 7)))
@@ -699,22 +718,22 @@ def common_prologue(b, dbg=(), mode='hs'):
             b.e('v_addc_co_u32_e32 %s, vcc, 0, %s, vcc' % (vreg(V_T + 11 + k), vreg(V_T + 9)))    # q + (r >= nt)
         # L0 slab read: row pr - pr0, units 4 h + 2 hi, + 1 (contiguous)
         b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 1), vreg(V_T + 11)))
-        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 8), vreg(V_T + 8)))
+        b.e('v_lshlrev_b32_e32 %s, %d, %s' % (vreg(V_T + 8), rsh, vreg(V_T + 8)))
         b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_T + 8), vreg(V_T + 6), vreg(V_T + 8)))
         b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_LL), L0S_OFF, vreg(V_T + 8)))
         # L0 slab DMA (wave 0): lane -> row min(pr0 + (lane >> 3), prmax), 16-byte unit lane & 7
-        b.e('v_lshrrev_b32_e32 %s, 3, %s' % (vreg(V_T + 8), vreg(V_LANE)))
+        b.e('v_lshrrev_b32_e32 %s, %d, %s' % (vreg(V_T + 8), 3 if bf else 2, vreg(V_LANE)))
         b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 11)))
         b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 12)))
         b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), sreg(S_LDL)))
-        b.e('v_and_b32_e32 %s, 7, %s' % (vreg(V_T + 9), vreg(V_LANE)))
+        b.e('v_and_b32_e32 %s, %d, %s' % (vreg(V_T + 9), 7 if bf else 3, vreg(V_LANE)))
         b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 9), vreg(V_T + 9)))
         b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 9)))
         b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_LOFF), vreg(V_T + 8)))
         # T slab DMA: this wave's 1-KiB chunk min(wave, nch - 1) of the nt * 128 bytes
-        b.e('s_lshl_b32 %s, %s, 7' % (sreg(S_TSLABB), sreg(S_NT)))
-        b.e('s_add_u32 %s, %s, 7' % (sreg(S_T), sreg(S_NT)))
-        b.e('s_lshr_b32 %s, %s, 3' % (sreg(S_T), sreg(S_T)))
+        b.e('s_lshl_b32 %s, %s, %d' % (sreg(S_TSLABB), sreg(S_NT), rsh))
+        b.e('s_add_u32 %s, %s, %d' % (sreg(S_T), sreg(S_NT), 7 if bf else 15))
+        b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_T), sreg(S_T), 3 if bf else 4))
         b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_T)))
         b.e('s_min_u32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_WAVE)))
         b.e('s_lshl_b32 %s, %s, 10' % (sreg(S_TCH), sreg(S_T)))
@@ -930,7 +949,7 @@ META_KERNEL = '''  - .name: {name}
         .value_kind: by_value
 '''
 
-VARIANTS = [('csi_band8', ()), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
+VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_nostagger', ('nostagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),

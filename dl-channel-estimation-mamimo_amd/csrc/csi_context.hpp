@@ -81,7 +81,7 @@ struct Model {
     float* T = nullptr;          // [nt][H1] pilot table incl. bias
     float* T_hs = nullptr;       // [nt][H1] 2^T_hs_shift * T: what the split-f16 pair kernel adds (gemm_hs.hip.h)
     int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
-    float* T_sw = nullptr;       // T in the slab order of the staged bf16 band kernel (band_tsw_kernel); rebuilt with the table
+    float* T_sw = nullptr;       // T (bf16 contexts) / T_hs (split engine) in the slab order of the staged band kernels (band_tsw_kernel); rebuilt with the table
     bool T_sw_ok = false;
     bool loaded = false;
     bool table_ok = false;
@@ -171,6 +171,7 @@ struct csi_ctx {
     hipFunction_t band_fn = nullptr;
     hipFunction_t band_fn_bf16 = nullptr;
     hipFunction_t band_fn_bf16_ns = nullptr;   // bf16 form without the staged T / L0 streams (nt outside 32 .. 64)
+    hipFunction_t band_fn_ns = nullptr;        // split-f16 form without them (nt outside 16 .. 128)
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;
     int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on

@@ -217,16 +217,16 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 ba.acc_scale1 = 1.f; ba.out_scale = 1.f;
                 ba.W2p = reinterpret_cast<const uint16_t*>(lr.Wb_p); ba.ldb2 = lr.ldwb; ba.bias2 = lr.bias; ba.n2 = cf.n_out; ba.acc_scale2 = 1.f;
                 ba.out = d_out + (size_t)p0 * nr * nt * cf.n_out; ba.ldo = cf.n_out; ba.peak = nullptr;
-                if (band8_serves(ba, true) && (c->hs_band == 2 || band8_staged(ba)) && l1.in == h1 && lr.in == l1.out && l1.ldwb == h1 && lr.ldwb == l1.out) {
-                    rc = band8_function(c, &fn, true, band8_staged(ba));
+                if (band8_serves(ba, true) && (c->hs_band >= 2 || band8_staged(ba)) && l1.in == h1 && lr.in == l1.out && l1.ldwb == h1 && lr.ldwb == l1.out) {
+                    rc = band8_function(c, &fn, true, band8_staged(ba) && c->hs_band != 3);
                     if (rc) return rc;
                 }
-                if (fn && band8_staged(ba)) {       // the kernel streams the pilot table slab by slab through LDS: its slab-ordered copy
+                if (fn && band8_staged(ba) && c->hs_band != 3) {       // the kernel streams the pilot table slab by slab through LDS: its slab-ordered copy
                     if (!m.T_sw_ok) {
                         const size_t floats = (size_t)(h1 / 32 + 1) * nt * 32;
                         if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + G_SLACK_FLOATS) * sizeof(float)) != hipSuccess)
                             return fail(c, CSI_ERR_NOMEM, "device allocation of the slab-ordered pilot table failed");
-                        hipLaunchKernelGGL(band_tsw_kernel, dim3(256), dim3(256), 0, c->stream, m.T, h1, nt, h1, m.T_sw);
+                        hipLaunchKernelGGL(band_tsw_kernel<32>, dim3(256), dim3(256), 0, c->stream, m.T, h1, nt, h1, m.T_sw);
                         HIP_TRY(c, hipGetLastError());
                         m.T_sw_ok = true;
                     }

@@ -211,14 +211,15 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
         const hipError_t le = ext && *ext ? hipModuleLoad(&c->band_mod, ext) : hipModuleLoadData(&c->band_mod, band8_hsaco);
         if (le != hipSuccess || hipModuleGetFunction(&c->band_fn, c->band_mod, ext && n_hs ? n_hs : "csi_band8") != hipSuccess ||
             hipModuleGetFunction(&c->band_fn_bf16, c->band_mod, ext && n_bf ? n_bf : "csi_band8_bf16") != hipSuccess ||
-            hipModuleGetFunction(&c->band_fn_bf16_ns, c->band_mod, "csi_band8_bf16_nostage") != hipSuccess) {
+            hipModuleGetFunction(&c->band_fn_bf16_ns, c->band_mod, "csi_band8_bf16_nostage") != hipSuccess ||
+            hipModuleGetFunction(&c->band_fn_ns, c->band_mod, "csi_band8_nostage") != hipSuccess) {
             (void)hipGetLastError();
             c->band_failed = true;       // not fatal: the separate kernels serve the call
-            c->band_fn = c->band_fn_bf16 = c->band_fn_bf16_ns = nullptr;
+            c->band_fn = c->band_fn_bf16 = c->band_fn_bf16_ns = c->band_fn_ns = nullptr;
             return CSI_OK;
         }
     }
-    *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : c->band_fn;
+    *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : (staged ? c->band_fn : c->band_fn_ns);
 #endif
     return CSI_OK;
 }
@@ -254,6 +255,7 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
                            cf.nt, h1, std::ldexp(1.f, s0));
         HIP_TRY(c, hipGetLastError());
         m.T_hs_shift = s0;
+        m.T_sw_ok = false;
     }
     PairSrc src{l0sum, m.T_hs, h1, cf.nt};
     GemmHsArgs p{};
@@ -276,9 +278,21 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         ba.W2p = lr.Wh_p; ba.ldb2 = lr.ldwh; ba.bias2 = lr.bias_hs; ba.n2 = cf.n_out; ba.acc_scale2 = std::ldexp(1.f, -(s1 + lr.wshift_f));
         ba.out = out; ba.ldo = cf.n_out; ba.peak = c->hs_peak;
         hipFunction_t fn = nullptr;
+        const bool staged = band8_staged(ba, false) && c->hs_band != 3;       // "hs_band" = 3: the form with per-lane global loads of L0 / T (A/B runs)
         if (band8_serves(ba) && h1 == l1.in && lr.in == l1.out) {
-            int rc = band8_function(c, &fn);
+            int rc = band8_function(c, &fn, false, staged);
             if (rc) return rc;
+        }
+        if (fn && staged) {     // the kernel streams the (pre-scaled) pilot table slab by slab through LDS: its slab-ordered copy
+            if (!m.T_sw_ok) {
+                const size_t floats = (size_t)(h1 / 16 + 1) * cf.nt * 16;
+                if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + G_SLACK_FLOATS) * sizeof(float)) != hipSuccess)
+                    return fail(c, CSI_ERR_NOMEM, "device allocation of the slab-ordered pilot table failed");
+                hipLaunchKernelGGL(band_tsw_kernel<16>, dim3(256), dim3(256), 0, c->stream, m.T_hs, h1, cf.nt, h1, m.T_sw);
+                HIP_TRY(c, hipGetLastError());
+                m.T_sw_ok = true;
+            }
+            ba.Ts = m.T_sw;
         }
         if (fn) {
             ++c->hs_launches;

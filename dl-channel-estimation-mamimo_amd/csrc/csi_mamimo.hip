@@ -980,7 +980,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         drop_graphs(c);
         c->hs_fuse_regressor = value != 0;
     } else if (n == "hs_band") {
-        if (value < 0 || value > 2) return fail(c, CSI_ERR_INVALID_ARG, "hs_band must be 0 (separate kernels), 1 (band kernel for fp32 contexts) or 2 (also for bf16 contexts)");
+        if (value < 0 || value > 3)
+            return fail(c, CSI_ERR_INVALID_ARG, "hs_band must be 0 (separate kernels), 1 (band kernel where its LDS-staged form applies, every fp32 shape it serves), "
+                                                "2 (bf16 contexts: also the form with per-lane loads, any nt) or 3 (fp32 contexts: only that form; A/B runs)");
         drop_graphs(c);
         c->hs_band = (int)value;
     } else if (n == "hs_min_blocks") {

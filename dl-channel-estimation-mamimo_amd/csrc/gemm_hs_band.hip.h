@@ -494,22 +494,25 @@ __global__ void f32_to_hs_band_w2_kernel(const float* __restrict__ src, int ld_s
     }
 }
 
-// The pilot table in the order the staged bf16 band kernel streams it (band_kernel_gen.py, TS_OFF): slab u = k-columns 32 u .. + 31
-// of all nt rows, [nt][32] floats, the 16-byte units of a row XOR-swizzled by (row >> 1) & 7 (the ds_read_b128 of 16 consecutive rows
-// then touches every bank once); K1 / 32 slabs plus one the kernel requests past the end of a column step and never reads.
+// The pilot table in the order the staged band kernels stream it (band_kernel_gen.py, TS_OFF): slab u = k-columns SK u .. + SK - 1
+// of all nt rows, [nt][SK] floats (SK = 32: bf16 form, 16: split-f16 form), the 16-byte units of a row XOR-swizzled - by (row >> 1) & 7
+// for 8 units per row, (row >> 2) & 3 for 4 - so that the ds_read_b128 of 16 consecutive rows touches every bank once; K1 / SK slabs
+// plus one the kernel requests past the end of a column step and never reads.
+template <int SK>
 __global__ void band_tsw_kernel(const float* __restrict__ T, int ldt, int nt, int K1, float* __restrict__ dst) {
-    const size_t total = (size_t)(K1 / 32 + 1) * nt * 8;              // 16-byte units
+    constexpr int U = SK / 4;
+    const size_t total = (size_t)(K1 / SK + 1) * nt * U;              // 16-byte units
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int pos = (int)(i & 7);
-        const size_t rt = i >> 3;
+        const int pos = (int)(i % U);
+        const size_t rt = i / U;
         const int t = (int)(rt % nt), u = (int)(rt / nt);
-        const int k = 32 * u + 4 * (pos ^ ((t >> 1) & 7));
+        const int k = SK * u + 4 * (pos ^ ((t >> (U == 8 ? 1 : 2)) & (U - 1)));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K1) v = *reinterpret_cast<const float4*>(T + (size_t)t * ldt + k);
         *reinterpret_cast<float4*>(dst + i * 4) = v;
     }
 }
-// which bf16 form serves a call: the staged one needs the band's L0 rows in one 1-KiB slab (<= 8 rows) and the T slab in 8 KiB
-inline bool band8_staged(const BandArgs& g) { return g.nt >= 32 && g.nt <= 64; }
+// which form serves a call: the staged ones need the band's L0 rows in one 1-KiB slab (8 rows of 32 k / 16 rows of 16 k) and the T slab in 8 KiB
+inline bool band8_staged(const BandArgs& g, bool bf16 = true) { return bf16 ? (g.nt >= 32 && g.nt <= 64) : (g.nt >= 16 && g.nt <= 128); }
 
 }  // namespace csi

@@ -255,9 +255,12 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 16)
  *   get only: "ls_mode" (the kernel the next LS call runs), "ls_pilot_pieces" (bf16 pieces the entries of P need: 1 - 3)
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
- *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor of an fp32 context's split engine as ONE
- *                         kernel, h2 in registers (generated gfx950 assembly, csrc/band_kernel_gen.py); 0: the two separate kernels
- *                         (A/B runs); 2: also the bf16 form for bf16 contexts (measured slower).  Read-only: "band_launches".
+ *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor as ONE kernel, h2 in registers (generated
+ *                         gfx950 assembly, csrc/band_kernel_gen.py): the split engine of fp32 contexts (the form that streams the
+ *                         L0 / pilot-table values through LDS at 16 <= nt <= 128, per-lane loads elsewhere) and bf16 contexts at
+ *                         32 <= nt <= 64 (streamed form); 0: the separate kernels (A/B runs); 2: bf16 contexts take the per-lane form
+ *                         at any other nt as well (measured slower than the separate kernels); 3: only the per-lane forms (A/B runs).
+ *                         Read-only: "band_launches".
  *   "hs_vm_cast", "hs_vm_pair"  vector-memory schedule of the split-f16 layer-0 / first per-pair kernel: 0 builtin LDS-DMA
  *                         with one drain per sub-tile, 1 hand-counted waits, 2 + one more sub-tile of look-ahead (default for
  *                         layer 0), 3 + one load and one 24-MFMA segment per sub-tile (default for the pair layer); same

@@ -164,7 +164,15 @@ int main(int argc, char** argv) {
     };
     if (hsaco && hipModuleLoad(&mod8, hsaco) != hipSuccess) { printf("cannot load %s\n", hsaco); mod8 = nullptr; }
     hipFunction_t k8 = get8(getenv("BAND8_NAME") ? getenv("BAND8_NAME") : "csi_band8");
-    Band8Args a8 = band8_args(ba);
+    // the staged kernels (every variant without "nostage" in its name) stream the pilot table in slab order
+    float* Tsw; CK(hipMalloc(&Tsw, ((size_t)(K / 16 + 1) * nt * 16 + 256) * sizeof(float)));
+    hipLaunchKernelGGL(band_tsw_kernel<16>, dim3(256), dim3(256), 0, 0, Ts, K, nt, K, Tsw);
+    CK(hipDeviceSynchronize());
+    Band8Args a8_plain = band8_args(ba);
+    BandArgs bas = ba; bas.Ts = Tsw;
+    const Band8Args a8_staged = band8_args(bas);
+    const char* k8name = getenv("BAND8_NAME") ? getenv("BAND8_NAME") : "csi_band8";
+    Band8Args a8 = strstr(k8name, "nostage") ? a8_plain : a8_staged;
     auto launch8f = [&](hipFunction_t f, const Band8Args& args) {
         Band8Args tmp = args;
         size_t sz = sizeof(tmp);
@@ -341,10 +349,11 @@ int main(int argc, char** argv) {
             t(kb8, "full, no barriers (invalid)");
             t(kb16, "no A side, no DMA, no fragment reads (invalid)");
             t(kb31, "MFMA only (invalid)");
-            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_nostagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8"}) {
+            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_nostagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8_nostage", "csi_band8_nostage_noreq", "csi_band8"}) {
                 hipFunction_t f = get8(nm);
                 if (!f) continue;
-                const double m = time_ms([&] { launch8f(f, a8); });
+                const Band8Args& av = strstr(nm, "nostage") ? a8_plain : a8_staged;
+                const double m = time_ms([&] { launch8f(f, av); });
                 printf("   %-58s %.3f ms\n", nm, m);
             }
         }
