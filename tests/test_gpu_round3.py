@@ -232,6 +232,12 @@ BAND_CASES = [
     (8, 2, 70, (128, 256)),         # K1 = 128: no trip of the stage-1 loop; one column step; ragged last band (1120 rows)
     (4, 1, 131, (192, 512)),        # K1 = 192: one loop trip; two column steps; 524 rows
     (12, 2, 21, (256, 768)),        # Nt that does not divide the band: rows of one band span several (packet, rx) items
+    # 16 <= Nt <= 128: the form that streams the L0 / pilot-table values through LDS (Nt = 32 above as well)
+    (16, 2, 41, (128, 256)),        # smallest Nt of that form: 8-9 L0 rows per band, a 1-KiB table slab; ragged last band (1312 rows)
+    (24, 2, 21, (256, 256)),        # L0 rows change inside a wave
+    (48, 3, 9, (192, 512)),
+    (100, 1, 5, (128, 256)),        # table slab of 6400 bytes: the last DMA chunk reaches into the next slab
+    (128, 2, 3, (256, 256)),        # largest: 8-KiB slabs, one chunk per wave
 ]
 
 
@@ -260,9 +266,13 @@ def test_band_kernel_matches_oracle_and_separate_kernels(pkg, oracle, nt, nr, np
     assert rel_rows(b_re[sel], r_re) < TOL and rel_rows(b_im[sel], r_im) < TOL
     b2_re, _ = e.predict(ltf)
     assert np.array_equal(b_re, b2_re)
+    e.set_option('hs_band', 3)                                # the form with per-lane global loads of L0 / T: the same arithmetic
+    p_re, p_im = e.predict(ltf)
+    assert e.get_option('band_launches') == n0 + 6
+    assert np.array_equal(b_re, p_re) and np.array_equal(b_im, p_im)
     e.set_option('hs_band', 0)
     s_re, s_im = e.predict(ltf)
-    assert e.get_option('band_launches') == n0 + 4
+    assert e.get_option('band_launches') == n0 + 6
     assert rel_rows(b_re, s_re) < 5e-6 and rel_rows(b_im, s_im) < 5e-6
 
 
