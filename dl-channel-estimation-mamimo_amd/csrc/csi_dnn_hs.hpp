@@ -205,7 +205,9 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
     if (!c->band_mod) {
         // timing experiments (tools/): CSI_BAND8_HSACO = a code object built by tools/build_band8.sh (every ablation variant of
         // band_kernel_gen.py), CSI_BAND8_NAME / CSI_BAND8_BF16_NAME = the variants to run in place of the two product kernels
-        const char* ext = std::getenv("CSI_BAND8_HSACO");
+        // Honoured only together with CSI_DEBUG_HOOKS=1: a production process never loads a code object named by its environment.
+        const char* hooks = std::getenv("CSI_DEBUG_HOOKS");
+        const char* ext = hooks && hooks[0] == '1' ? std::getenv("CSI_BAND8_HSACO") : nullptr;
         const char* n_hs = std::getenv("CSI_BAND8_NAME");
         const char* n_bf = std::getenv("CSI_BAND8_BF16_NAME");
         const hipError_t le = ext && *ext ? hipModuleLoad(&c->band_mod, ext) : hipModuleLoadData(&c->band_mod, band8_hsaco);
