@@ -261,12 +261,14 @@ class Role:
             if 'noconv' not in self.dbg:
                 if not self.staged:
                     b.wait_vm({'V%d' % g})             # g = register set of this fragment
-                for e in range(8):
-                    b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_LV + 8 * g + e), vreg(self.tv + 8 * g + e)))
-                for e in range(8):
-                    b.e('v_max_f32_e32 %s, 0, %s' % (vreg(V_GV + e), vreg(V_GV + e)))
+                # packed: 4 adds on the fp32 pairs, 4 conversions, relu on the PACKED bf16 as a signed 16-bit maximum with 0 (a negative
+                # bf16 is a negative int16, -0 included; rounding commutes with relu) - 12 operations instead of 20, same bits
+                for p in range(4):
+                    b.e('v_pk_add_f32 %s, %s, %s' % (vreg(V_GV + 2 * p, 2), vreg(V_LV + 8 * g + 2 * p, 2), vreg(self.tv + 8 * g + 2 * p, 2)))
                 for p in range(4):
                     b.e('v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(dst + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
+                for p in range(4):
+                    b.e('v_pk_max_i16 %s, %s, 0' % (vreg(dst + p), vreg(dst + p)))
             b.e('ds_write_b128 %s, %s offset:%d' % (vreg(V_AX), vreg(dst, 4), par_next * 2048 + 1024 * self.h))
             return
         if 'noconv' not in self.dbg and self.bf:
@@ -278,12 +280,12 @@ class Role:
                     for e in range(8):
                         b.e('v_accvgpr_read_b32 %s, %s' % (vreg(V_GV + e), areg(ACC1 + 16 * jj + 8 * half + e)))
                     b.e('s_waitcnt lgkmcnt(0)')
-                    for e in range(8):
-                        b.e('v_add_f32_e32 %s, %s, %s' % (vreg(V_GV + e), vreg(V_GV + e), vreg(V_BQ + e)))
-                for e in range(8):
-                    b.e('v_max_f32_e32 %s, 0, %s' % (vreg(V_GV + e), vreg(V_GV + e)))
+                    for p in range(4):
+                        b.e('v_pk_add_f32 %s, %s, %s' % (vreg(V_GV + 2 * p, 2), vreg(V_GV + 2 * p, 2), vreg(V_BQ + 2 * p, 2)))
                 for p in range(4):
                     b.e('v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(dst + p), vreg(V_GV + 2 * p), vreg(V_GV + 2 * p + 1)))
+                for p in range(4):
+                    b.e('v_pk_max_i16 %s, %s, 0' % (vreg(dst + p), vreg(dst + p)))
         elif 'noconv' not in self.dbg:
             if kind == 't1':
                 if not self.staged:
