@@ -170,14 +170,27 @@ def main():
             mine = 0.0
         use_lib_rccl = pkg.dist.all_reduce_min(mine) > 0.5
     if use_lib_rccl:
-        # the library's own communicator: rank 0 loads, every context receives the device buffers over RCCL
+        # the library's own communicator: rank 0 loads, every context receives the device buffers over RCCL.  An error on any rank
+        # (reported by the library, not a hang) sends EVERY rank to the torch.distributed path below: the ranks agree afterwards.
         t_b = time.perf_counter()
-        eng.comm_init(rank, world, pkg.dist.exchange_unique_id(rank, world))
-        if rank == 0:
-            eng.load_weights('real', wts['real'])
-            eng.load_weights('imag', wts['imag'])
-            eng.set_pilot(wts['P']['pilot'])
-        moved = eng.broadcast_weights(0)
+        moved, ok = 0, 1.0
+        try:
+            eng.comm_init(rank, world, pkg.dist.exchange_unique_id(rank, world))
+            if rank == 0:
+                eng.load_weights('real', wts['real'])
+                eng.load_weights('imag', wts['imag'])
+                eng.set_pilot(wts['P']['pilot'])
+            moved = eng.broadcast_weights(0)
+        except Exception as err:                       # noqa: BLE001
+            print('bench.py: rank %d: weight broadcast through the library failed (%s); torch.distributed path instead' % (rank, err), file=sys.stderr)
+            ok = 0.0
+        use_lib_rccl = pkg.dist.all_reduce_min(ok) > 0.5
+        if not use_lib_rccl:
+            try:
+                eng.comm_destroy()
+            except Exception:                          # noqa: BLE001
+                pass
+    if use_lib_rccl:
         via = 'csi_broadcast_weights: ncclBroadcast of %d device buffers, %.1f MB, %.0f ms incl. communicator setup and rank 0 load' % (
             eng.get_option('comm_blobs'), moved / 1e6, (time.perf_counter() - t_b) * 1e3)
         P_host = pkg.synth.hadamard(nt)             # the pilot matrix is a constant of the configuration (input synthesis below)
