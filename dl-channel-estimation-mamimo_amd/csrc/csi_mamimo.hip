@@ -38,20 +38,20 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     const int nt = c->cfg.nt, jt = (nt + 31) / 32, npp = std::min(3, std::max(1, c->p_pieces));
     LsRingB r{nullptr, 0, 8, 1};
     if (nt < 16 || nt > 128) return r;
-    int nstg = 1;
-#define LS_RB(J, W, NS, MB)                                                                                        \
+    int nstg = 1, nf = 1;
+#define LS_RB(J, W, NS, MB, DB)                                                                                    \
     {                                                                                                              \
-        r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 1, MB>                                   \
-               : (npp == 2 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 2, MB> : (const void*)ls_estimate_ringb_kernel<J, W, NS, 3, MB>); \
-        r.nw = W; nstg = NS; r.per_cu = MB;                                                                        \
+        r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 1, MB, DB>                               \
+               : (npp == 2 ? (const void*)ls_estimate_ringb_kernel<J, W, NS, 2, MB, DB> : (const void*)ls_estimate_ringb_kernel<J, W, NS, 3, MB, DB>); \
+        r.nw = W; nstg = NS; r.per_cu = MB; nf = DB ? 2 : 1;                                                       \
     }
-    // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the other ring depth for A/B runs
-    if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2) else LS_RB(1, 4, 1, 2) }
-    else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 2, 1) else LS_RB(2, 8, 1, 1) }
-    else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 1, 1) else LS_RB(3, 8, 2, 1) }
-    else { if (c->ls_v2 == 1) LS_RB(4, 8, 2, 1) else LS_RB(4, 8, 1, 1) }
+    // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the runner-up for A/B runs
+    if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2, false) else LS_RB(1, 4, 1, 2, false) }
+    else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
+    else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
+    else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
 #undef LS_RB
-    r.lds = (size_t)(2 * LSC_NTW + 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
+    r.lds = (size_t)(2 * LSC_NTW + nf * 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
     if (r.lds > 160 * 1024) r.fn = nullptr;
     r.per_cu = std::max(1, std::min(r.per_cu, (int)((160 * 1024) / r.lds)));
     return r;

@@ -1031,7 +1031,7 @@ __device__ __forceinline__ void ls_bf_split2(float x0, float x1, uint32_t& p1, u
 
 constexpr int LSB_BLOCK = 512;      // bf16 elements of one (chunk, piece, antenna tile) block: [2 k-halves][32 rows][8 symbols]
 
-template <int JT, int NW, int NSTG, int NPP, int MINB = 1>
+template <int JT, int NW, int NSTG, int NPP, int MINB = 1, bool DBF = false>
 __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const LsArgs a, int nblk) {
     constexpr int CH = 16, SPW = CH / NW, QW = 8 / NW;
     constexpr int NB = NPP * JT, NPD = (NB + NW - 1) / NW;      // P blocks per chunk, LDS-DMAs per wave for them
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW]
     f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW]
-    float* S = reinterpret_cast<float*>(Fc + CH * LSC_ROW);           // [NSTG][CH][2][256]
+    float* S = reinterpret_cast<float*>(Fc + (DBF ? 2 : 1) * CH * LSC_ROW);   // [NSTG][CH][2][256]
     uint16_t* Pb = reinterpret_cast<uint16_t*>(S + NSTG * CH * 2 * LS_FFT);   // [NPS][NB][LSB_BLOCK] bf16
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1157,11 +1157,18 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_next();
             if (ch == 0 && t > 0) store_item(blk - gridDim.x);
-            if (t > 0) ls_lds_barrier();          // spectra and P pieces of chunk t - 1 consumed
-            issue_pieces();                       // ... so the slot of those pieces takes chunk t + NSTG
-            lsc_stage0_write<SPW, NW>(Fc, wave, lane, y0);
-            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1)>(Fc, wave, twc, lane);
+            // DBF: two spectra images alternate - the image written now was last read two chunks ago, and every wave had finished that
+            // despread before it arrived at the previous "spectra complete" barrier: one barrier per chunk instead of two, a fast wave
+            // transforms chunk t + 1 while a slow one still despreads chunk t
+            f32x2* Fb = Fc + (DBF ? (t & 1) * CH * LSC_ROW : 0);
+            if (!DBF) {
+                if (t > 0) ls_lds_barrier();      // spectra and P pieces of chunk t - 1 consumed
+                issue_pieces();                   // ... so the slot of those pieces takes chunk t + NSTG
+            }
+            lsc_stage0_write<SPW, NW>(Fb, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1)>(Fb, wave, twc, lane);
             ls_lds_barrier();                     // spectra complete; every wave has seen its P blocks of chunk t land
+            if (DBF) issue_pieces();              // every wave is past the despread of chunk t - 1: its P slot takes chunk t + NSTG
 
             // ---- despread: one K = 16 step.  A = P pieces (row j = l31 of antenna tile jt, symbols 8 hi .. 8 hi + 7),
             // B = this lane's bin of the same 8 symbols, cut into pieces here.
@@ -1173,7 +1180,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
 #pragma unroll
                 for (int k = 0; k < NPP; ++k)
                     pa[jt][k] = __builtin_bit_cast(ls_bf16x8, *reinterpret_cast<const ls_u32x4*>(pbs + (k * JT + jt) * LSB_BLOCK));
-            const f32x2* frow = Fc + (size_t)(8 * hi) * LSC_ROW;
+            const f32x2* frow = Fb + (size_t)(8 * hi) * LSC_ROW;
             ls_u32x4 fb[QW][2][3];
 #pragma unroll
             for (int qi = 0; qi < QW; ++qi) {
