@@ -224,7 +224,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 if (fn && band8_staged(ba) && c->hs_band != 3) {       // the kernel streams the pilot table slab by slab through LDS: its slab-ordered copy
                     if (!m.T_sw_ok) {
                         const size_t floats = (size_t)(h1 / 32 + 1) * nt * 32;
-                        if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + G_SLACK_FLOATS) * sizeof(float)) != hipSuccess)
+                        if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + 512) * sizeof(float)) != hipSuccess)
                             return fail(c, CSI_ERR_NOMEM, "device allocation of the slab-ordered pilot table failed");
                         hipLaunchKernelGGL(band_tsw_kernel<32>, dim3(256), dim3(256), 0, c->stream, m.T, h1, nt, h1, m.T_sw);
                         HIP_TRY(c, hipGetLastError());

@@ -287,8 +287,9 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
         }
         if (fn && staged) {     // the kernel streams the (pre-scaled) pilot table slab by slab through LDS: its slab-ordered copy
             if (!m.T_sw_ok) {
+                // (+ 2 KiB: the last 1-KiB DMA chunk of a slab may reach past it, and the kernel requests one slab past the column step)
                 const size_t floats = (size_t)(h1 / 16 + 1) * cf.nt * 16;
-                if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + G_SLACK_FLOATS) * sizeof(float)) != hipSuccess)
+                if (!m.T_sw && hipMalloc((void**)&m.T_sw, (floats + 512) * sizeof(float)) != hipSuccess)
                     return fail(c, CSI_ERR_NOMEM, "device allocation of the slab-ordered pilot table failed");
                 hipLaunchKernelGGL(band_tsw_kernel<16>, dim3(256), dim3(256), 0, c->stream, m.T_hs, h1, cf.nt, h1, m.T_sw);
                 HIP_TRY(c, hipGetLastError());
