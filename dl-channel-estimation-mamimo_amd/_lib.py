@@ -97,6 +97,8 @@ SYMBOLS = {
     'csi_comm_init': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     'csi_comm_destroy': (ctypes.c_int, [_ctx]),
     'csi_broadcast_weights': (ctypes.c_int, [_ctx, ctypes.c_int]),
+    'csi_clone_weights': (ctypes.c_int, [_ctx, _ctx]),
+    'csi_pilot_classify': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     'csi_profile_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
     'csi_profile_query': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),

@@ -320,6 +320,33 @@ class Role:
         if not partner_half_only or self.h == 0:
             b.e('ds_read_b128 %s, %s offset:%d' % (vreg(V_ALO[par_next], 4), vreg(V_AX), par_next * 2048 + 1024))
 
+    def fill_operands(self, b):
+        """'rnd' (with the skeleton flags: no conversion, requests, LDS-DMA or fragment reads): the 48 operand registers the MFMAs of
+        the main loop read are filled ONCE with real operand data, so that the MFMA + barrier skeleton runs at the power point of the
+        real kernel instead of on whatever the registers held (round-3 verdict, Missing 6).  Weight fragments: the hi | lo halves of
+        W1 itself (row 4 w + jj, 16-k group `lane`: bytes 0-15 hi, 32-47 lo).  Activation fragments: the next hi halves with the
+        negative ones cleared (the exact zeros of a relu, about half of them) and the lo halves cleared where the hi half is."""
+        b.e('v_lshlrev_b32_e32 %s, 6, %s' % (vreg(V_T), vreg(V_LANE)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_WAVE)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_LDB1)))            # row 4 w: ldb1 halves per row
+        b.e('s_lshl_b32 %s, %s, 1' % (sreg(S_T), sreg(S_T)))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(V_T)))
+        b.e('s_lshl_b32 %s, %s, 1' % (sreg(S_T + 1), sreg(S_LDB1)))                  # bytes per row
+        for jj in range(4):
+            b.e('global_load_dwordx4 %s, %s, %s' % (vreg(V_WHI + 4 * jj, 4), vreg(V_T), sreg(S_W1, 2)))
+            b.e('global_load_dwordx4 %s, %s, %s offset:32' % (vreg(V_WLO + 4 * jj, 4), vreg(V_T), sreg(S_W1, 2)))
+            if jj < 2:
+                b.e('global_load_dwordx4 %s, %s, %s offset:16' % (vreg(V_AHI[jj], 4), vreg(V_T), sreg(S_W1, 2)))
+                b.e('global_load_dwordx4 %s, %s, %s offset:48' % (vreg(V_ALO[jj], 4), vreg(V_T), sreg(S_W1, 2)))
+            b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T + 1), vreg(V_T)))
+        b.e('s_waitcnt vmcnt(0)')
+        b.e('v_mov_b32_e32 %s, 0x3c003c00' % vreg(V_T + 1))
+        for par in range(2):
+            for p in range(4):
+                b.e('v_pk_max_i16 %s, %s, 0' % (vreg(V_AHI[par] + p), vreg(V_AHI[par] + p)))
+                b.e('v_pk_min_u16 %s, %s, %s' % (vreg(V_T + 2), vreg(V_AHI[par] + p), vreg(V_T + 1)))
+                b.e('v_pk_mul_f16 %s, %s, %s' % (vreg(V_ALO[par] + p), vreg(V_ALO[par] + p), vreg(V_T + 2)))
+
     def barrier(self, b):
         if 'nobarrier' not in self.dbg:
             b.e('s_barrier')
@@ -435,6 +462,8 @@ class Role:
         for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
             b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
             b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
+        if 'rnd' in self.dbg:
+            self.fill_operands(b)
         for t in range(4):
             self.pieces(b, 's1', t)
         if self.staged:                                     # slabs 0 .. 3 of the T / L0 streams; fragment 0 from slab 0
@@ -956,6 +985,7 @@ META_KERNEL = '''  - .name: {name}
 VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
+            ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_stagger', ('stagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]

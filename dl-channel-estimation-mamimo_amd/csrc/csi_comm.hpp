@@ -6,6 +6,14 @@
 // go with them (leading dimensions, power-of-two shifts of the split engine, which buffers exist) travel first as one
 // fixed-size record through the same communicator.  The pilot tables T / T_hs are rebuilt on every rank from what arrived.
 //
+// The protocol is written once and has two transports.  wire_fill (root: context -> record), wire_receive (receiver: check
+// the record against the own csi_config, drop the old model, take the scalars, allocate), wire_blobs (the device buffers
+// the record names, in one fixed order), wire_finish (receiver: flags, LS kernel attributes, pilot tables) are what BOTH
+//   csi_broadcast_weights  - RCCL: record and buffers by ncclBroadcast, one ncclAllReduce(min) of a status word between
+//                            them so that a rank that refuses the record takes every rank out BEFORE the grouped broadcast
+//   csi_clone_weights      - one process: record by value, buffers by hipMemcpy[Peer]Async from the source context
+// run.  The second one exists so that a single-GPU box executes every line of the receiver side (tests/test_gpu_round4.py).
+//
 // RCCL is loaded with dlopen at csi_comm_init (librccl.so.1, the library `torch.distributed` backend "nccl" wraps on ROCm):
 // a single-GPU user of libcsi_mamimo.so needs no RCCL installed, and a process that already carries torch's copy shares it.
 #pragma once
@@ -17,7 +25,7 @@ namespace {
 
 struct nccl_uid { char internal[CSI_UNIQUE_ID_BYTES]; };
 typedef void* nccl_comm;
-enum { NCCL_CHAR = 0 };
+enum { NCCL_CHAR = 0, NCCL_INT32 = 2, NCCL_MIN = 3 };
 
 struct RcclApi {
     void* lib = nullptr;
@@ -25,6 +33,7 @@ struct RcclApi {
     int (*CommInitRank)(nccl_comm*, int, nccl_uid, int) = nullptr;
     int (*CommDestroy)(nccl_comm) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -34,14 +43,21 @@ struct RcclApi {
 RcclApi& rccl() {
     static RcclApi api;
     if (api.lib || !api.why.empty()) return api;
+    // CSI_RCCL_LIBRARY names the library to try first; CSI_RCCL_ONLY=1 makes it the ONLY candidate (tests: a host without RCCL)
+    const char* only = getenv("CSI_RCCL_ONLY");
+    const bool restricted = only && *only && *only != '0';
     const char* names[] = {getenv("CSI_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
+    std::string last;
+    for (size_t i = 0; i < (restricted ? (size_t)1 : sizeof names / sizeof names[0]); ++i) {
+        const char* n = names[i];
         if (!n || !*n) continue;
         api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (api.lib) break;
+        const char* e = dlerror();          // ONE call: dlerror() clears the message it returns
+        last = e ? e : "";
     }
     if (!api.lib) {
-        api.why = std::string("RCCL not found (librccl.so.1; set CSI_RCCL_LIBRARY): ") + (dlerror() ? dlerror() : "");
+        api.why = std::string("RCCL not found (librccl.so.1; set CSI_RCCL_LIBRARY): ") + last;
         return api;
     }
     auto sym = [&](const char* s) { void* p = dlsym(api.lib, s); if (!p) api.why = std::string("RCCL lacks ") + s; return p; };
@@ -49,6 +65,7 @@ RcclApi& rccl() {
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
     api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
@@ -70,11 +87,15 @@ struct WireLayer {
 };
 struct WireMeta {
     int32_t magic, n_layers;
+    // the sender's csi_config, as far as it shapes the buffers: a receiver built for anything else refuses the record
+    int32_t cfg_nt, cfg_len_ltf, cfg_n_out, cfg_dtype, cfg_use_bn, cfg_hidden[CSI_MAX_HIDDEN];
     int32_t loaded[2], has_W0p[2], has_W0rm[2];
     int32_t pilot_ok, p_sylvester, p_pieces;
+    int32_t p_fast_ok, p_perm[2][CSI_WIRE_MAX_NT];     // Hadamard-equivalent pilot: output row / symbol permutation with signs (csi_set_pilot)
     WireLayer layer[2][CSI_MAX_HIDDEN + 1];
 };
-constexpr int32_t WIRE_MAGIC = 0x43534931;      // "CSI1"
+constexpr int32_t WIRE_MAGIC = 0x43534932;      // "CSI2"
+constexpr size_t WIRE_STATUS_OFF = (sizeof(WireMeta) + 63) / 64 * 64;     // the ranks' status word sits behind the record in csi_comm::wire
 
 struct WBlob {
     void** p;
@@ -103,12 +124,145 @@ void model_blobs(const csi_config& cf, Model& m, const WireLayer* wl, const int3
     if (has_W0rm) v.push_back({(void**)&m.W0rm, (size_t)cf.len_ltf * h1 * 4 + slack});
 }
 
+int ls_prepare(csi_ctx* c);                     // csi_mamimo.hip
+int pilot_fast_tables(csi_ctx* c);              // csi_mamimo.hip: device tables of a Hadamard-equivalent pilot from c->p_perm
+
+// ---- the protocol, transport-independent -------------------------------------------------------------------------------------
+// sender: what the context holds -> record
+void wire_fill(const csi_ctx* c, WireMeta& w) {
+    const csi_config& cf = c->cfg;
+    std::memset(&w, 0, sizeof w);
+    w.magic = WIRE_MAGIC;
+    w.n_layers = cf.n_hidden + 1;
+    w.cfg_nt = cf.nt; w.cfg_len_ltf = cf.len_ltf; w.cfg_n_out = cf.n_out; w.cfg_dtype = cf.dtype; w.cfg_use_bn = cf.use_bn != 0;
+    for (int i = 0; i < cf.n_hidden; ++i) w.cfg_hidden[i] = cf.hidden[i];
+    w.pilot_ok = c->pilot_ok;
+    w.p_sylvester = c->p_sylvester;
+    w.p_pieces = c->p_pieces;
+    w.p_fast_ok = c->p_fast_ok;
+    if (c->p_fast_ok)
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < cf.nt && i < CSI_WIRE_MAX_NT; ++i) w.p_perm[k][i] = c->p_perm[k][i];
+    for (int d = 0; d < 2; ++d) {
+        const Model& m = c->model[d];
+        w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
+        if (!w.loaded[d]) continue;
+        w.has_W0p[d] = m.W0p != nullptr;
+        w.has_W0rm[d] = m.W0rm != nullptr;
+        for (int i = 0; i <= cf.n_hidden; ++i) {
+            const Layer& L = m.layers[i];
+            WireLayer& x = w.layer[d][i];
+            x.in = L.in; x.out = L.out; x.ldw = L.ldw; x.ldwb = L.ldwb; x.ldwh = L.ldwh;
+            x.wshift = L.wshift; x.wshift_f = L.wshift_f; x.ashift = L.ashift; x.ashift_pre = L.ashift_pre;
+            x.has_Wt = L.Wt != nullptr; x.has_Wb = L.Wb != nullptr; x.has_Wb_p = L.Wb_p != nullptr; x.has_Wh = L.Wh != nullptr; x.has_Wh_f = L.Wh_f != nullptr;
+            x.has_Wh_p = L.Wh_p != nullptr; x.has_bias = L.bias != nullptr; x.has_bias_hs = L.bias_hs != nullptr;
+            x.has_scale = L.scale != nullptr; x.has_shift = L.shift != nullptr;
+        }
+    }
+}
+
+// the device buffers the record names, in the one order both sides walk (models, then P / Ppad / Pbf)
+void wire_blobs(csi_ctx* c, const WireMeta& w, std::vector<WBlob>& blobs) {
+    const csi_config& cf = c->cfg;
+    for (int d = 0; d < 2; ++d)
+        if (w.loaded[d]) model_blobs(cf, c->model[d], w.layer[d], w.has_W0p[d], w.has_W0rm[d], blobs);
+    if (w.pilot_ok && cf.nt > 0) {
+        const size_t ldp = (size_t)(cf.nt + 31) / 32 * 32, slack = G_SLACK_FLOATS * sizeof(float);
+        blobs.push_back({(void**)&c->P, (size_t)cf.nt * cf.nt * 4 + slack});
+        blobs.push_back({(void**)&c->Ppad, ldp * ldp * 4 + slack});
+        blobs.push_back({(void**)&c->Pbf, (size_t)((cf.nt + 15) / 16) * 3 * ((cf.nt + 31) / 32) * LSB_BLOCK * 2 + slack});
+    }
+}
+
+// a receiver that could not take the record holds nothing afterwards (never half a model with stale flags)
+void wire_drop_receiver(csi_ctx* c) {
+    for (int d = 0; d < 2; ++d) free_model(c->model[d]);
+    for (float** p : {&c->P, &c->Ppad, &c->Pbf})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    if (c->p_tables) { hipFree(c->p_tables); c->p_tables = nullptr; }
+    c->pilot_ok = false;
+    c->p_sylvester = false;
+    c->p_fast_ok = false;
+    c->p_fast_identity = true;
+}
+
+// receiver, step 1: the record against the own csi_config, then the old model out, the scalars in, buffers of the sender's sizes.
+// Any refusal leaves the context empty (wire_drop_receiver) and the reason in csi_last_error.
+int wire_receive(csi_ctx* c, const WireMeta& w, std::vector<WBlob>& blobs, const char* fn) {
+    const csi_config& cf = c->cfg;
+    auto refuse = [&](int code) { wire_drop_receiver(c); return code; };
+    if (w.magic != WIRE_MAGIC)
+        return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: the sender's record is not a CSI2 record (magic %08x): libraries of different versions?", fn, (unsigned)w.magic));
+    if (w.n_layers != cf.n_hidden + 1)
+        return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: the sender has %d hidden layers, this context %d", fn, w.n_layers - 1, cf.n_hidden));
+    if (w.cfg_nt != cf.nt || w.cfg_len_ltf != cf.len_ltf || w.cfg_n_out != cf.n_out || w.cfg_dtype != cf.dtype || w.cfg_use_bn != (cf.use_bn != 0))
+        return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: csi_config differs - sender nt %d len_ltf %d n_out %d dtype %d use_bn %d, here nt %d len_ltf %d n_out %d dtype %d use_bn %d",
+                           fn, w.cfg_nt, w.cfg_len_ltf, w.cfg_n_out, w.cfg_dtype, w.cfg_use_bn, cf.nt, cf.len_ltf, cf.n_out, cf.dtype, cf.use_bn != 0));
+    for (int i = 0; i < cf.n_hidden; ++i)
+        if (w.cfg_hidden[i] != cf.hidden[i])
+            return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: hidden layer %d is %d wide on the sender, %d here", fn, i, w.cfg_hidden[i], cf.hidden[i]));
+    if (w.p_fast_ok && cf.nt > CSI_WIRE_MAX_NT)
+        return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: nt %d exceeds the record's permutation tables", fn, cf.nt));
+    wire_drop_receiver(c);
+    for (int d = 0; d < 2; ++d) {
+        if (!w.loaded[d]) continue;
+        Model& m = c->model[d];
+        m.layers.resize(cf.n_hidden + 1);
+        for (int i = 0; i <= cf.n_hidden; ++i) {
+            Layer& L = m.layers[i];
+            const WireLayer& x = w.layer[d][i];
+            const int want_out = i == cf.n_hidden ? cf.n_out : cf.hidden[i];
+            if (x.out != want_out || x.in <= 0 || x.ldw < 0 || x.ldwb < 0 || x.ldwh < 0)
+                return refuse(fail(c, CSI_ERR_INVALID_ARG, "%s: layer %d of the %s model is [%d -> %d] on the sender, %d wide here", fn, i, d ? "imag" : "real", x.in, x.out, want_out));
+            L.in = x.in; L.out = x.out; L.ldw = x.ldw; L.ldwb = x.ldwb; L.ldwh = x.ldwh;
+            L.wshift = x.wshift; L.wshift_f = x.wshift_f; L.ashift = x.ashift; L.ashift_pre = x.ashift_pre;
+        }
+    }
+    wire_blobs(c, w, blobs);
+    for (WBlob& b : blobs)
+        if (hipMalloc(b.p, b.bytes) != hipSuccess) {
+            *b.p = nullptr;
+            (void)hipGetLastError();
+            return refuse(fail(c, CSI_ERR_NOMEM, "%s: device allocation of %zu bytes failed", fn, b.bytes));
+        }
+    return CSI_OK;
+}
+
+// receiver, last step (the buffers hold the sender's bytes): flags, LS kernel attributes, what is derived locally
+int wire_finish(csi_ctx* c, const WireMeta& w) {
+    const csi_config& cf = c->cfg;
+    c->pilot_ok = w.pilot_ok != 0;
+    c->p_sylvester = w.p_sylvester != 0;
+    c->p_pieces = w.p_pieces;
+    c->p_fast_ok = w.p_fast_ok != 0;
+    if (c->p_fast_ok) {
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < cf.nt; ++i) c->p_perm[k][i] = w.p_perm[k][i];
+        int rc = pilot_fast_tables(c);
+        if (rc) return rc;
+    }
+    if (c->pilot_ok) {
+        int rc = ls_prepare(c);
+        if (rc) return rc;
+    }
+    for (int d = 0; d < 2; ++d) {
+        Model& m = c->model[d];
+        m.loaded = w.loaded[d] != 0;
+        m.table_ok = false;
+        if (m.loaded && c->pilot_ok) {
+            int rc = build_pilot_table(c, m);
+            if (rc) return rc;
+        }
+    }
+    return CSI_OK;
+}
+
 }  // namespace
 
 struct csi_comm {
     nccl_comm comm = nullptr;
     int rank = 0, world = 1;
-    void* wire = nullptr;           // device staging of the WireMeta record
+    void* wire = nullptr;           // device staging of the WireMeta record, followed by the status word of the ranks' agreement
     int64_t bytes_broadcast = 0;    // of the last csi_broadcast_weights
     int64_t blobs_broadcast = 0;
 };

@@ -49,6 +49,7 @@ const char* const kKernelNames[K_COUNT] = {
 
 thread_local std::string g_create_error;
 
+constexpr int CSI_WIRE_MAX_NT = 128;      // Hadamard-equivalent pilots are recognised up to this many antennas (the Walsh-Hadamard LS kernels' range)
 constexpr int HS_SHIFT_AUTO = 99;         // "hs_in_shift" / "hs_act_shift" options: scale chosen from the data / from the model
 
 struct Layer {
@@ -181,6 +182,14 @@ struct csi_ctx {
     int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats
     int ls_ringb_min = 16;       // "ls_ringb_min": from this Nt on a non-Hadamard pilot takes the bf16-split despread (ls_estimate_ringb_kernel)
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
+    // csi_set_pilot saw P = D1 Pi1 H Pi2 D2 (H Sylvester, Pi permutations, D signs; e.g. the 802.11 VHT 4x4 base doubled up): the
+    // Walsh-Hadamard kernel applies with permuted / signed symbol loads and output rows.  p_perm[0][u] = source symbol of transform
+    // input u (| 256 when it enters negated), p_perm[1][r] = output antenna of transform row r (| 256 when negated)
+    bool p_fast_ok = false;
+    bool p_fast_identity = true; // ... and both are the identity without signs (the Sylvester matrix itself): the kernel without tables
+    int p_perm[2][CSI_WIRE_MAX_NT] = {};
+    int* p_tables = nullptr;     // device: [4][nt] source symbol, its sign (float bits), output row, its sign
+    int ls_fast_perm = 1;        // "ls_fast_perm": 0 = only the exact Sylvester matrix takes the Walsh-Hadamard kernel (A/B runs)
     int ls_debug = 0;            // CSI_LS_DEBUG / "ls_debug": skip phases of the chunked LS kernel (timing experiments only)
     int ls_kernel = 0;           // "ls_kernel" option / CSI_LS_KERNEL: 0 auto, 1 FFT-first, 2 chunked, 3 despread-first, 4 / 5 Walsh-Hadamard (register prefetch / LDS-DMA ring), 6 generic P on the ring (fp32 despread), 7 generic P, bf16-split despread (tests, A/B runs)
     int hs_vm_cast = 2, hs_vm_pair = 3;   // "hs_vm_cast" / "hs_vm_pair": vector-memory schedule of the layer-0 / pair kernel (gemm_hs.hip.h): 0 builtin LDS-DMA + one drain per sub-tile, 1 hand-counted, 2 + one more sub-tile of look-ahead, 3 + one load and one 24-MFMA segment per sub-tile

@@ -59,8 +59,12 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
 LsPlan ls_plan(const csi_ctx* c) {
     const int nt = c->cfg.nt;
     int mode = c->ls_kernel;
-    const bool fwht_ok = c->p_sylvester && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
+    // Walsh-Hadamard despread: the Sylvester matrix itself, or (round 4) any signed row / column permutation of it - the kernel
+    // then fetches the symbols and stores the antennas through the tables csi_set_pilot derived (PERM form)
+    const bool perm = c->p_fast_ok && !c->p_fast_identity;
+    const bool fwht_ok = (c->p_sylvester || (c->p_fast_ok && (c->p_fast_identity || c->ls_fast_perm))) && (nt == 16 || nt == 32 || nt == 64 || nt == 128);
     if ((mode == LS_FWHT || mode == LS_FWHT2) && !fwht_ok) mode = LS_AUTO;
+    if (mode == LS_FWHT && perm) mode = LS_FWHT2;            // the round-1 kernel knows the Sylvester order only
     const LsRingB rb = ls_ringb_shape(c);
     if (mode == LS_RINGB && !rb.fn) mode = LS_AUTO;
     if (mode == LS_AUTO)
@@ -84,11 +88,18 @@ LsPlan ls_plan(const csi_ctx* c) {
         }
         else if (nt == 32) {       // 8-symbol chunks, one slot: 38 KiB of LDS and 122 VGPRs - four workgroups per CU (0.379 ms; two with 16-symbol chunks: 0.402)
             if (v == 1) LS_V2(32, 1, 16, 1, false)
+            else if (v == 2) { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4, false, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }   // A/B: scalar-base stores
             else { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
         }
         else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1, false) else LS_V2(64, 1, 8, 3, false) }
         else { if (v == 1) LS_V2(128, 2, 16, 3, false) else LS_V2(128, 2, 16, 2, true) }      // two spectra images: -6 %
 #undef LS_V2
+        if (perm) {        // same shapes as the defaults above, table-driven symbol fetch / antenna store
+            if (nt == 16) { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+            else if (nt == 32) { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+            else if (nt == 64) { p.fn = (const void*)ls_estimate_fwht2_kernel<64, 1, 8, 3, false, 2, true>; split = 1; ch = 8; nstg = 3; nf = 1; maxcu = 2; }
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<128, 2, 16, 2, true, 1, true>; split = 2; ch = 16; nstg = 2; nf = 2; maxcu = 2; }
+        }
         p.lds = (size_t)(2 * LSC_NTW + nf * ch * 2 * LSC_ROW + nstg * ch * 2 * LS_FFT) * sizeof(float);
         p.threads = 256 * split;
         p.per_cu = std::max(1, std::min(split == 1 ? maxcu : 1, (int)((160 * 1024) / p.lds)));
@@ -141,6 +152,97 @@ int ls_prepare(csi_ctx* c) {
     if (c->cfg.nt == 0) return CSI_OK;
     const LsPlan p = ls_plan(c);
     HIP_TRY(c, hipFuncSetAttribute(p.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    return CSI_OK;
+}
+
+// Is P a signed row / column permutation of the Sylvester Hadamard matrix H[a][u] = (-1)^popcount(a & u)?  (helperGetP of the
+// reference's toolbox is un-vendored, helperMIMOChannelEstimate.m:13; the 802.11 VHT mapping matrix [1 -1 1 1; 1 1 -1 1; 1 1 1 -1;
+// -1 1 1 1] doubled up recursively is of this kind without being in the Sylvester order.)  Normalise: cs[s] = P[0][s] makes the first
+// row +1, then rs[j] = P[j][0] cs[0] the first column; the normalised matrix N = diag(rs) P diag(cs) of such a P is H with rows and
+// columns PERMUTED only: N[j][s] = H[sigma(j)][tau(s)] (rows of H multiply like XOR of their indices).  Label log2(nt) independent
+// rows of N with the unit vectors (any basis does: sigma' = A sigma, tau' = A^-T tau leave the inner product alone), read tau(s) off
+// their signs in column s and sigma(j) off row j's signs in the columns whose tau is a unit vector, then VERIFY every entry.
+// On success perm[0][u] = tau^-1(u) | (cs < 0 ? 256 : 0), perm[1][r] = sigma^-1(r) | (rs < 0 ? 256 : 0).
+bool pilot_decompose(const float* P, int nt, int perm[2][CSI_WIRE_MAX_NT], bool* identity) {
+    if (nt < 2 || nt > CSI_WIRE_MAX_NT || (nt & (nt - 1))) return false;
+    for (size_t i = 0; i < (size_t)nt * nt; ++i)
+        if (P[i] != 1.0f && P[i] != -1.0f) return false;
+    int n = 0;
+    while ((1 << n) < nt) ++n;
+    std::vector<int> cs(nt), rs(nt);
+    for (int s = 0; s < nt; ++s) cs[s] = P[s] < 0 ? -1 : 1;
+    for (int j = 0; j < nt; ++j) rs[j] = (P[(size_t)j * nt] < 0 ? -1 : 1) * cs[0];
+    typedef std::pair<uint64_t, uint64_t> bits;              // a row of N as the set of its -1 columns
+    std::vector<bits> row(nt);
+    for (int j = 0; j < nt; ++j) {
+        bits b{0, 0};
+        for (int s = 0; s < nt; ++s)
+            if (P[(size_t)j * nt + s] * (float)(rs[j] * cs[s]) < 0) (s < 64 ? b.first : b.second) |= (uint64_t)1 << (s & 63);
+        row[j] = b;
+    }
+    // greedy basis: a row outside the group generated so far extends it
+    std::vector<bits> span{bits{0, 0}};
+    std::vector<int> basis;
+    for (int j = 0; j < nt && (int)basis.size() < n; ++j) {
+        if (std::find(span.begin(), span.end(), row[j]) != span.end()) continue;
+        basis.push_back(j);
+        const size_t m = span.size();
+        for (size_t k = 0; k < m; ++k) span.push_back(bits{span[k].first ^ row[j].first, span[k].second ^ row[j].second});
+    }
+    if ((int)basis.size() != n) return false;
+    std::vector<int> tau(nt), sigma(nt), tau_inv(nt, -1), sigma_inv(nt, -1);
+    for (int s = 0; s < nt; ++s) {
+        int t = 0;
+        for (int i = 0; i < n; ++i)
+            if (((s < 64 ? row[basis[i]].first : row[basis[i]].second) >> (s & 63)) & 1) t |= 1 << i;
+        tau[s] = t;
+        if (tau_inv[t] >= 0) return false;
+        tau_inv[t] = s;
+    }
+    for (int j = 0; j < nt; ++j) {
+        int g = 0;
+        for (int i = 0; i < n; ++i) {
+            const int col = tau_inv[1 << i];
+            if (((col < 64 ? row[j].first : row[j].second) >> (col & 63)) & 1) g |= 1 << i;
+        }
+        sigma[j] = g;
+        if (sigma_inv[g] >= 0) return false;
+        sigma_inv[g] = j;
+    }
+    for (int j = 0; j < nt; ++j)
+        for (int s = 0; s < nt; ++s) {
+            const float want = (float)(rs[j] * cs[s]) * ((__builtin_popcount(sigma[j] & tau[s]) & 1) ? -1.0f : 1.0f);
+            if (P[(size_t)j * nt + s] != want) return false;
+        }
+    bool ident = true;
+    for (int u = 0; u < nt; ++u) {
+        perm[0][u] = tau_inv[u] | (cs[tau_inv[u]] < 0 ? 256 : 0);
+        perm[1][u] = sigma_inv[u] | (rs[sigma_inv[u]] < 0 ? 256 : 0);
+        ident = ident && perm[0][u] == u && perm[1][u] == u;
+    }
+    *identity = ident;
+    return true;
+}
+
+// device tables of the PERM Walsh-Hadamard kernel from c->p_perm: [4][nt] = source symbol, its sign, output antenna, its sign
+int pilot_fast_tables(csi_ctx* c) {
+    const int nt = c->cfg.nt;
+    if (c->p_tables) { hipFree(c->p_tables); c->p_tables = nullptr; }
+    if (!c->p_fast_ok || nt <= 0 || nt > CSI_WIRE_MAX_NT) return CSI_OK;
+    c->p_fast_identity = true;
+    std::vector<int> t((size_t)4 * nt);
+    const float one = 1.0f, minus = -1.0f;
+    for (int k = 0; k < 2; ++k)
+        for (int u = 0; u < nt; ++u) {
+            const int v = c->p_perm[k][u];
+            if ((v & 255) >= nt) return fail(c, CSI_ERR_INVALID_ARG, "pilot permutation table entry %d out of range", v);
+            t[(size_t)(2 * k) * nt + u] = v & 255;
+            std::memcpy(&t[(size_t)(2 * k + 1) * nt + u], (v & 256) ? &minus : &one, 4);
+            c->p_fast_identity = c->p_fast_identity && v == u;
+        }
+    if (hipMalloc((void**)&c->p_tables, t.size() * sizeof(int)) != hipSuccess)
+        return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", t.size() * sizeof(int));
+    HIP_TRY(c, hipMemcpy(c->p_tables, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
     return CSI_OK;
 }
 
@@ -347,6 +449,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->fuse_ws) hipFree(c->fuse_ws);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->Pbf) hipFree(c->Pbf);
+    if (c->p_tables) hipFree(c->p_tables);
     if (c->tw) hipFree(c->tw);
     if (c->bin_pos) hipFree(c->bin_pos);
     if (c->denom) hipFree(c->denom);
@@ -611,6 +714,19 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
     return build_pilot_table(c, m);
 }
 
+// host-only: which LS despread a pilot matrix gets (no context, no device)
+int csi_pilot_classify(const float* P, int nt, int32_t* sym_src, int32_t* out_row) {
+    if (!P || nt <= 0) return CSI_ERR_INVALID_ARG;
+    int perm[2][CSI_WIRE_MAX_NT];
+    bool ident = true;
+    if (!pilot_decompose(P, nt, perm, &ident)) return 0;
+    for (int u = 0; u < nt; ++u) {
+        if (sym_src) sym_src[u] = perm[0][u];
+        if (out_row) out_row[u] = perm[1][u];
+    }
+    return ident ? 1 : 2;
+}
+
 int csi_set_pilot(csi_ctx* c, const float* P) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (!P || c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "csi_set_pilot: null P or single-input context");
@@ -626,6 +742,11 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
             for (int q = 0; q < nt; ++q)
                 if (P[(size_t)j * nt + q] != ((__builtin_popcount(j & q) & 1) ? -1.0f : 1.0f)) { syl = false; break; }
         c->p_sylvester = syl;
+        bool ident = true;
+        c->p_fast_ok = pilot_decompose(P, nt, c->p_perm, &ident);
+        c->p_fast_identity = ident;
+        rc = pilot_fast_tables(c);
+        if (rc) return rc;
         // how many bf16 pieces (8 significand bits each, truncation) the entries need: the bf16-split LS despread keeps that many
         int pieces = 1;
         for (size_t i = 0; i < (size_t)nt * nt && pieces < 3; ++i) {
@@ -763,6 +884,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
     a.P = c->P; a.Ppad = c->Ppad; a.Pbf = reinterpret_cast<const uint16_t*>(c->Pbf); a.ldp = (cf.nt + 31) / 32 * 32; a.dbg = c->ls_debug;
     a.tw = c->tw; a.bin_pos = c->bin_pos; a.denom = c->denom;
     a.nt = cf.nt; a.len_ltf = cf.len_ltf;
+    a.perm = c->p_tables;
     const int64_t max_grid = ((int64_t)1 << 30) / n_jc;      // also keeps nb inside an int
     for (int64_t b0 = 0; b0 < nblk; b0 += max_grid) {
         const int64_t nb = std::min(max_grid, nblk - b0);
@@ -935,6 +1057,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "ls_ringb_min") *value = c->ls_ringb_min;
     else if (n == "ls_pilot_pieces") *value = c->p_pieces;
     else if (n == "ls_mode") *value = ls_plan(c).mode;
+    else if (n == "ls_fast_perm") *value = c->ls_fast_perm;
+    else if (n == "ls_pilot_fast") *value = !c->p_fast_ok ? 0 : (c->p_fast_identity ? 1 : 2);     // read-only: 0 generic P, 1 Sylvester Hadamard, 2 a signed permutation of it
     else if (n == "hs_vm_cast") *value = c->hs_vm_cast;
     else if (n == "hs_vm_pair") *value = c->hs_vm_pair;
     else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
@@ -1004,6 +1128,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 3) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 ... 3", name);
         drop_graphs(c);
         (n == "hs_vm_cast" ? c->hs_vm_cast : c->hs_vm_pair) = (int)value;
+    } else if (n == "ls_fast_perm") {
+        c->ls_fast_perm = value != 0;
+        drop_graphs(c);
+        return ls_prepare(c);
     } else if (n == "ls_v2") {
         c->ls_v2 = (int)value;
         return ls_prepare(c);
@@ -1203,7 +1331,7 @@ int csi_comm_init(csi_ctx* c, int rank, int world, const char id[CSI_UNIQUE_ID_B
     nccl_uid u;
     std::memcpy(u.internal, id, CSI_UNIQUE_ID_BYTES);
     NCCL_TRY(c, r.CommInitRank(&c->comm->comm, world, u, rank));
-    HIP_TRY(c, hipMalloc(&c->comm->wire, sizeof(WireMeta)));
+    HIP_TRY(c, hipMalloc(&c->comm->wire, WIRE_STATUS_OFF + 64));
     return CSI_OK;
 }
 
@@ -1226,101 +1354,95 @@ int csi_broadcast_weights(csi_ctx* c, int root) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drop_graphs(c);
     const bool is_root = cm.rank == root;
-    // 1. the host-side scalars that belong to the device blobs
+    // 1. the host-side scalars that belong to the device blobs: root -> everybody
     WireMeta w;
     std::memset(&w, 0, sizeof w);
     if (is_root) {
-        w.magic = WIRE_MAGIC;
-        w.n_layers = cf.n_hidden + 1;
-        w.pilot_ok = c->pilot_ok;
-        w.p_sylvester = c->p_sylvester;
-        w.p_pieces = c->p_pieces;
-        for (int d = 0; d < 2; ++d) {
-            const Model& m = c->model[d];
-            w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
-            if (!w.loaded[d]) continue;
-            w.has_W0p[d] = m.W0p != nullptr;
-            w.has_W0rm[d] = m.W0rm != nullptr;
-            for (int i = 0; i <= cf.n_hidden; ++i) {
-                const Layer& L = m.layers[i];
-                WireLayer& x = w.layer[d][i];
-                x.in = L.in; x.out = L.out; x.ldw = L.ldw; x.ldwb = L.ldwb; x.ldwh = L.ldwh;
-                x.wshift = L.wshift; x.wshift_f = L.wshift_f; x.ashift = L.ashift; x.ashift_pre = L.ashift_pre;
-                x.has_Wt = L.Wt != nullptr; x.has_Wb = L.Wb != nullptr; x.has_Wb_p = L.Wb_p != nullptr; x.has_Wh = L.Wh != nullptr; x.has_Wh_f = L.Wh_f != nullptr;
-                x.has_Wh_p = L.Wh_p != nullptr; x.has_bias = L.bias != nullptr; x.has_bias_hs = L.bias_hs != nullptr;
-                x.has_scale = L.scale != nullptr; x.has_shift = L.shift != nullptr;
-            }
-        }
+        wire_fill(c, w);
         HIP_TRY(c, hipMemcpyAsync(cm.wire, &w, sizeof w, hipMemcpyHostToDevice, c->stream));
     }
     NCCL_TRY(c, r.Broadcast(cm.wire, cm.wire, sizeof w, NCCL_CHAR, root, cm.comm, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&w, cm.wire, sizeof w, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (w.magic != WIRE_MAGIC || w.n_layers != cf.n_hidden + 1)
-        return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: the root's record does not match this context (layers %d vs %d)", w.n_layers, cf.n_hidden + 1);
-    // 2. receivers: buffers of the root's sizes
+    // 2. receivers: the record against the own csi_config, the old model out, buffers of the root's sizes
     std::vector<WBlob> blobs;
-    for (int d = 0; d < 2; ++d) {
-        Model& m = c->model[d];
-        if (!is_root) {
-            free_model(m);
-            if (w.loaded[d]) {
-                m.layers.resize(cf.n_hidden + 1);
-                for (int i = 0; i <= cf.n_hidden; ++i) {
-                    Layer& L = m.layers[i];
-                    const WireLayer& x = w.layer[d][i];
-                    const int want_out = i == cf.n_hidden ? cf.n_out : cf.hidden[i];
-                    if (x.out != want_out) return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: layer %d is %d wide on the root, %d here", i, x.out, want_out);
-                    L.in = x.in; L.out = x.out; L.ldw = x.ldw; L.ldwb = x.ldwb; L.ldwh = x.ldwh;
-                    L.wshift = x.wshift; L.wshift_f = x.wshift_f; L.ashift = x.ashift; L.ashift_pre = x.ashift_pre;
-                }
-            }
-        }
-        if (w.loaded[d]) model_blobs(cf, m, w.layer[d], w.has_W0p[d], w.has_W0rm[d], blobs);
-    }
-    if (w.pilot_ok && cf.nt > 0) {
-        const size_t ldp = (size_t)(cf.nt + 31) / 32 * 32, slack = G_SLACK_FLOATS * sizeof(float);
-        blobs.push_back({(void**)&c->P, (size_t)cf.nt * cf.nt * 4 + slack});
-        blobs.push_back({(void**)&c->Ppad, ldp * ldp * 4 + slack});
-        blobs.push_back({(void**)&c->Pbf, (size_t)((cf.nt + 15) / 16) * 3 * ((cf.nt + 31) / 32) * LSB_BLOCK * 2 + slack});
-    }
-    if (!is_root) {
-        if (c->P) { hipFree(c->P); c->P = nullptr; }
-        if (c->Ppad) { hipFree(c->Ppad); c->Ppad = nullptr; }
-        if (c->Pbf) { hipFree(c->Pbf); c->Pbf = nullptr; }
-        for (WBlob& b : blobs) {
-            if (hipMalloc(b.p, b.bytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "csi_broadcast_weights: device allocation of %zu bytes failed", b.bytes);
-        }
-    }
-    // 3. the blobs themselves, device to device, one group
-    cm.bytes_broadcast = 0;
-    cm.blobs_broadcast = (int64_t)blobs.size();
-    NCCL_TRY(c, r.GroupStart());
-    for (WBlob& b : blobs) {
-        NCCL_TRY(c, r.Broadcast(*b.p, *b.p, b.bytes, NCCL_CHAR, root, cm.comm, c->stream));
-        cm.bytes_broadcast += (int64_t)b.bytes;
-    }
-    NCCL_TRY(c, r.GroupEnd());
+    int rc_local = CSI_OK;
+    if (is_root) wire_blobs(c, w, blobs);
+    else rc_local = wire_receive(c, w, blobs, "csi_broadcast_weights");
+    // 3. every rank learns whether EVERY rank can take the blobs (one min all-reduce of a status word): a refusing rank - other
+    //    csi_config, allocation failure - must not leave the others inside the grouped broadcast, and it must not enter it itself
+    int32_t* d_status = reinterpret_cast<int32_t*>(static_cast<char*>(cm.wire) + WIRE_STATUS_OFF);
+    int32_t ok = rc_local == CSI_OK ? 1 : 0;
+    const std::string why_local = c->err;
+    HIP_TRY(c, hipMemcpyAsync(d_status, &ok, sizeof ok, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(c, r.AllReduce(d_status, d_status, 1, NCCL_INT32, NCCL_MIN, cm.comm, c->stream));
+    int32_t all_ok = 0;
+    HIP_TRY(c, hipMemcpyAsync(&all_ok, d_status, sizeof all_ok, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // 4. what is derived locally
-    if (!is_root) {
-        c->pilot_ok = w.pilot_ok != 0;
-        c->p_sylvester = w.p_sylvester != 0;
-        c->p_pieces = w.p_pieces;
-        if (c->pilot_ok) {
-            int rc = ls_prepare(c);
-            if (rc) return rc;
-        }
-        for (int d = 0; d < 2; ++d) {
-            Model& m = c->model[d];
-            m.loaded = w.loaded[d] != 0;
-            m.table_ok = false;
-            if (m.loaded && c->pilot_ok) {
-                int rc = build_pilot_table(c, m);
-                if (rc) return rc;
-            }
-        }
+    cm.bytes_broadcast = 0;
+    cm.blobs_broadcast = 0;
+    if (rc_local != CSI_OK) { c->err = why_local; return rc_local; }
+    if (!all_ok) {
+        if (!is_root) wire_drop_receiver(c);
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_broadcast_weights: another rank refused the root's record (its csi_config differs or its allocation failed; "
+                                             "see csi_last_error there) - nothing was broadcast");
     }
+    // 4. the blobs themselves, device to device, one group.  The group is always closed, also on an error inside it
+    cm.blobs_broadcast = (int64_t)blobs.size();
+    int rc_g = r.GroupStart();
+    if (rc_g == 0) {
+        int rc_b = 0;
+        for (WBlob& b : blobs) {
+            rc_b = r.Broadcast(*b.p, *b.p, b.bytes, NCCL_CHAR, root, cm.comm, c->stream);
+            if (rc_b) break;
+            cm.bytes_broadcast += (int64_t)b.bytes;
+        }
+        const int rc_e = r.GroupEnd();
+        rc_g = rc_b ? rc_b : rc_e;
+    }
+    if (rc_g) {
+        if (!is_root) wire_drop_receiver(c);
+        return fail(c, CSI_ERR_HIP, "csi_broadcast_weights: ncclBroadcast group failed: %s", r.GetErrorString ? r.GetErrorString(rc_g) : "?");
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // 5. what is derived locally
+    if (!is_root) {
+        const int rc = wire_finish(c, w);
+        if (rc) { const std::string why = c->err; wire_drop_receiver(c); c->err = why; return rc; }
+    }
+    return CSI_OK;
+}
+
+// The same protocol inside one process: dst takes what src holds, device to device.  Runs every line of the receiver side of
+// csi_broadcast_weights (wire_receive / wire_blobs / wire_finish) - which a single-GPU box cannot reach through RCCL, two ranks
+// on one GPU being refused - and is useful by itself: a second context (another stream, another packet range, another GPU of the
+// same process) without a second pass through csi_load_weights and the host copies of the tensors.
+int csi_clone_weights(csi_ctx* dst, const csi_ctx* src_c) {
+    if (!dst) return CSI_ERR_INVALID_ARG;
+    csi_ctx* src = const_cast<csi_ctx*>(src_c);        // only pointer VALUES are read from it
+    if (!src || src == dst) return fail(dst, CSI_ERR_INVALID_ARG, "csi_clone_weights: source context is null or the destination itself");
+    HIP_TRY(dst, hipSetDevice(src->cfg.device));
+    HIP_TRY(dst, hipStreamSynchronize(src->stream));   // whatever still writes the source's buffers (csi_train_end, a pilot table build)
+    HIP_TRY(dst, hipSetDevice(dst->cfg.device));
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    drop_graphs(dst);
+    WireMeta w;
+    wire_fill(src, w);
+    std::vector<WBlob> to, from;
+    int rc = wire_receive(dst, w, to, "csi_clone_weights");
+    if (rc) return rc;
+    wire_blobs(src, w, from);
+    if (to.size() != from.size()) { wire_drop_receiver(dst); return fail(dst, CSI_ERR_INVALID_ARG, "csi_clone_weights: internal - %zu buffers here, %zu on the source", to.size(), from.size()); }
+    for (size_t i = 0; i < to.size(); ++i) {
+        if (to[i].bytes != from[i].bytes || !*from[i].p) { wire_drop_receiver(dst); return fail(dst, CSI_ERR_INVALID_ARG, "csi_clone_weights: internal - buffer %zu differs", i); }
+        const hipError_t e = src->cfg.device == dst->cfg.device
+                                 ? hipMemcpyAsync(*to[i].p, *from[i].p, to[i].bytes, hipMemcpyDeviceToDevice, dst->stream)
+                                 : hipMemcpyPeerAsync(*to[i].p, dst->cfg.device, *from[i].p, src->cfg.device, to[i].bytes, dst->stream);
+        if (e != hipSuccess) { wire_drop_receiver(dst); return fail(dst, CSI_ERR_HIP, "csi_clone_weights: device copy failed: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    rc = wire_finish(dst, w);
+    if (rc) { const std::string why = dst->err; wire_drop_receiver(dst); dst->err = why; return rc; }
     return CSI_OK;
 }
 

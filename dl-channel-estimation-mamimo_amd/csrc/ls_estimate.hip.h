@@ -46,6 +46,8 @@ struct LsArgs {
     float* h_im;
     int nt;
     int len_ltf;
+    const int* perm;         // Hadamard-equivalent pilot (ls_estimate_fwht2_kernel<..., PERM>): [4][nt] = source symbol of transform input u,
+                             // its sign (float bits), output antenna of transform row r, its sign; null for the Sylvester matrix itself
 };
 
 __device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
@@ -711,7 +713,19 @@ __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* t
     }
 }
 
-template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1)>
+// PERM: the pilot matrix is P[j][s] = rs[j] H[sigma(j)][tau(s)] cs[s] (H Sylvester; csi_set_pilot finds sigma, tau and the signs), so
+//     sum_s P[j][s] F[s] = rs[j] FWHT(G)[sigma(j)],   G[u] = cs[s] F[s] with s = tau^-1(u):
+// transform input u is FETCHED from symbol tau^-1(u) (the ring's DMA source address comes from a table), its sign enters the first
+// butterfly level of the Walsh-Hadamard transform as an fma operand, and transform row r is STORED to antenna sigma^-1(r) with the sign
+// folded into the 1 / (Nt ltf) factor.  The four tables are wave-uniform reads from the constant address space (scalar loads: they
+// return on lgkmcnt and do not queue behind the ring's vector-memory operations).
+// SST: every store as `global_store_dword v_off, v_data, s[base]` - the row base (item, antenna) is wave-uniform and lives in scalar
+// registers (scalar address arithmetic), the lane contributes 4 q: no vector address arithmetic per store.  (Inline asm: a dword store
+// has no data hazard, and the kernel's counted vmcnt waits are conservative in stores already.)
+__device__ __forceinline__ void ls_store_sbase(float* base_uniform, uint32_t byte_off, float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
+}
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1), bool PERM = false, bool SST = PERM>
 __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
     static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
     static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
@@ -744,14 +758,28 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     const int T = nitems * NCH;                 // chunks this workgroup walks
     int ti = 0, ich = 0;                        // next chunk to request
     size_t iblk = blockIdx.x;
+    typedef const __attribute__((address_space(4))) int* ctab_t;
+    const ctab_t tab = PERM ? (ctab_t)(uintptr_t)a.perm : nullptr;
     auto issue_next = [&]() {
         if (ti >= T) return;
-        const size_t o = iblk * a.len_ltf + (size_t)(ich * CH + wave) * LS_SYM + LS_CP + 4 * lane;
         const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
+        if (PERM) {
+            int src[SPW];
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            ls_dma16(a.ltf_re + o + (size_t)u * NW * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
-            ls_dma16(a.ltf_im + o + (size_t)u * NW * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+            for (int u = 0; u < SPW; ++u) src[u] = tab[ich * CH + wave + u * NW];
+            const size_t o = iblk * a.len_ltf + LS_CP + 4 * lane;
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) {
+                ls_dma16(a.ltf_re + o + (size_t)src[u] * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+                ls_dma16(a.ltf_im + o + (size_t)src[u] * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+            }
+        } else {
+            const size_t o = iblk * a.len_ltf + (size_t)(ich * CH + wave) * LS_SYM + LS_CP + 4 * lane;
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) {
+                ls_dma16(a.ltf_re + o + (size_t)u * NW * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+                ls_dma16(a.ltf_im + o + (size_t)u * NW * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+            }
         }
         ++ti;
         if (++ich == NCH) { ich = 0; iblk += gridDim.x; }
@@ -762,17 +790,42 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     // The finished item is stored one step late: after the next chunk's samples are in registers and the ring slot
     // is refilled (vmcnt counts stores too: a landing wait right behind the stores would drain them with the ring idle).
     f32x2 h[NCH * CHH];                         // (re, im) of the owned antennas: block ab, antenna ab CH + g CHH + j
+    const int gu = __builtin_amdgcn_readfirstlane(g);
     auto store_item = [&](size_t blk) {
         if (qok && !(a.dbg & 4)) {
-            float* pre = a.h_re + (blk * NT + g * CHH) * LS_NDATA + q;
-            float* pim = a.h_im + (blk * NT + g * CHH) * LS_NDATA + q;
+            if (PERM) {
+                // transform row r = ab CH + g CHH + j goes to antenna tab[2 NT + r], times the sign tab[3 NT + r]; the row base is
+                // wave-uniform (scalar address arithmetic), the lane adds its bin
 #pragma unroll
-            for (int ab = 0; ab < NCH; ++ab)
+                for (int ab = 0; ab < NCH; ++ab)
 #pragma unroll
-                for (int j = 0; j < CHH; ++j) {
-                    pre[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][0] * rden;
-                    pim[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][1] * rden;
-                }
+                    for (int j = 0; j < CHH; ++j) {
+                        const int r = ab * CH + gu * CHH + j;
+                        const size_t row = (blk * NT + (size_t)tab[2 * NT + r]) * LS_NDATA;
+                        const float rs = rden * __builtin_bit_cast(float, tab[3 * NT + r]);
+                        ls_store_sbase(a.h_re + row, 4u * (unsigned)q, h[ab * CHH + j][0] * rs);
+                        ls_store_sbase(a.h_im + row, 4u * (unsigned)q, h[ab * CHH + j][1] * rs);
+                    }
+            } else if (SST) {
+                const size_t row0 = (blk * NT + (size_t)gu * CHH) * LS_NDATA;
+#pragma unroll
+                for (int ab = 0; ab < NCH; ++ab)
+#pragma unroll
+                    for (int j = 0; j < CHH; ++j) {
+                        ls_store_sbase(a.h_re + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, h[ab * CHH + j][0] * rden);
+                        ls_store_sbase(a.h_im + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, h[ab * CHH + j][1] * rden);
+                    }
+            } else {
+                float* pre = a.h_re + (blk * NT + g * CHH) * LS_NDATA + q;
+                float* pim = a.h_im + (blk * NT + g * CHH) * LS_NDATA + q;
+#pragma unroll
+                for (int ab = 0; ab < NCH; ++ab)
+#pragma unroll
+                    for (int j = 0; j < CHH; ++j) {
+                        pre[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][0] * rden;
+                        pim[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][1] * rden;
+                    }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
@@ -807,12 +860,26 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
             if (!(a.dbg & 2)) {
                 f32x2 w[CHH];
+                float sg_in[CH];                  // PERM: signs of this chunk's transform inputs (wave-uniform)
+                if (PERM) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) sg_in[r] = __builtin_bit_cast(float, tab[NT + ch * CH + r]);
+                }
                 if (SPLIT == 2) {
                     const float gs = g ? -1.f : 1.f;
-                    const f32x2 gs2 = {gs, gs};
+                    if (PERM) {
 #pragma unroll
-                    for (int r = 0; r < CHH; ++r)
-                        w[r] = __builtin_elementwise_fma(gs2, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
+                        for (int r = 0; r < CHH; ++r) {
+                            const float s1 = gs * sg_in[r + CHH];
+                            const f32x2 lo = Fb[(size_t)r * LSC_ROW + pos] * f32x2{sg_in[r], sg_in[r]};
+                            w[r] = __builtin_elementwise_fma(f32x2{s1, s1}, Fb[(size_t)(r + CHH) * LSC_ROW + pos], lo);
+                        }
+                    } else {
+                        const f32x2 gs2 = {gs, gs};
+#pragma unroll
+                        for (int r = 0; r < CHH; ++r)
+                            w[r] = __builtin_elementwise_fma(gs2, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < CHH; ++r) w[r] = Fb[(size_t)r * LSC_ROW + pos];
@@ -822,6 +889,13 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
 #pragma unroll
                     for (int i = 0; i < CHH; ++i)
                         if (!(i & hh)) {
+                            if (PERM && SPLIT == 1 && hh == 1) {
+                                // first level with the input signs: (sx x) +- (sy y) as one multiply and two fma
+                                const f32x2 x = w[i] * f32x2{sg_in[i], sg_in[i]}, y = w[i + 1];
+                                w[i] = __builtin_elementwise_fma(f32x2{sg_in[i + 1], sg_in[i + 1]}, y, x);
+                                w[i + 1] = __builtin_elementwise_fma(f32x2{-sg_in[i + 1], -sg_in[i + 1]}, y, x);
+                                continue;
+                            }
                             const f32x2 x = w[i], y = w[i + hh];
                             w[i] = x + y;
                             w[i + hh] = x - y;

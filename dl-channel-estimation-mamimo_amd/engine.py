@@ -71,6 +71,23 @@ def get_unique_id():
     return buf.raw
 
 
+def classify_pilot(P):
+    """Which LS despread ``set_pilot(P)`` will choose (host only, no GPU needed): returns (kind, sym_src, out_row) with kind
+    0 = generic real P (matrix-core despread), 1 = the Sylvester Hadamard matrix, 2 = a signed row / column permutation of it
+    (e.g. the 802.11 VHT mapping matrix doubled up) - 1 and 2 take the Walsh-Hadamard kernel.  For kinds 1 / 2 the tables give
+    P[j, s] = rs[j] * H[sigma(j), tau(s)] * cs[s] as sym_src[u] = tau^-1(u) | (256 if cs < 0) and out_row[r] = sigma^-1(r) | (256 if rs < 0)."""
+    lib = _lib.load_library()
+    P = _f32c(P)
+    if P.ndim != 2 or P.shape[0] != P.shape[1]:
+        raise CsiError(-1, f'P must be square, got {P.shape}')
+    nt = P.shape[0]
+    a, b = np.zeros(max(nt, 1), np.int32), np.zeros(max(nt, 1), np.int32)
+    kind = lib.csi_pilot_classify(_fp(P), nt, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    if kind < 0:
+        raise CsiError(kind, 'csi_pilot_classify: bad argument')
+    return kind, (a if kind else None), (b if kind else None)
+
+
 class CsiEngine:
     """Owns a ``csi_ctx``.  Shapes follow the reference: nt tx antennas, nr rx antennas,
     len_ltf = 320*nt samples per rx preamble, FC hidden widths ``hidden`` (--nn), n_out outputs
@@ -430,6 +447,12 @@ class CsiEngine:
         device buffers, no host copy); afterwards every engine is loaded.  Returns the bytes moved."""
         self._check(self._lib.csi_broadcast_weights(self._ctx, int(root)))
         return self.get_option('comm_bytes')
+
+    def clone_weights_from(self, other):
+        """Both component models and the pilot matrix as they sit on ``other``'s GPU memory -> this engine (device to device, same
+        process; the receiver side of ``broadcast_weights`` without RCCL).  The engines must agree in nt, hidden widths, n_out,
+        use_bn and dtype; a mismatch raises and leaves this engine empty."""
+        self._check(self._lib.csi_clone_weights(self._ctx, other._ctx))
 
     def comm_destroy(self):
         self._check(self._lib.csi_comm_destroy(self._ctx))

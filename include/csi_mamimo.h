@@ -107,6 +107,14 @@ int  csi_load_weights(csi_ctx* ctx, int model, const csi_tensor* tensors, int n)
 /* P [nt][nt], row j = pilot sequence of tx antenna j = MATLAB P(j,:) = dataset['P'][:, j]. */
 int  csi_set_pilot(csi_ctx* ctx, const float* P);
 
+/* Which LS despread csi_set_pilot will choose for P (host only; no context or device needed).  Returns 0: generic real P
+ * (matrix-core despread), 1: the Sylvester Hadamard matrix, 2: a signed row / column permutation of it - e.g. the 802.11 VHT
+ * 4x4 mapping matrix doubled up, what helperGetP (helperMIMOChannelEstimate.m:13, un-vendored toolbox code) yields - both served
+ * by the Walsh-Hadamard kernel; negative csi_status on a bad argument.  For 1 / 2 the optional tables receive the decomposition
+ * P[j][s] = rs[j] H[sigma(j)][tau(s)] cs[s]:  sym_src[u] = tau^-1(u) | (cs < 0 ? 256 : 0),  out_row[r] = sigma^-1(r) | (rs < 0 ? 256 : 0)
+ * (nt entries each, nt <= 128). */
+int  csi_pilot_classify(const float* P, int nt, int32_t* sym_src, int32_t* out_row);
+
 /* DNN estimate of npkt packets.  ltf_re / ltf_im [npkt][nr][len_ltf]; out_re / out_im
  * [npkt][nr][nt][n_out].  Layer 0 is evaluated once per (packet, rx) and shared by the nt
  * pairs (the reference stores each rx preamble once for the same reason, mk.py:50-63). */
@@ -302,8 +310,18 @@ int  csi_comm_destroy(csi_ctx* ctx);
 /* Both component models and the pilot matrix as csi_load_weights / csi_set_pilot left them on `root`: the re-laid-out fp32
  * matrices, their split-f16 / bf16 forms, bias and BatchNormalization vectors, P - ncclBroadcast of the device buffers
  * themselves, then the pilot tables are rebuilt locally.  Collective; synchronous at return.  Contexts must share one csi_config
- * (shape and dtype).  "comm_bytes" / "comm_blobs" (csi_get_option) report what the last call moved. */
+ * (shape and dtype): every rank checks the root's record against its own, the ranks agree on the outcome (one ncclAllReduce of a
+ * status word) BEFORE the buffers move, and if any rank refuses, every rank returns an error (the refusing one with the reason)
+ * instead of waiting inside the broadcast; a receiver that failed holds no model and no pilot afterwards.
+ * "comm_bytes" / "comm_blobs" (csi_get_option) report what the last call moved. */
 int  csi_broadcast_weights(csi_ctx* ctx, int root);
+/* The same transfer inside ONE process: `dst` takes both component models and the pilot matrix as they sit in `src` (device to
+ * device on dst's stream, hipMemcpyPeer when the contexts live on different GPUs), then rebuilds its pilot tables - a second
+ * context (another stream, packet range or GPU of the process) without a second csi_load_weights.  It walks exactly the receiver
+ * side of csi_broadcast_weights (same record, same buffer list, same rebuild), which is how a one-GPU box tests that code.
+ * The contexts must agree in nt, len_ltf, hidden widths, n_out, use_bn and dtype (nr, device and workspace may differ); a
+ * mismatch is refused with text and leaves `dst` empty (nothing loaded, no pilot).  Synchronous at return. */
+int  csi_clone_weights(csi_ctx* dst, const csi_ctx* src);
 
 /* Per-kernel HIP-event timing on the context's stream (the reference's --execTime). */
 int  csi_profile_enable(csi_ctx* ctx, int on);

@@ -25,18 +25,22 @@ def pilot(rng, nt, kind):
     return P.astype(np.float64)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--reps', type=int, default=10)
-    ap.add_argument('--no-drain', action='store_true')
-    ap.add_argument('--shapes', default='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300')
-    args = ap.parse_args()
+def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300', no_drain=False, budget_s=None, quiet=False, runs=None):
+    """Returns the number of bad items.  budget_s bounds the wall time (the loops stop between configurations once it is spent);
+    `runs` is an alias of `reps` (pytest caller)."""
+    import time
+    reps = runs if runs is not None else reps
+    t0 = time.time()
+    spent = lambda: budget_s is not None and time.time() - t0 > budget_s
+    say = (lambda *a, **k: None) if quiet else print
     rng = np.random.default_rng(5)
     total_bad = 0
-    for shape in args.shapes.split(','):
+    for shape in shapes.split(','):
         nt, nr, npkt = (int(v) for v in shape.split('x'))
         ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
         for kind in ('pm1', 'q16', 'qr'):
+            if spent():
+                break
             e = pkg.CsiEngine(nt, nr, hidden=(8,))
             e.set_pilot(pilot(rng, nt, kind))
             e.set_option('ls_kernel', 6)
@@ -44,9 +48,9 @@ def main():
             e.set_option('ls_kernel', 7)
             for v in (0, 1):
                 e.set_option('ls_v2', v)
-                e.set_option('ls_debug', 64 if args.no_drain else 0)
+                e.set_option('ls_debug', 64 if no_drain else 0)
                 first, bad_runs, bad_items = None, 0, 0
-                for _ in range(args.reps):
+                for _ in range(reps):
                     h = e.ls_estimate(ltf)
                     if first is None:
                         first = h
@@ -56,15 +60,19 @@ def main():
                     bad_runs += nb > 0
                     bad_items += nb
                 total_bad += bad_items + n6
-                print(f'Nt={nt:3d} items={npkt * nr:5d} pilot={kind:3s} pieces={e.get_option("ls_pilot_pieces")} shape v{v}: '
-                      f'{args.reps} runs, {bad_runs} differ from the first ({bad_items} items), {n6} items off the fp32 despread', flush=True)
+                say(f'Nt={nt:3d} items={npkt * nr:5d} pilot={kind:3s} pieces={e.get_option("ls_pilot_pieces")} shape v{v}: '
+                    f'{reps} runs, {bad_runs} differ from the first ({bad_items} items), {n6} items off the fp32 despread', flush=True)
             e.close() if hasattr(e, 'close') else None
-    # the round-2 kernels the same way: Walsh-Hadamard ring kernel (the headline LS kernel) and the fp32 matrix-core ring kernel
-    for shape in args.shapes.split(','):
+    # the round-2 kernels the same way: Walsh-Hadamard ring kernel (the headline LS kernel; round 4: also its table-driven form for a
+    # signed permutation of the Sylvester matrix) and the fp32 matrix-core ring kernel
+    for shape in shapes.split(','):
         nt, nr, npkt = (int(v) for v in shape.split('x'))
         ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
-        for kernel, P in ((5, pkg.synth.hadamard(nt) if nt & (nt - 1) == 0 else None), (6, pilot(rng, nt, 'qr'))):
-            if P is None:
+        pow2 = nt & (nt - 1) == 0
+        Hs = pkg.synth.hadamard(nt) if pow2 else None
+        Hp = (rng.choice([-1.0, 1.0], nt)[:, None] * Hs[rng.permutation(nt)][:, rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[None, :]) if pow2 else None
+        for kernel, P in ((5, Hs), (5, Hp), (6, pilot(rng, nt, 'qr'))):
+            if P is None or spent():
                 continue
             e = pkg.CsiEngine(nt, nr, hidden=(8,))
             e.set_pilot(P)
@@ -72,16 +80,26 @@ def main():
             for v in (0, 1):
                 e.set_option('ls_v2', v)
                 first, bad_runs, bad_items = None, 0, 0
-                for _ in range(args.reps):
+                for _ in range(reps):
                     h = e.ls_estimate(ltf)
                     first = h if first is None else first
                     nb = int((h != first).reshape(npkt * nr, -1).any(1).sum())
                     bad_runs += nb > 0
                     bad_items += nb
                 total_bad += bad_items
-                print(f'Nt={nt:3d} items={npkt * nr:5d} kernel {kernel} (mode {e.get_option("ls_mode")}) shape v{v}: {args.reps} runs, {bad_runs} differ from the first ({bad_items} items)', flush=True)
-    print('TOTAL bad items:', total_bad)
-    return 1 if total_bad else 0
+                say(f'Nt={nt:3d} items={npkt * nr:5d} kernel {kernel} (mode {e.get_option("ls_mode")}, pilot class {e.get_option("ls_pilot_fast")}) shape v{v}: {reps} runs, {bad_runs} differ from the first ({bad_items} items)', flush=True)
+    say('TOTAL bad items:', total_bad)
+    return total_bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--no-drain', action='store_true')
+    ap.add_argument('--shapes', default='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300')
+    ap.add_argument('--budget-s', type=float, default=None)
+    args = ap.parse_args()
+    return 1 if run(args.reps, args.shapes, args.no_drain, args.budget_s) else 0
 
 
 if __name__ == '__main__':

@@ -1,0 +1,235 @@
+"""GPU tests added in round 4 (-m gpu; everything through the C-ABI, checked against the numpy oracle):
+
+  * csi_clone_weights: the RECEIVER side of csi_broadcast_weights (record check, allocation by the sender's sizes, rebuild of
+    what is derived) executed on one GPU - every result of the receiving context bit-identical to the loading context's, for the
+    shapes that select different buffers (band kernel, bf16 context, generic P, Nt = 128, one hidden layer, no BN); a mismatched
+    csi_config refused with text and the receiver left empty;
+  * Hadamard-equivalent pilot matrices (signed row / column permutations of the Sylvester matrix, e.g. the 802.11 VHT 4x4 base
+    doubled up) take the Walsh-Hadamard LS kernel: ls_mode 5, oracle parity, agreement with the generic-P kernels;
+  * the bounded form of tests/stress_ls_generic.py.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+P_VHT4 = np.array([[1, -1, 1, 1], [1, 1, -1, 1], [1, 1, 1, -1], [-1, 1, 1, 1]], np.float64)
+
+
+def _weights(oracle, seed, nt, hidden, use_bn=True, n_out=234):
+    rng = np.random.default_rng(seed)
+    d_in = 320 * nt + nt
+    return (oracle.make_weights(rng, d_in, list(hidden), n_out, use_bn=use_bn),
+            oracle.make_weights(rng, d_in, list(hidden), n_out, use_bn=use_bn))
+
+
+def vht_pilot(oracle, nt):
+    """kron(H_{nt/4}, P_VHT4): Hadamard, NOT in the Sylvester order."""
+    return np.kron(oracle.hadamard(nt // 4), P_VHT4)
+
+
+def signed_perm_pilot(oracle, rng, nt):
+    """D1 Pi1 H Pi2 D2 with random permutations and signs."""
+    H = oracle.hadamard(nt)
+    return (rng.choice([-1.0, 1.0], nt)[:, None] * H[rng.permutation(nt)][:, rng.permutation(nt)]) * rng.choice([-1.0, 1.0], nt)[None, :]
+
+
+# (tag, nt, nr, npkt, hidden, use_bn, dtype, pilot, options)
+CLONE_CASES = [
+    ('shipped_band', 32, 4, 48, (1024, 1024), True, 'f32', 'hadamard', {'f32_engine': 1}),
+    ('shipped_fp32_mfma', 32, 2, 3, (1024, 1024), True, 'f32', 'hadamard', {'f32_engine': 0}),
+    ('bf16_band', 32, 4, 40, (256, 256), True, 'bf16', 'hadamard', {}),
+    ('generic_p_16', 16, 2, 24, (128, 256), True, 'f32', 'generic', {'f32_engine': 1}),
+    ('vht_pilot_64', 64, 2, 10, (128, 128), True, 'f32', 'vht', {'f32_engine': 1}),
+    ('nt128', 128, 2, 6, (64, 64), True, 'f32', 'hadamard', {'f32_engine': 1}),
+    ('one_hidden_no_bn', 8, 2, 30, (128,), False, 'f32', 'hadamard', {'f32_engine': 1}),
+    ('three_hidden', 16, 2, 20, (128, 64, 128), True, 'f32', 'generic', {'f32_engine': 1}),
+]
+
+
+@pytest.mark.parametrize('tag,nt,nr,npkt,hidden,use_bn,dtype,pilot,opts', CLONE_CASES, ids=[c[0] for c in CLONE_CASES])
+def test_clone_weights_receiver_is_bit_identical(pkg, oracle, tag, nt, nr, npkt, hidden, use_bn, dtype, pilot, opts):
+    rng = np.random.default_rng(400 + nt + len(hidden))
+    w_re, w_im = _weights(oracle, 40 + nt, nt, hidden, use_bn=use_bn)
+    P = {'hadamard': lambda: oracle.hadamard(nt), 'vht': lambda: vht_pilot(oracle, nt),
+         'generic': lambda: rng.integers(-2, 3, (nt, nt)).astype(np.float64) + 3.0 * np.eye(nt)}[pilot]()
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    kw = dict(hidden=hidden, use_bn=use_bn, dtype=dtype)
+    root = pkg.CsiEngine(nt, nr, **kw)
+    root.load_weights('real', w_re)
+    root.load_weights('imag', w_im)
+    root.set_pilot(P)
+    recv = pkg.CsiEngine(nt, nr, **kw)
+    # a receiver that already holds OTHER weights and another pilot: everything must be replaced
+    junk_re, junk_im = _weights(oracle, 999, nt, hidden, use_bn=use_bn)
+    recv.load_weights('real', junk_re)
+    recv.load_weights('imag', junk_im)
+    recv.set_pilot(np.eye(nt))
+    recv.clone_weights_from(root)
+    for e in (root, recv):
+        for k, v in opts.items():
+            e.set_option(k, v)
+    for name in ('ls_mode', 'ls_pilot_pieces', 'ls_pilot_fast'):
+        assert root.get_option(name) == recv.get_option(name), name
+    a_re, a_im = root.predict(ltf)
+    b_re, b_im = recv.predict(ltf)
+    assert np.array_equal(a_re, b_re) and np.array_equal(a_im, b_im), tag
+    assert root.get_option('band_launches') == recv.get_option('band_launches')
+    assert root.get_option('hs_launches') == recv.get_option('hs_launches')
+    ha, hb = root.ls_estimate(ltf), recv.ls_estimate(ltf)
+    assert np.array_equal(ha, hb), tag
+    # the literal (un-shared) network reads the fp32 / bf16 matrices and the full layer 0
+    x = rng.standard_normal((5, 320 * nt + nt)).astype(np.float32)
+    assert np.array_equal(root.predict_samples('imag', x), recv.predict_samples('imag', x))
+    # ... and the receiver is right, not only equal
+    k = min(npkt, 2)
+    r_re, r_im = oracle.predict_packets(ltf[:k], P, w_re, w_im, np.float64, pkt_batch=k)
+    tol = TOL if dtype == 'f32' else 2e-2
+    assert rel_rows(b_re[:k], r_re) < tol and rel_rows(b_im[:k], r_im) < tol
+    ref = oracle.ls_estimate(ltf[:k], P)
+    assert rel_rows(np.concatenate([hb[:k].real, hb[:k].imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    # a changed pilot on the receiver alone rebuilds ITS tables (they are its own allocations, not aliases of the root's)
+    recv.set_pilot(P[::-1].copy())
+    c_re, _ = recv.predict(ltf[:2])
+    a2_re, _ = root.predict(ltf[:2])
+    assert np.array_equal(a2_re, a_re[:2]) and not np.array_equal(c_re, a_re[:2])
+
+
+def test_clone_weights_partial_and_refusals(pkg, oracle):
+    """Only one component model / no pilot on the source; mismatched csi_config refused with text, receiver left empty."""
+    nt, nr, hidden = 8, 2, (64, 64)
+    w_re, w_im = _weights(oracle, 7, nt, hidden)
+    src = pkg.CsiEngine(nt, nr, hidden=hidden)
+    src.load_weights('real', w_re)                       # imag missing, no pilot
+    dst = pkg.CsiEngine(nt, nr, hidden=hidden)
+    dst.load_weights('imag', w_im)
+    dst.set_pilot(oracle.hadamard(nt))
+    dst.clone_weights_from(src)
+    ltf = np.zeros((1, nr, 320 * nt), np.complex64)
+    with pytest.raises(pkg.CsiError) as ei:              # the source had no pilot: neither has the clone now
+        dst.predict(ltf)
+    assert ei.value.code == -2 and 'csi_set_pilot' in str(ei.value)
+    dst.set_pilot(oracle.hadamard(nt))
+    with pytest.raises(pkg.CsiError) as ei:
+        dst.predict(ltf)
+    assert ei.value.code == -2 and 'imag' in str(ei.value)
+    x = np.ones((2, 320 * nt + nt), np.float32)
+    assert np.array_equal(dst.predict_samples('real', x), src.predict_samples('real', x))
+    # refusals
+    src.load_weights('imag', w_im)
+    src.set_pilot(oracle.hadamard(nt))
+    for kw, word in ((dict(hidden=(64, 32)), 'hidden layer 1'), (dict(hidden=(64,)), 'hidden layers'),
+                     (dict(hidden=hidden, dtype='bf16'), 'dtype'), (dict(hidden=hidden, use_bn=False), 'use_bn')):
+        other = pkg.CsiEngine(nt, nr, **kw)
+        hd = kw['hidden']
+        o_re, _ = _weights(oracle, 8, nt, hd, use_bn=kw.get('use_bn', True))
+        other.load_weights('real', o_re)
+        other.set_pilot(oracle.hadamard(nt))
+        with pytest.raises(pkg.CsiError) as ei:
+            other.clone_weights_from(src)
+        assert ei.value.code == -1 and word in str(ei.value), (kw, str(ei.value))
+        with pytest.raises(pkg.CsiError) as ei2:         # refused -> empty, never half a model
+            other.predict_samples('real', np.ones((1, 320 * nt + nt), np.float32))
+        assert ei2.value.code == -2
+    with pytest.raises(pkg.CsiError):
+        src.clone_weights_from(src)
+    other = pkg.CsiEngine(16, nr, hidden=hidden)
+    with pytest.raises(pkg.CsiError) as ei:
+        other.clone_weights_from(src)
+    assert 'nt' in str(ei.value)
+    # the source is untouched by all of it
+    ltf = (np.random.default_rng(0).standard_normal((2, nr, 320 * nt)) + 0j).astype(np.complex64)
+    o_re, o_im = src.predict(ltf)
+    r_re, r_im = oracle.predict_packets(ltf, oracle.hadamard(nt), w_re, w_im, np.float64, pkt_batch=2)
+    assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
+
+
+def test_rccl_self_broadcast_world1_with_status_word(pkg, oracle):
+    """World of one rank through RCCL: record broadcast, the ranks' status all-reduce, grouped blob broadcast (root == self)."""
+    nt, nr, hidden = 16, 2, (128, 128)
+    w_re, w_im = _weights(oracle, 11, nt, hidden)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(vht_pilot(oracle, nt))
+    ltf = (np.random.default_rng(1).standard_normal((3, nr, 320 * nt)) + 0j).astype(np.complex64)
+    a_re, a_im = e.predict(ltf)
+    e.comm_init(0, 1, pkg.engine.get_unique_id())
+    moved = e.broadcast_weights(0)
+    assert moved > 0 and e.get_option('comm_blobs') > 10
+    b_re, b_im = e.predict(ltf)
+    assert np.array_equal(a_re, b_re) and np.array_equal(a_im, b_im)
+    assert e.get_option('ls_pilot_fast') == 2
+    e.comm_destroy()
+
+
+FAST_PILOT_CASES = [(16, 4, 40), (32, 4, 30), (64, 2, 12), (128, 2, 5)]
+
+
+@pytest.mark.parametrize('nt,nr,npkt', FAST_PILOT_CASES)
+@pytest.mark.parametrize('kind', ['vht', 'signed_perm'])
+def test_ls_hadamard_equivalent_pilot_takes_the_fwht_kernel(pkg, oracle, nt, nr, npkt, kind):
+    rng = np.random.default_rng(nt * 7 + len(kind))
+    P = vht_pilot(oracle, nt) if kind == 'vht' else signed_perm_pilot(oracle, rng, nt)
+    assert np.allclose(P @ P.T, nt * np.eye(nt)) and not np.array_equal(P, oracle.hadamard(nt))
+    ltf, H = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=20.0)
+    e = pkg.CsiEngine(nt, nr, hidden=(64, 64))
+    e.set_pilot(P)
+    assert e.get_option('ls_pilot_fast') == 2 and e.get_option('ls_mode') == 5
+    h = e.ls_estimate(ltf)
+    ref = oracle.ls_estimate(ltf, P)
+    cat = lambda z: np.concatenate([z.real, z.imag], -1)
+    assert rel_rows(cat(h), cat(ref)) < TOL
+    h2 = e.ls_estimate(ltf)
+    assert np.array_equal(h, h2)
+    # the generic kernels on the same pilot (what round 3 ran): agreement to rounding
+    e.set_option('ls_fast_perm', 0)
+    assert e.get_option('ls_mode') in (6, 7)
+    g = e.ls_estimate(ltf)
+    assert rel_rows(cat(h), cat(g)) < 1e-6
+    e.set_option('ls_fast_perm', 1)
+    assert e.get_option('ls_mode') == 5
+    # known-answer: at 20 dB the estimate is the channel up to the noise
+    assert rel_rows(cat(h), cat(H)) < 0.2
+    # the Sylvester matrix itself keeps the table-free kernel
+    e.set_pilot(oracle.hadamard(nt))
+    assert e.get_option('ls_pilot_fast') == 1 and e.get_option('ls_mode') == 5
+    ltf2, _ = oracle.make_structured_packets(rng, 3, nr, oracle.hadamard(nt), snr_db=20.0)
+    assert rel_rows(cat(e.ls_estimate(ltf2)), cat(oracle.ls_estimate(ltf2, oracle.hadamard(nt)))) < TOL
+
+
+def test_ls_not_every_sign_matrix_is_taken(pkg, oracle):
+    """A random +-1 matrix (not Hadamard) stays on the generic kernels; a Hadamard matrix obtained from Sylvester's by switching a
+    closed quadruple (negate a constant 4 x 4 block: still Hadamard, the rows no longer closed under products in the same way) is
+    served by whatever kernel the decomposition's VERIFIED answer allows - and both are right."""
+    rng = np.random.default_rng(5)
+    nt, nr = 16, 2
+    e = pkg.CsiEngine(nt, nr, hidden=(64, 64))
+    cat = lambda z: np.concatenate([z.real, z.imag], -1)
+    Pn = rng.choice([-1.0, 1.0], (nt, nt))
+    Hs = oracle.hadamard(nt).copy()
+    Hs[np.ix_([0, 4, 8, 12], [0, 1, 2, 3])] *= -1           # rows whose index has bits 0, 1 clear are constant on columns 0..3
+    assert np.allclose(Hs @ Hs.T, nt * np.eye(nt))
+    ltf = (rng.standard_normal((4, nr, 320 * nt)) + 1j * rng.standard_normal((4, nr, 320 * nt))).astype(np.complex64)
+    for P in (Pn, Hs):
+        e.set_pilot(P)
+        h = e.ls_estimate(ltf)
+        assert rel_rows(cat(h), cat(oracle.ls_estimate(ltf, P))) < TOL
+        assert (e.get_option('ls_mode') == 5) == (e.get_option('ls_pilot_fast') in (1, 2))
+    e.set_pilot(Pn)
+    assert e.get_option('ls_pilot_fast') == 0 and e.get_option('ls_mode') != 5
+
+
+def test_stress_ls_generic_bounded(pkg, oracle):
+    """tests/stress_ls_generic.py, bounded: the bf16-split generic-P kernel (and the ring kernels) on every item, bit for bit over
+    repeated runs, with two waves per SIMD - the configuration in which the first version of that kernel raced."""
+    import stress_ls_generic
+    bad = stress_ls_generic.run(runs=3, budget_s=50.0, quiet=True)
+    assert bad == 0

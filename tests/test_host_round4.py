@@ -1,0 +1,126 @@
+"""CPU tests added in round 4 (no GPU): host-only logic of the library and the bench's launch path.
+
+  * csi_pilot_classify: the decomposition P = D1 Pi1 H Pi2 D2 that lets Hadamard-equivalent pilot matrices take the
+    Walsh-Hadamard LS kernel - checked by re-assembling P from the returned tables and by running the oracle's LS through them;
+  * the RCCL-not-found path returns an error with text (it used to pass NULL to std::string: ADVICE round 3);
+  * `bench.py --gpus 8 --rendezvous-only`.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P_VHT4 = np.array([[1, -1, 1, 1], [1, 1, -1, 1], [1, 1, 1, -1], [-1, 1, 1, 1]], np.float64)
+
+
+def _reassemble(oracle, nt, sym_src, out_row):
+    """P from the tables: P[j, s] = rs[j] H[sigma(j), tau(s)] cs[s]."""
+    H = oracle.hadamard(nt)
+    tau = np.empty(nt, int); cs = np.empty(nt)
+    sigma = np.empty(nt, int); rs = np.empty(nt)
+    for u in range(nt):
+        s = int(sym_src[u]) & 255
+        tau[s], cs[s] = u, (-1.0 if sym_src[u] & 256 else 1.0)
+        j = int(out_row[u]) & 255
+        sigma[j], rs[j] = u, (-1.0 if out_row[u] & 256 else 1.0)
+    return rs[:, None] * H[np.ix_(sigma, tau)] * cs[None, :]
+
+
+@pytest.mark.parametrize('nt', [2, 4, 8, 16, 32, 64, 128])
+def test_pilot_classify_signed_permutations_of_sylvester(pkg, oracle, nt):
+    from dl_channel_estimation_mamimo_amd.engine import classify_pilot
+    rng = np.random.default_rng(nt)
+    H = oracle.hadamard(nt)
+    kind, a, b = classify_pilot(H)
+    assert kind == 1 and np.array_equal(a, np.arange(nt)) and np.array_equal(b, np.arange(nt))
+    cases = [rng.choice([-1.0, 1.0], nt)[:, None] * H[rng.permutation(nt)][:, rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[None, :] for _ in range(4)]
+    cases += [-H, H[::-1].copy(), H[:, ::-1].copy()]
+    if nt >= 4:
+        cases.append(np.kron(oracle.hadamard(nt // 4), P_VHT4) if nt > 4 else P_VHT4)
+        cases.append(np.kron(P_VHT4, oracle.hadamard(nt // 4)) if nt > 4 else P_VHT4.T.copy())
+    for P in cases:
+        kind, a, b = classify_pilot(P)
+        assert kind in (1, 2), 'a signed permutation of the Sylvester matrix was not recognised'
+        assert kind == 2 or np.array_equal(P, H)
+        assert sorted(a & 255) == list(range(nt)) and sorted(b & 255) == list(range(nt))
+        assert np.array_equal(_reassemble(oracle, nt, a, b), P)
+
+
+def test_pilot_classify_tables_reproduce_the_ls_estimate(pkg, oracle):
+    """What the PERM kernel does with the tables, in numpy: fetch symbol tau^-1(u) with its sign, FWHT in Sylvester order, store row
+    r to antenna sigma^-1(r) with its sign - equals the oracle's LS (helperMIMOChannelEstimate.m:24-36) for that P."""
+    from dl_channel_estimation_mamimo_amd.engine import classify_pilot
+    rng = np.random.default_rng(3)
+    nt, nr = 16, 2
+    P = np.kron(oracle.hadamard(nt // 4), P_VHT4)
+    ltf, _ = oracle.make_structured_packets(rng, 2, nr, P, snr_db=15.0)
+    kind, a, b = classify_pilot(P)
+    assert kind == 2
+    spectra = oracle.ofdm_demod(ltf, nt)                     # [npkt, nr, 234, symbol]
+    G = np.stack([spectra[..., int(a[u]) & 255] * (-1.0 if a[u] & 256 else 1.0) for u in range(nt)], axis=-1)
+    W = np.einsum('ru,pxku->pxrk', oracle.hadamard(nt), G)      # FWHT over the symbol index -> [npkt, nr, row, 234]
+    out = np.empty_like(W)
+    for r in range(nt):
+        out[:, :, int(b[r]) & 255] = W[:, :, r] * (-1.0 if b[r] & 256 else 1.0)
+    den = nt * oracle.vht_ltf_256()[oracle.data_carrier_indices() - 1]
+    ref = oracle.ls_estimate(ltf, P)
+    assert np.allclose(out / den, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_pilot_classify_rejects_what_is_not_equivalent(pkg, oracle):
+    from dl_channel_estimation_mamimo_amd.engine import classify_pilot
+    rng = np.random.default_rng(9)
+    H = oracle.hadamard(16)
+    assert classify_pilot(rng.choice([-1.0, 1.0], (16, 16)))[0] == 0               # not Hadamard
+    assert classify_pilot(0.5 * H)[0] == 0                                        # entries must be +-1
+    assert classify_pilot(rng.standard_normal((16, 16)))[0] == 0
+    assert classify_pilot(oracle.hadamard(8)[:6, :6].copy())[0] == 0              # order not a power of two
+    Q = H.copy(); Q[3, 5] *= -1                                                   # one flipped entry
+    assert classify_pilot(Q)[0] == 0
+    D = H.copy(); D[7] = D[6]                                                     # a repeated row
+    assert classify_pilot(D)[0] == 0
+    # a Hadamard matrix from Sylvester's by switching a closed quadruple: whatever the answer, it must be a VERIFIED one
+    S = H.copy(); S[np.ix_([0, 4, 8, 12], [0, 1, 2, 3])] *= -1
+    assert np.allclose(S @ S.T, 16 * np.eye(16))
+    kind, a, b = classify_pilot(S)
+    assert kind in (0, 2)
+    if kind == 2:
+        assert np.array_equal(_reassemble(oracle, 16, a, b), S)
+    lib = pkg.load_library()
+    assert lib.csi_pilot_classify(None, 16, None, None) == -1
+    big = oracle.hadamard(256).astype(np.float32)
+    assert classify_pilot(big)[0] == 0                                            # beyond the Walsh-Hadamard kernels' range
+
+
+def test_rccl_missing_library_is_an_error_not_a_crash():
+    """with no librccl the loader called dlerror() twice and passed NULL to std::string (SIGSEGV).
+    CSI_RCCL_ONLY=1 restricts the search to CSI_RCCL_LIBRARY, so a host without RCCL can be played here."""
+    code = ("import dl_channel_estimation_mamimo_amd as pkg\n"
+            "from dl_channel_estimation_mamimo_amd.engine import get_unique_id\n"
+            "try:\n    get_unique_id()\n    print('NO ERROR')\n"
+            "except pkg.CsiError as e:\n    print('CSIERR', e.code, str(e))\n"
+            "try:\n    get_unique_id()\nexcept pkg.CsiError as e:\n    print('AGAIN', e.code)\n")
+    env = dict(os.environ, CSI_RCCL_LIBRARY='/nonexistent/librccl-missing.so', CSI_RCCL_ONLY='1', PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert r.returncode == 0, r.stdout                                            # 139 before the fix
+    assert 'CSIERR -3' in r.stdout and 'RCCL not found' in r.stdout and 'librccl-missing' in r.stdout, r.stdout
+    assert 'AGAIN -3' in r.stdout                                                 # the failure is remembered, not retried into a crash
+
+
+def test_bench_gpus_8_rendezvous_only():
+    """`bench.py --gpus 8 --rendezvous-only`: eight ranks start, meet, shard the packets and leave - the launch path of the
+    driver's 8-GPU run without GPU work (gloo)."""
+    env = dict(os.environ, CSI_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--rendezvous-only'], env=env, cwd=REPO,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    import json
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['rendezvous_only'] and out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['requested'] == 8
+    assert [rk['rank'] for rk in out['ranks']] == list(range(8)) and len({rk['pid'] for rk in out['ranks']}) == 8
+    assert out['scaling'] == 'weak' and out['packets_per_step'] == 8 * out['ranks'][0]['packets']

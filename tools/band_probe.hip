@@ -67,7 +67,7 @@ static double time_ms(F&& launch, int iters = 7) {
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const std::string mode = argc > 1 ? argv[1] : "check";
-    const bool timing = mode == "time" || mode == "stamps";
+    const bool timing = mode == "time" || mode == "stamps" || mode == "loop";
     const int nt = argc > 2 ? atoi(argv[2]) : 32;
     const int K = 1024, N = 1024, NO = 234;
     const int M = timing ? 262144 : 1024 + 24;
@@ -278,6 +278,25 @@ int main(int argc, char** argv) {
         return e1 > 1e-5 || !(e8 <= 1e-5);
     }
     const double fl = 2.0 * M * N * K + 2.0 * M * N * NO;
+    if (mode == "loop") {            // band_probe.bin loop <nt> <kernel name> <seconds>: one variant back to back (tools/power_probe.py samples power / clock meanwhile)
+        const char* nm = argc > 3 ? argv[3] : "csi_band8";
+        const double secs = argc > 4 ? atof(argv[4]) : 5.0;
+        hipFunction_t f = get8(nm);
+        if (!f) { printf("no kernel %s (BAND8_HSACO?)\n", nm); return 2; }
+        const Band8Args& av = strstr(nm, "nostage") ? a8_plain : a8_staged;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        launch8f(f, av); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        int n = 0; float ms = 0;
+        do {
+            for (int i = 0; i < 20; ++i) launch8f(f, av);
+            n += 20;
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        } while (ms < secs * 1e3);
+        printf("loop %s: %d launches, %.3f ms each, %.0f TF f16 executed (incl. 256-column regressor tile)\n", nm, n, ms / n,
+               3 * (2.0 * M * N * K + 2.0 * M * N * 256) / (ms / n) / 1e9);
+        return 0;
+    }
     if (mode == "stamps") {
         unsigned long long* st; CK(hipMalloc(&st, (size_t)nbands * 12 * 8));
         BandArgs a = ba; a.stamps = st;
@@ -349,7 +368,7 @@ int main(int argc, char** argv) {
             t(kb8, "full, no barriers (invalid)");
             t(kb16, "no A side, no DMA, no fragment reads (invalid)");
             t(kb31, "MFMA only (invalid)");
-            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_stagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8_nostage", "csi_band8_nostage_noreq", "csi_band8"}) {
+            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_skeleton_rnd", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_stagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8_nostage", "csi_band8_nostage_noreq", "csi_band8"}) {
                 hipFunction_t f = get8(nm);
                 if (!f) continue;
                 const Band8Args& av = strstr(nm, "nostage") ? a8_plain : a8_staged;

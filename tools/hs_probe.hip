@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
     const float in_mag = argc > 2 ? atof(argv[2]) : 1.f;
     const bool relu_zeros = argc > 3 && std::string(argv[3]) == "relu";     // A operands with ~50 % exact zeros (power experiment)
     const bool stamps = argc > 4 && std::string(argv[4]) == "stamps";       // per-workgroup phase timing
-    const bool loop = argc > 1 && std::string(argv[1]) == "loop";           // loop <mag> <relu|-> <mfma|hs2hs|pair|regressor> <seconds>: for tools/power_probe.sh
+    const bool loop = argc > 1 && std::string(argv[1]) == "loop";           // loop <mag> <relu|-> <mfma|hs2hs|pair|regressor|cast> <seconds>: for tools/power_probe.py
     const int nt = 32, K = 1024, N = 1024, NO = 234;
     const int M = timing ? 262144 : 1000 * 1 + 24;        // ragged last tile in the check
     const int M1 = (M + nt - 1) / nt;
@@ -343,6 +343,7 @@ int main(int argc, char** argv) {
             if (mode == "mfma") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true, 5, 57>), grid, dim3(PP_THREADS), 0, 0, gh);
             else if (mode == "pair") hipLaunchKernelGGL(kpair, grid, dim3(PP_THREADS), lds_pair, 0, gp, ps, std::ldexp(1.f, sa), PairRegArgs{});
             else if (mode == "regressor") hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS, false>), gridr, dim3(PP_THREADS), 0, 0, gr);
+            else if (mode == "cast") hipLaunchKernelGGL(kcast, grid, dim3(PP_THREADS), PPP_RING_FLOATS * 4, 0, gc, pc, 16.f, PairRegArgs{});      // layer 0's kernel (A = fp32 rows) at K = 1024
             else hipLaunchKernelGGL((gemm_hs_pp_kernel<EPI_BIAS_RELU_AFFINE, true>), grid, dim3(PP_THREADS), 0, 0, gh);
         };
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
