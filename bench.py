@@ -223,8 +223,11 @@ def main():
         name, value = kv.split('=')
         eng.set_option(name, int(value))
 
+    # LS + DNN as one unit (csi_estimate_device) when the step is a hipGraph or when the LS kernel runs beside the DNN kernels
+    one_unit = args.graph or (args.dtype == 'f32' and not args.no_ls and eng.get_option('ls_overlap_cus') > 0)
+
     def step():
-        if args.graph:
+        if one_unit:
             eng.estimate_device(d_re, d_im, npkt, d_ore, d_oim, d_hre, d_him)
             return
         if not args.no_ls:

@@ -142,6 +142,16 @@ struct csi_ctx {
     char *aux_ws = nullptr, *aux_l0skinny = nullptr, *aux_skbuf = nullptr, *aux_fuse_ws = nullptr;
     size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0, aux_fuse_ws_bytes = 0;
     int small_call_overlap = 1;  // "small_call_overlap" option
+    // "ls_overlap_cus" = n > 0: inside csi_estimate_device the LS kernel runs on its own stream, restricted to n compute units
+    // (hipExtStreamCreateWithCUMask), BESIDE the DNN kernels of the same packets instead of in front of them: it is HBM-bound and
+    // draws little power, the matrix kernels are bound by the power budget and by one workgroup per CU - a few CUs lent to it cost
+    // them less than the 0.4 ms it occupies the whole chip for (both orders give bit-identical results)
+    int ls_overlap_cus = 0;
+    int ls_overlap_stride = 0;   // "ls_overlap_stride": CU i of the n is mask bit i * stride (0 = spread evenly over 256)
+    hipStream_t ls_stream = nullptr;
+    int ls_stream_cus = 0, ls_stream_stride = 0;
+    hipEvent_t ls_fork = nullptr, ls_join = nullptr;
+    int ls_grid_cus = 0;         // set while the LS kernel is launched for the masked stream: persistent grid = this many CUs
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;

@@ -246,6 +246,26 @@ int pilot_fast_tables(csi_ctx* c) {
     return CSI_OK;
 }
 
+// the CU-masked side stream of "ls_overlap_cus"
+int ls_stream_ensure(csi_ctx* c) {
+    const int n = std::max(1, std::min(255, c->ls_overlap_cus));
+    const int stride = c->ls_overlap_stride > 0 ? c->ls_overlap_stride : std::max(1, 256 / n);
+    if (c->ls_stream && c->ls_stream_cus == n && c->ls_stream_stride == stride) return CSI_OK;
+    drop_graphs(c);
+    if (c->ls_stream) { hipStreamSynchronize(c->ls_stream); hipStreamDestroy(c->ls_stream); c->ls_stream = nullptr; }
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int bit = (i * stride) % 256;
+        mask[bit >> 5] |= 1u << (bit & 31);
+    }
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->ls_stream, 8, mask));
+    if (!c->ls_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_fork, hipEventDisableTiming));
+    if (!c->ls_join) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_join, hipEventDisableTiming));
+    c->ls_stream_cus = n;
+    c->ls_stream_stride = stride;
+    return CSI_OK;
+}
+
 int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): only csi_predict_samples is available");
@@ -462,6 +482,9 @@ void csi_destroy(csi_ctx* c) {
     if (c->aux_fork) hipEventDestroy(c->aux_fork);
     if (c->aux_join) hipEventDestroy(c->aux_join);
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
+    if (c->ls_fork) hipEventDestroy(c->ls_fork);
+    if (c->ls_join) hipEventDestroy(c->ls_join);
+    if (c->ls_stream) hipStreamDestroy(c->ls_stream);
     if (c->skbuf) hipFree(c->skbuf);
     if (c->l0skinny) hipFree(c->l0skinny);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -859,8 +882,29 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
         const bool g = c->use_graph;
         c->use_graph = false;                      // the two calls below are the graph's content, not graphs of their own
         c->in_graph_call = g;
-        int r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
-        if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+        int r = CSI_OK;
+        if (c->ls_overlap_cus > 0) {
+            // LS beside the DNN kernels: fork a CU-masked stream behind whatever precedes this call, join before returning
+            r = ls_stream_ensure(c);
+            if (!r) {
+                hipError_t e = hipEventRecord(c->ls_fork, c->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->ls_stream, c->ls_fork, 0);
+                if (e == hipSuccess) {
+                    std::swap(c->stream, c->ls_stream);
+                    c->ls_grid_cus = c->ls_overlap_cus;
+                    r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
+                    c->ls_grid_cus = 0;
+                    if (!r) e = hipEventRecord(c->ls_join, c->stream);
+                    std::swap(c->stream, c->ls_stream);
+                }
+                if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ls_join, 0);      // also on a DNN error: the fork must be joined (graph capture)
+                if (e != hipSuccess && !r) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: LS stream fork / join failed: %s", hipGetErrorString(e));
+            }
+        } else {
+            r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
+            if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+        }
         c->use_graph = g;
         c->in_graph_call = false;
         return r;
@@ -899,7 +943,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
             hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), plan.lds, c->stream, a, n_jc);
         } else {
             // persistent grid: as many workgroups as can reside (x256 CUs)
-            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)256 * plan.per_cu);
+            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)(c->ls_grid_cus > 0 ? c->ls_grid_cus : 256) * plan.per_cu);
             void* kargs[] = {(void*)&a, (void*)&nb32};
             HIP_TRY(c, hipLaunchKernel(plan.fn, dim3(grid), dim3(plan.threads), kargs, plan.lds, c->stream));
         }
@@ -1058,6 +1102,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "ls_pilot_pieces") *value = c->p_pieces;
     else if (n == "ls_mode") *value = ls_plan(c).mode;
     else if (n == "ls_fast_perm") *value = c->ls_fast_perm;
+    else if (n == "ls_overlap_cus") *value = c->ls_overlap_cus;
+    else if (n == "ls_overlap_stride") *value = c->ls_overlap_stride;
     else if (n == "ls_pilot_fast") *value = !c->p_fast_ok ? 0 : (c->p_fast_identity ? 1 : 2);     // read-only: 0 generic P, 1 Sylvester Hadamard, 2 a signed permutation of it
     else if (n == "hs_vm_cast") *value = c->hs_vm_cast;
     else if (n == "hs_vm_pair") *value = c->hs_vm_pair;
@@ -1128,6 +1174,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 3) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 ... 3", name);
         drop_graphs(c);
         (n == "hs_vm_cast" ? c->hs_vm_cast : c->hs_vm_pair) = (int)value;
+    } else if (n == "ls_overlap_cus" || n == "ls_overlap_stride") {
+        if (value < 0 || value > 255) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 (LS in front of the DNN kernels on one stream) .. 255", name);
+        drop_graphs(c);
+        (n == "ls_overlap_cus" ? c->ls_overlap_cus : c->ls_overlap_stride) = (int)value;
     } else if (n == "ls_fast_perm") {
         c->ls_fast_perm = value != 0;
         drop_graphs(c);

@@ -96,10 +96,13 @@ def test_clone_weights_receiver_is_bit_identical(pkg, oracle, tag, nt, nr, npkt,
     ref = oracle.ls_estimate(ltf[:k], P)
     assert rel_rows(np.concatenate([hb[:k].real, hb[:k].imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
     # a changed pilot on the receiver alone rebuilds ITS tables (they are its own allocations, not aliases of the root's)
+    s_re, _ = root.predict(ltf[:2])
+    c0_re, _ = recv.predict(ltf[:2])
+    assert np.array_equal(s_re, c0_re)
     recv.set_pilot(P[::-1].copy())
     c_re, _ = recv.predict(ltf[:2])
-    a2_re, _ = root.predict(ltf[:2])
-    assert np.array_equal(a2_re, a_re[:2]) and not np.array_equal(c_re, a_re[:2])
+    s2_re, _ = root.predict(ltf[:2])
+    assert np.array_equal(s2_re, s_re) and not np.array_equal(c_re, s_re)
 
 
 def test_clone_weights_partial_and_refusals(pkg, oracle):

@@ -286,6 +286,7 @@ int main(int argc, char** argv) {
         const Band8Args& av = strstr(nm, "nostage") ? a8_plain : a8_staged;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         launch8f(f, av); CK(hipDeviceSynchronize());
+        printf("LOOP START\n"); fflush(stdout);
         CK(hipEventRecord(e0));
         int n = 0; float ms = 0;
         do {

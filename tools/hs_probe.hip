@@ -348,6 +348,7 @@ int main(int argc, char** argv) {
         };
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         one(); CK(hipDeviceSynchronize());
+        printf("LOOP START\n"); fflush(stdout);
         CK(hipEventRecord(e0));
         int n = 0;
         float ms = 0;

@@ -30,11 +30,13 @@ def main():
         H = hadamard(nt).astype(np.float64)
         pilots = {'sylvester': H, 'vht_kron': np.kron(hadamard(nt // 4), P_VHT4),
                   'signed_perm': rng.choice([-1.0, 1.0], nt)[:, None] * H[rng.permutation(nt)][:, rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[None, :]}
+        pilots['cols_only'] = H[:, rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[None, :]       # symbol fetch permuted, antenna store in order
+        pilots['rows_only'] = rng.choice([-1.0, 1.0], nt)[:, None] * H[rng.permutation(nt)]        # the other way round
         eng = CsiEngine(nt, nr, hidden=(32,), n_out=234)
         d_re, d_im = eng.empty((npkt, nr, 320 * nt)), eng.empty((npkt, nr, 320 * nt))
         eng.synth_white(7, 0, npkt, d_re, d_im)
         d_hr, d_hi = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
-        cases = [('sylvester', 1, 0), ('vht_kron', 1, 0), ('signed_perm', 1, 0), ('vht_kron', 0, 0), ('signed_perm', 0, 0)]
+        cases = [('sylvester', 1, 0), ('vht_kron', 1, 0), ('signed_perm', 1, 0), ('cols_only', 1, 0), ('rows_only', 1, 0), ('vht_kron', 0, 0), ('signed_perm', 0, 0)]
         if nt == 32:
             cases.insert(1, ('sylvester', 1, 2))              # scalar-base stores on the table-free kernel (A/B)
         times = {c: [] for c in cases}

@@ -27,6 +27,7 @@ a = torch.relu(torch.randn(m, k, device='cuda')).half()
 b = (torch.randn(k, n, device='cuda') * 0.03).half()
 c = a @ b
 torch.cuda.synchronize()
+print('LOOP START', flush=True)
 t0 = time.perf_counter(); it = 0
 while time.perf_counter() - t0 < secs:
     for _ in range(20):
@@ -103,10 +104,14 @@ def main():
     print('target            power W (sysfs)         sclk MHz (sysfs)        power W (rocm-smi)      sclk MHz (rocm-smi)     child')
     for t in args.targets.split(','):
         cmd = cmds[t]
-        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True) if cmd else None
-        time.sleep(2.0 if t.startswith('blas') else 1.5)       # start-up, clocks settled (torch needs its import)
-        if t.startswith('blas'):
-            time.sleep(3.0)
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, bufsize=1) if cmd else None
+        head = []
+        if child:                       # the child says when its set-up is over and the loop runs
+            for ln in child.stdout:
+                head.append(ln.rstrip())
+                if 'LOOP START' in ln:
+                    break
+        time.sleep(1.5)                 # clocks and the power controller settled
         rows = []
         for _ in range(args.samples):
             s = sysfs_sample()
@@ -118,7 +123,7 @@ def main():
         tail = ''
         if child:
             out, _ = child.communicate()
-            tail = (out.strip().splitlines() or [''])[-1]
+            tail = ((out.strip().splitlines() or head) or [''])[-1]
 
         def stat(key):
             v = [r[key] for r in rows if key in r]
