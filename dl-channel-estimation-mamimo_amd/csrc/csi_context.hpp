@@ -152,6 +152,10 @@ struct csi_ctx {
     int ls_stream_cus = 0, ls_stream_stride = 0;
     hipEvent_t ls_fork = nullptr, ls_join = nullptr;
     int ls_grid_cus = 0;         // set while the LS kernel is launched for the masked stream: persistent grid = this many CUs
+    // csi_estimate_device parks the LS launch here; the DNN path fires it behind its FIRST layer-0 kernel (ls_deferred_fire), so that
+    // the LS kernel runs beside the per-pair kernels (many rounds of workgroups per CU: a few CUs less cost them nothing measurable)
+    // and not beside layer 0 (ONE round of 252 tiles on 256 CUs at config 2: any CU less costs it a whole second round)
+    struct { bool active = false, forked = false; const float *re = nullptr, *im = nullptr; int64_t npkt = 0; float *h_re = nullptr, *h_im = nullptr; } ls_deferred;
     // staging for host-buffer entry points
     char* stage = nullptr;
     size_t stage_bytes = 0;
@@ -284,6 +288,48 @@ void drop_graphs(csi_ctx* c) {
     for (auto& g : c->graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
     c->graphs.clear();
+}
+
+// the CU-masked side stream of "ls_overlap_cus"
+int ls_stream_ensure(csi_ctx* c) {
+    const int n = std::max(1, std::min(255, c->ls_overlap_cus));
+    const int stride = c->ls_overlap_stride > 0 ? c->ls_overlap_stride : std::max(1, 256 / n);
+    if (c->ls_stream && c->ls_stream_cus == n && c->ls_stream_stride == stride) return CSI_OK;
+    drop_graphs(c);
+    if (c->ls_stream) { hipStreamSynchronize(c->ls_stream); hipStreamDestroy(c->ls_stream); c->ls_stream = nullptr; }
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int bit = (i * stride) % 256;
+        mask[bit >> 5] |= 1u << (bit & 31);
+    }
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->ls_stream, 8, mask));
+    if (!c->ls_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_fork, hipEventDisableTiming));
+    if (!c->ls_join) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_join, hipEventDisableTiming));
+    c->ls_stream_cus = n;
+    c->ls_stream_stride = stride;
+    return CSI_OK;
+}
+
+// the LS launch csi_estimate_device parked: fork the side stream behind what the main stream holds so far, launch the LS kernel
+// there, record the join event (csi_estimate_device waits for it before it returns)
+int ls_deferred_fire(csi_ctx* c) {
+    if (!c->ls_deferred.active) return CSI_OK;
+    c->ls_deferred.active = false;
+    const auto d = c->ls_deferred;
+    int r = ls_stream_ensure(c);
+    if (r) return r;
+    HIP_TRY(c, hipEventRecord(c->ls_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->ls_stream, c->ls_fork, 0));
+    c->ls_deferred.forked = true;
+    std::swap(c->stream, c->ls_stream);
+    c->ls_grid_cus = c->ls_overlap_cus;
+    r = csi_ls_estimate_device(c, d.re, d.im, d.npkt, d.h_re, d.h_im);
+    c->ls_grid_cus = 0;
+    const hipError_t e = hipEventRecord(c->ls_join, c->stream);
+    std::swap(c->stream, c->ls_stream);
+    if (r) return r;
+    HIP_TRY(c, e);
+    return CSI_OK;
 }
 
 int ensure_bytes(csi_ctx* c, char** buf, size_t* have, size_t need) {

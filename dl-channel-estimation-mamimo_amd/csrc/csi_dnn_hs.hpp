@@ -240,6 +240,7 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
 // ping-pong activation buffers of the fp32 path re-used as hs matrices (same 4 bytes per element)
 int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, float* hbuf1, float* out) {
     const csi_config& cf = c->cfg;
+    if (int rc_ls = ls_deferred_fire(c)) return rc_ls;       // csi_estimate_device with "ls_overlap_cus": the LS kernel starts here, beside the per-pair kernels
     const int nh = cf.n_hidden, h1 = cf.hidden[0];
     const Layer& l1 = m.layers[1];
     const int s0 = hs_act_shift_of(c, m, 0, true);

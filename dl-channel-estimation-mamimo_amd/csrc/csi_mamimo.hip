@@ -246,26 +246,6 @@ int pilot_fast_tables(csi_ctx* c) {
     return CSI_OK;
 }
 
-// the CU-masked side stream of "ls_overlap_cus"
-int ls_stream_ensure(csi_ctx* c) {
-    const int n = std::max(1, std::min(255, c->ls_overlap_cus));
-    const int stride = c->ls_overlap_stride > 0 ? c->ls_overlap_stride : std::max(1, 256 / n);
-    if (c->ls_stream && c->ls_stream_cus == n && c->ls_stream_stride == stride) return CSI_OK;
-    drop_graphs(c);
-    if (c->ls_stream) { hipStreamSynchronize(c->ls_stream); hipStreamDestroy(c->ls_stream); c->ls_stream = nullptr; }
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
-        const int bit = (i * stride) % 256;
-        mask[bit >> 5] |= 1u << (bit & 31);
-    }
-    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->ls_stream, 8, mask));
-    if (!c->ls_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_fork, hipEventDisableTiming));
-    if (!c->ls_join) HIP_TRY(c, hipEventCreateWithFlags(&c->ls_join, hipEventDisableTiming));
-    c->ls_stream_cus = n;
-    c->ls_stream_stride = stride;
-    return CSI_OK;
-}
-
 int check_ready(csi_ctx* c, bool need_models, int model = -1) {
     if (!c) return CSI_ERR_INVALID_ARG;
     if (c->cfg.nt == 0) return fail(c, CSI_ERR_INVALID_ARG, "single-input context (nt=0): only csi_predict_samples is available");
@@ -884,23 +864,19 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
         c->in_graph_call = g;
         int r = CSI_OK;
         if (c->ls_overlap_cus > 0) {
-            // LS beside the DNN kernels: fork a CU-masked stream behind whatever precedes this call, join before returning
-            r = ls_stream_ensure(c);
-            if (!r) {
-                hipError_t e = hipEventRecord(c->ls_fork, c->stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(c->ls_stream, c->ls_fork, 0);
-                if (e == hipSuccess) {
-                    std::swap(c->stream, c->ls_stream);
-                    c->ls_grid_cus = c->ls_overlap_cus;
-                    r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
-                    c->ls_grid_cus = 0;
-                    if (!r) e = hipEventRecord(c->ls_join, c->stream);
-                    std::swap(c->stream, c->ls_stream);
-                }
-                if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
-                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ls_join, 0);      // also on a DNN error: the fork must be joined (graph capture)
-                if (e != hipSuccess && !r) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: LS stream fork / join failed: %s", hipGetErrorString(e));
+            // LS beside the per-pair kernels: parked here, fired by the DNN path behind its first layer-0 kernel on a CU-masked side
+            // stream (ls_deferred_fire); joined below.  A path that never reaches the hook fires it here, behind the DNN kernels.
+            c->ls_deferred.active = true;
+            c->ls_deferred.forked = false;
+            c->ls_deferred.re = d_ltf_re; c->ls_deferred.im = d_ltf_im; c->ls_deferred.npkt = npkt; c->ls_deferred.h_re = d_h_re; c->ls_deferred.h_im = d_h_im;
+            r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+            const int r2 = ls_deferred_fire(c);            // no-op when the hook has fired
+            c->ls_deferred.active = false;
+            if (c->ls_deferred.forked) {                   // also on an error: a forked stream must be joined (graph capture)
+                const hipError_t e = hipStreamWaitEvent(c->stream, c->ls_join, 0);
+                if (e != hipSuccess && !r) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: joining the LS stream failed: %s", hipGetErrorString(e));
             }
+            if (!r) r = r2;
         } else {
             r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
             if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
