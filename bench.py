@@ -99,7 +99,7 @@ def main():
                     help='fp32 contexts: auto = split-f16 engine for GEMMs that fill the chip (library default), '
                          'native = fp32 MFMA kernels only, split = split engine wherever the shapes allow')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE', help='csi_set_option before the timed region (A/B runs), repeatable')
-    ap.add_argument('--check', type=int, default=2, help='packets checked against the oracle after timing')
+    ap.add_argument('--check', type=int, default=8, help='packets checked against the oracle after timing (spread over the batch: with the mixed-SNR input one per SNR level)')
     ap.add_argument('--host-path', type=int, default=4000,
                     help='also time the host-buffer (PCIe-inclusive) entry points on this many packets (0 = skip; rank 0, N = 1)')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -109,6 +109,7 @@ def main():
                     help='N > 1: rccl = rank 0 loads the weights into its context and the library broadcasts its device buffers '
                          '(csi_comm_init / csi_broadcast_weights: ncclBroadcast inside the C-ABI); torch = dist.broadcast_weights '
                          '(torch.distributed, host round trip).  CSI_DIST_BACKEND=gloo implies torch.')
+    ap.add_argument('--no-next-rows', action='store_true', help='skip the "next_rows" legs (LMMSE smoother, one training step, LS on a non-Sylvester pilot) measured after the timed region')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()
@@ -329,6 +330,19 @@ def main():
         host_path['python_c128_to_c64']['dnn_only'] = {'pairs_per_s': k * nr * nt / t3, 'ms': t3 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t3s],
                                                        'd2h_bytes': int(bufs[0].nbytes),
                                                        'note': 'CsiEngine.estimate(ls=False): what CSIPredictor.inference returns (model_real + 1j * model_imag)'}
+        # the link itself, same process, same byte counts: pinned host memory <-> device on the pipeline's two copy streams
+        up = int(2 * h_re.nbytes)                      # two float32 planes (the complex128 batch is split on the host)
+        try:
+            for key, down in (('dnn_only', int(bufs[0].nbytes)), ('dnn_and_ls', int(bufs[0].nbytes + bufs[1].nbytes))):
+                a, b, ab = eng.pcie_probe(up, down)
+                tgt = host_path['python_c128_to_c64']['dnn_only'] if key == 'dnn_only' else host_path['python_c128_to_c64']
+                tgt['pcie_bound_ms'] = round(ab, 3)
+                tgt['pcie'] = {'h2d_bytes': up, 'd2h_bytes': down, 'h2d_alone_ms': round(a, 3), 'd2h_alone_ms': round(b, 3), 'both_ms': round(ab, 3),
+                               'h2d_gbs': round(up / a / 1e6, 1), 'd2h_gbs': round(down / b / 1e6, 1),
+                               'what': 'csi_profile_pcie: bare hipMemcpyAsync of these byte counts between pinned host memory and the device, 32 MiB pieces, two streams'}
+                tgt['frac_of_pcie_bound'] = round(ab / tgt['ms'], 3)
+        except Exception as e:                      # a side measurement never takes the line down
+            host_path['pcie_probe_error'] = repr(e)
         del x128, bufs
 
     # ---- cpu_baseline leg (rank 0, N = 1, after the timed region): the only place that touches oracle/.
@@ -339,8 +353,9 @@ def main():
     if rank == 0 and args.check > 0:               # N > 1: rank 0 checks packets of ITS shard
         from oracle import csi_oracle as o
         k = min(args.check, npkt)
-        # first and last packets of the batch: with the mixed-SNR input these are the -25 dB and the +10 dB level
-        sel = sorted(set(list(range((k + 1) // 2)) + list(range(npkt - k // 2, npkt))))
+        # spread over the batch, first and last included: with the mixed-SNR input (8 blocks of npkt / 8) k = 8 takes one packet
+        # of every SNR level, the -25 dB and the +10 dB ends among them
+        sel = sorted(set(int(round(j * (npkt - 1) / max(k - 1, 1))) for j in range(k))) if k > 1 else [0]
         take = lambda d: np.concatenate([d.download(p, 1) for p in sel])
         ltf = take(d_re) + 1j * take(d_im)
         r_re, r_im = o.predict_packets(ltf, wts['P']['pilot'], wts['real'], wts['imag'], np.float64, pkt_batch=k)
@@ -435,6 +450,14 @@ def main():
                      'achieved counts each multiply-add of the algorithm once (executed f16 flops are 3x)')
     else:
         mfma_peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'
+    # the practical ceiling of the dominant kernel, measured here: its MFMA + barrier skeleton on the model's own operand data
+    practical = None
+    if band_kernel and world == 1:
+        try:
+            sk_ms, sk_tf = eng.band_skeleton(npkt * nr * nt, 5)
+            practical = {'skeleton_ms_per_launch': sk_ms, 'skeleton_executed_tflops': sk_tf}
+        except Exception as e:
+            practical = {'error': repr(e)}
     kernels = {}
     for name, p in prof.items():
         if p['launches']:
@@ -479,7 +502,14 @@ def main():
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
                      'traffic': hbm_per_launch(('csi_band8' if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
-                     'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1)},
+                     'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1),
+                     'practical_peak': (practical['skeleton_executed_tflops'] / SPLIT_PRODUCTS) if practical and 'error' not in practical else None,
+                     'frac_of_practical': (achieved / (practical['skeleton_executed_tflops'] / SPLIT_PRODUCTS)) if practical and 'error' not in practical else None,
+                     'practical_peak_note': ('csi_profile_band_skeleton on this box, this run: the same kernel with everything but its MFMAs, barriers and waits '
+                                             'removed and its operand registers holding the model\'s own split weights (relu-like zeros in the activation fragments), '
+                                             '%.3f ms per launch = %.0f TFLOP/s of executed f16 MFMA; divided by 3 products.  The part runs these kernels at its ~1.4 kW '
+                                             'power limit at 1.8-2.0 GHz, not 2.4 (profiles/r04_power.txt), so the table peak is not reachable on real data'
+                                             % (practical['skeleton_ms_per_launch'], practical['skeleton_executed_tflops'])) if practical and 'error' not in practical else (practical or {}).get('error')},
         'kernels': kernels,
         'parity_check': check,
         'latency': latency,
@@ -504,6 +534,11 @@ def main():
 
     if cpu_baseline:
         out['cpu_baseline'] = cpu_baseline
+    if world == 1 and not args.no_next_rows and args.dtype == 'f32' and nt > 0:
+        try:
+            out['next_rows'] = next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, min(npkt, 1000))
+        except Exception as e:                      # side measurements never take the headline down
+            out['next_rows'] = {'error': repr(e)}
     default_run = (nt, nr, args.packets, args.dtype, tuple(hidden), args.engine) == (32, 4, 4000, 'f32', (1024, 1024), 'auto')
     if world == 1 and default_run and not args.no_other_configs and not args.graph and not args.option:
         del d_re, d_im, d_ore, d_oim, d_hre, d_him
@@ -511,13 +546,114 @@ def main():
     print(json.dumps(out))
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6        # MI355X datasheet (fp64 vector = fp64 matrix); the microarchitecture guide has no fp64 row
+
+P_VHT4 = [[1, -1, 1, 1], [1, 1, -1, 1], [1, 1, 1, -1], [-1, 1, 1, 1]]
+
+
+def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
+    """SURVEY 8 'next' rows on the driver's record, outside the timed region, each with its own oracle check:
+    f-3 LMMSE smoother (LMMSE_ce.m:23-39), f-4 one training step (DNN.py:312-316), and the LS estimate with the pilot matrix real
+    pipelines carry (helperGetP, helperMIMOChannelEstimate.m:13: the 802.11 VHT 4x4 base doubled up - Hadamard, not Sylvester-ordered)."""
+    import ctypes
+    from oracle import csi_oracle as o
+    res = {}
+    rng = np.random.default_rng(77)
+    lib, ctx = eng._lib, eng._ctx
+    # ---- LS with a non-Sylvester +-1 pilot: the Walsh-Hadamard kernel through its symbol / antenna tables (round 4)
+    P0 = wts['P']['pilot']
+    Pv = np.kron(pkg.synth.hadamard(nt // 4), np.array(P_VHT4, np.float64)) if nt % 4 == 0 and nt >= 8 else None
+    h_re, h_im = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
+    if Pv is not None:
+        eng.set_pilot(Pv)
+        for _ in range(3):
+            eng.ls_estimate_device(d_re, d_im, npkt, h_re, h_im)
+        eng.synchronize()
+        eng.profile_enable(True); eng.profile_reset()
+        for _ in range(10):
+            eng.ls_estimate_device(d_re, d_im, npkt, h_re, h_im)
+        eng.synchronize()
+        p = eng.profile()['ls_estimate']
+        eng.profile_enable(False)
+        gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
+        ltf = d_re.download(0, 2) + 1j * d_im.download(0, 2)
+        ref = o.ls_estimate(ltf, Pv)
+        got = h_re.download(0, 2) + 1j * h_im.download(0, 2)
+        res['ls_vht_pilot'] = {'pilot': 'kron(H_%d, P_VHT4): Hadamard, not Sylvester-ordered' % (nt // 4), 'ls_mode': eng.get_option('ls_mode'),
+                               'pilot_class': eng.get_option('ls_pilot_fast'), 'packets': npkt, 'ms_per_launch': p['ms'] / p['launches'],
+                               'roofline_ls': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS},
+                               'ls_rel_err': max(o.row_rel_err(got.real, ref.real), o.row_rel_err(got.imag, ref.imag))}
+        eng.set_pilot(P0)
+    # ---- LMMSE smoother of the LS estimate (fp64 Levinson solves)
+    eng.ls_estimate_device(d_re, d_im, npkt, h_re, h_im)
+    o_re, o_im = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
+    hv_h = (np.sort(np.abs(rng.standard_normal((npkt, 100)))) * 1e-7).astype(np.float32)
+    snr_h = rng.choice([-10.0, 0.0, 10.0, 25.0], size=(npkt, nr)).astype(np.float32)
+    hv, snr = eng.to_device(hv_h), eng.to_device(snr_h)
+    run = lambda: eng._check(lib.csi_lmmse_estimate_device(ctx, h_re.ptr, h_im.ptr, npkt, hv.ptr, 100, snr.ptr, o_re.ptr, o_im.ptr))
+    run(); eng.synchronize()
+    eng.profile_enable(True); eng.profile_reset()
+    for _ in range(3):
+        run()
+    eng.synchronize()
+    p = eng.profile()['lmmse_levinson']
+    eng.profile_enable(False)
+    ms = p['ms'] / p['launches']
+    tf = p['flops'] / max(p['ms'], 1e-9) / 1e9
+    k = 1
+    hls = h_re.download(0, k) + 1j * h_im.download(0, k)
+    ref = o.lmmse_estimate(hls, hv_h[:k].astype(np.float64), snr_h[:k].astype(np.float64))
+    got = o_re.download(0, k) + 1j * o_im.download(0, k)
+    res['lmmse'] = {'what': 'LMMSE_ce.m:23-39 per link as one Hermitian-Toeplitz Levinson solve per (packet, rx) in fp64 (csrc/lmmse.hip.h)',
+                    'packets': npkt, 'ms_per_launch': ms, 'links_per_s': npkt * nr * nt / (ms * 1e-3),
+                    'roofline': {'bound': 'fp64 vector FMA', 'achieved': tf, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_VECTOR_PEAK_TFLOPS},
+                    'rel_err_vs_oracle': max(o.row_rel_err(got.real, ref.real), o.row_rel_err(got.imag, ref.imag)), 'checked_packets': k}
+    # ---- one training step of the shipped model (B = 256), resident dataset, against the fp64 oracle's loss
+    B, n_rows = 256, 64
+    table = (rng.standard_normal((n_rows, 320 * nt)) * 0.1).astype(np.float32)
+    N = n_rows * nt
+    ltf_row, itx = np.repeat(np.arange(n_rows), nt).astype(np.int32), np.tile(np.arange(nt), n_rows).astype(np.int32)
+    y = (rng.standard_normal((N, 234)) * 0.5).astype(np.float32)
+    w0 = {kk: np.array(v, copy=True) for kk, v in wts['real'].items()}
+    eng.train_begin('real', weights=w0, lr=1e-4, dropout=0.0, seed=1)
+    eng.train_set_dataset('real', table, ltf_row, itx, y)
+    ids = [rng.permutation(N)[:B].astype(np.int32) for _ in range(24)]
+    loss0 = eng.train_step_indexed('real', ids[0], noise_std=0.0)
+    x0 = np.concatenate([table[ltf_row[ids[0]]], np.asarray(P0, np.float32)[itx[ids[0]]]], axis=1)
+    refw = {kk: np.asarray(v, np.float64) for kk, v in w0.items() if kk != 'bn_eps'}
+    rloss = o.train_step_reference(refw, o.adam_init(refw), x0, y[ids[0]], lr=1e-4, use_bn=True)[0]
+    for i in range(1, 4):
+        eng.train_step_indexed('real', ids[i], noise_std=0.1)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for i in range(4, 24):
+        eng.train_step_indexed('real', ids[i], noise_std=0.1)
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    eng.profile_enable(True); eng.profile_reset()
+    for i in range(4, 9):
+        eng.train_step_indexed('real', ids[i], noise_std=0.1)
+    eng.synchronize()
+    pr = eng.profile()
+    eng.profile_enable(False)
+    eng.train_end('real', commit=False)
+    g = pr['train_gemm']
+    res['train_step'] = {'what': 'one optimiser step of DNN.py:312-316 (AWGN input noise, Dense+relu+BN x2, regressor, mse, Adam), B = %d, resident '
+                                 'de-duplicated dataset (csi_train_indexed)' % B, 'ms_per_step': dt * 1e3, 'samples_per_s': B / dt,
+                         'train_gemm_ms_per_step': g['ms'] / 5, 'train_gemm_tflops': g['flops'] / max(g['ms'], 1e-9) / 1e9,
+                         'train_gemm_frac_of_fp32_mfma_peak': g['flops'] / max(g['ms'], 1e-9) / 1e9 / FP32_MATRIX_PEAK_TFLOPS,
+                         'elementwise_ms_per_step': pr['train_elementwise']['ms'] / 5,
+                         'first_step_loss': loss0, 'first_step_loss_oracle_fp64': rloss, 'loss_rel_err': abs(loss0 - rloss) / max(abs(rloss), 1e-30)}
+    return res
+
+
 OTHER_CONFIGS = [
     ('configs[2]', 'Nt=64 Nr=4, 5000 packets, bf16 MFMA, 1 GPU',
-     ['--dtype', 'bf16', '--nt', '64', '--nr', '4', '--packets', '5000', '--steps', '3', '--warmup', '2']),
+     ['--dtype', 'bf16', '--nt', '64', '--nr', '4', '--packets', '5000', '--steps', '5', '--warmup', '2']),
     ('configs[3] share', 'Nt=64 Nr=8: one GPU\'s share (6250 packets) of the 50000 packets sharded over 8 GPUs, fp32',
-     ['--nt', '64', '--nr', '8', '--packets', '6250', '--steps', '3', '--warmup', '2']),
+     ['--nt', '64', '--nr', '8', '--packets', '6250', '--steps', '5', '--warmup', '2']),
     ('configs[4] share', 'Nt=128 Nr=16: one GPU\'s share (12500 packets) of the 100000 packets over 8 GPUs, fp32, one hipGraph per step',
-     ['--nt', '128', '--nr', '16', '--packets', '12500', '--steps', '3', '--warmup', '4', '--graph']),
+     ['--nt', '128', '--nr', '16', '--packets', '12500', '--steps', '5', '--warmup', '4', '--graph']),
 ]
 
 
@@ -529,7 +665,7 @@ def other_configs():
     res = []
     for name, what, flags in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-other-configs', '--no-cpu-baseline', '--no-latency',
-               '--host-path', '0', '--check', '2'] + flags
+               '--host-path', '0', '--check', '4', '--no-next-rows'] + flags
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)

@@ -99,6 +99,8 @@ SYMBOLS = {
     'csi_broadcast_weights': (ctypes.c_int, [_ctx, ctypes.c_int]),
     'csi_clone_weights': (ctypes.c_int, [_ctx, _ctx]),
     'csi_pilot_classify': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    'csi_profile_band_skeleton': (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    'csi_profile_pcie': (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'csi_profile_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
     'csi_profile_query': (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
@@ -123,7 +125,7 @@ def build_band_kernel(verbose=False):
     llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
     with tempfile.TemporaryDirectory() as tmp:
         asm, obj, co = (os.path.join(tmp, 'band8.' + e) for e in ('s', 'o', 'hsaco'))
-        cmds = [[sys.executable, gen, asm, 'csi_band8', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage'],
+        cmds = [[sys.executable, gen, asm, 'csi_band8', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd'],
                 [os.path.join(llvm, 'clang'), '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', asm, '-o', obj],
                 [os.path.join(llvm, 'ld.lld'), '-shared', obj, '-o', co]]
         for cmd in cmds:

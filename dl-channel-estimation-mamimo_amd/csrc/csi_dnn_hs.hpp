@@ -236,6 +236,62 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
     return CSI_OK;
 }
 
+// csi_profile_band_skeleton: the band kernel's MFMA + barrier skeleton (band_kernel_gen.py 'skeleton_rnd': no operand conversion, no
+// L0 / T streams, no LDS-DMA, no fragment reads; its 48 operand registers filled once from the model's own split weights, relu-like
+// zeros in the activation fragments) on `rows` pair rows of the loaded real model.  What it measures is the rate the matrix pipe of
+// THIS part sustains on THIS data inside the power budget with everything else of the kernel removed - the practical ceiling the
+// bench divides by next to the table peak (its output is garbage and goes to the workspace).
+int band_skeleton_time(csi_ctx* c, int64_t rows, int iters, double* ms_per_launch, double* executed_flops) {
+#ifdef CSI_HAVE_BAND8
+    const csi_config& cf = c->cfg;
+    Model& m = c->model[0];
+    if (cf.dtype != CSI_DTYPE_F32 || cf.n_hidden != 2 || !m.loaded || !m.layers[2].Wh_p || rows <= 0 || rows > (1 << 30) || iters < 1)
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_profile_band_skeleton: needs an fp32 context with the two-hidden-layer model loaded, rows > 0");
+    hipFunction_t fn = nullptr;
+    int rc = band8_function(c, &fn, false, true);
+    if (rc) return rc;
+    hipFunction_t sk = nullptr;
+    if (!fn || hipModuleGetFunction(&sk, c->band_mod, "csi_band8_skeleton_rnd") != hipSuccess || !sk) {
+        (void)hipGetLastError();
+        return fail(c, CSI_ERR_NOT_READY, "csi_profile_band_skeleton: the band kernel's code object holds no skeleton variant");
+    }
+    const Layer &l1 = m.layers[1], &lr = m.layers[2];
+    const int h1 = cf.hidden[0], M2 = (int)rows;
+    rc = ensure_bytes(c, &c->ws, &c->ws_bytes, (size_t)M2 * cf.n_out * sizeof(float) + ((size_t)M2 / std::max(cf.nt, 1) + 256) * h1 * sizeof(float));
+    if (rc) return rc;
+    BandArgs ba{};
+    ba.out = reinterpret_cast<float*>(c->ws); ba.ldo = cf.n_out;
+    ba.L0 = ba.out + (size_t)M2 * cf.n_out; ba.Ts = m.T_hs ? m.T_hs : m.T; ba.ldl = h1; ba.nt = cf.nt; ba.in_scale = 1.f;
+    ba.W1 = l1.Wh; ba.ldb1 = l1.ldwh; ba.bias1 = l1.bias_hs; ba.M = M2; ba.K1 = h1; ba.N1 = l1.out;
+    ba.acc_scale1 = 1.f; ba.out_scale = 1.f;
+    ba.W2p = lr.Wh_p; ba.ldb2 = lr.ldwh; ba.bias2 = lr.bias_hs; ba.n2 = cf.n_out; ba.acc_scale2 = 1.f;
+    ba.peak = nullptr;
+    if (!band8_serves(ba)) return fail(c, CSI_ERR_INVALID_ARG, "csi_profile_band_skeleton: the band kernel does not serve this shape");
+    Band8Args a8 = band8_args(ba);
+    size_t sz = sizeof(a8);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    const unsigned grid = (unsigned)((M2 + BAND_ROWS - 1) / BAND_ROWS);
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipModuleLaunchKernel(sk, grid, 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) HIP_TRY(c, hipModuleLaunchKernel(sk, grid, 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (ms_per_launch) *ms_per_launch = (double)ms / iters;
+    // executed f16 flop: 3 products, the padded 256-column regressor tile included (what the pipe really does)
+    if (executed_flops) *executed_flops = 3.0 * (2.0 * (double)grid * BAND_ROWS * l1.out * h1 + 2.0 * (double)grid * BAND_ROWS * 256.0 * l1.out);
+    return CSI_OK;
+#else
+    return fail(c, CSI_ERR_NOT_READY, "csi_profile_band_skeleton: the library was built without the band kernel");
+#endif
+}
+
 // the per-pair layers of one chunk: l0sum [M1][h1] fp32 -> out [M2][n_out] fp32; hbuf0 / hbuf1 are the
 // ping-pong activation buffers of the fp32 path re-used as hs matrices (same 4 bytes per element)
 int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, float* hbuf1, float* out) {

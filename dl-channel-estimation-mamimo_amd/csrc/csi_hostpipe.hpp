@@ -17,6 +17,7 @@
 // pinned (hipHostMalloc / hipHostRegister) are detected and DMA'd directly.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -139,8 +140,8 @@ inline void hp_stream_copy(void* __restrict__ dst, const void* __restrict__ src,
 
 }  // namespace
 
-struct csi_hostpipe {
-    // ---- host thread pool (parallel memcpy)
+// a small pool of host threads for the DRAM-bound staging loops (parallel memcpy / split / weave)
+struct HpPool {
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
@@ -148,14 +149,6 @@ struct csi_hostpipe {
     int job_n = 0, job_next = 0, job_left = 0;
     uint64_t job_gen = 0;
     bool stop = false;
-
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    char* pin_in[2] = {nullptr, nullptr};
-    char* pin_out[2] = {nullptr, nullptr};
-    size_t pin_in_bytes = 0, pin_out_bytes = 0;
-    char* dev[2] = {nullptr, nullptr};
-    size_t dev_bytes = 0;
 
     void worker_loop() {
         uint64_t seen = 0;
@@ -218,13 +211,33 @@ struct csi_hostpipe {
             if (b < e) f(b, e);
         });
     }
-    ~csi_hostpipe() {
+    ~HpPool() {
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
         }
         cv_job.notify_all();
         for (auto& t : workers) t.join();
+    }
+};
+
+struct csi_hostpipe {
+    // Two pools: the input side (user -> pinned staging) runs AHEAD on its own thread, beside the calling thread's output side
+    // (pinned staging -> user), so that neither waits for the other's DRAM-bound loop (round 4; they used to alternate on one pool)
+    HpPool pool_in, pool_out;
+    HpPool& pool() { return pool_out; }      // the single-pool users (plane entry points' copies)
+
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    char* pin_in[2] = {nullptr, nullptr};
+    char* pin_out[2] = {nullptr, nullptr};
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    char* dev[2] = {nullptr, nullptr};
+    size_t dev_bytes = 0;
+
+    void copy(void* dst, const void* src, size_t bytes) { pool_out.copy(dst, src, bytes); }
+    void copy_in(void* dst, const void* src, size_t bytes) { pool_in.copy(dst, src, bytes); }
+    ~csi_hostpipe() {
         for (int s = 0; s < 2; ++s) {
             if (pin_in[s]) hipHostFree(pin_in[s]);
             if (pin_out[s]) hipHostFree(pin_out[s]);
@@ -263,8 +276,12 @@ int hp_get(csi_ctx* c, csi_hostpipe** out) {
         int nt = c->host_threads;
         // copies and complex128 / complex64 conversions are DRAM-bound streams: one thread moves ~5-10 GB/s, the PCIe link
         // wants ~100 GB/s of staging in both directions together
-        if (nt <= 0) nt = (int)std::min<unsigned>(24, std::max<unsigned>(2, std::thread::hardware_concurrency() / 8));
-        h->start(nt - 1);
+        if (nt <= 0) nt = (int)std::min<unsigned>(32, std::max<unsigned>(2, std::thread::hardware_concurrency() / 6));
+        // the input side moves twice the bytes of the output side (complex128 read + two float planes written, against two planes
+        // read + complex64 written): two thirds of the threads
+        const int n_in = std::max(1, (2 * nt + 1) / 3), n_out = std::max(1, nt - n_in);
+        h->pool_in.start(n_in - 1);          // + the stager thread itself
+        h->pool_out.start(n_out - 1);        // + the calling thread
     }
     *out = c->hostpipe;
     return CSI_OK;
@@ -316,6 +333,69 @@ void hp_schedule(int64_t npkt, int64_t chunk, std::vector<int64_t>& first_of, st
     else if (npkt - p > 2 * small && npkt > chunk) { push(npkt - p - small); push(small); }
     else push(npkt - p);
 }
+
+// The input side of a pipelined call on its own thread: stage(i, slot) fills pinned_in[slot] for chunk i, at most two chunks ahead
+// of the uploads (slot i & 1 is free again once the H2D of chunk i - 2 has completed).  The calling thread asks wait_staged(i)
+// before it enqueues that upload and says uploaded(i) once the copy and its event are enqueued.
+struct HpStager {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t staged = 0, enqueued = 0;
+    bool abort = false;
+    hipError_t err = hipSuccess;
+
+    void start(int device, csi_hostpipe* h, int64_t nchunks, const std::function<void(int64_t, int)>& stage) {
+        th = std::thread([this, device, h, nchunks, stage] {
+            (void)hipSetDevice(device);
+            for (int64_t i = 0; i < nchunks; ++i) {
+                const int s = (int)(i & 1);
+                if (i >= 2) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return abort || enqueued >= i - 1; });
+                        if (abort) return;
+                    }
+                    const hipError_t e = hipEventSynchronize(h->ev_in[s]);       // the H2D of chunk i - 2 has left pinned_in[s]
+                    if (e != hipSuccess) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        err = e;
+                        abort = true;
+                        cv.notify_all();
+                        return;
+                    }
+                }
+                stage(i, s);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    staged = i + 1;
+                }
+                cv.notify_all();
+            }
+        });
+    }
+    bool wait_staged(int64_t i) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abort || staged > i; });
+        return !abort;
+    }
+    void uploaded(int64_t i) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            enqueued = i + 1;
+        }
+        cv.notify_all();
+    }
+    ~HpStager() { cancel(); }
+    void cancel() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            abort = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
 
 // run(d_re, d_im, np, d_ore, d_oim) enqueues the kernels of np packets on c->stream
 int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
@@ -400,6 +480,15 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
         }
         return CSI_OK;
     };
+    // pageable inputs: their staging copies run ahead on the stager thread (pool_in), beside this thread's drains (pool_out)
+    HpStager stager;
+    struct Guard { HpStager& st; ~Guard() { st.cancel(); } } guard{stager};      // any return below stops and joins it
+    if (!in_pinned)
+        stager.start(cf.device, h, nchunks, [&](int64_t i, int s) {
+            const size_t ioff = (size_t)first_of[(size_t)i] * cf.nr * cf.len_ltf;
+            h->copy_in(h->pin_in[s], re + ioff, in_pkt * np_of(i));
+            h->copy_in(h->pin_in[s] + in_pkt * chunk, im + ioff, in_pkt * np_of(i));
+        });
     for (int64_t i = 0; i < nchunks; ++i) {
         const int s = (int)(i & 1);
         const int64_t np = np_of(i);
@@ -414,13 +503,12 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
             HIP_TRY(c, hipMemcpyAsync(d_re, re + ioff, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
             HIP_TRY(c, hipMemcpyAsync(d_im, im + ioff, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         } else {
-            if (i >= 2) HIP_TRY(c, hipEventSynchronize(h->ev_in[s]));      // pinned_in[s] uploaded (chunk i-2)
-            h->copy(h->pin_in[s], re + ioff, in_pkt * np);
-            h->copy(h->pin_in[s] + in_pkt * chunk, im + ioff, in_pkt * np);
+            if (!stager.wait_staged(i)) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
             HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
             HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         }
         HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
+        stager.uploaded(i);
         // kernels: after the upload, and after the download of chunk i-2 released device[s] outputs
         HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
@@ -476,7 +564,7 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         const double* src = in + (size_t)first_of[(size_t)i] * in_n * 2;
         float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
         float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
-        h->parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
+        h->pool_in.parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
     };
     auto drain = [&](int64_t i) -> int {                                 // two float32 planes -> complex64, after the D2H of chunk i
         const int s = (int)(i & 1);
@@ -484,13 +572,17 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         const int64_t np = np_of(i);
         const float* p = reinterpret_cast<const float*>(h->pin_out[s]);
         auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
-            h->parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
+            h->pool_out.parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
         };
         // pinned[s] layout = device[s] output layout: dnn re | dnn im | ls re | ls im, each sized for `chunk` packets
         if (dnn_c64) weave(p, p + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
         if (ls_c64) weave(p + 2 * dnn_n * chunk, p + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
         return CSI_OK;
     };
+    // the complex128 -> float32 split runs ahead on the stager thread (pool_in), beside this thread's weaves (pool_out)
+    HpStager stager;
+    struct Guard { HpStager& st; ~Guard() { st.cancel(); } } guard{stager};      // any return below stops and joins it
+    stager.start(cf.device, h, nchunks, stage_in);
     for (int64_t i = 0; i < nchunks; ++i) {
         const int s = (int)(i & 1);
         const int64_t np = np_of(i);
@@ -498,11 +590,11 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
         float* d_out = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
-        if (i >= 2) HIP_TRY(c, hipEventSynchronize(h->ev_in[s]));      // pinned_in[s] uploaded (chunk i-2)
-        stage_in(i, s);
+        if (!stager.wait_staged(i)) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
         HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
+        stager.uploaded(i);
         HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
         if (ls_c64) {
@@ -533,6 +625,57 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         if (rc) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+// The link itself: `up` bytes host -> device and `down` bytes device -> host between PINNED host memory and device memory, in
+// 32 MiB pieces on the pipeline's two copy streams - each direction alone, then both at once (what a perfectly overlapped call of
+// these byte counts would need: the ceiling the host-buffer entry points are measured against).
+int hp_pcie_probe(csi_ctx* c, int64_t up, int64_t down, double* ms_up, double* ms_down, double* ms_both) {
+    csi_hostpipe* h = nullptr;
+    int rc = hp_get(c, &h);
+    if (rc) return rc;
+    const size_t piece = (size_t)32 << 20;
+    char *pu = nullptr, *pd = nullptr, *du = nullptr, *dd = nullptr;
+    auto release = [&] {
+        if (pu) hipHostFree(pu);
+        if (pd) hipHostFree(pd);
+        if (du) hipFree(du);
+        if (dd) hipFree(dd);
+    };
+    if (hipHostMalloc((void**)&pu, 2 * piece, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&pd, 2 * piece, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&du, 2 * piece) != hipSuccess || hipMalloc((void**)&dd, 2 * piece) != hipSuccess) {
+        release();
+        (void)hipGetLastError();
+        return fail(c, CSI_ERR_NOMEM, "csi_profile_pcie: staging allocation failed");
+    }
+    std::memset(pu, 1, 2 * piece);
+    std::memset(pd, 1, 2 * piece);
+    hipError_t e = hipMemset(dd, 0, 2 * piece);
+    auto run = [&](int64_t nu, int64_t nd, double* ms) {
+        if (e != hipSuccess) return;
+        e = hipDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
+        int k = 0;
+        for (int64_t o = 0; o < nu && e == hipSuccess; o += (int64_t)piece, ++k)
+            e = hipMemcpyAsync(du + (k & 1) * piece, pu + (k & 1) * piece, (size_t)std::min<int64_t>(piece, nu - o), hipMemcpyHostToDevice, h->s_in);
+        k = 0;
+        for (int64_t o = 0; o < nd && e == hipSuccess; o += (int64_t)piece, ++k)
+            e = hipMemcpyAsync(pd + (k & 1) * piece, dd + (k & 1) * piece, (size_t)std::min<int64_t>(piece, nd - o), hipMemcpyDeviceToHost, h->s_out);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->s_in);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->s_out);
+        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    double w = 0, a = 0, b = 0, ab = 0;
+    run(std::min<int64_t>(up, 4 * (int64_t)piece), std::min<int64_t>(down, 4 * (int64_t)piece), &w);      // warm-up
+    run(up, 0, &a);
+    run(0, down, &b);
+    run(up, down, &ab);
+    release();
+    if (e != hipSuccess) return fail(c, CSI_ERR_HIP, "csi_profile_pcie: %s", hipGetErrorString(e));
+    if (ms_up) *ms_up = a;
+    if (ms_down) *ms_down = b;
+    if (ms_both) *ms_both = ab;
     return CSI_OK;
 }
 

@@ -1744,6 +1744,20 @@ int csi_profile_reset(csi_ctx* c) {
     return rc;
 }
 
+int csi_profile_band_skeleton(csi_ctx* c, int64_t rows, int iters, double* ms_per_launch, double* executed_flops) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return band_skeleton_time(c, rows, iters, ms_per_launch, executed_flops);
+}
+
+int csi_profile_pcie(csi_ctx* c, int64_t h2d_bytes, int64_t d2h_bytes, double* ms_h2d, double* ms_d2h, double* ms_both) {
+    if (!c) return CSI_ERR_INVALID_ARG;
+    if (h2d_bytes < 0 || d2h_bytes < 0 || (h2d_bytes == 0 && d2h_bytes == 0)) return fail(c, CSI_ERR_INVALID_ARG, "csi_profile_pcie: bad byte counts");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return hp_pcie_probe(c, h2d_bytes, d2h_bytes, ms_h2d, ms_d2h, ms_both);
+}
+
 int csi_profile_num_kernels(void) { return K_COUNT; }
 
 const char* csi_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }

@@ -534,6 +534,20 @@ class CsiEngine:
     def profile_reset(self):
         self._check(self._lib.csi_profile_reset(self._ctx))
 
+    def pcie_probe(self, h2d_bytes, d2h_bytes):
+        """(ms up alone, ms down alone, ms both at once) for these byte counts between pinned host memory and the device on two
+        copy streams: the floor of a host-buffer call that moves them (csi_profile_pcie)."""
+        a, b, ab = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.csi_profile_pcie(self._ctx, int(h2d_bytes), int(d2h_bytes), ctypes.byref(a), ctypes.byref(b), ctypes.byref(ab)))
+        return a.value, b.value, ab.value
+
+    def band_skeleton(self, rows, iters=5):
+        """(ms per launch, executed f16 TFLOP/s) of the fused per-pair kernel's MFMA + barrier skeleton on the loaded model's own
+        operand data: the practical ceiling of that kernel on this part (csi_profile_band_skeleton)."""
+        ms, fl = ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.csi_profile_band_skeleton(self._ctx, int(rows), int(iters), ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value / (ms.value * 1e-3) / 1e12
+
     def profile(self):
         """dict kernel-name -> {ms, launches, flops, bytes} since the last reset."""
         out = {}

@@ -326,6 +326,17 @@ int  csi_clone_weights(csi_ctx* dst, const csi_ctx* src);
 /* Per-kernel HIP-event timing on the context's stream (the reference's --execTime). */
 int  csi_profile_enable(csi_ctx* ctx, int on);
 int  csi_profile_reset(csi_ctx* ctx);
+/* The practical ceiling of the dominant kernel, measured: the fused per-pair kernel's MFMA + barrier skeleton (no operand
+ * conversion, no operand streams, no LDS traffic; operand registers filled once with the loaded model's own split weights) over
+ * `rows` pair rows, `iters` launches timed with HIP events.  executed_flops = f16 flop per launch (3 MFMA products per multiply,
+ * padded regressor tile included).  The part clocks to its power budget (~1.4 kW, 1.8-2.0 GHz under these
+ * kernels), so the table peak of 2.5 PFLOP/s at 2.4 GHz is not reachable on real data; this is what is.  fp32 contexts with the
+ * two-hidden-layer model loaded; the outputs it writes are garbage and go to the context's workspace. */
+int  csi_profile_band_skeleton(csi_ctx* ctx, int64_t rows, int iters, double* ms_per_launch, double* executed_flops);
+/* The host link, measured in this process: h2d_bytes up and d2h_bytes down between pinned host memory and device memory on the
+ * host pipeline's two copy streams - each direction alone and both at once (ms).  ms_both is the floor of a host-buffer call that
+ * moves these byte counts; bench.py reports the host-buffer entry points as a fraction of it. */
+int  csi_profile_pcie(csi_ctx* ctx, int64_t h2d_bytes, int64_t d2h_bytes, double* ms_h2d, double* ms_d2h, double* ms_both);
 int  csi_profile_num_kernels(void);
 const char* csi_profile_kernel_name(int kernel_id);
 /* total_ms / launches / flops / bytes accumulated since the last reset. */
