@@ -120,12 +120,16 @@ def build_band_kernel(verbose=False):
     import tempfile
     csrc = os.path.join(_PKG_DIR, 'csrc')
     gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
+    names = ['csi_band8', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd']
+    tag = '// kernels: ' + ' '.join(names)
     if os.path.exists(inc) and os.path.getmtime(inc) >= os.path.getmtime(gen):
-        return inc
+        with open(inc) as f:
+            if f.readline().strip() == tag:           # same generator, same kernel list
+                return inc
     llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
     with tempfile.TemporaryDirectory() as tmp:
         asm, obj, co = (os.path.join(tmp, 'band8.' + e) for e in ('s', 'o', 'hsaco'))
-        cmds = [[sys.executable, gen, asm, 'csi_band8', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd'],
+        cmds = [[sys.executable, gen, asm] + names,
                 [os.path.join(llvm, 'clang'), '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', asm, '-o', obj],
                 [os.path.join(llvm, 'ld.lld'), '-shared', obj, '-o', co]]
         for cmd in cmds:
@@ -138,6 +142,7 @@ def build_band_kernel(verbose=False):
             blob = f.read()
     rows = [', '.join('0x%02x' % b for b in blob[i:i + 24]) for i in range(0, len(blob), 24)]
     with open(inc + '.tmp', 'w') as f:
+        f.write(tag + '\n')
         f.write('// generated by _lib.build_band_kernel from band_kernel_gen.py - gfx950 code object of csi_band8 (%d bytes)\n' % len(blob))
         f.write('alignas(4096) static const unsigned char band8_hsaco[] = {\n' + ',\n'.join(rows) + '};\n')
     os.replace(inc + '.tmp', inc)

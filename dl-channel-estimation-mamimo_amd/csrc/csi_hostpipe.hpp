@@ -235,6 +235,15 @@ struct csi_hostpipe {
     char* dev[2] = {nullptr, nullptr};
     size_t dev_bytes = 0;
 
+    // where the time of the last pipelined call went (microseconds; "hp_*_us" options, tools/hostpath_probe.py)
+    std::atomic<int64_t> us_stage{0};        // stager thread busy converting / copying user -> pinned
+    int64_t us_wait_stage = 0;               // calling thread waiting for a staged chunk
+    int64_t us_wait_out = 0;                 // ... for a download to finish
+    int64_t us_weave = 0;                    // ... converting / copying pinned -> user
+    int64_t us_total = 0;
+    void clock_reset() { us_stage = 0; us_wait_stage = us_wait_out = us_weave = us_total = 0; }
+    static int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
     void copy(void* dst, const void* src, size_t bytes) { pool_out.copy(dst, src, bytes); }
     void copy_in(void* dst, const void* src, size_t bytes) { pool_in.copy(dst, src, bytes); }
     ~csi_hostpipe() {
@@ -365,7 +374,9 @@ struct HpStager {
                         return;
                     }
                 }
+                const int64_t t0 = csi_hostpipe::now_us();
                 stage(i, s);
+                h->us_stage += csi_hostpipe::now_us() - t0;
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     staged = i + 1;
@@ -552,6 +563,7 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     const size_t out_pkt = (dnn_n + ls_n) * sizeof(float);              // one plane of everything that comes back
     int64_t chunk = std::max<int64_t>(1, (int64_t)65536 / std::max(1, cf.nr * cf.nt));
     chunk = std::max<int64_t>(chunk, ((int64_t)8 << 20) / (int64_t)in_pkt);
+    if (c->hp_chunk_packets > 0) chunk = c->hp_chunk_packets;
     chunk = std::min(chunk, npkt);
     rc = hp_reserve(c, h, 2 * in_pkt * chunk, 2 * out_pkt * chunk, true, true);
     if (rc) return rc;
@@ -566,9 +578,15 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
         h->pool_in.parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
     };
+    h->clock_reset();
+    const int64_t t_begin = csi_hostpipe::now_us();
     auto drain = [&](int64_t i) -> int {                                 // two float32 planes -> complex64, after the D2H of chunk i
         const int s = (int)(i & 1);
+        const int64_t t0 = csi_hostpipe::now_us();
         HIP_TRY(c, hipEventSynchronize(h->ev_out[s]));
+        const int64_t t1 = csi_hostpipe::now_us();
+        h->us_wait_out += t1 - t0;
+        struct Acc { csi_hostpipe* h; int64_t t1; ~Acc() { h->us_weave += csi_hostpipe::now_us() - t1; } } acc{h, t1};
         const int64_t np = np_of(i);
         const float* p = reinterpret_cast<const float*>(h->pin_out[s]);
         auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
@@ -590,7 +608,12 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
         float* d_out = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
-        if (!stager.wait_staged(i)) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
+        {
+            const int64_t t0 = csi_hostpipe::now_us();
+            const bool ok = stager.wait_staged(i);
+            h->us_wait_stage += csi_hostpipe::now_us() - t0;
+            if (!ok) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
+        }
         HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
         HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
@@ -625,6 +648,7 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         if (rc) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h->us_total = csi_hostpipe::now_us() - t_begin;
     return CSI_OK;
 }
 

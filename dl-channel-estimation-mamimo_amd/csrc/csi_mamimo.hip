@@ -1077,6 +1077,12 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "ls_ringb_min") *value = c->ls_ringb_min;
     else if (n == "ls_pilot_pieces") *value = c->p_pieces;
     else if (n == "ls_mode") *value = ls_plan(c).mode;
+    else if (n == "hp_stage_us") *value = c->hostpipe ? (int64_t)c->hostpipe->us_stage : 0;           // read-only: where the last csi_estimate_c128 spent its time
+    else if (n == "hp_wait_stage_us") *value = c->hostpipe ? c->hostpipe->us_wait_stage : 0;
+    else if (n == "hp_wait_out_us") *value = c->hostpipe ? c->hostpipe->us_wait_out : 0;
+    else if (n == "hp_weave_us") *value = c->hostpipe ? c->hostpipe->us_weave : 0;
+    else if (n == "hp_total_us") *value = c->hostpipe ? c->hostpipe->us_total : 0;
+    else if (n == "hp_chunk_packets") *value = c->hp_chunk_packets;
     else if (n == "ls_fast_perm") *value = c->ls_fast_perm;
     else if (n == "ls_overlap_cus") *value = c->ls_overlap_cus;
     else if (n == "ls_overlap_stride") *value = c->ls_overlap_stride;
@@ -1143,7 +1149,7 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         drop_graphs(c);
         c->bf16_fused_h1 = value != 0;
     } else if (n == "host_threads") {
-        if (value < 0 || value > 64) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 64");
+        if (value < 0 || value > 256) return fail(c, CSI_ERR_INVALID_ARG, "host_threads must be 0 (automatic) .. 256");
         if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
         c->host_threads = (int)value;
     } else if (n == "hs_vm_cast" || n == "hs_vm_pair") {
@@ -1154,6 +1160,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 255) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 (LS in front of the DNN kernels on one stream) .. 255", name);
         drop_graphs(c);
         (n == "ls_overlap_cus" ? c->ls_overlap_cus : c->ls_overlap_stride) = (int)value;
+    } else if (n == "hp_chunk_packets") {
+        if (value < 0 || value > (1 << 20)) return fail(c, CSI_ERR_INVALID_ARG, "hp_chunk_packets must be 0 (automatic) .. 2^20");
+        c->hp_chunk_packets = (int)value;
     } else if (n == "ls_fast_perm") {
         c->ls_fast_perm = value != 0;
         drop_graphs(c);

@@ -72,8 +72,12 @@ def main():
     x.imag = x.real
     dnn = np.zeros((npkt, nr, nt, 234), np.complex64)
     ls = np.zeros((npkt, nr, nt, 234), np.complex64)
-    for threads in ([a.threads] if a.threads else [0, 4, 8, 16, 24, 32, 48]):
+    up, down = x.nbytes // 2, dnn.nbytes
+    a_ms, b_ms, ab_ms = e.pcie_probe(up, down)
+    print(f'link: {up / 1e9:.2f} GB up alone {a_ms:.2f} ms ({up / a_ms / 1e6:.1f} GB/s), {down / 1e9:.2f} GB down alone {b_ms:.2f} ms ({down / b_ms / 1e6:.1f} GB/s), both at once {ab_ms:.2f} ms (os.cpu_count() = {os.cpu_count()})')
+    for threads, chunk in ([(a.threads, 0)] if a.threads else [(0, 0), (8, 0), (16, 0), (24, 0), (32, 0), (48, 0), (64, 0), (96, 0), (32, 256), (32, 128), (64, 256), (64, 128)]):
         e.set_option('host_threads', threads)
+        e.set_option('hp_chunk_packets', chunk)
         for what, kw in (('DNN + LS', dict(out=(dnn, ls))), ('DNN only', dict(ls=False, out=(dnn, None)))):
             e.estimate(x, **kw)
             ts = []
@@ -83,8 +87,10 @@ def main():
                 ts.append(time.perf_counter() - t0)
             t = min(ts)
             moved = x.nbytes // 2 + dnn.nbytes + (ls.nbytes if 'LS' in what else 0)
-            print(f'c128 -> c64 {what:9s} host_threads={threads:2d} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
-                  f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions)')
+            us = {k: e.get_option('hp_' + k + '_us') / 1e3 for k in ('total', 'stage', 'wait_stage', 'wait_out', 'weave')}
+            print(f'c128 -> c64 {what:9s} host_threads={threads:2d} chunk={chunk:3d} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
+                  f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions) | last call: total {us["total"]:.1f} ms, stager busy {us["stage"]:.1f}, '
+                  f'main waits: staged chunk {us["wait_stage"]:.1f}, download {us["wait_out"]:.1f}, weave {us["weave"]:.1f}')
 
 
 if __name__ == '__main__':
