@@ -239,9 +239,10 @@ struct csi_hostpipe {
     std::atomic<int64_t> us_stage{0};        // stager thread busy converting / copying user -> pinned
     int64_t us_wait_stage = 0;               // calling thread waiting for a staged chunk
     int64_t us_wait_out = 0;                 // ... for a download to finish
-    int64_t us_weave = 0;                    // ... converting / copying pinned -> user
+    std::atomic<int64_t> us_weave_thread{0}; // drainer thread busy converting / copying pinned -> user
+    int64_t us_weave = 0;                    // (copy of it when the call ends)
     int64_t us_total = 0;
-    void clock_reset() { us_stage = 0; us_wait_stage = us_wait_out = us_weave = us_total = 0; }
+    void clock_reset() { us_stage = 0; us_weave_thread = 0; us_wait_stage = us_wait_out = us_weave = us_total = 0; }
     static int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     void copy(void* dst, const void* src, size_t bytes) { pool_out.copy(dst, src, bytes); }
@@ -343,29 +344,36 @@ void hp_schedule(int64_t npkt, int64_t chunk, std::vector<int64_t>& first_of, st
     else push(npkt - p);
 }
 
-// The input side of a pipelined call on its own thread: stage(i, slot) fills pinned_in[slot] for chunk i, at most two chunks ahead
-// of the uploads (slot i & 1 is free again once the H2D of chunk i - 2 has completed).  The calling thread asks wait_staged(i)
-// before it enqueues that upload and says uploaded(i) once the copy and its event are enqueued.
-struct HpStager {
+// A pipelined call is run by three threads (round 4; one thread used to do all of it in turn, and the H2D stream stood still
+// whenever that thread was converting results):
+//   stager   stage(i, slot): user memory -> pinned_in[slot]      at most two chunks ahead of the uploads (the slot is free again
+//                                                                once the H2D of chunk i - 2 has completed)
+//   caller   enqueues H2D(i), the kernels of chunk i, D2H(i) and records the events; blocks only on real dependencies
+//   drainer  weave(i, slot): pinned_out[slot] -> user memory     behind the D2H of chunk i; the caller enqueues D2H(i + 2) into the
+//                                                                same slot only after that
+// Each side owns a pool of helper threads for its DRAM-bound loop (csi_hostpipe::pool_in / pool_out).
+struct HpSide {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    int64_t staged = 0, enqueued = 0;
+    int64_t done = 0;           // chunks this side has finished (staged / drained)
+    int64_t released = 0;       // chunks the caller has handed over (H2D enqueued / D2H enqueued)
     bool abort = false;
     hipError_t err = hipSuccess;
 
-    void start(int device, csi_hostpipe* h, int64_t nchunks, const std::function<void(int64_t, int)>& stage) {
-        th = std::thread([this, device, h, nchunks, stage] {
+    // stager: needs_release_of(i) = i - 2 (the upload that frees its slot); drainer: = i (its own download)
+    void start(int device, int64_t nchunks, int lag, hipEvent_t* ev, std::atomic<int64_t>* busy_us, const std::function<void(int64_t, int)>& work) {
+        th = std::thread([this, device, nchunks, lag, ev, busy_us, work] {
             (void)hipSetDevice(device);
             for (int64_t i = 0; i < nchunks; ++i) {
                 const int s = (int)(i & 1);
-                if (i >= 2) {
+                if (i - lag >= 0) {
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return abort || enqueued >= i - 1; });
+                        cv.wait(lk, [&] { return abort || released > i - lag; });
                         if (abort) return;
                     }
-                    const hipError_t e = hipEventSynchronize(h->ev_in[s]);       // the H2D of chunk i - 2 has left pinned_in[s]
+                    const hipError_t e = hipEventSynchronize(ev[s]);
                     if (e != hipSuccess) {
                         std::lock_guard<std::mutex> lk(mu);
                         err = e;
@@ -375,29 +383,28 @@ struct HpStager {
                     }
                 }
                 const int64_t t0 = csi_hostpipe::now_us();
-                stage(i, s);
-                h->us_stage += csi_hostpipe::now_us() - t0;
+                work(i, s);
+                if (busy_us) *busy_us += csi_hostpipe::now_us() - t0;
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    staged = i + 1;
+                    done = i + 1;
                 }
                 cv.notify_all();
             }
         });
     }
-    bool wait_staged(int64_t i) {
+    bool wait_done(int64_t n) {               // until chunks 0 .. n - 1 are through this side
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return abort || staged > i; });
+        cv.wait(lk, [&] { return abort || done >= n; });
         return !abort;
     }
-    void uploaded(int64_t i) {
+    void release(int64_t i) {
         {
             std::lock_guard<std::mutex> lk(mu);
-            enqueued = i + 1;
+            released = i + 1;
         }
         cv.notify_all();
     }
-    ~HpStager() { cancel(); }
     void cancel() {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -406,7 +413,68 @@ struct HpStager {
         cv.notify_all();
         if (th.joinable()) th.join();
     }
+    void join() { if (th.joinable()) th.join(); }
+    ~HpSide() { cancel(); }
 };
+
+struct HpPipe {
+    int64_t nchunks = 0;
+    std::function<void(int64_t, int)> stage;          // empty: the caller's inputs are pinned, H2D straight from them
+    std::function<int(int64_t, int)> enqueue_in;      // H2D of chunk i on h->s_in
+    std::function<int(int64_t, int)> compute;         // kernels of chunk i on c->stream
+    std::function<int(int64_t, int)> enqueue_out;     // D2H of chunk i on h->s_out
+    std::function<void(int64_t, int)> weave;          // empty: the caller's outputs are pinned, D2H straight into them
+};
+
+int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
+    const int dev = c->cfg.device;
+    h->clock_reset();
+    const int64_t t_begin = csi_hostpipe::now_us();
+    HpSide stager, drainer;                            // their destructors stop and join them on every return path
+    if (p.stage) stager.start(dev, p.nchunks, 2, h->ev_in, &h->us_stage, p.stage);
+    if (p.weave) drainer.start(dev, p.nchunks, 0, h->ev_out, &h->us_weave_thread, p.weave);
+    auto timed_wait = [&](HpSide& side, int64_t n, int64_t* acc) {
+        const int64_t t0 = csi_hostpipe::now_us();
+        const bool ok = side.wait_done(n);
+        *acc += csi_hostpipe::now_us() - t0;
+        return ok;
+    };
+    for (int64_t i = 0; i < p.nchunks; ++i) {
+        const int s = (int)(i & 1);
+        // device[s] inputs are free once the kernels of chunk i - 2 are done
+        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
+        if (p.stage && !timed_wait(stager, i + 1, &h->us_wait_stage))
+            return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
+        int rc = p.enqueue_in(i, s);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
+        if (p.stage) stager.release(i);
+        // kernels: behind the upload, and behind the download of chunk i - 2 that releases device[s]'s output half
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
+        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
+        rc = p.compute(i, s);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
+        // pinned_out[s] must have been handed to the user (chunk i - 2) before the next download lands in it
+        if (p.weave && i >= 2 && !timed_wait(drainer, i - 1, &h->us_wait_out))
+            return fail(c, CSI_ERR_HIP, "host pipeline: result staging failed: %s", hipGetErrorString(drainer.err));
+        HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
+        rc = p.enqueue_out(i, s);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(h->ev_out[s], h->s_out));
+        if (p.weave) drainer.release(i);
+    }
+    if (p.weave) {
+        if (!timed_wait(drainer, p.nchunks, &h->us_wait_out))
+            return fail(c, CSI_ERR_HIP, "host pipeline: result staging failed: %s", hipGetErrorString(drainer.err));
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(h->s_out));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h->us_weave = (int64_t)h->us_weave_thread;
+    h->us_total = csi_hostpipe::now_us() - t_begin;
+    return CSI_OK;
+}
 
 // run(d_re, d_im, np, d_ore, d_oim) enqueues the kernels of np packets on c->stream
 int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* im, int64_t npkt, float* o_re, float* o_im, int n_out,
@@ -480,71 +548,41 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
         return CSI_OK;
     }
     auto np_of = [&](int64_t i) { return size_of[(size_t)i]; };
-    auto drain = [&](int64_t i) -> int {                 // pinned[slot] -> user, after the D2H of chunk i
-        const int s = (int)(i & 1);
-        HIP_TRY(c, hipEventSynchronize(h->ev_out[s]));
-        if (!out_pinned) {
-            const int64_t np = np_of(i);
-            const size_t off = (size_t)first_of[(size_t)i] * cf.nr * cf.nt * n_out;
-            h->copy(o_re + off, h->pin_out[s], out_pkt * np);
-            h->copy(o_im + off, h->pin_out[s] + out_pkt * chunk, out_pkt * np);
-        }
-        return CSI_OK;
-    };
-    // pageable inputs: their staging copies run ahead on the stager thread (pool_in), beside this thread's drains (pool_out)
-    HpStager stager;
-    struct Guard { HpStager& st; ~Guard() { st.cancel(); } } guard{stager};      // any return below stops and joins it
+    HpPipe p;
+    p.nchunks = nchunks;
     if (!in_pinned)
-        stager.start(cf.device, h, nchunks, [&](int64_t i, int s) {
+        p.stage = [&](int64_t i, int s) {
             const size_t ioff = (size_t)first_of[(size_t)i] * cf.nr * cf.len_ltf;
             h->copy_in(h->pin_in[s], re + ioff, in_pkt * np_of(i));
             h->copy_in(h->pin_in[s] + in_pkt * chunk, im + ioff, in_pkt * np_of(i));
-        });
-    for (int64_t i = 0; i < nchunks; ++i) {
-        const int s = (int)(i & 1);
-        const int64_t np = np_of(i);
+        };
+    p.enqueue_in = [&](int64_t i, int s) -> int {
         const size_t ioff = (size_t)first_of[(size_t)i] * cf.nr * cf.len_ltf;
-        float* d_re = reinterpret_cast<float*>(h->dev[s]);
-        float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
-        float* d_ore = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
-        float* d_oim = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk + out_pkt * chunk);
-        // device[s] inputs are free once the kernels of chunk i-2 are done
-        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
-        if (in_pinned) {
-            HIP_TRY(c, hipMemcpyAsync(d_re, re + ioff, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-            HIP_TRY(c, hipMemcpyAsync(d_im, im + ioff, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-        } else {
-            if (!stager.wait_staged(i)) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
-            HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-            HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-        }
-        HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
-        stager.uploaded(i);
-        // kernels: after the upload, and after the download of chunk i-2 released device[s] outputs
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
-        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
-        rc = run(d_re, d_im, np, d_ore, d_oim);
-        if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
-        // pinned_out[s] must have been drained to the user (chunk i-2) before it is overwritten
-        if (i >= 2) { rc = drain(i - 2); if (rc) return rc; }
-        HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
+        const float* s_re = in_pinned ? re + ioff : reinterpret_cast<const float*>(h->pin_in[s]);
+        const float* s_im = in_pinned ? im + ioff : reinterpret_cast<const float*>(h->pin_in[s] + in_pkt * chunk);
+        HIP_TRY(c, hipMemcpyAsync(h->dev[s], s_re, in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
+        HIP_TRY(c, hipMemcpyAsync(h->dev[s] + in_pkt * chunk, s_im, in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
+        return CSI_OK;
+    };
+    p.compute = [&](int64_t i, int s) -> int {
+        return run(reinterpret_cast<float*>(h->dev[s]), reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk), np_of(i),
+                   reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk), reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk + out_pkt * chunk));
+    };
+    p.enqueue_out = [&](int64_t i, int s) -> int {
         const size_t ooff = (size_t)first_of[(size_t)i] * cf.nr * cf.nt * n_out;
-        if (out_pinned) {
-            HIP_TRY(c, hipMemcpyAsync(o_re + ooff, d_ore, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
-            HIP_TRY(c, hipMemcpyAsync(o_im + ooff, d_oim, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s], d_ore, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + out_pkt * chunk, d_oim, out_pkt * np, hipMemcpyDeviceToHost, h->s_out));
-        }
-        HIP_TRY(c, hipEventRecord(h->ev_out[s], h->s_out));
-    }
-    for (int64_t i = std::max<int64_t>(0, nchunks - 2); i < nchunks; ++i) {
-        rc = drain(i);
-        if (rc) return rc;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return CSI_OK;
+        float* t_re = out_pinned ? o_re + ooff : reinterpret_cast<float*>(h->pin_out[s]);
+        float* t_im = out_pinned ? o_im + ooff : reinterpret_cast<float*>(h->pin_out[s] + out_pkt * chunk);
+        HIP_TRY(c, hipMemcpyAsync(t_re, h->dev[s] + 2 * in_pkt * chunk, out_pkt * np_of(i), hipMemcpyDeviceToHost, h->s_out));
+        HIP_TRY(c, hipMemcpyAsync(t_im, h->dev[s] + 2 * in_pkt * chunk + out_pkt * chunk, out_pkt * np_of(i), hipMemcpyDeviceToHost, h->s_out));
+        return CSI_OK;
+    };
+    if (!out_pinned)
+        p.weave = [&](int64_t i, int s) {
+            const size_t off = (size_t)first_of[(size_t)i] * cf.nr * cf.nt * n_out;
+            h->copy(o_re + off, h->pin_out[s], out_pkt * np_of(i));
+            h->copy(o_im + off, h->pin_out[s] + out_pkt * chunk, out_pkt * np_of(i));
+        };
+    return hp_run(c, h, p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -571,85 +609,54 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     hp_schedule(npkt, chunk, first_of, size_of);
     const int64_t nchunks = (int64_t)size_of.size();
     auto np_of = [&](int64_t i) { return size_of[(size_t)i]; };
-    auto stage_in = [&](int64_t i, int s) {                              // complex128 -> two float32 planes in pinned[s]
-        const int64_t np = np_of(i);
+    HpPipe p;
+    p.nchunks = nchunks;
+    p.stage = [&](int64_t i, int s) {                                    // complex128 -> two float32 planes in pinned_in[s]
         const double* src = in + (size_t)first_of[(size_t)i] * in_n * 2;
         float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
         float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
-        h->pool_in.parallel_range((size_t)np * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
+        h->pool_in.parallel_range((size_t)np_of(i) * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
     };
-    h->clock_reset();
-    const int64_t t_begin = csi_hostpipe::now_us();
-    auto drain = [&](int64_t i) -> int {                                 // two float32 planes -> complex64, after the D2H of chunk i
-        const int s = (int)(i & 1);
-        const int64_t t0 = csi_hostpipe::now_us();
-        HIP_TRY(c, hipEventSynchronize(h->ev_out[s]));
-        const int64_t t1 = csi_hostpipe::now_us();
-        h->us_wait_out += t1 - t0;
-        struct Acc { csi_hostpipe* h; int64_t t1; ~Acc() { h->us_weave += csi_hostpipe::now_us() - t1; } } acc{h, t1};
-        const int64_t np = np_of(i);
-        const float* p = reinterpret_cast<const float*>(h->pin_out[s]);
-        auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
-            h->pool_out.parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
-        };
-        // pinned[s] layout = device[s] output layout: dnn re | dnn im | ls re | ls im, each sized for `chunk` packets
-        if (dnn_c64) weave(p, p + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
-        if (ls_c64) weave(p + 2 * dnn_n * chunk, p + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
+    p.enqueue_in = [&](int64_t i, int s) -> int {
+        HIP_TRY(c, hipMemcpyAsync(h->dev[s], h->pin_in[s], in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
+        HIP_TRY(c, hipMemcpyAsync(h->dev[s] + in_pkt * chunk, h->pin_in[s] + in_pkt * chunk, in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
         return CSI_OK;
     };
-    // the complex128 -> float32 split runs ahead on the stager thread (pool_in), beside this thread's weaves (pool_out)
-    HpStager stager;
-    struct Guard { HpStager& st; ~Guard() { st.cancel(); } } guard{stager};      // any return below stops and joins it
-    stager.start(cf.device, h, nchunks, stage_in);
-    for (int64_t i = 0; i < nchunks; ++i) {
-        const int s = (int)(i & 1);
-        const int64_t np = np_of(i);
+    // device[s] / pinned_out[s] output layout: dnn re | dnn im | ls re | ls im, each sized for `chunk` packets
+    p.compute = [&](int64_t i, int s) -> int {
         float* d_re = reinterpret_cast<float*>(h->dev[s]);
         float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
         float* d_out = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
-        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
-        {
-            const int64_t t0 = csi_hostpipe::now_us();
-            const bool ok = stager.wait_staged(i);
-            h->us_wait_stage += csi_hostpipe::now_us() - t0;
-            if (!ok) return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
-        }
-        HIP_TRY(c, hipMemcpyAsync(d_re, h->pin_in[s], in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-        HIP_TRY(c, hipMemcpyAsync(d_im, h->pin_in[s] + in_pkt * chunk, in_pkt * np, hipMemcpyHostToDevice, h->s_in));
-        HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
-        stager.uploaded(i);
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
-        if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
-        if (ls_c64) {
-            rc = csi_ls_estimate_device(c, d_re, d_im, np, d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk);
-            if (rc) return rc;
-        }
+        int r = CSI_OK;
+        if (ls_c64) r = csi_ls_estimate_device(c, d_re, d_im, np_of(i), d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk);
+        if (!r && dnn_c64) r = csi_predict_device(c, d_re, d_im, np_of(i), d_out, d_out + dnn_n * chunk);
+        return r;
+    };
+    p.enqueue_out = [&](int64_t i, int s) -> int {                      // one D2H per plane actually filled (np of chunk packets)
+        const float* d_out = reinterpret_cast<const float*>(h->dev[s] + 2 * in_pkt * chunk);
+        float* t = reinterpret_cast<float*>(h->pin_out[s]);
+        const int64_t np = np_of(i);
         if (dnn_c64) {
-            rc = csi_predict_device(c, d_re, d_im, np, d_out, d_out + dnn_n * chunk);
-            if (rc) return rc;
-        }
-        HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
-        if (i >= 2) { rc = drain(i - 2); if (rc) return rc; }
-        HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
-        // one D2H per plane actually filled (np of chunk packets)
-        if (dnn_c64) {
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s], d_out, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + dnn_n * chunk * sizeof(float), d_out + dnn_n * chunk, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(t, d_out, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(t + dnn_n * chunk, d_out + dnn_n * chunk, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
         }
         if (ls_c64) {
             const size_t o = 2 * dnn_n * chunk;
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + o * sizeof(float), d_out + o, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
-            HIP_TRY(c, hipMemcpyAsync(h->pin_out[s] + (o + ls_n * chunk) * sizeof(float), d_out + o + ls_n * chunk, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(t + o, d_out + o, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            HIP_TRY(c, hipMemcpyAsync(t + o + ls_n * chunk, d_out + o + ls_n * chunk, ls_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
         }
-        HIP_TRY(c, hipEventRecord(h->ev_out[s], h->s_out));
-    }
-    for (int64_t i = std::max<int64_t>(0, nchunks - 2); i < nchunks; ++i) {
-        rc = drain(i);
-        if (rc) return rc;
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    h->us_total = csi_hostpipe::now_us() - t_begin;
-    return CSI_OK;
+        return CSI_OK;
+    };
+    p.weave = [&](int64_t i, int s) {                                    // two float32 planes -> complex64 in the caller's arrays
+        const int64_t np = np_of(i);
+        const float* t = reinterpret_cast<const float*>(h->pin_out[s]);
+        auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
+            h->pool_out.parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
+        };
+        if (dnn_c64) weave(t, t + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
+        if (ls_c64) weave(t + 2 * dnn_n * chunk, t + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
+    };
+    return hp_run(c, h, p);
 }
 
 // The link itself: `up` bytes host -> device and `down` bytes device -> host between PINNED host memory and device memory, in
