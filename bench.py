@@ -329,7 +329,30 @@ def main():
         t3 = sorted(t3s)[1]
         host_path['python_c128_to_c64']['dnn_only'] = {'pairs_per_s': k * nr * nt / t3, 'ms': t3 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t3s],
                                                        'd2h_bytes': int(bufs[0].nbytes),
-                                                       'note': 'CsiEngine.estimate(ls=False): what CSIPredictor.inference returns (model_real + 1j * model_imag)'}
+                                                       'note': 'CsiEngine.estimate(ls=False): what CSIPredictor.inference returns (model_real + 1j * model_imag).  Between this and the link\'s floor '
+                                                               '(pcie_bound_ms) lie the two host passes a pageable complex128 / complex64 pair needs (split into float32 planes in pinned '
+                                                               'staging, weave of the result planes): DRAM-bound loops on the CPUs the container grants (host_cpu_quota)'}
+        # the plane entry point with buffers the CALLER has pinned (csi_host_malloc): no staging pass on the host at all
+        try:
+            pr, pi = eng.pinned_empty(h_re.shape), eng.pinned_empty(h_im.shape)
+            po = (eng.pinned_empty(o_nn[0].shape), eng.pinned_empty(o_nn[1].shape))
+            pr[...] = h_re; pi[...] = h_im
+            eng.predict(pr, pi, out=po)
+            tp = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                eng.predict(pr, pi, out=po)
+                tp.append(time.perf_counter() - t0)
+            tpm = sorted(tp)[1]
+            host_path['pinned_planes_dnn'] = {'ms': tpm * 1e3, 'pairs_per_s': k * nr * nt / tpm, 'ms_all': [round(t * 1e3, 2) for t in tp],
+                                              'note': 'csi_predict on float32 planes in caller-pinned memory (csi_host_malloc): H2D / D2H straight from / into them'}
+            del pr, pi, po
+        except Exception as e:
+            host_path['pinned_planes_error'] = repr(e)
+        try:
+            host_path['host_cpu_quota'] = open('/sys/fs/cgroup/cpu.max').read().strip() + ' (cgroup cpu.max: quota / period us); os.cpu_count() = %d' % os.cpu_count()
+        except OSError:
+            host_path['host_cpu_quota'] = 'no cgroup v2 cpu.max; os.cpu_count() = %d' % os.cpu_count()
         # the link itself, same process, same byte counts: pinned host memory <-> device on the pipeline's two copy streams
         up = int(2 * h_re.nbytes)                      # two float32 planes (the complex128 batch is split on the host)
         try:
@@ -341,6 +364,9 @@ def main():
                                'h2d_gbs': round(up / a / 1e6, 1), 'd2h_gbs': round(down / b / 1e6, 1),
                                'what': 'csi_profile_pcie: bare hipMemcpyAsync of these byte counts between pinned host memory and the device, 32 MiB pieces, two streams'}
                 tgt['frac_of_pcie_bound'] = round(ab / tgt['ms'], 3)
+                if key == 'dnn_only' and 'pinned_planes_dnn' in host_path:
+                    host_path['pinned_planes_dnn']['pcie_bound_ms'] = round(ab, 3)
+                    host_path['pinned_planes_dnn']['frac_of_pcie_bound'] = round(ab / host_path['pinned_planes_dnn']['ms'], 3)
         except Exception as e:                      # a side measurement never takes the line down
             host_path['pcie_probe_error'] = repr(e)
         del x128, bufs

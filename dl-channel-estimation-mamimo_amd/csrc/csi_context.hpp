@@ -118,6 +118,7 @@ struct csi_ctx {
     csi_hostpipe* hostpipe = nullptr;               // streams / pinned slots / host threads of the host-buffer entry points
     csi_comm* comm = nullptr;                       // RCCL communicator of csi_comm_init (weight broadcast)
     int host_threads = 0;                           // "host_threads" option: threads of the user <-> pinned copies (0 = automatic)
+    int hp_side_threads = 1;                        // "hp_side_threads": 1 = input staging and result staging on their own threads beside the caller's enqueue loop, 0 = inline, in turn
     int hp_chunk_packets = 0;                       // "hp_chunk_packets": packets per pipeline slot of the host-buffer entry points (0 = automatic)
     float* P = nullptr;          // device [nt][nt]
     float* Pbf = nullptr;        // device: bf16 pieces of P in MFMA operand order (ls_pilot layout of ls_estimate_ringb_kernel), 2 per float

@@ -286,12 +286,22 @@ int hp_get(csi_ctx* c, csi_hostpipe** out) {
         int nt = c->host_threads;
         // copies and complex128 / complex64 conversions are DRAM-bound streams: one thread moves ~5-10 GB/s, the PCIe link
         // wants ~100 GB/s of staging in both directions together
-        if (nt <= 0) nt = (int)std::min<unsigned>(32, std::max<unsigned>(2, std::thread::hardware_concurrency() / 6));
+        if (nt <= 0) {
+            nt = (int)std::min<unsigned>(32, std::max<unsigned>(2, std::thread::hardware_concurrency() / 6));
+            // a container's CPU quota (cgroup v2 cpu.max "<quota> <period>"): more runnable threads than that are throttled, not faster
+            // (measured on the pool's boxes: 256 hardware threads visible, quota 16 CPUs - profiles/r04_hostpath_probe.txt)
+            if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                long long quota = 0, period = 0;
+                if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                    nt = std::max(2, std::min(nt, (int)((quota + period - 1) / period)));
+                std::fclose(f);
+            }
+        }
         // the input side moves twice the bytes of the output side (complex128 read + two float planes written, against two planes
         // read + complex64 written): two thirds of the threads
         const int n_in = std::max(1, (2 * nt + 1) / 3), n_out = std::max(1, nt - n_in);
-        h->pool_in.start(n_in - 1);          // + the stager thread itself
-        h->pool_out.start(n_out - 1);        // + the calling thread
+        if (c->hp_side_threads == 0) { h->pool_in.start(nt - 1); h->pool_out.start(nt - 1); }      // used in turn: each the full count
+        else { h->pool_in.start(n_in - 1); h->pool_out.start(n_out - 1); }                         // + the stager / drainer thread itself
     }
     *out = c->hostpipe;
     return CSI_OK;
@@ -431,8 +441,25 @@ int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
     h->clock_reset();
     const int64_t t_begin = csi_hostpipe::now_us();
     HpSide stager, drainer;                            // their destructors stop and join them on every return path
-    if (p.stage) stager.start(dev, p.nchunks, 2, h->ev_in, &h->us_stage, p.stage);
-    if (p.weave) drainer.start(dev, p.nchunks, 0, h->ev_out, &h->us_weave_thread, p.weave);
+    const bool threads = c->hp_side_threads != 0;      // 0: stage / weave inline on the calling thread, in turn (the round-3 arrangement; A/B)
+    if (threads && p.stage) stager.start(dev, p.nchunks, 2, h->ev_in, &h->us_stage, p.stage);
+    if (threads && p.weave) drainer.start(dev, p.nchunks, 0, h->ev_out, &h->us_weave_thread, p.weave);
+    auto inline_stage = [&](int64_t i, int s) -> int {
+        if (i >= 2) HIP_TRY(c, hipEventSynchronize(h->ev_in[s]));
+        const int64_t t0 = csi_hostpipe::now_us();
+        p.stage(i, s);
+        h->us_stage += csi_hostpipe::now_us() - t0;
+        return CSI_OK;
+    };
+    auto inline_drain = [&](int64_t i) -> int {
+        const int64_t t0 = csi_hostpipe::now_us();
+        HIP_TRY(c, hipEventSynchronize(h->ev_out[i & 1]));
+        const int64_t t1 = csi_hostpipe::now_us();
+        p.weave(i, (int)(i & 1));
+        h->us_wait_out += t1 - t0;
+        h->us_weave_thread += csi_hostpipe::now_us() - t1;
+        return CSI_OK;
+    };
     auto timed_wait = [&](HpSide& side, int64_t n, int64_t* acc) {
         const int64_t t0 = csi_hostpipe::now_us();
         const bool ok = side.wait_done(n);
@@ -443,12 +470,13 @@ int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
         const int s = (int)(i & 1);
         // device[s] inputs are free once the kernels of chunk i - 2 are done
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));
-        if (p.stage && !timed_wait(stager, i + 1, &h->us_wait_stage))
+        if (p.stage && !threads) { const int r0 = inline_stage(i, s); if (r0) return r0; }
+        if (p.stage && threads && !timed_wait(stager, i + 1, &h->us_wait_stage))
             return fail(c, CSI_ERR_HIP, "host pipeline: input staging failed: %s", hipGetErrorString(stager.err));
         int rc = p.enqueue_in(i, s);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(h->ev_in[s], h->s_in));
-        if (p.stage) stager.release(i);
+        if (p.stage && threads) stager.release(i);
         // kernels: behind the upload, and behind the download of chunk i - 2 that releases device[s]'s output half
         HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
@@ -456,15 +484,18 @@ int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
         // pinned_out[s] must have been handed to the user (chunk i - 2) before the next download lands in it
-        if (p.weave && i >= 2 && !timed_wait(drainer, i - 1, &h->us_wait_out))
+        if (p.weave && !threads && i >= 2) { const int r0 = inline_drain(i - 2); if (r0) return r0; }
+        if (p.weave && threads && i >= 2 && !timed_wait(drainer, i - 1, &h->us_wait_out))
             return fail(c, CSI_ERR_HIP, "host pipeline: result staging failed: %s", hipGetErrorString(drainer.err));
         HIP_TRY(c, hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
         rc = p.enqueue_out(i, s);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(h->ev_out[s], h->s_out));
-        if (p.weave) drainer.release(i);
+        if (p.weave && threads) drainer.release(i);
     }
-    if (p.weave) {
+    if (p.weave && !threads) {
+        for (int64_t i = std::max<int64_t>(0, p.nchunks - 2); i < p.nchunks; ++i) { const int r0 = inline_drain(i); if (r0) return r0; }
+    } else if (p.weave) {
         if (!timed_wait(drainer, p.nchunks, &h->us_wait_out))
             return fail(c, CSI_ERR_HIP, "host pipeline: result staging failed: %s", hipGetErrorString(drainer.err));
     } else {

@@ -1083,6 +1083,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hp_weave_us") *value = c->hostpipe ? c->hostpipe->us_weave : 0;
     else if (n == "hp_total_us") *value = c->hostpipe ? c->hostpipe->us_total : 0;
     else if (n == "hp_chunk_packets") *value = c->hp_chunk_packets;
+    else if (n == "hp_side_threads") *value = c->hp_side_threads;
     else if (n == "ls_fast_perm") *value = c->ls_fast_perm;
     else if (n == "ls_overlap_cus") *value = c->ls_overlap_cus;
     else if (n == "ls_overlap_stride") *value = c->ls_overlap_stride;
@@ -1160,6 +1161,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 255) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 (LS in front of the DNN kernels on one stream) .. 255", name);
         drop_graphs(c);
         (n == "ls_overlap_cus" ? c->ls_overlap_cus : c->ls_overlap_stride) = (int)value;
+    } else if (n == "hp_side_threads") {
+        if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
+        c->hp_side_threads = value != 0;
     } else if (n == "hp_chunk_packets") {
         if (value < 0 || value > (1 << 20)) return fail(c, CSI_ERR_INVALID_ARG, "hp_chunk_packets must be 0 (automatic) .. 2^20");
         c->hp_chunk_packets = (int)value;

@@ -75,7 +75,13 @@ def main():
     up, down = x.nbytes // 2, dnn.nbytes
     a_ms, b_ms, ab_ms = e.pcie_probe(up, down)
     print(f'link: {up / 1e9:.2f} GB up alone {a_ms:.2f} ms ({up / a_ms / 1e6:.1f} GB/s), {down / 1e9:.2f} GB down alone {b_ms:.2f} ms ({down / b_ms / 1e6:.1f} GB/s), both at once {ab_ms:.2f} ms (os.cpu_count() = {os.cpu_count()})')
-    for threads, chunk in ([(a.threads, 0)] if a.threads else [(0, 0), (8, 0), (16, 0), (24, 0), (32, 0), (48, 0), (64, 0), (96, 0), (32, 256), (32, 128), (64, 256), (64, 128)]):
+    try:
+        print('cgroup cpu.max:', open('/sys/fs/cgroup/cpu.max').read().strip(), '| affinity:', len(os.sched_getaffinity(0)), 'cpus')
+    except OSError as err:
+        print('cgroup cpu.max: n/a', err)
+    combos = [(a.threads, 0, 1)] if a.threads else [(0, 0, 1), (0, 0, 0), (16, 0, 1), (16, 0, 0), (32, 0, 1), (32, 0, 0), (0, 0, 1), (0, 0, 0), (32, 256, 1), (32, 256, 0), (32, 128, 1), (32, 128, 0)]
+    for threads, chunk, side in combos:
+        e.set_option('hp_side_threads', side)
         e.set_option('host_threads', threads)
         e.set_option('hp_chunk_packets', chunk)
         for what, kw in (('DNN + LS', dict(out=(dnn, ls))), ('DNN only', dict(ls=False, out=(dnn, None)))):
@@ -88,7 +94,7 @@ def main():
             t = min(ts)
             moved = x.nbytes // 2 + dnn.nbytes + (ls.nbytes if 'LS' in what else 0)
             us = {k: e.get_option('hp_' + k + '_us') / 1e3 for k in ('total', 'stage', 'wait_stage', 'wait_out', 'weave')}
-            print(f'c128 -> c64 {what:9s} host_threads={threads:2d} chunk={chunk:3d} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
+            print(f'c128 -> c64 {what:9s} host_threads={threads:2d} chunk={chunk:3d} side_threads={side} {t * 1e3:8.2f} ms  {npkt * nr * nt / t / 1e6:7.2f} M pairs/s  '
                   f'{moved / t / 1e9:6.1f} GB/s over PCIe (both directions) | last call: total {us["total"]:.1f} ms, stager busy {us["stage"]:.1f}, '
                   f'main waits: staged chunk {us["wait_stage"]:.1f}, download {us["wait_out"]:.1f}, weave {us["weave"]:.1f}')
 
