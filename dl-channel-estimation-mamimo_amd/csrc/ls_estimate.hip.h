@@ -38,7 +38,7 @@ struct LsArgs {
     const float* Ppad;       // [ceil32(nt)][ldp] zero-padded copy of P (chunked kernel)
     const uint16_t* Pbf;     // [ceil16(nt)/16][3 pieces][ceil32(nt)/32][2][32][8] bf16 pieces of P in MFMA operand order (ls_estimate_ringb_kernel)
     int ldp;                 // ceil32(nt)
-    int dbg;                 // timing experiments only ("ls_debug" option): 1 skip FFT, 2 skip despread, 4 skip stores, 8 skip scatter, 64 no MFMA drain (ringb)
+    int dbg;                 // timing experiments only ("ls_debug" option): 1 skip FFT, 2 skip despread, 4 skip stores, 8 skip scatter, 64 WITH the MFMA drain of round 3 (ringb)
     const float* tw;         // [2][256] cos / -sin table, exp(-2 pi i u / 256)
     const int* bin_pos;      // [234] natural-order FFT index f(q) of data bin q
     const float* denom;      // [234] nt * ltf[q]
@@ -1289,12 +1289,22 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
                         d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[jt][0], __builtin_bit_cast(ls_bf16x8, fb[qi][c][0]), d, 0, 0, 0);
                         acc[qi][jt][c] = d;
                     }
-            // Drain before leaving the block.  Measured (tools/ls_dbg.py, round 3): with a second wave on the SIMD feeding the
-            // same matrix pipe, LDS reads issued right behind the last MFMA - the stage-0 reads of the next chunk, which the
-            // register allocator had put into the registers of this chunk's A operand - corrupted one or two spectra of a few
-            // items per thousand; a dependent read of every accumulator (the MFMAs of a chain retire in order) followed by a
-            // use of every operand register closes it: nothing the MFMAs read is recycled before they have finished.
-            if (!(a.dbg & 64)) {
+            // No drain is needed here.  History: the FIRST version of this kernel (round 3; operand loads interleaved with the MFMA
+            // chains, never committed) produced 1-5 wrong items per 4000 with 8 waves per workgroup, and a "drain" - a dependent read
+            // of every accumulator, then a use of every operand register - went in together with the restructuring above (every
+            // operand in registers before the first MFMA) on the theory that LDS reads issued right behind the last MFMA landed in
+            // its A / B source registers before the MFMA had read them.  Round 4 tested that theory on the hardware
+            // (tools/mfma_war_probe.hip, profiles/r04_mfma_war_probe.txt): chains of 1 / 6 / 12 MFMAs followed after 0 ... 64 wait
+            // states by ds_read_b128 OR v_mov_b32 into their A and / or B registers, the SIMD's other wave idle or issuing MFMAs back
+            // to back - 36 variants x 1.3e8 accumulator values, not one wrong.  gfx950 interlocks an in-flight MFMA's sources against
+            // both writers; that hazard does not exist, so the drain was not what cured the first version - the restructuring was
+            // (with operands fetched between the MFMAs of a chain a slow wave could still be reading the spectra image / P slot of
+            // chunk t after a fast wave had passed the next barrier and started to overwrite them: the reads must be retired before
+            // the wave's own arrival at that barrier, which "all operands first" guarantees by construction).  The kernel as it stands is
+            // bit-for-bit reproducible without the drain: 72 configurations x 12 runs, every item compared
+            // (profiles/r04_ls_generic_stress_nodrain.txt; tests/stress_ls_generic.py, bounded form in tests/test_gpu_round4.py).
+            // ls_debug 64 puts the drain back for A/B runs.
+            if (a.dbg & 64) {
 #pragma unroll
                 for (int qi = 0; qi < QW; ++qi)
 #pragma unroll

@@ -76,6 +76,64 @@ __global__ __launch_bounds__(512) void probe(unsigned* errs, unsigned* first_bad
     if (bad) atomicAdd(&errs[0], bad);
 }
 
+// the same with a VALU overwrite (v_mov_b32 into every A and B register right behind the chain): physical registers named in the asm
+template <int CHAIN, int PAD>
+__global__ __launch_bounds__(512) void probe_valu(unsigned* errs, unsigned* first_bad, int iters, int hammer) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave < 4) {
+        if (!hammer) return;
+        f32x16 h0 = {}, h1 = {}, h2 = {}, h3 = {};
+        u32x4 x = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        for (int it = 0; it < iters * (CHAIN + 8); ++it) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %4, %0\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %1, %4, %4, %1\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %2, %4, %4, %2\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %3, %4, %4, %3\n\t"
+                         : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(x));
+        }
+        if (h0[0] + h1[0] + h2[0] + h3[0] == 12345.f) errs[1] = 1;
+        return;
+    }
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        float r0, r15;
+        asm volatile(
+            "v_mov_b32 v100, 0x3f803f80\n\tv_mov_b32 v101, 0x3f803f80\n\tv_mov_b32 v102, 0x3f803f80\n\tv_mov_b32 v103, 0x3f803f80\n\t"
+            "v_mov_b32 v104, 0x3f803f80\n\tv_mov_b32 v105, 0x3f803f80\n\tv_mov_b32 v106, 0x3f803f80\n\tv_mov_b32 v107, 0x3f803f80\n\t"
+            "s_nop 4\n\t"
+            "v_mfma_f32_32x32x16_bf16 v[110:125], v[100:103], v[104:107], 0\n\t"
+            ".rept %c2 - 1\n\t"
+            "v_mfma_f32_32x32x16_bf16 v[110:125], v[100:103], v[104:107], v[110:125]\n\t"
+            ".endr\n\t"
+            ".rept %c3\n\t"
+            "s_nop 0\n\t"
+            ".endr\n\t"
+            "v_mov_b32 v100, 0x40004000\n\tv_mov_b32 v101, 0x40004000\n\tv_mov_b32 v102, 0x40004000\n\tv_mov_b32 v103, 0x40004000\n\t"
+            "v_mov_b32 v104, 0x40004000\n\tv_mov_b32 v105, 0x40004000\n\tv_mov_b32 v106, 0x40004000\n\tv_mov_b32 v107, 0x40004000\n\t"
+            "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+            "v_mov_b32 %0, v110\n\t"
+            "v_mov_b32 %1, v125\n\t"
+            : "=v"(r0), "=v"(r15) : "n"(CHAIN), "n"(PAD)
+            : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",
+              "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125");
+        const float want = 16.f * CHAIN;
+        if (r0 != want || r15 != want) { ++bad; if (!atomicAdd(&first_bad[0], 1u)) { first_bad[1] = __builtin_bit_cast(unsigned, r0 != want ? r0 : r15); first_bad[2] = it; first_bad[3] = wave * 64 + lane; } }
+    }
+    if (bad) atomicAdd(&errs[0], bad);
+}
+
+template <int CHAIN, int PAD>
+static void run_valu(unsigned* d, int hammer, int blocks) {
+    CK(hipMemset(d, 0, 64));
+    hipLaunchKernelGGL((probe_valu<CHAIN, PAD>), dim3(blocks), dim3(512), 0, 0, d, d + 4, 2000, hammer);
+    CK(hipDeviceSynchronize());
+    unsigned h[8];
+    CK(hipMemcpy(h, d, 32, hipMemcpyDeviceToHost));
+    printf("chain %d  pad %2d wait states  overwrite A + B by v_mov_b32  partner %-9s : %8u wrong accumulator values", CHAIN, PAD, hammer ? "hammering" : "idle", h[0]);
+    if (h[0]) printf("   (first: %g instead of %g, iteration %u, thread %u)", __builtin_bit_cast(float, h[5]), 16.f * CHAIN, h[6], h[7]);
+    printf("\n");
+}
+
 template <int CHAIN, int PAD, int OVER>
 static void run(unsigned* d, int hammer, int blocks) {
     CK(hipMemset(d, 0, 64));
@@ -107,6 +165,11 @@ int main() {
         run<6, 32, 1>(d, hammer, blocks);
         run<6, 64, 1>(d, hammer, blocks);
         run<12, 0, 1>(d, hammer, blocks);
+        run_valu<1, 0>(d, hammer, blocks);
+        run_valu<6, 0>(d, hammer, blocks);
+        run_valu<6, 1>(d, hammer, blocks);
+        run_valu<6, 4>(d, hammer, blocks);
+        run_valu<12, 0>(d, hammer, blocks);
     }
     return 0;
 }
