@@ -98,6 +98,7 @@ SYMBOLS = {
     'csi_comm_destroy': (ctypes.c_int, [_ctx]),
     'csi_broadcast_weights': (ctypes.c_int, [_ctx, ctypes.c_int]),
     'csi_clone_weights': (ctypes.c_int, [_ctx, _ctx]),
+    'csi_crc32c': (ctypes.c_uint32, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_uint32]),
     'csi_pilot_classify': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     'csi_profile_band_skeleton': (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'csi_profile_pcie': (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),

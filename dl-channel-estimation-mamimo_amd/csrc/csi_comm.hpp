@@ -89,7 +89,7 @@ struct WireMeta {
     int32_t magic, n_layers;
     // the sender's csi_config, as far as it shapes the buffers: a receiver built for anything else refuses the record
     int32_t cfg_nt, cfg_len_ltf, cfg_n_out, cfg_dtype, cfg_use_bn, cfg_hidden[CSI_MAX_HIDDEN];
-    int32_t loaded[2], has_W0p[2], has_W0rm[2];
+    int32_t loaded[2], has_W0p[2], has_W0rm[2], hs_repr_ok[2];
     int32_t pilot_ok, p_sylvester, p_pieces;
     int32_t p_fast_ok, p_perm[2][CSI_WIRE_MAX_NT];     // Hadamard-equivalent pilot: output row / symbol permutation with signs (csi_set_pilot)
     WireLayer layer[2][CSI_MAX_HIDDEN + 1];
@@ -147,6 +147,7 @@ void wire_fill(const csi_ctx* c, WireMeta& w) {
         const Model& m = c->model[d];
         w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
         if (!w.loaded[d]) continue;
+        w.hs_repr_ok[d] = m.hs_repr_ok;
         w.has_W0p[d] = m.W0p != nullptr;
         w.has_W0rm[d] = m.W0rm != nullptr;
         for (int i = 0; i <= cf.n_hidden; ++i) {
@@ -248,6 +249,7 @@ int wire_finish(csi_ctx* c, const WireMeta& w) {
     for (int d = 0; d < 2; ++d) {
         Model& m = c->model[d];
         m.loaded = w.loaded[d] != 0;
+        m.hs_repr_ok = !m.loaded || w.hs_repr_ok[d] != 0;
         m.table_ok = false;
         if (m.loaded && c->pilot_ok) {
             int rc = build_pilot_table(c, m);

@@ -86,6 +86,12 @@ struct Model {
     bool T_sw_ok = false;
     bool loaded = false;
     bool table_ok = false;
+    // csi_load_weights measures how well the split-f16 copies represent the fp32 matrices: the weight scale comes from max |w| of a
+    // whole matrix, so a matrix whose bulk sits ~2^20 below its largest entry would lose its lo halves to the f16 denormals -
+    // silently (the range guard watches activations).  Worst ||W s - (hi + lo)||_F / ||W s||_F over the split matrices of this
+    // model; above 2^-20 the model is pinned to the fp32 MFMA kernels (hs_static_ok) and "hs_weight_pins" counts it.
+    double hs_repr_err = 0.0;
+    bool hs_repr_ok = true;
 };
 
 struct GraphEntry {           // one captured csi_predict_device / csi_estimate_device call
@@ -175,6 +181,7 @@ struct csi_ctx {
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
+    int64_t hs_weight_pins = 0;  // models csi_load_weights pinned to the fp32 MFMA kernels: their split-f16 weight copies were not fp32-grade (read-only option)
     int hs_blocked = 1;          // "hs_blocked": hs activation buffers between split-engine layers in the blocked layout (gemm_hs.hip.h)
     int hs_fuse_regressor = 0;   // "hs_fuse_regressor": two hidden layers -> the regressor runs inside the pair kernel (h2 stays on the CU).
                                  // Off by default: measured SLOWER (2.45 vs 1.88 ms per 262144 rows, profiles/r02_hs_probe.txt) - the
@@ -392,6 +399,8 @@ void free_model(Model& m) {
     m.T_sw_ok = false;
     m.T_hs_shift = HS_SHIFT_AUTO;
     m.loaded = m.table_ok = false;
+    m.hs_repr_err = 0.0;
+    m.hs_repr_ok = true;
 }
 
 const csi_tensor* find_tensor(const csi_tensor* t, int n, const std::string& name) {

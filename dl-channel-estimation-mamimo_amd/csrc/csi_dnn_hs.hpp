@@ -13,6 +13,7 @@ constexpr int HS_L0_MAX_SPLITS = 8;
 bool hs_static_ok(const csi_ctx* c, const Model& m) {
     const csi_config& cf = c->cfg;
     if (c->f32_engine == 0 || cf.dtype != CSI_DTYPE_F32 || cf.nt <= 0 || (cf.len_ltf % HS_G) != 0) return false;
+    if (!m.hs_repr_ok) return false;          // split copies of this model's weights are not fp32-grade (csi_load_weights): fp32 MFMA kernels
     for (int i = 0; i < cf.n_hidden; ++i)
         if (cf.hidden[i] % HS_G) return false;
     for (size_t i = 0; i < m.layers.size(); ++i)
@@ -196,6 +197,8 @@ int hs_launch_gemm(csi_ctx* c, int kid, GemmHsArgs g) {
 #if __has_include("band8_hsaco.inc")
 #include "band8_hsaco.inc"
 #define CSI_HAVE_BAND8 1
+#else
+#warning "band8_hsaco.inc not found: this build has NO fused band kernel (the separate pair + regressor kernels serve every call; option band_available reads 0).  _lib.build_library() generates it: band_kernel_gen.py -> clang -x assembler -mcpu=gfx950 -> ld.lld"
 #endif
 
 int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged = false) {

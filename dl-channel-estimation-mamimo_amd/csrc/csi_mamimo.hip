@@ -1,6 +1,8 @@
 // csi_mamimo.hip - C-ABI (include/csi_mamimo.h) and host-side orchestration of the MI355X
 // channel-estimation hot path.  gfx950 only; built with
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Xarch_host -march=x86-64-v3 csi_mamimo.hip -o libcsi_mamimo.so
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csi_mamimo.hip -o libcsi_mamimo.so
+// (host code for the baseline x86-64 ISA; the AVX2 staging loops of csi_hostpipe.hpp carry their own target attribute), after
+// band_kernel_gen.py -> clang -x assembler -mcpu=gfx950 -> ld.lld -> band8_hsaco.inc (_lib.build_library does all of it)
 //
 // What runs where (reference call sites in include/csi_mamimo.h):
 //   csi_predict*        layer 0 once per (packet, rx)  -> gemm_f32_kernel<EPI_RAW> (optional split-K)
@@ -566,6 +568,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             const float ws = std::ldexp(1.f, L.wshift);
             L.ldwh = 2 * ((kh + HS_G - 1) / HS_G * HS_G);
             std::vector<uint16_t> wh((size_t)out * L.ldwh, 0);
+            double e_num = 0.0, e_den = 0.0;                 // representation error of this split copy (Frobenius)
             for (int o = 0; o < out; ++o)
                 for (int i = 0; i < kh; ++i) {
                     const float x = wv(o, i) * ws;
@@ -574,7 +577,12 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                     uint16_t* d = &wh[(size_t)o * L.ldwh + (i >> 4) * 32 + (i & 15)];
                     std::memcpy(d, &hi, 2);
                     std::memcpy(d + 16, &lo, 2);
+                    const double r = (double)x - ((double)(float)hi + (double)(float)lo);
+                    e_num += r * r;
+                    e_den += (double)x * (double)x;
                 }
+            if (e_den > 0.0 && std::isfinite(e_den)) m.hs_repr_err = std::max(m.hs_repr_err, std::sqrt(e_num / e_den));
+            else if (!std::isfinite(e_den)) m.hs_repr_err = 1.0;
             const size_t hbytes = wh.size() * 2 + 4096;
             if (hipMalloc((void**)&L.Wh, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
             HIP_TRY(c, hipMemset(L.Wh, 0, hbytes));
@@ -591,6 +599,7 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 L.wshift_f = std::max(-40, std::min(40, 13 - ef));
                 const float wsf = std::ldexp(1.f, L.wshift_f);
                 std::fill(wh.begin(), wh.end(), 0);
+                double f_num = 0.0, f_den = 0.0;
                 for (int o = 0; o < out; ++o)
                     for (int i = 0; i < kh; ++i) {
                         const float x = (float)((double)wt[(size_t)o * L.ldw + i] * (double)prev_scale[i]) * wsf;
@@ -599,7 +608,12 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                         uint16_t* d = &wh[(size_t)o * L.ldwh + (i >> 4) * 32 + (i & 15)];
                         std::memcpy(d, &hi, 2);
                         std::memcpy(d + 16, &lo, 2);
+                        const double r = (double)x - ((double)(float)hi + (double)(float)lo);
+                        f_num += r * r;
+                        f_den += (double)x * (double)x;
                     }
+                if (f_den > 0.0 && std::isfinite(f_den)) m.hs_repr_err = std::max(m.hs_repr_err, std::sqrt(f_num / f_den));
+                else if (!std::isfinite(f_den)) m.hs_repr_err = 1.0;
                 if (hipMalloc((void**)&L.Wh_f, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
                 HIP_TRY(c, hipMemset(L.Wh_f, 0, hbytes));
                 HIP_TRY(c, hipMemcpy(L.Wh_f, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
@@ -714,7 +728,38 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
     }
     m.loaded = true;
     m.table_ok = false;
+    if (cf.dtype == CSI_DTYPE_F32) {
+        m.hs_repr_ok = m.hs_repr_err <= 0x1p-20;
+        if (!m.hs_repr_ok) {
+            ++c->hs_weight_pins;
+            // not an error (the fp32 MFMA kernels serve the model); the text is there for whoever asks
+            c->err = "csi_load_weights: the split-f16 copies of the " + std::string(model ? "imag" : "real") + " model's weights are not fp32-grade (relative error " +
+                     std::to_string(m.hs_repr_err) + " > 2^-20: a matrix whose bulk lies far below its largest entry) - this model runs on the fp32 MFMA kernels";
+        }
+    }
     return build_pilot_table(c, m);
+}
+
+// host-only: CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) - the per-tensor checksum of TensorFlow's TensorBundle files
+// (keras_files.py); continuing value in, value out (both un-inverted outside: crc = 0 starts a new checksum)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_sse42(const unsigned char* p, size_t n, uint32_t c) {
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7)) { c = __builtin_ia32_crc32qi(c, *p++); --n; }
+    uint64_t c64 = c;
+    for (; n >= 8; n -= 8, p += 8) { uint64_t v; std::memcpy(&v, p, 8); c64 = __builtin_ia32_crc32di(c64, v); }
+    c = (uint32_t)c64;
+    while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+    return c;
+}
+uint32_t csi_crc32c(const void* data, int64_t bytes, uint32_t crc) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    if (!p || bytes <= 0) return crc;
+    if (__builtin_cpu_supports("sse4.2")) return crc32c_sse42(p, (size_t)bytes, c) ^ 0xFFFFFFFFu;
+    for (int64_t i = 0; i < bytes; ++i) {
+        c ^= p[i];
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+    }
+    return c ^ 0xFFFFFFFFu;
 }
 
 // host-only: which LS despread a pilot matrix gets (no context, no device)
@@ -1093,6 +1138,17 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "graph_replays") *value = c->graph_replays;                // read-only counters
     else if (n == "hs_launches") *value = c->hs_launches;
     else if (n == "hs_range_fallbacks") *value = c->hs_range_fallbacks;
+    else if (n == "hs_weight_pins") *value = c->hs_weight_pins;                  // models pinned to the fp32 MFMA kernels by the load-time check of their split copies
+    else if (n == "hs_weight_err_e12") *value = (int64_t)(1e12 * std::max(c->model[0].hs_repr_err, c->model[1].hs_repr_err));    // worst relative representation error x 1e12
+    else if (n == "band_available") {                                            // 1: the fused band kernel's code object is embedded in this build and loads
+#ifdef CSI_HAVE_BAND8
+        hipFunction_t f = nullptr;
+        band8_function(c, &f, false, true);
+        *value = f != nullptr;
+#else
+        *value = 0;
+#endif
+    }
     else return fail(c, CSI_ERR_INVALID_ARG, "csi_get_option: unknown option '%s'", name);
     return CSI_OK;
 }

@@ -75,9 +75,9 @@ def broadcast_weights(weights, src=0, device=None):
 
 def exchange_unique_id(rank, world, timeout_s=120.0):
     """The RCCL unique id of the library's own communicator (engine.get_unique_id) from rank 0 to every rank.  With
-    ``torch.distributed`` initialised it rides on its object broadcast; without it, through a file next to the
-    rendezvous (``CSI_RCCL_ID_FILE``, default /tmp/csi_rccl_id_<MASTER_ADDR>_<MASTER_PORT>_<WORLD_SIZE>) that rank 0 writes
-    atomically and removes at exit - no torch in the process at all."""
+    ``torch.distributed`` initialised it rides on its object broadcast; without it, through a file (``CSI_RCCL_ID_FILE``,
+    default <XDG_RUNTIME_DIR or /tmp>/csi_rccl_<uid>/id_<hash of the launch token>, mode 0600) that rank 0 writes atomically
+    and removes at exit - no torch in the process at all."""
     import time
     from .engine import get_unique_id
     try:
@@ -89,13 +89,31 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
         box = [get_unique_id() if rank == 0 else None]
         tdist.broadcast_object_list(box, src=0)
         return box[0]
-    path = os.environ.get('CSI_RCCL_ID_FILE') or '/tmp/csi_rccl_id_%s_%s_%d' % (
-        os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world)
+    # The file carries a launch token in front of the 128 id bytes: a reader accepts it only with ITS launch's token, so a
+    # leftover of a crashed launch (any age) is never taken for the id of this one and a late rank (slow import, first-use
+    # build) is never rejected for being late.  Token: CSI_RCCL_ID_TOKEN, else torchrun's TORCHELASTIC_RUN_ID, else the
+    # rendezvous triple.  Default location: a directory of this user (mode 0700), the file itself mode 0600.
+    token = (os.environ.get('CSI_RCCL_ID_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID') or
+             '%s:%s:%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world)).encode()
+    import hashlib
+    tag = hashlib.sha256(token).digest()                       # 32 bytes in front of the id
+    path = os.environ.get('CSI_RCCL_ID_FILE')
+    if not path:
+        base = os.path.join(os.environ.get('XDG_RUNTIME_DIR') or '/tmp', 'csi_rccl_%d' % os.getuid())
+        os.makedirs(base, mode=0o700, exist_ok=True)
+        if os.stat(base).st_uid != os.getuid():
+            raise RuntimeError('%s belongs to another user: set CSI_RCCL_ID_FILE' % base)
+        path = os.path.join(base, 'id_%s' % hashlib.sha256(token).hexdigest()[:24])
     if rank == 0:
+        try:
+            os.remove(path)                                    # a stale file of an earlier launch with the same token
+        except FileNotFoundError:
+            pass
         uid = get_unique_id()
         tmp = '%s.%d' % (path, os.getpid())
-        with open(tmp, 'wb') as f:
-            f.write(uid)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, 'wb') as f:
+            f.write(tag + uid)
         os.replace(tmp, path)
         import atexit
         atexit.register(lambda: os.path.exists(path) and os.remove(path))
@@ -103,14 +121,14 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
     t0 = time.time()
     while time.time() - t0 < timeout_s:
         try:
-            st = os.stat(path)
-            if st.st_size == 128 and st.st_mtime >= t0 - 30.0:         # a file of THIS launch, not a leftover
-                with open(path, 'rb') as f:
-                    return f.read()
+            with open(path, 'rb') as f:
+                blob = f.read()
+            if len(blob) == 32 + 128 and blob[:32] == tag:
+                return blob[32:]
         except FileNotFoundError:
             pass
         time.sleep(0.05)
-    raise RuntimeError('no RCCL unique id at %s after %.0f s' % (path, timeout_s))
+    raise RuntimeError('no RCCL unique id of this launch at %s after %.0f s' % (path, timeout_s))
 
 
 def local_device_count():

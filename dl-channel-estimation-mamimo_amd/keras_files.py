@@ -526,9 +526,30 @@ def _proto_fields(b):
 _CRC32C_TABLE = None
 
 
-def crc32c(data, crc=0):
+_CRC32C_NATIVE = None
+
+
+def _crc32c_native():
+    """csi_crc32c of the HIP library (host code: the SSE4.2 crc32 instruction, ~10 GB/s) when the library is built; the pure-Python
+    table walk below (~10 MB/s: 30 s for the two models of a Nt = 32 SavedModel) stays as the fallback and as its cross-check."""
+    global _CRC32C_NATIVE
+    if _CRC32C_NATIVE is None:
+        try:
+            import ctypes
+            from . import _lib
+            fn = _lib.load_library().csi_crc32c
+            _CRC32C_NATIVE = lambda buf, crc: int(fn((ctypes.c_char * len(buf)).from_buffer_copy(buf) if not isinstance(buf, bytes) else buf, len(buf), crc)) & 0xFFFFFFFF
+        except Exception:
+            _CRC32C_NATIVE = False
+    return _CRC32C_NATIVE
+
+
+def crc32c(data, crc=0, native=True):
     """CRC-32C (Castagnoli), the checksum TensorBundle stores (masked) per tensor."""
     global _CRC32C_TABLE
+    if native and _crc32c_native():
+        buf = data if isinstance(data, bytes) else bytes(memoryview(data).cast('B'))
+        return _crc32c_native()(buf, int(crc))
     if _CRC32C_TABLE is None:
         t = np.arange(256, dtype=np.uint32)
         for _ in range(8):

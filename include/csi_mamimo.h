@@ -115,6 +115,10 @@ int  csi_set_pilot(csi_ctx* ctx, const float* P);
  * (nt entries each, nt <= 128). */
 int  csi_pilot_classify(const float* P, int nt, int32_t* sym_src, int32_t* out_row);
 
+/* CRC-32C (Castagnoli) of a host buffer - the per-tensor checksum of the SavedModel variable files the reference writes
+ * (DNN.py:411) and keras_files.py verifies; host only (SSE4.2 when the CPU has it).  crc = 0 starts, a returned value continues. */
+uint32_t csi_crc32c(const void* data, int64_t bytes, uint32_t crc);
+
 /* DNN estimate of npkt packets.  ltf_re / ltf_im [npkt][nr][len_ltf]; out_re / out_im
  * [npkt][nr][nt][n_out].  Layer 0 is evaluated once per (packet, rx) and shared by the nt
  * pairs (the reference stores each rx preamble once for the same reason, mk.py:50-63). */

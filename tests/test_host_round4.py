@@ -124,3 +124,42 @@ def test_bench_gpus_8_rendezvous_only():
     assert out['rendezvous_only'] and out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['requested'] == 8
     assert [rk['rank'] for rk in out['ranks']] == list(range(8)) and len({rk['pid'] for rk in out['ranks']}) == 8
     assert out['scaling'] == 'weak' and out['packets_per_step'] == 8 * out['ranks'][0]['packets']
+
+
+def test_native_crc32c_matches_the_table_walk_and_known_answers(pkg):
+    """csi_crc32c (SSE4.2 inside the library, ADVICE round 3: the pure-Python walk needs ~30 s for a Nt = 32 SavedModel) against the
+    RFC 3720 known answers and against the Python implementation, chained calls included."""
+    from dl_channel_estimation_mamimo_amd import keras_files as k
+    assert k._crc32c_native(), 'the library must export csi_crc32c'
+    assert k.crc32c(b'123456789') == 0xE3069283 == k.crc32c(b'123456789', native=False)
+    assert k.crc32c(bytes(32)) == 0x8A9136AA and k.crc32c(b'\xff' * 32) == 0x62A8AB43
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 7, 8, 9, 63, 4097):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert k.crc32c(d) == k.crc32c(d, native=False), n
+        h = n // 3
+        assert k.crc32c(d[h:], k.crc32c(d[:h])) == k.crc32c(d), n                  # continuing value
+    a = np.arange(1000, dtype=np.float32)
+    assert k.crc32c(a) == k.crc32c(a.tobytes(), native=False)                      # array-likes
+
+
+def test_unique_id_file_carries_the_launch_token(pkg, tmp_path, monkeypatch):
+    """dist.exchange_unique_id without torch.distributed: the file is accepted only with THIS launch's token -
+    a leftover of another launch is ignored however fresh it is, and the file is private (0600)."""
+    import hashlib
+    import stat
+    from dl_channel_estimation_mamimo_amd import dist, engine
+    path = tmp_path / 'id'
+    monkeypatch.setenv('CSI_RCCL_ID_FILE', str(path))
+    monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-A')
+    monkeypatch.setattr(engine, 'get_unique_id', lambda: bytes(range(128)))
+    uid = dist.exchange_unique_id(0, 2)
+    assert uid == bytes(range(128)) and path.read_bytes() == hashlib.sha256(b'launch-A').digest() + uid
+    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    assert dist.exchange_unique_id(1, 2, timeout_s=1.0) == uid
+    monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-B')                            # another launch finds launch A's file
+    with pytest.raises(RuntimeError):
+        dist.exchange_unique_id(1, 2, timeout_s=0.3)
+    os.utime(path, (1, 1))                                                           # an OLD file of the right launch is fine (late rank)
+    monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-A')
+    assert dist.exchange_unique_id(3, 4, timeout_s=1.0) == uid

@@ -13,7 +13,7 @@
 #include <cmath>
 #include <algorithm>
 #include <random>
-#include "../dl-channel-estimation-mamimo_amd/csrc/gemm_hs_band.hip.h"
+#include "gemm_hs_band4.hip.h"
 using namespace csi;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
