@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs"
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs --no-next-rows"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/bench_kt.json 2> $OUT/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/bench_write.json 2> $OUT/pmc_write.err
