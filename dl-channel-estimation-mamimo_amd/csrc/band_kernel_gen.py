@@ -136,7 +136,7 @@ def simulate(blocks_in_order, queue=None, with_opt=True):
     for b in blocks_in_order:
         for it in b.items:
             if isinstance(it, tuple):
-                if it[0] == 'vmopt' and not with_opt:
+                if it[0] == 'unit' or (it[0] == 'vmopt' and not with_opt):
                     continue
                 q.append(it[1])
             elif isinstance(it, Wait):
@@ -245,8 +245,10 @@ class Role:
                 b.e('s_add_u32 m0, %s, %d' % (sreg(S_DMA if p < 2 else S_DMA2), slot * RING_SLOT + (p & 1) * 1024))
                 b.e('s_nop 0')
                 b.vm('global_load_lds_dwordx4 %s, %s' % (vreg(vo + p), sreg(ptr, 2)), 'P%d' % slot)
+                b.items.append(('unit',))            # (p2first: what may be placed between two MFMAs as one piece)
         b.e('s_add_u32 %s, %s, 64' % (sreg(ptr), sreg(ptr)))
         b.e('s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1)))
+        b.items.append(('unit',))
 
     def convert(self, b, kind, par_next, jj=0, g=0):
         """fragment of the NEXT sub-step into the two operand registers quads [par_next] and the exchange slot.
@@ -434,6 +436,46 @@ class Role:
             P(0)
             after()
             P(1)
+        elif 'p2first' in self.dbg:
+            # Round 4.  Behind the barrier BOTH waves of a SIMD used to issue their LDS-DMA pieces, weight / fragment / slab reads
+            # and pointer arithmetic (after()) before the first MFMA of P2 - a few hundred cycles per sub-step in which the SIMD's
+            # matrix pipe had nothing queued by either wave.  P2's operands (w_hi, a_lo of this sub-step) sit in registers since
+            # before the barrier: its first MFMA goes first, and the post-barrier work is dealt out behind its MFMAs - the LDS reads the
+            # next sub-step's P0 waits for first, the LDS-DMA issue last.
+            P(0)
+            b.e('s_waitcnt lgkmcnt(0)')
+            P(1)
+            sync()
+            tmp = Block('after')
+            self.read_w(tmp, 1, nslot)                    # (1) what the next sub-step's P0 waits for
+            if consume:
+                self.read_frag(tmp, par ^ 1, partner_half_only=(consume == 'half'))
+            tmp.items.append(('unit',))
+            if stage and stage.get('read') is not None and (len(stage['read']) < 3 or stage['read'][2] == self.h):
+                self.stage_read(tmp, stage['read'][0], stage['read'][1])
+                tmp.items.append(('unit',))
+            if pre_piece:
+                for ln in pre_piece:
+                    tmp.e(ln)
+            self.pieces(tmp, piece, slot, who)            # (2) the LDS-DMA issue: one unit per piece
+            if stage and stage.get('issue') is not None:
+                self.stage_issue(tmp, stage['issue'][0], reset=stage['issue'][1])
+                tmp.items.append(('unit',))
+            units, cur = [], []
+            for it in tmp.items:
+                if it == ('unit',):
+                    if cur:
+                        units.append(cur)
+                    cur = []
+                else:
+                    cur.append(it)
+            if cur:
+                units.append(cur)
+            for jj in range(4):
+                self.mfma(b, acc + 16 * jj, V_WHI + 4 * jj, V_ALO[par])
+                take = (len(units) + (3 - jj)) // (4 - jj)
+                for _ in range(take):
+                    b.items.extend(units.pop(0))
         elif self.h == 0 or 'stagger' not in self.dbg:
             # split-f16 form: both halves in the same order.  (The staggered order of the bf16 form - 'stagger' - was the default until the
             # conversion was dripped between the MFMAs and the operand streams staged: since then 1.650 against 1.662 ms per 262144 rows)
@@ -985,7 +1027,8 @@ META_KERNEL = '''  - .name: {name}
 VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
-            ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')),
+            ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')), ('csi_band8_skeleton_rnd_nobarrier', ('noconv', 'noreq', 'nodma', 'noread', 'rnd', 'nobarrier')),
+            ('csi_band8_noaside_rnd', ('noconv', 'noreq', 'rnd')), ('csi_band8_p2first', ('p2first',)), ('csi_band8_p2first_noaside', ('p2first', 'noconv', 'noreq')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_stagger', ('stagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
