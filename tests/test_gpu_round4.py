@@ -269,3 +269,112 @@ def test_split_weight_copies_are_checked_at_load(pkg, oracle):
     r_re, r_im = oracle.predict_packets(ltf, P, w_re, bad, np.float64, pkt_batch=npkt)
     assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
     assert e.get_option('band_available') == 1
+
+
+def test_ls_on_a_side_stream_is_bit_identical_eager_and_graph(pkg, oracle):
+    """"ls_overlap_cus": csi_estimate_device forks the LS kernel onto a CU-masked side stream behind the first layer-0 kernel (DESIGN
+    4.8: measured slower, off by default - but it is product code).  Same kernels on the same data: DNN and LS results bit-identical
+    to the serial order, eagerly, captured into a hipGraph and replayed, and with the fp32 MFMA engine (where no hook fires and the
+    fork happens behind the DNN kernels)."""
+    rng = np.random.default_rng(31)
+    nt, nr, npkt, hidden = 32, 4, 96, (256, 256)
+    w_re, w_im = _weights(oracle, 55, nt, hidden)
+    P = vht_pilot(oracle, nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=3.0)[0].astype(np.complex64)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    d_re, d_im = e.to_device(np.ascontiguousarray(ltf.real)), e.to_device(np.ascontiguousarray(ltf.imag))
+    outs = [e.empty((npkt, nr, nt, 234)) for _ in range(4)]
+
+    def run():
+        for o in outs:
+            o.upload(np.zeros((npkt, nr, nt, 234), np.float32))
+        e.estimate_device(d_re, d_im, npkt, *outs)
+        e.synchronize()
+        return [o.download().copy() for o in outs]
+
+    for engine in (1, 0):
+        e.set_option('f32_engine', engine)
+        e.set_option('ls_overlap_cus', 0)
+        ref = run()
+        for cus in (8, 64):
+            e.set_option('ls_overlap_cus', cus)
+            got = run()
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (engine, cus)
+        e.set_option('use_graph', 1)
+        n0 = e.get_option('graph_replays')
+        for _ in range(4):                                   # eager, capture, replay, replay
+            got = run()
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (engine, 'graph')
+        assert e.get_option('graph_replays') >= n0 + 2
+        e.set_option('use_graph', 0)
+    r_re, r_im = oracle.predict_packets(ltf[:2], P, w_re, w_im, np.float64, pkt_batch=2)
+    assert rel_rows(ref[0][:2], r_re) < TOL and rel_rows(ref[1][:2], r_im) < TOL
+    h = oracle.ls_estimate(ltf[:2], P)
+    assert rel_rows(np.concatenate([ref[2][:2], ref[3][:2]], -1), np.concatenate([h.real, h.imag], -1)) < TOL
+
+
+def test_host_pipeline_modes_agree(pkg, oracle):
+    """The host-buffer entry points with the staging on side threads (default), inline on the caller (round 3's arrangement) and
+    with small pipeline slots: identical bits, on pageable and on caller-pinned buffers, planes and complex128 surface."""
+    rng = np.random.default_rng(8)
+    nt, nr, npkt, hidden = 8, 2, 3000, (64, 64)            # 3000 packets x 20 KB: several chunks at every slot size
+    w_re, w_im = _weights(oracle, 5, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex128)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    re, im = np.ascontiguousarray(ltf.real, np.float32), np.ascontiguousarray(ltf.imag, np.float32)
+    ref_p = e.predict(re, im)
+    ref_c = e.estimate(ltf)
+    ref_l = e.ls_estimate(re, im)
+    for side, chunk, threads in ((0, 0, 0), (1, 100, 3), (0, 100, 2), (1, 37, 0), (1, 0, 8)):
+        e.set_option('hp_side_threads', side)
+        e.set_option('hp_chunk_packets', chunk)
+        e.set_option('host_threads', threads)
+        p = e.predict(re, im)
+        assert np.array_equal(p[0], ref_p[0]) and np.array_equal(p[1], ref_p[1]), (side, chunk, threads)
+        c = e.estimate(ltf)
+        assert np.array_equal(c[0], ref_c[0]) and np.array_equal(c[1], ref_c[1]), (side, chunk, threads)
+        assert np.array_equal(e.ls_estimate(re, im), ref_l)
+        assert e.get_option('hp_total_us') > 0
+    pr, pi = e.pinned_empty(re.shape), e.pinned_empty(im.shape)
+    pr[...] = re; pi[...] = im
+    po = (e.pinned_empty(ref_p[0].shape), e.pinned_empty(ref_p[1].shape))
+    e.predict(pr, pi, out=po)
+    assert np.array_equal(po[0], ref_p[0]) and np.array_equal(po[1], ref_p[1])
+    k = 3
+    r_re, r_im = oracle.predict_packets(ltf[:k].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=k)
+    assert rel_rows(ref_p[0][:k], r_re) < TOL and rel_rows(ref_c[0][:k].imag, r_im) < TOL
+
+
+def test_profile_entry_points(pkg, oracle):
+    """csi_profile_band_skeleton / csi_profile_pcie: plausible numbers, arguments checked, the context still right afterwards."""
+    rng = np.random.default_rng(2)
+    nt, nr, hidden = 32, 4, (1024, 1024)
+    w_re, w_im = _weights(oracle, 77, nt, hidden)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    with pytest.raises(pkg.CsiError):
+        e.band_skeleton(4096)                                 # nothing loaded
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(oracle.hadamard(nt))
+    ltf = oracle.make_structured_packets(rng, 40, nr, oracle.hadamard(nt), snr_db=0.0)[0].astype(np.complex64)
+    e.set_option('f32_engine', 1)
+    a = e.predict(ltf)
+    ms, tf = e.band_skeleton(65536, 3)
+    assert 0.05 < ms < 5.0 and 300.0 < tf < 2500.0, (ms, tf)   # 512 bands = 2 rounds of 256 CUs: a fraction of a millisecond
+    b = e.predict(ltf)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    up, down, both = e.pcie_probe(256 << 20, 128 << 20)
+    assert up > 0 and down > 0 and max(up, down) * 0.9 <= both <= (up + down) * 1.2
+    assert 10.0 < (256 << 20) / up / 1e6 < 80.0                 # GB/s of a PCIe Gen5 x16 link
+    with pytest.raises(pkg.CsiError):
+        e.pcie_probe(0, 0)
+    e2 = pkg.CsiEngine(8, 2, hidden=(64,))
+    with pytest.raises(pkg.CsiError):
+        e2.band_skeleton(1024)
