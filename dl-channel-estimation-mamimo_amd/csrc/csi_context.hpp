@@ -88,8 +88,9 @@ struct Model {
     bool table_ok = false;
     // csi_load_weights measures how well the split-f16 copies represent the fp32 matrices: the weight scale comes from max |w| of a
     // whole matrix, so a matrix whose bulk sits ~2^20 below its largest entry would lose its lo halves to the f16 denormals -
-    // silently (the range guard watches activations).  Worst ||W s - (hi + lo)||_F / ||W s||_F over the split matrices of this
-    // model; above 2^-20 the model is pinned to the fp32 MFMA kernels (hs_static_ok) and "hs_weight_pins" counts it.
+    // silently (the range guard watches activations).  Worst OUTPUT ROW ||w_o s - (hi + lo)_o|| / ||w_o s|| over the split matrices of
+    // this model (per row: a whole-matrix norm is carried by the outlier itself); above 2^-20 the model is pinned to the fp32 MFMA
+    // kernels (hs_static_ok) and "hs_weight_pins" counts it.
     double hs_repr_err = 0.0;
     bool hs_repr_ok = true;
 };

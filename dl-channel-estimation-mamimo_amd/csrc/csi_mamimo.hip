@@ -568,8 +568,11 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
             const float ws = std::ldexp(1.f, L.wshift);
             L.ldwh = 2 * ((kh + HS_G - 1) / HS_G * HS_G);
             std::vector<uint16_t> wh((size_t)out * L.ldwh, 0);
-            double e_num = 0.0, e_den = 0.0;                 // representation error of this split copy (Frobenius)
-            for (int o = 0; o < out; ++o)
+            // representation error of this split copy: worst OUTPUT ROW, ||x_o - (hi + lo)_o|| / ||x_o|| (a whole-matrix norm would be
+            // carried by the very outlier that causes the damage: the scale follows max |w|, the rows far below it lose their lo halves)
+            double e_worst = 0.0;
+            for (int o = 0; o < out; ++o) {
+                double e_num = 0.0, e_den = 0.0;
                 for (int i = 0; i < kh; ++i) {
                     const float x = wv(o, i) * ws;
                     const _Float16 hi = (_Float16)x;
@@ -581,8 +584,10 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                     e_num += r * r;
                     e_den += (double)x * (double)x;
                 }
-            if (e_den > 0.0 && std::isfinite(e_den)) m.hs_repr_err = std::max(m.hs_repr_err, std::sqrt(e_num / e_den));
-            else if (!std::isfinite(e_den)) m.hs_repr_err = 1.0;
+                if (e_den > 0.0 && std::isfinite(e_den)) e_worst = std::max(e_worst, std::sqrt(e_num / e_den));
+                else if (!std::isfinite(e_den)) e_worst = 1.0;
+            }
+            m.hs_repr_err = std::max(m.hs_repr_err, e_worst);
             const size_t hbytes = wh.size() * 2 + 4096;
             if (hipMalloc((void**)&L.Wh, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
             HIP_TRY(c, hipMemset(L.Wh, 0, hbytes));
@@ -599,8 +604,9 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                 L.wshift_f = std::max(-40, std::min(40, 13 - ef));
                 const float wsf = std::ldexp(1.f, L.wshift_f);
                 std::fill(wh.begin(), wh.end(), 0);
-                double f_num = 0.0, f_den = 0.0;
-                for (int o = 0; o < out; ++o)
+                double f_worst = 0.0;
+                for (int o = 0; o < out; ++o) {
+                    double f_num = 0.0, f_den = 0.0;
                     for (int i = 0; i < kh; ++i) {
                         const float x = (float)((double)wt[(size_t)o * L.ldw + i] * (double)prev_scale[i]) * wsf;
                         const _Float16 hi = (_Float16)x;
@@ -612,8 +618,10 @@ int csi_load_weights(csi_ctx* c, int model, const csi_tensor* tensors, int n) {
                         f_num += r * r;
                         f_den += (double)x * (double)x;
                     }
-                if (f_den > 0.0 && std::isfinite(f_den)) m.hs_repr_err = std::max(m.hs_repr_err, std::sqrt(f_num / f_den));
-                else if (!std::isfinite(f_den)) m.hs_repr_err = 1.0;
+                    if (f_den > 0.0 && std::isfinite(f_den)) f_worst = std::max(f_worst, std::sqrt(f_num / f_den));
+                    else if (!std::isfinite(f_den)) f_worst = 1.0;
+                }
+                m.hs_repr_err = std::max(m.hs_repr_err, f_worst);
                 if (hipMalloc((void**)&L.Wh_f, hbytes) != hipSuccess) return fail(c, CSI_ERR_NOMEM, "weight allocation failed");
                 HIP_TRY(c, hipMemset(L.Wh_f, 0, hbytes));
                 HIP_TRY(c, hipMemcpy(L.Wh_f, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
