@@ -27,6 +27,23 @@ def pilot(rng, nt, kind):
     return P.astype(np.float64)
 
 
+def describe(tag, h, ref, grid_hint=None, limit=8):
+    """where the bad items of one run sit and what is wrong inside them (printed whenever a run differs)"""
+    n_items = h.shape[0] * h.shape[1]
+    nt = h.shape[2]
+    d = np.abs(h - ref).reshape(n_items, nt, 234)
+    scale = np.abs(ref).reshape(n_items, -1).max(1)
+    bad = np.nonzero(d.reshape(n_items, -1).max(1) > 2e-6 * scale)[0]
+    print('   !! %s: %d bad items of %d: %s' % (tag, len(bad), n_items, bad.tolist()[:24]), flush=True)
+    for b in bad[:limit]:
+        w = d[b] > 2e-6 * scale[b]
+        ants = np.nonzero(w.any(1))[0]
+        bins = np.nonzero(w.any(0))[0]
+        print('      item %d (packet %d rx %d): %d wrong values; antennas %s; %d bins, first %s, bins mod 4 %s, per 32 %s; worst abs err / item max %.3g; got max %.3g ref max %.3g'
+              % (b, b // h.shape[1], b % h.shape[1], int(w.sum()), ants.tolist()[:32], len(bins), bins.tolist()[:10], np.bincount(bins % 4, minlength=4).tolist(),
+                 np.bincount(bins // 32, minlength=8).tolist(), float(d[b].max() / scale[b]), float(np.abs(h.reshape(n_items, -1)[b]).max()), float(scale[b])), flush=True)
+
+
 def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300', no_drain=True, budget_s=None, quiet=False, runs=None):
     """Returns the number of bad items.  budget_s bounds the wall time (the loops stop between configurations once it is spent);
     `runs` is an alias of `reps` (pytest caller)."""
@@ -34,7 +51,7 @@ def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x40
     reps = runs if runs is not None else reps
     t0 = time.time()
     spent = lambda: budget_s is not None and time.time() - t0 > budget_s
-    say = (lambda *a, **k: None) if quiet else print
+    say = (lambda *a, **k: None) if quiet else print       # (describe() always prints)
     rng = np.random.default_rng(5)
     total_bad = 0
     for shape in shapes.split(','):
@@ -58,7 +75,11 @@ def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x40
                         first = h
                         d = np.abs(h - h6).reshape(npkt * nr, -1).max(1) / np.abs(h6).reshape(npkt * nr, -1).max(1)
                         n6 = int((d > 2e-6).sum())
+                        if n6:
+                            describe('Nt=%d %s v%d first run against the fp32 despread' % (nt, kind, v), h, h6)
                     nb = int((h != first).reshape(npkt * nr, -1).any(1).sum())
+                    if nb and not n6:
+                        describe('Nt=%d %s v%d a later run against the first' % (nt, kind, v), h, first)
                     bad_runs += nb > 0
                     bad_items += nb
                 total_bad += bad_items + n6
@@ -86,6 +107,8 @@ def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x40
                     h = e.ls_estimate(ltf)
                     first = h if first is None else first
                     nb = int((h != first).reshape(npkt * nr, -1).any(1).sum())
+                    if nb:
+                        describe('Nt=%d kernel %d v%d a later run against the first' % (nt, kernel, v), h, first)
                     bad_runs += nb > 0
                     bad_items += nb
                 total_bad += bad_items
