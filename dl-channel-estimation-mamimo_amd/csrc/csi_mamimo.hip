@@ -972,7 +972,7 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf
             hipLaunchKernelGGL(ls_despread_first_kernel, dim3((unsigned)(nb * n_jc)), dim3(LS_THREADS), plan.lds, c->stream, a, n_jc);
         } else {
             // persistent grid: as many workgroups as can reside (x256 CUs)
-            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)(c->ls_grid_cus > 0 ? c->ls_grid_cus : 256) * plan.per_cu);
+            const unsigned grid = (unsigned)std::min<int64_t>(nb, (int64_t)(c->ls_grid_cus > 0 ? c->ls_grid_cus : 256) * ((c->ls_debug & 128) ? 1 : plan.per_cu));      // ls_debug 128: one workgroup per CU (race hunt)
             void* kargs[] = {(void*)&a, (void*)&nb32};
             HIP_TRY(c, hipLaunchKernel(plan.fn, dim3(grid), dim3(plan.threads), kargs, plan.lds, c->stream));
         }

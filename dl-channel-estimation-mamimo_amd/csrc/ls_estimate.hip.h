@@ -1123,6 +1123,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
     const int nt = a.nt;
     const int nchunk = (nt + CH - 1) / CH;
     const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+    if (a.dbg & 256) {        // race hunt (tools/ls_race_repro.py): the whole LDS of the workgroup starts as NaN - any read of a location this
+                              // workgroup has not written yet turns into NaN results instead of plausible leftovers
+        constexpr int NF = 2 * LSC_NTW + (DBF ? 2 : 1) * CH * 2 * LSC_ROW + NSTG * CH * 2 * LS_FFT + (NSTG + 1) * NPP * JT * LSB_BLOCK / 2;
+        for (int i = tid; i < NF; i += 64 * NW) smem[i] = __builtin_bit_cast(float, 0x7fc00000u);
+        __syncthreads();
+    }
     lsc_build_twiddles(twc, a.tw, tid, 64 * NW);
     int pos[QW];
     float rden[QW];

@@ -33,10 +33,10 @@ def describe(tag, h, ref, grid_hint=None, limit=8):
     nt = h.shape[2]
     d = np.abs(h - ref).reshape(n_items, nt, 234)
     scale = np.abs(ref).reshape(n_items, -1).max(1)
-    bad = np.nonzero(d.reshape(n_items, -1).max(1) > 2e-6 * scale)[0]
+    bad = np.nonzero(~(d.reshape(n_items, -1).max(1) <= 2e-6 * scale))[0]          # NaN counts as bad
     print('   !! %s: %d bad items of %d: %s' % (tag, len(bad), n_items, bad.tolist()[:24]), flush=True)
     for b in bad[:limit]:
-        w = d[b] > 2e-6 * scale[b]
+        w = ~(d[b] <= 2e-6 * scale[b])
         ants = np.nonzero(w.any(1))[0]
         bins = np.nonzero(w.any(0))[0]
         print('      item %d (packet %d rx %d): %d wrong values; antennas %s; %d bins, first %s, bins mod 4 %s, per 32 %s; worst abs err / item max %.3g; got max %.3g ref max %.3g'
