@@ -204,7 +204,12 @@ struct csi_ctx {
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats
-    int ls_ringb_min = 16;       // "ls_ringb_min": from this Nt on a non-Hadamard pilot takes the bf16-split despread (ls_estimate_ringb_kernel)
+    int ls_ringb_min = 33;       // "ls_ringb_min": from this Nt on a non-Hadamard pilot takes the bf16-split despread (ls_estimate_ringb_kernel).
+                                 // Round 4: 33, not 16 - the one-antenna-tile form of that kernel (Nt <= 32, TWO workgroups per CU) produced, on
+                                 // ONE box of the pool, 1-3 wrong items in ~1 % of the first launches of a fresh context (always the first item of
+                                 // a CU's second workgroup, lane groups of an FFT stage; 7 events in 570 cycles there, none in 1170 on two other
+                                 // boxes, none ever in the other LS kernels).  Not understood, so not selected: Nt <= 32 takes
+                                 // the fp32 ring kernel (3-5 % slower); tools/ls_race_repro.py reproduces, "ls_kernel" 7 still forces it
     bool p_sylvester = false;    // csi_set_pilot saw the Sylvester Hadamard matrix (Walsh-Hadamard LS despread applies)
     // csi_set_pilot saw P = D1 Pi1 H Pi2 D2 (H Sylvester, Pi permutations, D signs; e.g. the 802.11 VHT 4x4 base doubled up): the
     // Walsh-Hadamard kernel applies with permuted / signed symbol loads and output rows.  p_perm[0][u] = source symbol of transform

@@ -44,7 +44,7 @@ def describe(tag, h, ref, grid_hint=None, limit=8):
                  np.bincount(bins // 32, minlength=8).tolist(), float(d[b].max() / scale[b]), float(np.abs(h.reshape(n_items, -1)[b]).max()), float(scale[b])), flush=True)
 
 
-def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300', no_drain=True, budget_s=None, quiet=False, runs=None):
+def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300', no_drain=True, budget_s=None, quiet=False, runs=None, small_ringb=False):
     """Returns the number of bad items.  budget_s bounds the wall time (the loops stop between configurations once it is spent);
     `runs` is an alias of `reps` (pytest caller)."""
     import time
@@ -58,8 +58,8 @@ def run(reps=10, shapes='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x40
         nt, nr, npkt = (int(v) for v in shape.split('x'))
         ltf = pkg.synth.white_packets(rng, npkt, nr, nt)
         for kind in ('pm1', 'q16', 'qr'):
-            if spent():
-                break
+            if spent() or (nt <= 32 and not small_ringb):
+                break          # (round 4: the one-antenna-tile form of kernel 7 is no longer selected by the library - see csi_context.hpp, ls_ringb_min)
             e = pkg.CsiEngine(nt, nr, hidden=(8,))
             e.set_pilot(pilot(rng, nt, kind))
             e.set_option('ls_kernel', 6)
@@ -124,8 +124,9 @@ def main():
     ap.add_argument('--drain', action='store_true', help='run the bf16-split kernel WITH the round-3 MFMA drain (ls_debug 64)')
     ap.add_argument('--shapes', default='16x4x2000,24x4x1500,32x4x1500,48x4x800,64x4x800,96x4x400,128x4x300')
     ap.add_argument('--budget-s', type=float, default=None)
+    ap.add_argument('--small-ringb', action='store_true', help='also force kernel 7 at Nt <= 32 (two workgroups per CU: the configuration with the open rare failure)')
     args = ap.parse_args()
-    return 1 if run(args.reps, args.shapes, not args.drain, args.budget_s) else 0
+    return 1 if run(args.reps, args.shapes, not args.drain, args.budget_s, small_ringb=args.small_ringb) else 0
 
 
 if __name__ == '__main__':
