@@ -235,7 +235,7 @@ def test_stress_ls_generic_bounded(pkg, oracle):
     """tests/stress_ls_generic.py, bounded: the bf16-split generic-P kernel (and the ring kernels) on every item, bit for bit over
     repeated runs, with two waves per SIMD - the configuration in which the first version of that kernel raced."""
     import stress_ls_generic
-    bad = stress_ls_generic.run(runs=3, budget_s=50.0, quiet=True)
+    bad = stress_ls_generic.run(runs=3, budget_s=30.0, quiet=True)
     assert bad == 0
 
 
