@@ -760,19 +760,24 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     size_t iblk = blockIdx.x;
     typedef const __attribute__((address_space(4))) int* ctab_t;
     const ctab_t tab = PERM ? (ctab_t)(uintptr_t)a.perm : nullptr;
+    int nsrc[SPW];                              // PERM: source symbols of the chunk issue_next() issues next
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) nsrc[u] = PERM ? tab[wave + u * NW] : 0;
     auto issue_next = [&]() {
         if (ti >= T) return;
         const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
         if (PERM) {
-            int src[SPW];
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) src[u] = tab[ich * CH + wave + u * NW];
+            // the source symbols of this chunk were looked up one chunk ago (nsrc): a scalar load in front of the DMA issue would put
+            // its latency on the ring's critical path (measured: +5 % at Nt = 128 whatever the permutation was)
             const size_t o = iblk * a.len_ltf + LS_CP + 4 * lane;
 #pragma unroll
             for (int u = 0; u < SPW; ++u) {
-                ls_dma16(a.ltf_re + o + (size_t)src[u] * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
-                ls_dma16(a.ltf_im + o + (size_t)src[u] * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
+                ls_dma16(a.ltf_re + o + (size_t)nsrc[u] * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
+                ls_dma16(a.ltf_im + o + (size_t)nsrc[u] * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
             }
+            const int nich = ich + 1 == NCH ? 0 : ich + 1;
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) nsrc[u] = tab[nich * CH + wave + u * NW];
         } else {
             const size_t o = iblk * a.len_ltf + (size_t)(ich * CH + wave) * LS_SYM + LS_CP + 4 * lane;
 #pragma unroll
@@ -837,6 +842,15 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch, ++t) {
+            // PERM: the signs of this chunk's transform inputs, requested here - a whole chunk of work ahead of their use in the despread
+            float sg_in[CH];
+            if (PERM) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    sg_in[r] = __builtin_bit_cast(float, tab[NT + ch * CH + r]);
+                    asm volatile("" : "+s"(sg_in[r]));          // materialise now (the scheduler would sink the scalar loads to their use)
+                }
+            }
             // ---- this wave's rows of chunk t have landed?
             const int younger = ti - t - 1;
             if (NSTG == 1 || younger <= 0) ls_wait_vm<0>();
@@ -860,11 +874,6 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
             if (!(a.dbg & 2)) {
                 f32x2 w[CHH];
-                float sg_in[CH];                  // PERM: signs of this chunk's transform inputs (wave-uniform)
-                if (PERM) {
-#pragma unroll
-                    for (int r = 0; r < CH; ++r) sg_in[r] = __builtin_bit_cast(float, tab[NT + ch * CH + r]);
-                }
                 if (SPLIT == 2) {
                     const float gs = g ? -1.f : 1.f;
                     if (PERM) {
