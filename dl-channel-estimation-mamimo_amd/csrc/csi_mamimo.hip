@@ -86,15 +86,25 @@ LsPlan ls_plan(const csi_ctx* c) {
 #define LS_V2(NTV, SP, CHV, NS, DB) { p.fn = (const void*)ls_estimate_fwht2_kernel<NTV, SP, CHV, NS, DB>; split = SP; ch = CHV; nstg = NS; nf = DB ? 2 : 1; }
         if (nt == 16) {
             if (v == 1) LS_V2(16, 1, 16, 1, false)
-            else { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+            else if (v == 3) { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }      // A/B: vector-address stores (round 3)
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4, false, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
         }
         else if (nt == 32) {       // 8-symbol chunks, one slot: 38 KiB of LDS and 122 VGPRs - four workgroups per CU (0.379 ms; two with 16-symbol chunks: 0.402)
             if (v == 1) LS_V2(32, 1, 16, 1, false)
-            else if (v == 2) { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4, false, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }   // A/B: scalar-base stores
-            else { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
+            else if (v == 3) { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }   // A/B: vector-address stores (round 3)
+            // round 4: stores with the row base in scalar registers (SST): -3 ... -5 % at Nt = 32 / 64 (profiles/r04_ls_pilot_probe_c.txt)
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4, false, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
         }
-        else if (nt == 64) { if (v == 1) LS_V2(64, 1, 16, 1, false) else LS_V2(64, 1, 8, 3, false) }
-        else { if (v == 1) LS_V2(128, 2, 16, 3, false) else LS_V2(128, 2, 16, 2, true) }      // two spectra images: -6 %
+        else if (nt == 64) {
+            if (v == 1) LS_V2(64, 1, 16, 1, false)
+            else if (v == 3) LS_V2(64, 1, 8, 3, false)
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<64, 1, 8, 3, false, 2, false, true>; split = 1; ch = 8; nstg = 3; nf = 1; }
+        }
+        else {
+            if (v == 1) LS_V2(128, 2, 16, 3, false)
+            else if (v == 2) { p.fn = (const void*)ls_estimate_fwht2_kernel<128, 2, 16, 2, true, 1, false, true>; split = 2; ch = 16; nstg = 2; nf = 2; }    // A/B: scalar-base stores
+            else LS_V2(128, 2, 16, 2, true)       // two spectra images: -6 %
+        }
 #undef LS_V2
         if (perm) {        // same shapes as the defaults above, table-driven symbol fetch / antenna store
             if (nt == 16) { p.fn = (const void*)ls_estimate_fwht2_kernel<16, 1, 8, 1, false, 4, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }

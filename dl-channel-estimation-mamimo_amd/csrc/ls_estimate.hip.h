@@ -759,6 +759,10 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     int ti = 0, ich = 0;                        // next chunk to request
     size_t iblk = blockIdx.x;
     typedef const __attribute__((address_space(4))) int* ctab_t;
+    typedef int ls_i32x8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) ls_i32x8* ctab8_t;        // eight consecutive table entries = one s_load_dwordx8 (32-byte aligned:
+                                                                              // the table starts on a 256-byte boundary, every run starts at a multiple of 8)
+    static_assert(!PERM || CHH == 8, "the table-driven form reads its tables in runs of eight");
     const ctab_t tab = PERM ? (ctab_t)(uintptr_t)a.perm : nullptr;
     int nsrc[SPW];                              // PERM: source symbols of the chunk issue_next() issues next
 #pragma unroll
@@ -802,15 +806,16 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                 // transform row r = ab CH + g CHH + j goes to antenna tab[2 NT + r], times the sign tab[3 NT + r]; the row base is
                 // wave-uniform (scalar address arithmetic), the lane adds its bin
 #pragma unroll
-                for (int ab = 0; ab < NCH; ++ab)
+                for (int ab = 0; ab < NCH; ++ab) {
+                    const ls_i32x8 orow = *(ctab8_t)(tab + 2 * NT + ab * CH + gu * CHH), osgn = *(ctab8_t)(tab + 3 * NT + ab * CH + gu * CHH);
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
-                        const int r = ab * CH + gu * CHH + j;
-                        const size_t row = (blk * NT + (size_t)tab[2 * NT + r]) * LS_NDATA;
-                        const float rs = rden * __builtin_bit_cast(float, tab[3 * NT + r]);
+                        const size_t row = (blk * NT + (size_t)orow[j]) * LS_NDATA;
+                        const float rs = rden * __builtin_bit_cast(float, osgn[j]);
                         ls_store_sbase(a.h_re + row, 4u * (unsigned)q, h[ab * CHH + j][0] * rs);
                         ls_store_sbase(a.h_im + row, 4u * (unsigned)q, h[ab * CHH + j][1] * rs);
                     }
+                }
             } else if (SST) {
                 const size_t row0 = (blk * NT + (size_t)gu * CHH) * LS_NDATA;
 #pragma unroll
@@ -846,9 +851,11 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             float sg_in[CH];
             if (PERM) {
 #pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    sg_in[r] = __builtin_bit_cast(float, tab[NT + ch * CH + r]);
-                    asm volatile("" : "+s"(sg_in[r]));          // materialise now (the scheduler would sink the scalar loads to their use)
+                for (int r8 = 0; r8 < CH; r8 += 8) {
+                    ls_i32x8 sg8 = *(ctab8_t)(tab + NT + ch * CH + r8);
+                    asm volatile("" : "+s"(sg8));               // materialise now (the scheduler would sink the scalar load to its use)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sg_in[r8 + r] = __builtin_bit_cast(float, sg8[r]);
                 }
             }
             // ---- this wave's rows of chunk t have landed?
