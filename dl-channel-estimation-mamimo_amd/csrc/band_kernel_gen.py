@@ -501,6 +501,8 @@ class Role:
         # ---- prologue: the state a column step starts from
         b = pro
         b.label(L('start'))
+        if ('prio1' in self.dbg and h == 1) or ('prio0' in self.dbg and h == 0):
+            b.e('s_setprio 1')                              # static priority for one half of the workgroup (A/B: MI355X_MICROARCH.md, two waves per SIMD, item 4)
         for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
             b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
             b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
@@ -1028,7 +1030,7 @@ VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')), ('csi_band8_skeleton_rnd_nobarrier', ('noconv', 'noreq', 'nodma', 'noread', 'rnd', 'nobarrier')),
-            ('csi_band8_noaside_rnd', ('noconv', 'noreq', 'rnd')), ('csi_band8_p2first', ('p2first',)), ('csi_band8_p2first_noaside', ('p2first', 'noconv', 'noreq')),
+            ('csi_band8_noaside_rnd', ('noconv', 'noreq', 'rnd')), ('csi_band8_p2first', ('p2first',)), ('csi_band8_prio1', ('prio1',)), ('csi_band8_prio0', ('prio0',)), ('csi_band8_p2first_noaside', ('p2first', 'noconv', 'noreq')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_stagger', ('stagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]

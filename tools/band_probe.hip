@@ -369,7 +369,7 @@ int main(int argc, char** argv) {
             t(kb8, "full, no barriers (invalid)");
             t(kb16, "no A side, no DMA, no fragment reads (invalid)");
             t(kb31, "MFMA only (invalid)");
-            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_skeleton_rnd", "csi_band8_skeleton_rnd_nobarrier", "csi_band8_noaside_rnd", "csi_band8_p2first_noaside", "csi_band8_p2first", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_stagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8_nostage", "csi_band8_nostage_noreq", "csi_band8"}) {
+            for (const char* nm : {"csi_band8_noconv", "csi_band8_noreq", "csi_band8_noaside", "csi_band8_noaside_nodma", "csi_band8_noaside_noread", "csi_band8_skeleton", "csi_band8_skeleton_rnd", "csi_band8_skeleton_rnd_nobarrier", "csi_band8_noaside_rnd", "csi_band8_p2first_noaside", "csi_band8_p2first", "csi_band8_prio1", "csi_band8_prio0", "csi_band8", "csi_band8_nodma", "csi_band8_noread", "csi_band8_nobarrier", "csi_band8_stagger", "csi_band8_ownpieces", "csi_band8_nointerleave", "csi_band8_nostage", "csi_band8_nostage_noreq", "csi_band8"}) {
                 hipFunction_t f = get8(nm);
                 if (!f) continue;
                 const Band8Args& av = strstr(nm, "nostage") ? a8_plain : a8_staged;
