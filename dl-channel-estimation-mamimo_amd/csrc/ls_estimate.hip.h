@@ -811,7 +811,8 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
                         const size_t row = (blk * NT + (size_t)orow[j]) * LS_NDATA;
-                        const float rs = rden * __builtin_bit_cast(float, osgn[j]);
+                        const int sbits = osgn[j];          // (a scalar copy first: __builtin_bit_cast on the element expression itself reads element 0 - clang, ROCm 7.2)
+                        const float rs = rden * __builtin_bit_cast(float, sbits);
                         ls_store_sbase(a.h_re + row, 4u * (unsigned)q, h[ab * CHH + j][0] * rs);
                         ls_store_sbase(a.h_im + row, 4u * (unsigned)q, h[ab * CHH + j][1] * rs);
                     }
@@ -855,7 +856,10 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                     ls_i32x8 sg8 = *(ctab8_t)(tab + NT + ch * CH + r8);
                     asm volatile("" : "+s"(sg8));               // materialise now (the scheduler would sink the scalar load to its use)
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) sg_in[r8 + r] = __builtin_bit_cast(float, sg8[r]);
+                    for (int r = 0; r < 8; ++r) {
+                        const int sbits = sg8[r];           // (scalar copy first, see store_item)
+                        sg_in[r8 + r] = __builtin_bit_cast(float, sbits);
+                    }
                 }
             }
             // ---- this wave's rows of chunk t have landed?
