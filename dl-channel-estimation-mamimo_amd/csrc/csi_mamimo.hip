@@ -236,7 +236,7 @@ bool pilot_decompose(const float* P, int nt, int perm[2][CSI_WIRE_MAX_NT], bool*
     return true;
 }
 
-// device tables of the PERM Walsh-Hadamard kernel from c->p_perm: [4][nt] = source symbol, its sign, output antenna, its sign
+// device tables of the PERM Walsh-Hadamard kernel from c->p_perm: [4][nt] = source symbol, its sign, byte offset of the output antenna's row, its sign
 int pilot_fast_tables(csi_ctx* c) {
     const int nt = c->cfg.nt;
     if (c->p_tables) { hipFree(c->p_tables); c->p_tables = nullptr; }
@@ -248,7 +248,7 @@ int pilot_fast_tables(csi_ctx* c) {
         for (int u = 0; u < nt; ++u) {
             const int v = c->p_perm[k][u];
             if ((v & 255) >= nt) return fail(c, CSI_ERR_INVALID_ARG, "pilot permutation table entry %d out of range", v);
-            t[(size_t)(2 * k) * nt + u] = v & 255;
+            t[(size_t)(2 * k) * nt + u] = k == 0 ? (v & 255) : (v & 255) * LS_NDATA * (int)sizeof(float);      // source symbol; BYTE offset of the output antenna's row inside an item
             std::memcpy(&t[(size_t)(2 * k + 1) * nt + u], (v & 256) ? &minus : &one, 4);
             c->p_fast_identity = c->p_fast_identity && v == u;
         }

@@ -47,7 +47,7 @@ struct LsArgs {
     int nt;
     int len_ltf;
     const int* perm;         // Hadamard-equivalent pilot (ls_estimate_fwht2_kernel<..., PERM>): [4][nt] = source symbol of transform input u,
-                             // its sign (float bits), output antenna of transform row r, its sign; null for the Sylvester matrix itself
+                             // its sign (float bits), byte offset (antenna * 234 * 4) of the output row of transform row r, its sign; null for the Sylvester matrix itself
 };
 
 __device__ __forceinline__ int ls_phys(int p) { return p + ((p >> 5) << 2); }
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                     const ls_i32x8 orow = *(ctab8_t)(tab + 2 * NT + ab * CH + gu * CHH), osgn = *(ctab8_t)(tab + 3 * NT + ab * CH + gu * CHH);
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
-                        const size_t row = (blk * NT + (size_t)orow[j]) * LS_NDATA;
+                        const size_t row = blk * NT * LS_NDATA + (size_t)(unsigned)orow[j] / sizeof(float);     // the table holds the row's byte offset: one scalar add per plane
                         const int sbits = osgn[j];          // (a scalar copy first: __builtin_bit_cast on the element expression itself reads element 0 - clang, ROCm 7.2)
                         const float rs = rden * __builtin_bit_cast(float, sbits);
                         ls_store_sbase(a.h_re + row, 4u * (unsigned)q, h[ab * CHH + j][0] * rs);
