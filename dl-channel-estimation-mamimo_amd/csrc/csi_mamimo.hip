@@ -252,6 +252,28 @@ int pilot_fast_tables(csi_ctx* c) {
             std::memcpy(&t[(size_t)(2 * k + 1) * nt + u], (v & 256) ? &minus : &one, 4);
             c->p_fast_identity = c->p_fast_identity && v == u;
         }
+    // Row 1 as the Walsh-Hadamard kernels consume it (ls_estimate_fwht2_kernel, PERM): the input signs S of a chunk of CH symbols are
+    // multiplied out into butterfly coefficients, so that the kernel spends no instruction on them.  Per chunk: [S_r S_{r+8}, r < 8:
+    // the fold of the two-threads-per-bin kernel (Nt = 128, CH = 16)], S_0, then for the levels of stride hh = 1, 2, 4 of the
+    // 8-point transform one coefficient S_{i0} S_{i0+hh} per group i0 = 0, 2 hh, ..
+    if (nt >= 16) {
+        const int CH = nt == 128 ? 16 : 8, CHH = 8, L0 = CH - CHH;
+        std::vector<float> sg(nt), cf(nt);
+        std::memcpy(sg.data(), &t[(size_t)nt], sizeof(float) * nt);
+        for (int ch = 0; ch < nt / CH; ++ch) {
+            const float* s = sg.data() + ch * CH;
+            float* o = cf.data() + ch * CH;
+            float pend[8];
+            for (int r = 0; r < CHH; ++r) { pend[r] = s[r]; if (L0) o[r] = s[r] * s[r + CHH]; }
+            o[L0] = pend[0];
+            int idx = L0 + 1;
+            for (int hh = 1; hh < CHH; hh <<= 1) {
+                for (int grp = 0; grp < CHH / (2 * hh); ++grp) o[idx + grp] = pend[grp * 2 * hh] * pend[grp * 2 * hh + hh];
+                idx += CHH / (2 * hh);
+            }
+        }
+        std::memcpy(&t[(size_t)nt], cf.data(), sizeof(float) * nt);
+    }
     if (hipMalloc((void**)&c->p_tables, t.size() * sizeof(int)) != hipSuccess)
         return fail(c, CSI_ERR_NOMEM, "device allocation of %zu bytes failed", t.size() * sizeof(int));
     HIP_TRY(c, hipMemcpy(c->p_tables, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -805,16 +805,19 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             if (PERM) {
                 // transform row r = ab CH + g CHH + j goes to antenna tab[2 NT + r], times the sign tab[3 NT + r]; the row base is
                 // wave-uniform (scalar address arithmetic), the lane adds its bin
+                char* const item_re = reinterpret_cast<char*>(a.h_re + blk * NT * LS_NDATA);
+                char* const item_im = reinterpret_cast<char*>(a.h_im + blk * NT * LS_NDATA);
 #pragma unroll
                 for (int ab = 0; ab < NCH; ++ab) {
                     const ls_i32x8 orow = *(ctab8_t)(tab + 2 * NT + ab * CH + gu * CHH), osgn = *(ctab8_t)(tab + 3 * NT + ab * CH + gu * CHH);
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
-                        const size_t row = blk * NT * LS_NDATA + (size_t)(unsigned)orow[j] / sizeof(float);     // the table holds the row's byte offset: one scalar add per plane
+                        const unsigned rowb = (unsigned)orow[j];     // the table holds the row's byte offset inside the item: one 64-bit scalar add per plane
                         const int sbits = osgn[j];          // (a scalar copy first: __builtin_bit_cast on the element expression itself reads element 0 - clang, ROCm 7.2)
                         const float rs = rden * __builtin_bit_cast(float, sbits);
-                        ls_store_sbase(a.h_re + row, 4u * (unsigned)q, h[ab * CHH + j][0] * rs);
-                        ls_store_sbase(a.h_im + row, 4u * (unsigned)q, h[ab * CHH + j][1] * rs);
+                        const f32x2 v = h[ab * CHH + j] * f32x2{rs, rs};
+                        ls_store_sbase(reinterpret_cast<float*>(item_re + rowb), 4u * (unsigned)q, v[0]);
+                        ls_store_sbase(reinterpret_cast<float*>(item_im + rowb), 4u * (unsigned)q, v[1]);
                     }
                 }
             } else if (SST) {
@@ -848,18 +851,16 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch, ++t) {
-            // PERM: the signs of this chunk's transform inputs, requested here - a whole chunk of work ahead of their use in the despread
-            float sg_in[CH];
+            // PERM: this chunk's butterfly coefficients (the input signs, multiplied out on the host: see the despread), requested here -
+            // a whole chunk of work ahead of their use
+            int cfb[CH];
             if (PERM) {
 #pragma unroll
                 for (int r8 = 0; r8 < CH; r8 += 8) {
                     ls_i32x8 sg8 = *(ctab8_t)(tab + NT + ch * CH + r8);
                     asm volatile("" : "+s"(sg8));               // materialise now (the scheduler would sink the scalar load to its use)
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int sbits = sg8[r];           // (scalar copy first, see store_item)
-                        sg_in[r8 + r] = __builtin_bit_cast(float, sbits);
-                    }
+                    for (int r = 0; r < 8; ++r) cfb[r8 + r] = sg8[r];
                 }
             }
             // ---- this wave's rows of chunk t have landed?
@@ -885,14 +886,22 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
             if (!(a.dbg & 2)) {
                 f32x2 w[CHH];
+                // PERM: input s carries the sign S_s.  No multiply is spent on it: a butterfly (S_a A) +- (S_b B) = S_a (A +- (S_a S_b) B)
+                // is an fma with the scalar coefficient S_a S_b (from the table) and leaves BOTH outputs with the pending sign S_a; after
+                // the level of stride hh element j is pending S_{j with its low bits cleared}, after the last one every element is pending
+                // S_0 - which joins the sign of the cross-chunk stage, an fma coefficient already.  The instruction count is the
+                // Sylvester kernel's.  Table row 1, per chunk: [the CHH fold coefficients (SPLIT = 2)], S_0, then CHH/2 + CHH/4 + .. + 1
+                // level coefficients.
+                constexpr int L0 = CH - CHH;
                 if (SPLIT == 2) {
                     const float gs = g ? -1.f : 1.f;
                     if (PERM) {
+                        const int gneg = gu << 31;
 #pragma unroll
                         for (int r = 0; r < CHH; ++r) {
-                            const float s1 = gs * sg_in[r + CHH];
-                            const f32x2 lo = Fb[(size_t)r * LSC_ROW + pos] * f32x2{sg_in[r], sg_in[r]};
-                            w[r] = __builtin_elementwise_fma(f32x2{s1, s1}, Fb[(size_t)(r + CHH) * LSC_ROW + pos], lo);
+                            const int kb = cfb[r] ^ gneg;
+                            const float k = __builtin_bit_cast(float, kb);
+                            w[r] = __builtin_elementwise_fma(f32x2{k, k}, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
                         }
                     } else {
                         const f32x2 gs2 = {gs, gs};
@@ -909,11 +918,12 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
 #pragma unroll
                     for (int i = 0; i < CHH; ++i)
                         if (!(i & hh)) {
-                            if (PERM && SPLIT == 1 && hh == 1) {
-                                // first level with the input signs: (sx x) +- (sy y) as one multiply and two fma
-                                const f32x2 x = w[i] * f32x2{sg_in[i], sg_in[i]}, y = w[i + 1];
-                                w[i] = __builtin_elementwise_fma(f32x2{sg_in[i + 1], sg_in[i + 1]}, y, x);
-                                w[i + 1] = __builtin_elementwise_fma(f32x2{-sg_in[i + 1], -sg_in[i + 1]}, y, x);
+                            if (PERM) {
+                                const int cb = cfb[L0 + 1 + CHH - CHH / hh + i / (2 * hh)];
+                                const float cp = __builtin_bit_cast(float, cb), cn = -cp;
+                                const f32x2 x = w[i], y = w[i + hh];
+                                w[i] = __builtin_elementwise_fma(f32x2{cp, cp}, y, x);
+                                w[i + hh] = __builtin_elementwise_fma(f32x2{cn, cn}, y, x);
                                 continue;
                             }
                             const f32x2 x = w[i], y = w[i + hh];
@@ -923,7 +933,8 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                 // cross-chunk stages: output block ab takes +-w by the sign of H_{NT/CH}[ab][ch]
 #pragma unroll
                 for (int ab = 0; ab < NCH; ++ab) {
-                    const float sg = (__builtin_popcount(ab & ch) & 1) ? -1.f : 1.f;
+                    const int sgb = ((__builtin_popcount(ab & ch) & 1) << 31) ^ (PERM ? cfb[L0] : 0x3f800000);     // PERM: times the chunk's pending sign
+                    const float sg = __builtin_bit_cast(float, sgb);
                     const f32x2 sgn = {sg, sg};
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) h[ab * CHH + j] = __builtin_elementwise_fma(sgn, w[j], h[ab * CHH + j]);
