@@ -102,8 +102,8 @@ LsPlan ls_plan(const csi_ctx* c) {
         }
         else {
             if (v == 1) LS_V2(128, 2, 16, 3, false)
-            else if (v == 2) { p.fn = (const void*)ls_estimate_fwht2_kernel<128, 2, 16, 2, true, 1, false, true>; split = 2; ch = 16; nstg = 2; nf = 2; }    // A/B: scalar-base stores
-            else LS_V2(128, 2, 16, 2, true)       // two spectra images: -6 %
+            else if (v == 3) LS_V2(128, 2, 16, 2, true)       // two spectra images: -6 %; vector-address stores
+            else { p.fn = (const void*)ls_estimate_fwht2_kernel<128, 2, 16, 2, true, 1, false, true>; split = 2; ch = 16; nstg = 2; nf = 2; }    // + scalar-base stores: -1 ... -1.9 %
         }
 #undef LS_V2
         if (perm) {        // same shapes as the defaults above, table-driven symbol fetch / antenna store

@@ -826,8 +826,9 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                 for (int ab = 0; ab < NCH; ++ab)
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
-                        ls_store_sbase(a.h_re + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, h[ab * CHH + j][0] * rden);
-                        ls_store_sbase(a.h_im + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, h[ab * CHH + j][1] * rden);
+                        const f32x2 v = h[ab * CHH + j] * f32x2{rden, rden};          // one packed multiply for both planes
+                        ls_store_sbase(a.h_re + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, v[0]);
+                        ls_store_sbase(a.h_im + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, v[1]);
                     }
             } else {
                 float* pre = a.h_re + (blk * NT + g * CHH) * LS_NDATA + q;
@@ -836,8 +837,9 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
                 for (int ab = 0; ab < NCH; ++ab)
 #pragma unroll
                     for (int j = 0; j < CHH; ++j) {
-                        pre[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][0] * rden;
-                        pim[(ab * CH + j) * LS_NDATA] = h[ab * CHH + j][1] * rden;
+                        const f32x2 v = h[ab * CHH + j] * f32x2{rden, rden};
+                        pre[(ab * CH + j) * LS_NDATA] = v[0];
+                        pim[(ab * CH + j) * LS_NDATA] = v[1];
                     }
             }
         }

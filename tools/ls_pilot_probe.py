@@ -37,7 +37,7 @@ def main():
         eng.synth_white(7, 0, npkt, d_re, d_im)
         d_hr, d_hi = eng.empty((npkt, nr, nt, 234)), eng.empty((npkt, nr, nt, 234))
         cases = [('sylvester', 1, 0), ('vht_kron', 1, 0), ('signed_perm', 1, 0), ('cols_only', 1, 0), ('rows_only', 1, 0), ('vht_kron', 0, 0), ('signed_perm', 0, 0)]
-        cases.insert(1, ('sylvester', 1, 2 if nt == 128 else 3))      # A/B of the store form on the table-free kernel: Nt = 128: v2 = scalar-base stores (default: vector addresses); else v3 = vector addresses (default: scalar base)
+        cases.insert(1, ('sylvester', 1, 3))      # A/B of the store form on the table-free kernel: v3 = vector addresses (default: scalar base)
         times = {c: [] for c in cases}
         info = {}
         ref = {}
