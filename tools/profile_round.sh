@@ -10,7 +10,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs --no-next-rows"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/bench_kt.json 2> $OUT/kt.err
+# the kernel trace runs the bench's default step counts (20 + 5 warmup), so that its per-kernel averages are the timed region's
+BENCH_KT="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs --no-next-rows"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH_KT > $OUT/bench_kt.json 2> $OUT/kt.err
+[ "${2:-}" = "kt-only" ] && exit 0
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/bench_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/bench_sq.json 2> $OUT/pmc_sq.err

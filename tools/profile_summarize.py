@@ -59,7 +59,7 @@ def mean(v):
     return sum(v) / len(v) if v else 0.0
 
 
-def main(src, tag, dst='profiles', cmd='python bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --no-latency'):
+def main(src, tag, dst='profiles', cmd='python bench.py --steps 20 --warmup 5 --no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs --no-next-rows'):
     os.makedirs(dst, exist_ok=True)
     trace = read_trace(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))
     total = sum(sum(d) for k in trace for d in trace[k].values())
