@@ -92,7 +92,7 @@ LsPlan ls_plan(const csi_ctx* c) {
         else if (nt == 32) {       // 8-symbol chunks, one slot: 38 KiB of LDS and 122 VGPRs - four workgroups per CU (0.379 ms; two with 16-symbol chunks: 0.402)
             if (v == 1) LS_V2(32, 1, 16, 1, false)
             else if (v == 3) { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }   // A/B: vector-address stores (round 3)
-            // round 4: stores with the row base in scalar registers (SST): -3 ... -5 % at Nt = 32 / 64 (profiles/r04_ls_pilot_probe_c.txt)
+            // round 4: stores with the row base in scalar registers (SST): -3 ... -5 % at Nt = 32 / 64 (profiles/r04_ls_probe.txt)
             else { p.fn = (const void*)ls_estimate_fwht2_kernel<32, 1, 8, 1, false, 4, false, true>; split = 1; ch = 8; nstg = 1; nf = 1; maxcu = 4; }
         }
         else if (nt == 64) {
