@@ -278,6 +278,17 @@ def main():
         eng.synchronize()
     prof = eng.profile()
     eng.profile_enable(False)
+    # the same steps once more WITHOUT the per-kernel events (round-3 verdict: the timed region carries them, so headline and
+    # breakdown could not be told apart): what the event records between the kernels cost.  Rank-local, after the timed region.
+    no_events = None
+    if not args.graph:
+        step(); step()
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.synchronize()
+        no_events = (time.perf_counter() - t1) / args.steps * 1e3
     pairs_per_step = total_pkts * nr * nt          # all ranks together
     value = pairs_per_step * args.steps / dt
     split_engine = args.dtype == 'f32' and eng.get_option('hs_launches') > 0
@@ -543,6 +554,10 @@ def main():
         'devices': [i['device'] for i in infos],
         'ranks': infos,
     }
+    if no_events is not None:
+        out['timed_region_events'] = {'ms_per_step_with_kernel_events': round(dt_rank / args.steps * 1e3, 4), 'ms_per_step_without': round(no_events, 4),
+                                      'note': 'rank 0, the same %d steps again behind the timed region with csi_profile_enable(0): `value` is the run WITH the per-kernel '
+                                              'HIP events (they feed `kernels` and `roofline`), this is what they cost' % args.steps}
     if guard:
         out['split_engine_range_guard'] = guard
     if native:
