@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--kinds', default='pm1,q16,qr')
     ap.add_argument('--dbg', type=int, default=0, help='ls_debug for the kernel-7 calls: 128 = one workgroup per CU, 256 = LDS pre-filled with NaN')
     ap.add_argument('--first', type=int, default=6, help='kernel run before kernel 7 (6 = the stress; 0 = none)')
+    ap.add_argument('--warm', type=int, default=0, help='packets of a small kernel-7 launch in front of the three full ones (device mode): is it the cold start of the code?')
     a = ap.parse_args()
     rng = np.random.default_rng(5)
     events, firsts = 0, 0
@@ -49,6 +50,9 @@ def main():
                 e.set_option('ls_kernel', 7)
                 e.set_option('ls_v2', 0)
                 e.set_option('ls_debug', a.dbg)
+                if a.warm and a.device:
+                    e.ls_estimate_device(d_re, d_im, a.warm, o_re, o_im)
+                    e.synchronize()
                 hs = [call() for _ in range(3)]
                 e.set_option('ls_debug', 0)
                 if h6 is None:
@@ -62,7 +66,7 @@ def main():
                         events += 1
                         st.describe('loop %d Nt=%d %s call %d' % (loop, nt, kind, k), h, h6, limit=4)
                 e.close()
-    print('events: %d in %d engine cycles (shapes %s, side %d, device %s, first %d, dbg %d)' % (events, firsts, a.shapes, a.side, a.device, a.first, a.dbg))
+    print('events: %d in %d engine cycles (shapes %s, side %d, device %s, first %d, dbg %d, warm %d)' % (events, firsts, a.shapes, a.side, a.device, a.first, a.dbg, a.warm))
 
 
 if __name__ == '__main__':
