@@ -49,6 +49,14 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     }
     // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the runner-up for A/B runs
     if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2, false) else LS_RB(1, 4, 1, 2, false) }
+    // race hunt (tools/ls_race_fast.py): ls_debug bits 0x200 / 0x400 / 0x800 / 0x1000 select the VAR 1 / 2 / 4 / 8 forms of the
+    // two-workgroups-per-CU instantiation (ls_estimate.hip.h, lsc_stage0_write); pilots of one or two pieces only
+    if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0x1e00)) {
+        const int var = (c->ls_debug >> 9) & 15;
+#define LS_RBV(V) if (var == V) r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<1, 4, 1, 1, 2, false, V> : (const void*)ls_estimate_ringb_kernel<1, 4, 1, 2, 2, false, V>;
+        LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(3) LS_RBV(15)
+#undef LS_RBV
+    }
     else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
     else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
     else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
@@ -1271,7 +1279,8 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         c->ls_v2 = (int)value;
         return ls_prepare(c);
     } else if (n == "ls_debug") {
-        c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero
+        c->ls_debug = (int)value;          // timing experiments: results are wrong when non-zero (bits 1 / 2 / 4)
+        return ls_prepare(c);              // bits 0x200 ... 0x1000 select another instantiation (ls_ringb_shape)
     } else if (n == "ls_kernel") {
         if (value < 0 || value > 7)
             return fail(c, CSI_ERR_INVALID_ARG, "ls_kernel must be 0 (auto), 1 (FFT first), 2 (chunked), 3 (despread first), 4 (Walsh-Hadamard), "

@@ -602,6 +602,23 @@ __device__ __forceinline__ f32x2 pk_add_pi(f32x2 a, f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// race-hunt forms (ls_estimate_ringb_kernel<..., VAR & 2>): the destination never shares registers with a source
+__device__ __forceinline__ f32x2 pk_add_mi_ec(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add_pi_ec(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_cmul_ec(f32x2 x, f32x2 w) {
+    f32x2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=&v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=&v"(d) : "v"(x), "v"(w), "v"(t));
+    return d;
+}
 // x * w for w = (c, s):  (xr c - xi s, xi c + xr s)
 __device__ __forceinline__ f32x2 pk_cmul(f32x2 x, f32x2 w) {
     f32x2 t, d;
@@ -639,21 +656,26 @@ __device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32
         y[u][3] = pk_add_pi(b, d);
     }
 }
-template <int SPW, int NW>
+// VAR (race hunt, tools/ls_race_fast.py; 0 in every product instantiation): 1 = s_waitcnt lgkmcnt(0) behind every stage's writes
+// (LDS write -> read order inside the wave), 2 = op_sel operations never in place, 4 = idle cycles between a stage's last VALU
+// operation and its first ds_write, 8 (kernel) = every LDS-DMA of the wave landed before the "spectra complete" barrier
+template <int SPW, int NW, int VAR = 0>
 __device__ __forceinline__ void lsc_stage0_write(f32x2* Fc, int wave, int lane, const f32x2 (&y)[SPW][4]) {
     const int p0 = 4 * lane + 4 * (lane >> 2);           // lsc_phys(4 lane): elements 4 lane .. 4 lane + 3, 32-byte aligned
+    if (VAR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
         f32x2* fc = Fc + (size_t)(wave + NW * u) * LSC_ROW + p0;
         *reinterpret_cast<f32x4*>(fc) = f32x4{y[u][0][0], y[u][0][1], y[u][1][0], y[u][1][1]};
         *reinterpret_cast<f32x4*>(fc + 2) = f32x4{y[u][2][0], y[u][2][1], y[u][3][0], y[u][3][1]};
     }
+    if (VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // stages 1-3, NS rows interleaved in one instruction stream
-template <int NS>
+template <int NS, int VAR = 0>
 __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32x2* twc, int lane) {
 #pragma unroll
     for (int st = 1; st < 4; ++st) {
@@ -674,41 +696,43 @@ __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
 #pragma unroll
-            for (int m = 1; m < 4; ++m) x[n][m] = pk_cmul(x[n][m], w[m]);
+            for (int m = 1; m < 4; ++m) x[n][m] = (VAR & 2) ? pk_cmul_ec(x[n][m], w[m]) : pk_cmul(x[n][m], w[m]);
             const f32x2 a = x[n][0] + x[n][2], b = x[n][0] - x[n][2], c = x[n][1] + x[n][3], d = x[n][1] - x[n][3];
             y[n][0] = a + c;
-            y[n][1] = pk_add_mi(b, d);
+            y[n][1] = (VAR & 2) ? pk_add_mi_ec(b, d) : pk_add_mi(b, d);
             y[n][2] = a - c;
-            y[n][3] = pk_add_pi(b, d);
+            y[n][3] = (VAR & 2) ? pk_add_pi_ec(b, d) : pk_add_pi(b, d);
         }
         __builtin_amdgcn_wave_barrier();          // every lane has read before anyone overwrites
+        if (VAR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
             for (int m = 0; m < 4; ++m) fr[n][p[m]] = y[n][m];
+        if (VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 // stages 1-3 of this wave's rows wave, wave + NW, ...: pairs interleaved when PAIR
-template <int SPW, int NW, bool PAIR>
+template <int SPW, int NW, bool PAIR, int VAR = 0>
 __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* twc, int lane) {
     if (PAIR && SPW >= 2) {
 #pragma unroll
         for (int u = 0; u + 1 < SPW; u += 2) {
             f32x2* const pr[2] = {Fc + (size_t)(wave + NW * u) * LSC_ROW, Fc + (size_t)(wave + NW * (u + 1)) * LSC_ROW};
-            lsc_fft_stages<2>(pr, twc, lane);
+            lsc_fft_stages<2, VAR>(pr, twc, lane);
         }
         if (SPW & 1) {
             f32x2* const pr[1] = {Fc + (size_t)(wave + NW * (SPW - 1)) * LSC_ROW};
-            lsc_fft_stages<1>(pr, twc, lane);
+            lsc_fft_stages<1, VAR>(pr, twc, lane);
         }
     } else {
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
             f32x2* const pr[1] = {Fc + (size_t)(wave + NW * u) * LSC_ROW};
-            lsc_fft_stages<1>(pr, twc, lane);
+            lsc_fft_stages<1, VAR>(pr, twc, lane);
         }
     }
 }
@@ -1138,7 +1162,7 @@ __device__ __forceinline__ void ls_bf_split2(float x0, float x1, uint32_t& p1, u
 
 constexpr int LSB_BLOCK = 512;      // bf16 elements of one (chunk, piece, antenna tile) block: [2 k-halves][32 rows][8 symbols]
 
-template <int JT, int NW, int NSTG, int NPP, int MINB = 1, bool DBF = false>
+template <int JT, int NW, int NSTG, int NPP, int MINB = 1, bool DBF = false, int VAR = 0>
 __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const LsArgs a, int nblk) {
     constexpr int CH = 16, SPW = CH / NW, QW = 8 / NW;
     constexpr int NB = NPP * JT, NPD = (NB + NW - 1) / NW;      // P blocks per chunk, LDS-DMAs per wave for them
@@ -1278,8 +1302,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
                 if (t > 0) ls_lds_barrier();      // spectra and P pieces of chunk t - 1 consumed
                 issue_pieces();                   // ... so the slot of those pieces takes chunk t + NSTG
             }
-            lsc_stage0_write<SPW, NW>(Fb, wave, lane, y0);
-            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1)>(Fb, wave, twc, lane);
+            lsc_stage0_write<SPW, NW, VAR>(Fb, wave, lane, y0);
+            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, (JT == 1), VAR>(Fb, wave, twc, lane);
+            if (VAR & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // race hunt: no LDS-DMA of this wave in flight across the barrier
             ls_lds_barrier();                     // spectra complete; every wave has seen its P blocks of chunk t land
             if (DBF) issue_pieces();              // every wave is past the despread of chunk t - 1: its P slot takes chunk t + NSTG
 
