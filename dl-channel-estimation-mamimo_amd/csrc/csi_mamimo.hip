@@ -49,6 +49,9 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     }
     // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the runner-up for A/B runs
     if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2, false) else LS_RB(1, 4, 1, 2, false) }
+    else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
+    else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
+    else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
     // race hunt (tools/ls_race_fast.py): ls_debug bits 0x200 / 0x400 / 0x800 / 0x1000 select the VAR 1 / 2 / 4 / 8 forms of the
     // two-workgroups-per-CU instantiation (ls_estimate.hip.h, lsc_stage0_write); pilots of one or two pieces only
     if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0x1e00)) {
@@ -57,9 +60,6 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
         LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(3) LS_RBV(15)
 #undef LS_RBV
     }
-    else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
-    else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
-    else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
 #undef LS_RB
     r.lds = (size_t)(2 * LSC_NTW + nf * 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
     if (r.lds > 160 * 1024) r.fn = nullptr;

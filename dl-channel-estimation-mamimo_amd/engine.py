@@ -1,6 +1,8 @@
 """CsiEngine: one HIP context (one GPU, one stream) holding the two regressors (real, imag),
 the pilot matrix and the activation workspace.  Thin object wrapper over the C-ABI."""
 import ctypes
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -28,6 +30,7 @@ class DeviceArray:
         p = ctypes.c_void_p()
         engine._check(engine._lib.csi_device_malloc(engine._ctx, ctypes.byref(p), self.nbytes))
         self.ptr = p.value or 0
+        engine._arrays.add(self)          # close() frees what is still alive: an array never outlives its engine as leaked HBM
 
     def upload(self, host, first=0):
         """Copy `host` into rows [first, first + len(host)) along axis 0 (default: the whole array)."""
@@ -119,6 +122,7 @@ class CsiEngine:
         if rc != 0:
             raise CsiError(rc, (self._lib.csi_last_error(None) or b'').decode())
         self._ctx = ctx
+        self._arrays = weakref.WeakSet()
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -127,6 +131,8 @@ class CsiEngine:
 
     def close(self):
         if self._ctx:
+            for arr in list(getattr(self, '_arrays', ())):
+                arr.free()
             self._lib.csi_destroy(self._ctx)
             self._ctx = None
 

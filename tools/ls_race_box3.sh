@@ -7,6 +7,9 @@ P2=${3:-900}
 mkdir -p $OUT
 rocm-smi --showuniqueid 2>/dev/null | grep "Unique ID" > $OUT/box.txt
 cat $OUT/box.txt
+# every variant is a correct kernel?  (a handful of cycles each; an "event" in all of them would be a bug of the variant, not the race)
+timeout 120 python tools/ls_race_fast.py --loops 4 --variants 0,0x200,0x400,0x800,0x1000,128 > $OUT/sanity.txt 2>&1
+tail -7 $OUT/sanity.txt | cut -c1-160
 timeout $((P1 + 120)) python tools/ls_race_fast.py --loops 100000 --seconds $P1 --variants 0 > $OUT/phase1.txt 2>&1
 tail -2 $OUT/phase1.txt
 if grep -q "!!" $OUT/phase1.txt; then

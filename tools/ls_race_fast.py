@@ -87,6 +87,8 @@ def main():
                         where[v].append((loop, kind, k, np.nonzero(~(d <= 2e-6))[0].tolist()[:6]))
                         st.describe('variant %#x loop %d Nt=%d %s call %d' % (v, loop, nt, kind, k), h, h6, limit=3)
                 if not a.reuse:
+                    for arr in (d_re, d_im, o_re, o_im):
+                        arr.free()              # (a DeviceArray outlives its engine only as a leak)
                     e.close()
     dt = time.time() - t0
     for v in variants:
