@@ -52,12 +52,12 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
     else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
     else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
-    // race hunt (tools/ls_race_fast.py): ls_debug bits 0x200 / 0x400 / 0x800 / 0x1000 select the VAR 1 / 2 / 4 / 8 forms of the
+    // race hunt (tools/ls_race_fast.py): ls_debug bits 0x200 ... 0x8000 select the VAR 1 ... 64 forms (and a few sums) of the
     // two-workgroups-per-CU instantiation (ls_estimate.hip.h, lsc_stage0_write); pilots of one or two pieces only
-    if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0x1e00)) {
-        const int var = (c->ls_debug >> 9) & 15;
+    if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0xfe00)) {
+        const int var = (c->ls_debug >> 9) & 127;
 #define LS_RBV(V) if (var == V) r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<1, 4, 1, 1, 2, false, V> : (const void*)ls_estimate_ringb_kernel<1, 4, 1, 2, 2, false, V>;
-        LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(3) LS_RBV(15)
+        LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(5) LS_RBV(6) LS_RBV(12) LS_RBV(16) LS_RBV(20) LS_RBV(32) LS_RBV(36) LS_RBV(64) LS_RBV(68)
 #undef LS_RBV
     }
 #undef LS_RB

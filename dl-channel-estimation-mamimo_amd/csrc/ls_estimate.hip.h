@@ -619,12 +619,63 @@ __device__ __forceinline__ f32x2 pk_cmul_ec(f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=&v"(d) : "v"(x), "v"(w), "v"(t));
     return d;
 }
+// VAR & 32: two idle cycles behind every op_sel operation (the next VALU instruction cannot follow it back to back)
+__device__ __forceinline__ f32x2 pk_add_mi_np(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\ts_nop 1" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add_pi_np(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\ts_nop 1" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_cmul_np(f32x2 x, f32x2 w) {
+    f32x2 t, d;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\ts_nop 1" : "=v"(t) : "v"(x), "v"(w));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\ts_nop 1" : "=v"(d) : "v"(x), "v"(w), "v"(t));
+    return d;
+}
+// VAR & 64: the same three operations without any op_sel / packed instruction (scalar fp32 adds and fmas; same rounding: one
+// rounding per add, the product term of the complex multiply rounded once before the fma as in the packed form)
+__device__ __forceinline__ f32x2 sc_add_mi(f32x2 a, f32x2 b) {
+    float dx, dy;
+    asm("v_add_f32 %0, %1, %2" : "=v"(dx) : "v"(a[0]), "v"(b[1]));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(a[1]), "v"(b[0]));
+    return f32x2{dx, dy};
+}
+__device__ __forceinline__ f32x2 sc_add_pi(f32x2 a, f32x2 b) {
+    float dx, dy;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(a[0]), "v"(b[1]));
+    asm("v_add_f32 %0, %1, %2" : "=v"(dy) : "v"(a[1]), "v"(b[0]));
+    return f32x2{dx, dy};
+}
+__device__ __forceinline__ f32x2 sc_cmul(f32x2 x, f32x2 w) {
+    float t0, t1, dx, dy;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(x[0]), "v"(w[0]));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(x[1]), "v"(w[0]));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(dx) : "v"(x[1]), "v"(w[1]), "v"(t0));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dy) : "v"(x[0]), "v"(w[1]), "v"(t1));
+    return f32x2{dx, dy};
+}
 // x * w for w = (c, s):  (xr c - xi s, xi c + xr s)
 __device__ __forceinline__ f32x2 pk_cmul(f32x2 x, f32x2 w) {
     f32x2 t, d;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(t));
     return d;
+}
+template <int VAR>
+__device__ __forceinline__ f32x2 lsc_cmul_v(f32x2 x, f32x2 w) {
+    return (VAR & 64) ? sc_cmul(x, w) : ((VAR & 32) ? pk_cmul_np(x, w) : ((VAR & 2) ? pk_cmul_ec(x, w) : pk_cmul(x, w)));
+}
+template <int VAR>
+__device__ __forceinline__ f32x2 lsc_add_mi_v(f32x2 a, f32x2 b) {
+    return (VAR & 64) ? sc_add_mi(a, b) : ((VAR & 32) ? pk_add_mi_np(a, b) : ((VAR & 2) ? pk_add_mi_ec(a, b) : pk_add_mi(a, b)));
+}
+template <int VAR>
+__device__ __forceinline__ f32x2 lsc_add_pi_v(f32x2 a, f32x2 b) {
+    return (VAR & 64) ? sc_add_pi(a, b) : ((VAR & 32) ? pk_add_pi_np(a, b) : ((VAR & 2) ? pk_add_pi_ec(a, b) : pk_add_pi(a, b)));
 }
 
 // twc[off(st) + (m - 1) L + j] = exp(-2 pi i j m / (4 L)),  L = 4^st, off = 0 / 12 / 60: the three twiddles of butterfly
@@ -641,7 +692,7 @@ __device__ __forceinline__ void lsc_build_twiddles(f32x2* twc, const float* tw, 
 
 // stage 0 of the DIT transform for this wave's SPW rows of a raw (planar, natural-order) chunk slot: butterfly `lane`
 // takes samples rev3(lane) + 64 m; no twiddles
-template <int SPW, int NW>
+template <int SPW, int NW, int VAR = 0>
 __device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32x2 (&y)[SPW][4]) {
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
@@ -651,14 +702,16 @@ __device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32
         for (int m = 0; m < 4; ++m) x[m] = f32x2{sr[64 * m], sr[LS_FFT + 64 * m]};
         const f32x2 a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = x[1] - x[3];
         y[u][0] = a + c;
-        y[u][1] = pk_add_mi(b, d);
+        y[u][1] = lsc_add_mi_v<VAR>(b, d);
         y[u][2] = a - c;
-        y[u][3] = pk_add_pi(b, d);
+        y[u][3] = lsc_add_pi_v<VAR>(b, d);
     }
 }
 // VAR (race hunt, tools/ls_race_fast.py; 0 in every product instantiation): 1 = s_waitcnt lgkmcnt(0) behind every stage's writes
-// (LDS write -> read order inside the wave), 2 = op_sel operations never in place, 4 = idle cycles between a stage's last VALU
-// operation and its first ds_write, 8 (kernel) = every LDS-DMA of the wave landed before the "spectra complete" barrier
+// (LDS write -> read order inside the wave), 2 = op_sel operations never in place, 4 = sixteen idle cycles per stage (the compiler
+// places them between the stage's VALU operations: a schedule perturbation, measured to RAISE the event rate ~70 x), 8 (kernel) =
+// every LDS-DMA of the wave landed before the "spectra complete" barrier, 16 = the sources of the op_sel adds stay live until the
+// stage's writes are out, 32 = two idle cycles behind every op_sel operation, 64 = no op_sel / packed operation at all (scalar forms)
 template <int SPW, int NW, int VAR = 0>
 __device__ __forceinline__ void lsc_stage0_write(f32x2* Fc, int wave, int lane, const f32x2 (&y)[SPW][4]) {
     const int p0 = 4 * lane + 4 * (lane >> 2);           // lsc_phys(4 lane): elements 4 lane .. 4 lane + 3, 32-byte aligned
@@ -686,7 +739,7 @@ __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32
         int p[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) p[m] = lsc_phys(base + m * L);
-        f32x2 x[NS][4], y[NS][4], w[4];
+        f32x2 x[NS][4], y[NS][4], w[4], bb[NS], dd[NS];
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
@@ -696,12 +749,13 @@ __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
 #pragma unroll
-            for (int m = 1; m < 4; ++m) x[n][m] = (VAR & 2) ? pk_cmul_ec(x[n][m], w[m]) : pk_cmul(x[n][m], w[m]);
+            for (int m = 1; m < 4; ++m) x[n][m] = lsc_cmul_v<VAR>(x[n][m], w[m]);
             const f32x2 a = x[n][0] + x[n][2], b = x[n][0] - x[n][2], c = x[n][1] + x[n][3], d = x[n][1] - x[n][3];
             y[n][0] = a + c;
-            y[n][1] = (VAR & 2) ? pk_add_mi_ec(b, d) : pk_add_mi(b, d);
+            y[n][1] = lsc_add_mi_v<VAR>(b, d);
             y[n][2] = a - c;
-            y[n][3] = (VAR & 2) ? pk_add_pi_ec(b, d) : pk_add_pi(b, d);
+            y[n][3] = lsc_add_pi_v<VAR>(b, d);
+            if (VAR & 16) { bb[n] = b; dd[n] = d; }
         }
         __builtin_amdgcn_wave_barrier();          // every lane has read before anyone overwrites
         if (VAR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -710,6 +764,10 @@ __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32
 #pragma unroll
             for (int m = 0; m < 4; ++m) fr[n][p[m]] = y[n][m];
         if (VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (VAR & 16) {          // the sources of the op_sel adds stay live (nothing may be allocated over them) until the stage's writes are out
+#pragma unroll
+            for (int n = 0; n < NS; ++n) asm volatile("" ::"v"(bb[n]), "v"(dd[n]) : "memory");
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1290,7 +1348,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
             else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
             else ls_wait_vm<3 * R>();
             f32x2 y0[SPW][4];
-            lsc_stage0_read<SPW, NW>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
+            lsc_stage0_read<SPW, NW, VAR>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_next();
             if (ch == 0 && t > 0) store_item(blk - gridDim.x);

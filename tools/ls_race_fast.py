@@ -6,6 +6,8 @@ per CU): the events only ever hit the first item of a CU's second workgroup, so 
     0x400  op_sel operations never in place (early-clobber destinations)
     0x800  idle cycles between a stage's last VALU operation and its first ds_write
     0x1000 no LDS-DMA of the wave in flight across the "spectra complete" barrier
+    0x2000 sources of the op_sel adds live until the stage's writes are out,  0x4000 two idle cycles behind every op_sel operation,
+    0x8000 no op_sel / packed operation at all; sums combine (0x8800 = 0x800 + 0x8000: the instantiations csi_mamimo.hip lists)
     128    one workgroup per CU,  256  LDS pre-filled with NaN
 --variants a,b,c interleaves them cycle by cycle (same box, same minutes).
     python tools/ls_race_fast.py --loops 2000 --variants 0,0x200,0x400"""
@@ -31,6 +33,7 @@ def main():
     ap.add_argument('--kinds', default='pm1,q16')
     ap.add_argument('--variants', default='0')
     ap.add_argument('--seconds', type=float, default=0, help='stop after this many seconds (0 = run all loops)')
+    ap.add_argument('--nok6', action='store_true', help='with --reuse: the fp32 ring kernel runs ONCE per engine (reference), afterwards only the kernel under test is launched')
     ap.add_argument('--reuse', action='store_true', help='ONE engine per variant and pilot kind for the whole run (is the fresh context needed?)')
     a = ap.parse_args()
     variants = [int(v, 0) for v in a.variants.split(',')]
@@ -43,7 +46,7 @@ def main():
     events = {v: 0 for v in variants}
     cycles = {v: 0 for v in variants}
     where = {v: [] for v in variants}
-    kept = {}
+    kept, refs = {}, {}
     t0 = time.time()
 
     def engine(kind):
@@ -69,9 +72,12 @@ def main():
                     e.ls_estimate_device(d_re, d_im, npkt, o_re, o_im)
                     e.synchronize()
                     return o_re.download() + 1j * o_im.download()
-                e.set_option('ls_debug', 0)
-                e.set_option('ls_kernel', 6)
-                h6 = call()
+                if a.nok6 and a.reuse and (kind, v) in refs:
+                    h6 = refs[(kind, v)]
+                else:
+                    e.set_option('ls_debug', 0)
+                    e.set_option('ls_kernel', 6)
+                    h6 = refs[(kind, v)] = call()
                 e.set_option('ls_kernel', 7)
                 e.set_option('ls_v2', 0)
                 e.set_option('ls_debug', v)
