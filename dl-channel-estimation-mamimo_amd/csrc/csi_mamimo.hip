@@ -57,7 +57,7 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0xfe00)) {
         const int var = (c->ls_debug >> 9) & 127;
 #define LS_RBV(V) if (var == V) r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<1, 4, 1, 1, 2, false, V> : (const void*)ls_estimate_ringb_kernel<1, 4, 1, 2, 2, false, V>;
-        LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(5) LS_RBV(6) LS_RBV(12) LS_RBV(16) LS_RBV(20) LS_RBV(32) LS_RBV(36) LS_RBV(64) LS_RBV(68)
+        LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(5) LS_RBV(6) LS_RBV(12) LS_RBV(16) LS_RBV(20) LS_RBV(32) LS_RBV(36) LS_RBV(64) LS_RBV(68) LS_RBV(96) LS_RBV(48)
 #undef LS_RBV
     }
 #undef LS_RB

@@ -665,16 +665,40 @@ __device__ __forceinline__ f32x2 pk_cmul(f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(t));
     return d;
 }
+// VAR & 96 == 96: the scalar forms with the same two idle cycles behind each operation group (volatile like the _np forms)
+__device__ __forceinline__ f32x2 sc_add_mi_np(f32x2 a, f32x2 b) {
+    float dx, dy;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(dx) : "v"(a[0]), "v"(b[1]));
+    asm volatile("v_sub_f32 %0, %1, %2\n\ts_nop 1" : "=v"(dy) : "v"(a[1]), "v"(b[0]));
+    return f32x2{dx, dy};
+}
+__device__ __forceinline__ f32x2 sc_add_pi_np(f32x2 a, f32x2 b) {
+    float dx, dy;
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(a[0]), "v"(b[1]));
+    asm volatile("v_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(dy) : "v"(a[1]), "v"(b[0]));
+    return f32x2{dx, dy};
+}
+__device__ __forceinline__ f32x2 sc_cmul_np(f32x2 x, f32x2 w) {
+    float t0, t1, dx, dy;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(x[0]), "v"(w[0]));
+    asm volatile("v_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(t1) : "v"(x[1]), "v"(w[0]));
+    asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(dx) : "v"(x[1]), "v"(w[1]), "v"(t0));
+    asm volatile("v_fma_f32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(dy) : "v"(x[0]), "v"(w[1]), "v"(t1));
+    return f32x2{dx, dy};
+}
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_cmul_v(f32x2 x, f32x2 w) {
+    if ((VAR & 96) == 96) return sc_cmul_np(x, w);
     return (VAR & 64) ? sc_cmul(x, w) : ((VAR & 32) ? pk_cmul_np(x, w) : ((VAR & 2) ? pk_cmul_ec(x, w) : pk_cmul(x, w)));
 }
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_add_mi_v(f32x2 a, f32x2 b) {
+    if ((VAR & 96) == 96) return sc_add_mi_np(a, b);
     return (VAR & 64) ? sc_add_mi(a, b) : ((VAR & 32) ? pk_add_mi_np(a, b) : ((VAR & 2) ? pk_add_mi_ec(a, b) : pk_add_mi(a, b)));
 }
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_add_pi_v(f32x2 a, f32x2 b) {
+    if ((VAR & 96) == 96) return sc_add_pi_np(a, b);
     return (VAR & 64) ? sc_add_pi(a, b) : ((VAR & 32) ? pk_add_pi_np(a, b) : ((VAR & 2) ? pk_add_pi_ec(a, b) : pk_add_pi(a, b)));
 }
 
