@@ -164,6 +164,9 @@ def build_library(force=False, verbose=False):
     # host side: baseline x86-64; the three AVX2 staging loops of the host pipeline carry their own target attribute and a
     # run-time CPU check (csi_hostpipe.hpp)
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', _SRC, '-o', _SO]
+    # CSI_BUILD_DEFINES="NAME ..." adds -DNAME: CSI_LS_RACE_VARIANTS compiles the race-hunt instantiations of the LS kernel
+    # (tools/ls_race_box*.sh); the product build carries none of them
+    cmd[1:1] = ['-D' + d for d in os.environ.get('CSI_BUILD_DEFINES', '').split()]
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

@@ -54,12 +54,14 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
     else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
     // race hunt (tools/ls_race_fast.py): ls_debug bits 0x200 ... 0x8000 select the VAR 1 ... 64 forms (and a few sums) of the
     // two-workgroups-per-CU instantiation (ls_estimate.hip.h, lsc_stage0_write); pilots of one or two pieces only
+#ifdef CSI_LS_RACE_VARIANTS       // build with CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS (python -c "import __graft_entry__ as g; g.build()")
     if (jt == 1 && c->ls_v2 != 1 && npp <= 2 && (c->ls_debug & 0xfe00)) {
         const int var = (c->ls_debug >> 9) & 127;
 #define LS_RBV(V) if (var == V) r.fn = npp == 1 ? (const void*)ls_estimate_ringb_kernel<1, 4, 1, 1, 2, false, V> : (const void*)ls_estimate_ringb_kernel<1, 4, 1, 2, 2, false, V>;
         LS_RBV(1) LS_RBV(2) LS_RBV(4) LS_RBV(8) LS_RBV(5) LS_RBV(6) LS_RBV(12) LS_RBV(16) LS_RBV(20) LS_RBV(32) LS_RBV(36) LS_RBV(64) LS_RBV(68) LS_RBV(96) LS_RBV(48)
 #undef LS_RBV
     }
+#endif
 #undef LS_RB
     r.lds = (size_t)(2 * LSC_NTW + nf * 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
     if (r.lds > 160 * 1024) r.fn = nullptr;

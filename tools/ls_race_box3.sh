@@ -5,6 +5,8 @@ OUT=${1:-gpurun_out/ls_race_box3}
 P1=${2:-120}
 P2=${3:-900}
 mkdir -p $OUT
+# the variant instantiations are not part of the product build
+CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS python -c "import sys; sys.path.insert(0, '.'); import dl_channel_estimation_mamimo_amd as p; p._lib.build_library(force=True)" || exit 1
 rocm-smi --showuniqueid 2>/dev/null | grep "Unique ID" > $OUT/box.txt
 cat $OUT/box.txt
 # every variant is a correct kernel?  (a handful of cycles each; an "event" in all of them would be a bug of the variant, not the race)

@@ -6,6 +6,8 @@ OUT=${1:-gpurun_out/ls_race_box4}
 P1=${2:-60}
 P2=${3:-600}
 mkdir -p $OUT
+# the variant instantiations are not part of the product build
+CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS python -c "import sys; sys.path.insert(0, '.'); import dl_channel_estimation_mamimo_amd as p; p._lib.build_library(force=True)" || exit 1
 rocm-smi --showuniqueid 2>/dev/null | grep "Unique ID" > $OUT/box.txt
 cat $OUT/box.txt
 V="0x800,0xa00,0xc00,0x1800,0x2800,0x4800,0x8800,0x880"
