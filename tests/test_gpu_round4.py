@@ -388,3 +388,17 @@ def test_profile_entry_points(pkg, oracle):
     e2 = pkg.CsiEngine(8, 2, hidden=(64,))
     with pytest.raises(pkg.CsiError):
         e2.band_skeleton(1024)
+
+
+def test_engine_close_frees_its_device_arrays(pkg, oracle):
+    """A DeviceArray that is still alive when its engine closes is freed by close() (it used to survive as leaked HBM: the loop of
+    tools/ls_race_fast.py ran a 288 GB part out of memory), and freeing it again afterwards is harmless."""
+    e = pkg.CsiEngine(4, 2, hidden=(8,))
+    a = e.empty((3, 5))
+    b = e.to_device(np.arange(12, dtype=np.float32).reshape(3, 4))
+    assert a.ptr and b.ptr
+    np.testing.assert_array_equal(b.download(), np.arange(12, dtype=np.float32).reshape(3, 4))
+    e.close()
+    assert a.ptr == 0 and b.ptr == 0
+    a.free()
+    e.close()
