@@ -573,6 +573,30 @@ def test_probe_tools_still_compile(src, tmp_path):
     assert res.returncode == 0, res.stdout[-3000:]
 
 
+def test_pkadd_probe_uses_the_kernels_own_instructions(tmp_path):
+    """tools/pkadd_mfma_probe.hip re-states the three op_sel operations of the LS kernels' transform (every rare bad item
+    of the two-workgroups-per-CU kernel is one of their results): the instruction strings must stay the product's, and it must compile."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = open(os.path.join(root, 'dl-channel-estimation-mamimo_amd', 'csrc', 'ls_estimate.hip.h')).read()
+    probe = open(os.path.join(root, 'tools', 'pkadd_mfma_probe.hip')).read()
+
+    def ops(text, fn):
+        body = text[text.index('f32x2 %s(' % fn):]
+        body = body[:body.index('return d;')]
+        return re.findall(r'asm\("([^"]+)"', body)
+    for fn, n in (('pk_add_mi', 1), ('pk_add_pi', 1), ('pk_cmul', 2)):
+        a, b = ops(prod, fn), ops(probe, fn)
+        assert len(a) == n and a == b, (fn, a, b)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-c',
+                          os.path.join(root, 'tools', 'pkadd_mfma_probe.hip'), '-o', str(tmp_path / 'probe.o')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
 def test_cli_prefers_the_checkpoint_over_a_stale_model_folder(pkg, tmp_path):
     """cli._find_weights: <d>_weights-improvement.* (what a fit writes, DNN.py:279-281,319) wins over the <d>_keras_model/
     folder an earlier --test run left in the same directory (DNN.py:411); the folder is still found when it is all there is."""
