@@ -1,6 +1,6 @@
 #!/bin/bash
 # Short form of tools/pkadd_probe_box.sh for the last GPU minutes of a round: everything prebuilt in the build container
-# (tools/pkadd_probe.bin = hipcc of tools/pkadd_mfma_probe.hip; tools/_variants/libcsi_mamimo.so = the library built with
+# by tools/prebuild_probes.sh (tools/pkadd_probe.bin = hipcc of tools/pkadd_mfma_probe.hip; tools/_variants/libcsi_mamimo.so = the library built with
 # CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS), nothing compiled on the box.
 #   1. the one GPU test added after the last full suite run, and smoke()
 #   2. the op_sel probe in four neighbour modes, T seconds each
