@@ -163,3 +163,30 @@ def test_unique_id_file_carries_the_launch_token(pkg, tmp_path, monkeypatch):
     os.utime(path, (1, 1))                                                           # an OLD file of the right launch is fine (late rank)
     monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-A')
     assert dist.exchange_unique_id(3, 4, timeout_s=1.0) == uid
+
+
+def test_integration_doc_indexes_every_entry_point_of_the_header():
+    """INTEGRATION.md 9 names every symbol include/csi_mamimo.h declares (written out or as `csi_x` / `_y` shorthand inside one cell),
+    and names nothing the header does not declare - the drop-in boundary and its documentation cannot drift apart."""
+    import re
+    with open(os.path.join(REPO, 'include', 'csi_mamimo.h')) as f:
+        declared = set(re.findall(r'\b(csi_[a-z0-9_]+)\(', f.read()))
+    with open(os.path.join(REPO, 'INTEGRATION.md')) as f:
+        doc = f.read()
+    sec = doc[doc.index('## 9. Entry-point index'):]
+    named, unknown = set(), []
+    for row in sec.splitlines():
+        if not row.startswith('| `csi_'):
+            continue
+        cell = row.split('|')[1]
+        base = None
+        for tok in re.findall(r'`([a-z0-9_]+)`', cell):
+            if tok.startswith('csi_'):
+                base = tok
+                name = tok
+            else:                               # `_step` behind `csi_train_begin`: replace trailing components of the last full name
+                parts = base.split('_')
+                name = next(('_'.join(parts[:k]) + tok for k in range(len(parts) - 1, 0, -1) if '_'.join(parts[:k]) + tok in declared), None)
+            (named.add(name) if name in declared else unknown.append((tok, name)))
+    assert not unknown, unknown
+    assert declared - named == set(), sorted(declared - named)
