@@ -127,6 +127,8 @@ struct csi_ctx {
     int host_threads = 0;                           // "host_threads" option: threads of the user <-> pinned copies (0 = automatic)
     int hp_side_threads = 1;                        // "hp_side_threads": 1 = input staging and result staging on their own threads beside the caller's enqueue loop, 0 = inline, in turn
     int hp_chunk_packets = 0;                       // "hp_chunk_packets": packets per pipeline slot of the host-buffer entry points (0 = automatic)
+    int hp_device_weave = 1;                        // "hp_device_weave": csi_estimate_c128 with PINNED result arrays assembles the complex64 values on the device and downloads into the arrays themselves (0 = host threads weave, as for pageable arrays)
+    int64_t hp_direct_out_calls = 0;                // "hp_direct_out_calls": calls that took that path
     float* P = nullptr;          // device [nt][nt]
     float* Pbf = nullptr;        // device: bf16 pieces of P in MFMA operand order (ls_pilot layout of ls_estimate_ringb_kernel), 2 per float
     float* Ppad = nullptr;       // device [ceil32(nt)][ceil32(nt)], zero padded (chunked LS kernel)

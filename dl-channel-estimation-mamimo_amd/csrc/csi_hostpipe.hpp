@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "csi_context.hpp"
+#include "weave.hip.h"
 
 // AVX2 only inside the three staging loops below, each compiled for that ISA by a target attribute and entered behind a
 // run-time CPU check - the rest of the host code is built for the baseline x86-64 ISA (a host or VM without AVX2 would
@@ -220,6 +221,22 @@ struct HpPool {
         for (auto& t : workers) t.join();
     }
 };
+
+// f(begin, end) over [0, n) on TWO pools at once, the range divided in proportion to their thread counts: `a` is driven by the calling
+// thread, `b` by a helper thread that lives for the call (pools block their caller).  For the input staging of calls whose result side
+// needs no host pass (pinned result arrays): the output pool's threads would idle while the input side is what the call waits for.
+inline void hp_parallel_range2(HpPool& a, HpPool& b, size_t n, size_t min_part, size_t align, const std::function<void(size_t, size_t)>& f) {
+    const size_t ta = a.workers.size() + 1, tb = b.workers.size() + 1;
+    size_t na = n * ta / (ta + tb);
+    na -= na % std::max<size_t>(align, 1);
+    if (n < 2 * min_part || na == 0 || na == n) {
+        a.parallel_range(n, min_part, f);
+        return;
+    }
+    std::thread helper([&] { b.parallel_range(n - na, min_part, [&](size_t lo, size_t hi) { f(na + lo, na + hi); }); });
+    a.parallel_range(na, min_part, f);
+    helper.join();
+}
 
 struct csi_hostpipe {
     // Two pools: the input side (user -> pinned staging) runs AHEAD on its own thread, beside the calling thread's output side
@@ -634,8 +651,14 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     chunk = std::max<int64_t>(chunk, ((int64_t)8 << 20) / (int64_t)in_pkt);
     if (c->hp_chunk_packets > 0) chunk = c->hp_chunk_packets;
     chunk = std::min(chunk, npkt);
-    rc = hp_reserve(c, h, 2 * in_pkt * chunk, 2 * out_pkt * chunk, true, true);
+    // Result arrays in pinned host memory (csi_host_malloc; engine.pinned_empty(shape, np.complex64)): the complex values are
+    // assembled on the device behind the chunk's kernels (weave_c64_kernel) and downloaded straight into the caller's arrays - no
+    // staging buffer, no host pass on the result side ("hp_device_weave" = 0: the host threads weave as for pageable arrays).
+    const bool direct_out = c->hp_device_weave != 0 && (!dnn_c64 || hp_is_pinned(dnn_c64)) && (!ls_c64 || hp_is_pinned(ls_c64));
+    // device[s]: in re | in im | result planes (dnn re | dnn im | ls re | ls im) | direct_out only: dnn complex64 | ls complex64
+    rc = hp_reserve(c, h, 2 * in_pkt * chunk, (direct_out ? 4 : 2) * out_pkt * chunk, true, !direct_out);
     if (rc) return rc;
+    if (direct_out) ++c->hp_direct_out_calls;
     std::vector<int64_t> first_of, size_of;
     hp_schedule(npkt, chunk, first_of, size_of);
     const int64_t nchunks = (int64_t)size_of.size();
@@ -646,7 +669,11 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         const double* src = in + (size_t)first_of[(size_t)i] * in_n * 2;
         float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
         float* p_im = reinterpret_cast<float*>(h->pin_in[s] + in_pkt * chunk);
-        h->pool_in.parallel_range((size_t)np_of(i) * in_n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); });
+        const auto split = [&](size_t b, size_t e) { hp_split_c128(src, p_re, p_im, b, e); };
+        // no host pass on the result side: the output pool's threads join the input side (side-thread arrangement only: with
+        // hp_side_threads = 0 each pool already holds the full thread count)
+        if (direct_out && c->hp_side_threads != 0) hp_parallel_range2(h->pool_in, h->pool_out, (size_t)np_of(i) * in_n, (size_t)1 << 16, 16, split);
+        else h->pool_in.parallel_range((size_t)np_of(i) * in_n, (size_t)1 << 16, split);
     };
     p.enqueue_in = [&](int64_t i, int s) -> int {
         HIP_TRY(c, hipMemcpyAsync(h->dev[s], h->pin_in[s], in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
@@ -661,12 +688,30 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         int r = CSI_OK;
         if (ls_c64) r = csi_ls_estimate_device(c, d_re, d_im, np_of(i), d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk);
         if (!r && dnn_c64) r = csi_predict_device(c, d_re, d_im, np_of(i), d_out, d_out + dnn_n * chunk);
+        if (!r && direct_out) {                                          // planes -> complex64 behind them, same stream
+            float* d_c64 = d_out + 2 * (dnn_n + ls_n) * chunk;
+            auto weave = [&](const float* re, const float* im, float* dst, size_t n) -> int {
+                const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+                hipLaunchKernelGGL(weave_c64_kernel, dim3(blocks), dim3(256), 0, c->stream, re, im, reinterpret_cast<float2*>(dst), n);
+                HIP_TRY(c, hipGetLastError());
+                return CSI_OK;
+            };
+            if (dnn_c64) r = weave(d_out, d_out + dnn_n * chunk, d_c64, (size_t)np_of(i) * dnn_n);
+            if (!r && ls_c64) r = weave(d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk, d_c64 + 2 * dnn_n * chunk, (size_t)np_of(i) * ls_n);
+        }
         return r;
     };
     p.enqueue_out = [&](int64_t i, int s) -> int {                      // one D2H per plane actually filled (np of chunk packets)
         const float* d_out = reinterpret_cast<const float*>(h->dev[s] + 2 * in_pkt * chunk);
-        float* t = reinterpret_cast<float*>(h->pin_out[s]);
         const int64_t np = np_of(i);
+        if (direct_out) {                                                // the chunk's complex64 values into the caller's pinned arrays
+            const float* d_c64 = d_out + 2 * (dnn_n + ls_n) * chunk;
+            const size_t first = (size_t)first_of[(size_t)i];
+            if (dnn_c64) HIP_TRY(c, hipMemcpyAsync(dnn_c64 + first * dnn_n * 2, d_c64, dnn_n * np * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            if (ls_c64) HIP_TRY(c, hipMemcpyAsync(ls_c64 + first * ls_n * 2, d_c64 + 2 * dnn_n * chunk, ls_n * np * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            return CSI_OK;
+        }
+        float* t = reinterpret_cast<float*>(h->pin_out[s]);
         if (dnn_c64) {
             HIP_TRY(c, hipMemcpyAsync(t, d_out, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
             HIP_TRY(c, hipMemcpyAsync(t + dnn_n * chunk, d_out + dnn_n * chunk, dnn_n * np * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
@@ -678,15 +723,16 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         }
         return CSI_OK;
     };
-    p.weave = [&](int64_t i, int s) {                                    // two float32 planes -> complex64 in the caller's arrays
-        const int64_t np = np_of(i);
-        const float* t = reinterpret_cast<const float*>(h->pin_out[s]);
-        auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
-            h->pool_out.parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
+    if (!direct_out)
+        p.weave = [&](int64_t i, int s) {                                // two float32 planes -> complex64 in the caller's arrays
+            const int64_t np = np_of(i);
+            const float* t = reinterpret_cast<const float*>(h->pin_out[s]);
+            auto weave = [&](const float* re, const float* im, float* dst, size_t n) {
+                h->pool_out.parallel_range(n, (size_t)1 << 16, [&](size_t b, size_t e) { hp_weave_c64(re, im, dst, b, e); });
+            };
+            if (dnn_c64) weave(t, t + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
+            if (ls_c64) weave(t + 2 * dnn_n * chunk, t + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
         };
-        if (dnn_c64) weave(t, t + dnn_n * chunk, dnn_c64 + (size_t)first_of[(size_t)i] * dnn_n * 2, (size_t)np * dnn_n);
-        if (ls_c64) weave(t + 2 * dnn_n * chunk, t + 2 * dnn_n * chunk + ls_n * chunk, ls_c64 + (size_t)first_of[(size_t)i] * ls_n * 2, (size_t)np * ls_n);
-    };
     return hp_run(c, h, p);
 }
 

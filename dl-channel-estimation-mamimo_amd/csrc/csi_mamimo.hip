@@ -1179,6 +1179,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hp_total_us") *value = c->hostpipe ? c->hostpipe->us_total : 0;
     else if (n == "hp_chunk_packets") *value = c->hp_chunk_packets;
     else if (n == "hp_side_threads") *value = c->hp_side_threads;
+    else if (n == "hp_device_weave") *value = c->hp_device_weave;
+    else if (n == "hp_direct_out_calls") *value = c->hp_direct_out_calls;
     else if (n == "ls_fast_perm") *value = c->ls_fast_perm;
     else if (n == "ls_overlap_cus") *value = c->ls_overlap_cus;
     else if (n == "ls_overlap_stride") *value = c->ls_overlap_stride;
@@ -1270,6 +1272,8 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "hp_side_threads") {
         if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
         c->hp_side_threads = value != 0;
+    } else if (n == "hp_device_weave") {
+        c->hp_device_weave = value != 0;
     } else if (n == "hp_chunk_packets") {
         if (value < 0 || value > (1 << 20)) return fail(c, CSI_ERR_INVALID_ARG, "hp_chunk_packets must be 0 (automatic) .. 2^20");
         c->hp_chunk_packets = (int)value;

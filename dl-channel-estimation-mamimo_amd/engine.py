@@ -377,7 +377,8 @@ class CsiEngine:
         complex128 [npkt, nr, len_ltf] in, complex64 [npkt, nr, nt, n_out] (DNN) and / or [npkt, nr, nt, 234] (LS)
         out - one upload for both, the real / imag split and the complex assembly done inside the library's
         staging copies (csi_estimate_c128).  Returns (dnn, ls); an estimator that was not asked for is None.
-        ``out=(dnn_buf, ls_buf)`` reuses complex64 arrays."""
+        ``out=(dnn_buf, ls_buf)`` reuses complex64 arrays; arrays from ``pinned_empty(shape, np.complex64)`` receive the
+        downloads directly (complex values assembled on the device, no host pass on the result side; same bits)."""
         ltf = np.ascontiguousarray(ltf, dtype=np.complex128)
         if ltf.ndim != 3 or ltf.shape[1:] != (self.nr, self.len_ltf):
             raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {ltf.shape}')

@@ -147,7 +147,10 @@ int  csi_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf
  * interleaved (re, im) doubles; dnn_c64 [npkt][nr][nt][n_out] and ls_c64 [npkt][nr][nt][234] as interleaved
  * (re, im) floats, either may be NULL.  One upload of the preambles serves both; the complex128 -> 2 x float32
  * split and the complex64 interleave run in the staging copies of the host pipeline, chunk by chunk beside the
- * transfers and kernels, instead of as whole-array passes in the caller (X.real / X.imag, inference.py:29-31). */
+ * transfers and kernels, instead of as whole-array passes in the caller (X.real / X.imag, inference.py:29-31).
+ * Result arrays in pinned host memory (csi_host_malloc) skip the result-side host pass: the complex64 values are
+ * assembled on the device and downloaded into the arrays themselves (option "hp_device_weave", default 1; counter
+ * "hp_direct_out_calls"); same bits either way. */
 int  csi_estimate_c128(csi_ctx* ctx, const double* ltf_c128, int64_t npkt, float* dnn_c64, float* ls_c64);
 
 /* LMMSE smoothing of an LS estimate (the 'hDmmse' output of helperMIMOChannelEstimate.m:37-39,

@@ -402,3 +402,53 @@ def test_engine_close_frees_its_device_arrays(pkg, oracle):
     assert a.ptr == 0 and b.ptr == 0
     a.free()
     e.close()
+
+
+def test_estimate_c128_into_pinned_result_arrays(pkg, oracle):
+    """csi_estimate_c128 with result arrays in pinned host memory (engine.pinned_empty(shape, np.complex64)): the complex values are
+    assembled on the device (weave_c64_kernel) and the downloads land in the caller's arrays themselves - same bits as with pageable
+    arrays (host threads weave out of the staging buffer), several chunks with the short first / last ones, either estimator alone,
+    both pipeline arrangements, and `hp_device_weave` = 0 puts the host weave back."""
+    rng = np.random.default_rng(12)
+    nt, nr, npkt, hidden = 8, 2, 700, (64, 64)
+    w_re, w_im = _weights(oracle, 6, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex128)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    shape = (npkt, nr, nt, 234)
+    assert e.get_option('hp_device_weave') == 1
+    for chunk, side in ((0, 1), (96, 1), (96, 0), (37, 1)):
+        e.set_option('hp_chunk_packets', chunk)
+        e.set_option('hp_side_threads', side)
+        ref = e.estimate(ltf)                                                    # pageable result arrays: host weave
+        n0 = e.get_option('hp_direct_out_calls')
+        po = (e.pinned_empty(shape, np.complex64), e.pinned_empty(shape, np.complex64))
+        po[0][...] = np.nan
+        po[1][...] = np.nan
+        got = e.estimate(ltf, out=po)
+        assert got[0] is po[0] and got[1] is po[1]
+        assert e.get_option('hp_direct_out_calls') == n0 + 1, (chunk, side)
+        assert np.array_equal(po[0], ref[0]) and np.array_equal(po[1], ref[1]), (chunk, side)
+        only_dnn = e.pinned_empty(shape, np.complex64)
+        e.estimate(ltf, ls=False, out=(only_dnn, None))
+        only_ls = e.pinned_empty(shape, np.complex64)
+        e.estimate(ltf, dnn=False, out=(None, only_ls))
+        assert np.array_equal(only_dnn, ref[0]) and np.array_equal(only_ls, ref[1]), (chunk, side)
+        assert e.get_option('hp_direct_out_calls') == n0 + 3
+        # one pinned, one pageable array: the host weave serves both
+        mixed = (e.pinned_empty(shape, np.complex64), np.empty(shape, np.complex64))
+        e.estimate(ltf, out=mixed)
+        assert e.get_option('hp_direct_out_calls') == n0 + 3
+        assert np.array_equal(mixed[0], ref[0]) and np.array_equal(mixed[1], ref[1])
+    e.set_option('hp_device_weave', 0)
+    n0 = e.get_option('hp_direct_out_calls')
+    po = (e.pinned_empty(shape, np.complex64), e.pinned_empty(shape, np.complex64))
+    e.estimate(ltf, out=po)
+    assert e.get_option('hp_direct_out_calls') == n0
+    assert np.array_equal(po[0], ref[0]) and np.array_equal(po[1], ref[1])
+    k = 3
+    r_re, r_im = oracle.predict_packets(ltf[:k].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=k)
+    assert rel_rows(ref[0][:k].real, r_re) < TOL and rel_rows(ref[0][:k].imag, r_im) < TOL

@@ -190,3 +190,17 @@ def test_integration_doc_indexes_every_entry_point_of_the_header():
             (named.add(name) if name in declared else unknown.append((tok, name)))
     assert not unknown, unknown
     assert declared - named == set(), sorted(declared - named)
+
+
+def test_host_pipeline_pools_cover_every_range_once(tmp_path):
+    """tests/hostpool_check.cpp: the host pipeline's thread pools (one range on one pool, one range on two pools at once - the input
+    staging of calls with pinned result arrays) visit every element exactly once for awkward sizes / alignments / thread counts, and
+    the complex128 -> planes and planes -> complex64 loops driven through them give the scalar loops' bits.  Host code only."""
+    exe = str(tmp_path / 'hostpool_check')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O2', '-std=c++17', '-Wno-unused-value', '-pthread',
+                          os.path.join(REPO, 'tests', 'hostpool_check.cpp'), '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout
+    for _ in range(3):
+        run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+        assert run.returncode == 0 and 'hostpool_check: ok' in run.stdout, run.stdout
