@@ -360,6 +360,29 @@ def main():
             del pr, pi, po
         except Exception as e:
             host_path['pinned_planes_error'] = repr(e)
+        # the deployment surface once more with the RESULT array in pinned memory (a serving loop that reuses its arrays): the complex64
+        # values are assembled on the device and the downloads land in the array itself - no host pass on the result side
+        try:
+            pc = eng.pinned_empty(bufs[0].shape, np.complex64)
+            pc[...] = 0
+            n_direct = eng.get_option('hp_direct_out_calls')
+            eng.estimate(x128, ls=False, out=(pc, None))
+            t4s = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                eng.estimate(x128, ls=False, out=(pc, None))
+                t4s.append(time.perf_counter() - t0)
+            t4 = sorted(t4s)[1]
+            host_path['python_c128_to_c64']['dnn_only_pinned_result'] = {
+                'pairs_per_s': k * nr * nt / t4, 'ms': t4 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t4s],
+                'bit_identical_with_pageable_result': bool(np.array_equal(pc, bufs[0])),
+                'direct_downloads': eng.get_option('hp_direct_out_calls') - n_direct,
+                'where_us': {n: eng.get_option(n) for n in ('hp_total_us', 'hp_stage_us', 'hp_wait_stage_us', 'hp_wait_out_us', 'hp_weave_us')},
+                'note': 'CsiEngine.estimate(ls=False, out=(engine.pinned_empty(shape, complex64), None)): weave_c64_kernel + one download per chunk into the caller\'s array; '
+                        'what is left is the input side (complex128 -> float32 planes on the host CPUs: where_us.hp_stage_us)'}
+            del pc
+        except Exception as e:                      # a side measurement never takes the line down
+            host_path['python_c128_to_c64']['dnn_only_pinned_result_error'] = repr(e)
         try:
             host_path['host_cpu_quota'] = open('/sys/fs/cgroup/cpu.max').read().strip() + ' (cgroup cpu.max: quota / period us); os.cpu_count() = %d' % os.cpu_count()
         except OSError:
@@ -375,6 +398,10 @@ def main():
                                'h2d_gbs': round(up / a / 1e6, 1), 'd2h_gbs': round(down / b / 1e6, 1),
                                'what': 'csi_profile_pcie: bare hipMemcpyAsync of these byte counts between pinned host memory and the device, 32 MiB pieces, two streams'}
                 tgt['frac_of_pcie_bound'] = round(ab / tgt['ms'], 3)
+                if key == 'dnn_only' and 'dnn_only_pinned_result' in host_path['python_c128_to_c64']:
+                    pr_ = host_path['python_c128_to_c64']['dnn_only_pinned_result']
+                    pr_['pcie_bound_ms'] = round(ab, 3)
+                    pr_['frac_of_pcie_bound'] = round(ab / pr_['ms'], 3)
                 if key == 'dnn_only' and 'pinned_planes_dnn' in host_path:
                     host_path['pinned_planes_dnn']['pcie_bound_ms'] = round(ab, 3)
                     host_path['pinned_planes_dnn']['frac_of_pcie_bound'] = round(ab / host_path['pinned_planes_dnn']['ms'], 3)
