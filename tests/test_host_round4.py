@@ -201,6 +201,8 @@ def test_host_pipeline_pools_cover_every_range_once(tmp_path):
     res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O2', '-std=c++17', '-Wno-unused-value', '-pthread',
                           os.path.join(REPO, 'tests', 'hostpool_check.cpp'), '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     assert res.returncode == 0, res.stdout
-    for _ in range(3):
-        run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
-        assert run.returncode == 0 and 'hostpool_check: ok' in run.stdout, run.stdout
+    # every alignment case of the complex128 split / complex64 weave / streaming copy under each SIMD choice the CPU offers
+    # (CSI_HOST_SIMD: 0 scalar, 2 AVX2, 5 AVX-512 with 64-byte streaming stores)
+    for cap in ('0', '2', '5', '5'):
+        run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120, env=dict(os.environ, CSI_HOST_SIMD=cap))
+        assert run.returncode == 0 and 'hostpool_check: ok' in run.stdout and 'simd: cap %s,' % cap in run.stdout, run.stdout
