@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "csi_context.hpp"
@@ -295,7 +296,13 @@ inline void hp_parallel_range2(HpPool& a, HpPool& b, size_t n, size_t min_part, 
         a.parallel_range(n, min_part, f);
         return;
     }
-    std::thread helper([&] { b.parallel_range(n - na, min_part, [&](size_t lo, size_t hi) { f(na + lo, na + hi); }); });
+    std::thread helper;
+    try {
+        helper = std::thread([&] { b.parallel_range(n - na, min_part, [&](size_t lo, size_t hi) { f(na + lo, na + hi); }); });
+    } catch (const std::system_error&) {          // no thread to be had (pids limit): the first pool does all of it
+        a.parallel_range(n, min_part, f);
+        return;
+    }
     a.parallel_range(na, min_part, f);
     helper.join();
 }
