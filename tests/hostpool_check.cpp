@@ -1,13 +1,15 @@
 // hostpool_check.cpp - CPU check of the host pipeline's thread pools (csrc/csi_hostpipe.hpp): HpPool::parallel_range and
 // hp_parallel_range2 (one range on two pools at once) cover [0, n) exactly once for awkward sizes, and hp_split_c128 / hp_weave_c64
 // driven through them give the bits of the scalar loops.  No HIP call is made: it runs in the build container (tests/test_host_round4.py
-// compiles it with hipcc and runs it).
+// compiles it with hipcc and runs it).  Clean under `-Xarch_host -fsanitize=thread` and `-fsanitize=address` as well (round 4, by hand).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../dl-channel-estimation-mamimo_amd/csrc/csi_hostpipe.hpp"
+
+static size_t up64(size_t b) { return (b + 63) / 64 * 64; }      // aligned_alloc: the size is a multiple of the alignment
 
 int main() {
     int bad = 0;
@@ -44,10 +46,10 @@ int main() {
     // ranges that start and end anywhere, against the scalar statement of the same loop; CSI_HOST_SIMD=0 / 2 / 5 caps the choice
     {
         const size_t n = 100003, pad = 64;
-        float* R = static_cast<float*>(std::aligned_alloc(64, (n + 2 * pad) * 4));
-        float* M = static_cast<float*>(std::aligned_alloc(64, (n + 2 * pad) * 4));
-        float* C = static_cast<float*>(std::aligned_alloc(64, (2 * n + 2 * pad) * 4));
-        char* B = static_cast<char*>(std::aligned_alloc(64, 8 * n + 2 * pad));
+        float* R = static_cast<float*>(std::aligned_alloc(64, up64((n + 2 * pad) * 4)));
+        float* M = static_cast<float*>(std::aligned_alloc(64, up64((n + 2 * pad) * 4)));
+        float* C = static_cast<float*>(std::aligned_alloc(64, up64((2 * n + 2 * pad) * 4)));
+        char* B = static_cast<char*>(std::aligned_alloc(64, up64(8 * n + 2 * pad)));
         std::vector<double> src(2 * n);
         for (size_t i = 0; i < 2 * n; ++i) src[i] = (double)((i * 2246822519u) % 999983) / 1013.0 - 490.0;
         const int offs[][2] = {{0, 0}, {3, 3}, {3, 5}, {8, 0}, {16, 0}, {1, 17}, {7, 8}};
