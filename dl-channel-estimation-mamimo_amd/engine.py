@@ -64,6 +64,46 @@ class DeviceArray:
             pass
 
 
+class PinnedPool:
+    """Fresh numpy arrays over RECYCLED pinned host buffers.  ``take(shape, dtype)`` returns an array nobody else holds - the
+    reference's wrapper returns fresh arrays (inference.py:31-32) and so does this - whose memory goes back to the pool once the
+    array and every view of it are garbage-collected, so a serving loop pins its result memory once, not per call (pinning a
+    gigabyte costs more than the host pass it saves).  ``alloc(nbytes)`` returns an object with the buffer protocol that frees
+    its memory when it is collected (CsiEngine: csi_host_malloc behind a ctypes array with a finalizer)."""
+
+    def __init__(self, alloc, max_idle_bytes=4 << 30):
+        self._alloc, self._free, self._idle, self._max = alloc, {}, 0, int(max_idle_bytes)
+        self.allocated = self.reused = 0
+
+    def take(self, shape, dtype):
+        count = int(np.prod(shape))
+        n = max(count * np.dtype(dtype).itemsize, 1)
+        idle = self._free.get(n)
+        if idle:
+            buf = idle.pop()
+            self._idle -= n
+            self.reused += 1
+        else:
+            buf = self._alloc(n)
+            self.allocated += 1
+        flat = np.frombuffer(buf, dtype=dtype, count=count)      # every later view has THIS array as its base: it dies last
+        weakref.finalize(flat, self._give_back, n, buf)
+        return flat.reshape(shape)
+
+    def _give_back(self, n, buf):
+        if self._idle + n <= self._max:                           # beyond the cap the buffer is simply dropped (and freed)
+            self._free.setdefault(n, []).append(buf)
+            self._idle += n
+
+    def clear(self):
+        self._free.clear()
+        self._idle = 0
+
+    @property
+    def idle_bytes(self):
+        return self._idle
+
+
 def get_unique_id():
     """128-byte RCCL unique id (ncclGetUniqueId through the C-ABI) - create on ONE rank, hand to all."""
     lib = _lib.load_library()
@@ -123,6 +163,8 @@ class CsiEngine:
             raise CsiError(rc, (self._lib.csi_last_error(None) or b'').decode())
         self._ctx = ctx
         self._arrays = weakref.WeakSet()
+        me = weakref.ref(self)                                  # (no engine -> pool -> engine cycle: an engine is freed when its last reference goes)
+        self.result_pool = PinnedPool(lambda n: me()._pinned_buffer(n))       # estimate(..., pinned_results=True)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -133,6 +175,8 @@ class CsiEngine:
         if self._ctx:
             for arr in list(getattr(self, '_arrays', ())):
                 arr.free()
+            if getattr(self, 'result_pool', None) is not None:
+                self.result_pool.clear()                             # idle pinned buffers (those behind live arrays free themselves later)
             self._lib.csi_destroy(self._ctx)
             self._ctx = None
 
@@ -372,13 +416,14 @@ class CsiEngine:
         h.imag = h_im
         return h
 
-    def estimate(self, ltf, dnn=True, ls=True, out=None):
+    def estimate(self, ltf, dnn=True, ls=True, out=None, pinned_results=False):
         """Both estimators on the arrays of the reference's deployment wrapper (inference.py:24-32): ``ltf``
         complex128 [npkt, nr, len_ltf] in, complex64 [npkt, nr, nt, n_out] (DNN) and / or [npkt, nr, nt, 234] (LS)
         out - one upload for both, the real / imag split and the complex assembly done inside the library's
         staging copies (csi_estimate_c128).  Returns (dnn, ls); an estimator that was not asked for is None.
         ``out=(dnn_buf, ls_buf)`` reuses complex64 arrays; arrays from ``pinned_empty(shape, np.complex64)`` receive the
-        downloads directly (complex values assembled on the device, no host pass on the result side; same bits)."""
+        downloads directly (complex values assembled on the device, no host pass on the result side; same bits).
+        ``pinned_results=True`` takes the result arrays from ``self.result_pool``: fresh arrays over recycled pinned buffers."""
         ltf = np.ascontiguousarray(ltf, dtype=np.complex128)
         if ltf.ndim != 3 or ltf.shape[1:] != (self.nr, self.len_ltf):
             raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {ltf.shape}')
@@ -390,7 +435,7 @@ class CsiEngine:
                 continue
             shape = (npkt, self.nr, self.nt, width)
             if given is None:
-                given = np.empty(shape, dtype=np.complex64)
+                given = self.result_pool.take(shape, np.complex64) if pinned_results else np.empty(shape, dtype=np.complex64)
             elif given.dtype != np.complex64 or given.shape != shape or not given.flags['C_CONTIGUOUS']:
                 raise CsiError(-1, f'out arrays must be C-contiguous complex64 {shape}')
             bufs.append(given)
@@ -400,6 +445,15 @@ class CsiEngine:
                                                 bufs[0].ctypes.data if bufs[0] is not None else None,
                                                 bufs[1].ctypes.data if bufs[1] is not None else None))
         return bufs[0], bufs[1]
+
+    def _pinned_buffer(self, nbytes):
+        """ctypes array over ``nbytes`` of pinned host memory (csi_host_malloc), freed when the ctypes array is collected."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.csi_host_malloc(self._ctx, ctypes.byref(p), max(int(nbytes), 1)))
+        buf = (ctypes.c_char * max(int(nbytes), 1)).from_address(p.value)
+        lib, addr = self._lib, p.value
+        weakref.finalize(buf, lambda: lib.csi_host_free(None, ctypes.c_void_p(addr)))      # (no context: the buffer may outlive the engine)
+        return buf
 
     def pinned_empty(self, shape, dtype=np.float32):
         """numpy array in pinned host memory (csi_host_malloc); freed with the array."""

@@ -16,7 +16,7 @@ from .model import CSIModel, load_weight_file, config_from_weights, WEIGHT_FILE,
 class CSIPredictor:
 
     def __init__(self, model_path, experiment='RICE_RENEW', verbose=False, device=0, pilot=None,
-                 workspace_bytes=0, nr=None):
+                 workspace_bytes=0, nr=None, pinned_results=False):
         self.path = model_path
         self.experiment = experiment
         self.verbose = verbose
@@ -26,6 +26,9 @@ class CSIPredictor:
         self._pilot = pilot
         self._nr = nr
         self._any_nr = False
+        # matlab_maMimo: result arrays over recycled pinned buffers (fresh array objects as ever; the library then downloads
+        # straight into them and assembles real + 1j*imag on the device - engine.PinnedPool, csi_estimate_c128)
+        self.pinned_results = bool(pinned_results)
         self.model_real, self.model_imag = self.load_model()
 
     # inference.py:14-22
@@ -94,10 +97,10 @@ class CSIPredictor:
             # the ``real + 1j*imag`` of :31 happen inside the library's staging copies (csi_estimate_c128)
             if self._any_nr:        # engine built for one rx antenna per item: [nPkt, nRx, L] -> [nPkt*nRx, 1, L] and back
                 npkt, nrx = X.shape[:2]
-                out, _ = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=True, ls=False)
+                out, _ = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=True, ls=False, pinned_results=self.pinned_results)
                 out = out.reshape(npkt, nrx, *out.shape[2:])
             else:
-                out, _ = self.engine.estimate(X, dnn=True, ls=False)
+                out, _ = self.engine.estimate(X, dnn=True, ls=False, pinned_results=self.pinned_results)
             return self.postprocess_data(out)
         else:
             bs = X.shape[0]   # assumes num. of samples in the first dimension
@@ -116,9 +119,9 @@ class CSIPredictor:
         X = self.preprocess_data(input_batch)
         if self._any_nr:
             npkt, nrx = X.shape[:2]
-            outs = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=dnn, ls=ls)
+            outs = self.engine.estimate(X.reshape(npkt * nrx, 1, X.shape[2]), dnn=dnn, ls=ls, pinned_results=self.pinned_results)
             return tuple(None if o is None else o.reshape(npkt, nrx, *o.shape[2:]) for o in outs)
-        return self.engine.estimate(X, dnn=dnn, ls=ls)
+        return self.engine.estimate(X, dnn=dnn, ls=ls, pinned_results=self.pinned_results)
 
     # inference.py:35-46
     def preprocess_data(self, input_batch):

@@ -206,3 +206,79 @@ def test_host_pipeline_pools_cover_every_range_once(tmp_path):
     for cap in ('0', '2', '5', '5'):
         run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120, env=dict(os.environ, CSI_HOST_SIMD=cap))
         assert run.returncode == 0 and 'hostpool_check: ok' in run.stdout and 'simd: cap %s,' % cap in run.stdout, run.stdout
+
+
+def test_pinned_pool_recycles_buffers_behind_fresh_arrays(pkg):
+    """engine.PinnedPool (the memory behind estimate(..., pinned_results=True) / CSIPredictor(pinned_results=True)): every take() is a
+    fresh array; its buffer returns to the pool only when the array AND every view of it are gone; the next take of that size reuses it
+    (a serving loop pins once); other sizes allocate; the idle cap drops buffers instead of hoarding them.  Fake allocator: no GPU."""
+    import ctypes
+    import gc
+    from dl_channel_estimation_mamimo_amd.engine import PinnedPool
+    made = []
+
+    def alloc(n):
+        buf = (ctypes.c_char * n)()
+        made.append(ctypes.addressof(buf))
+        return buf
+
+    pool = PinnedPool(alloc, max_idle_bytes=1 << 20)
+    a = pool.take((4, 3, 5), np.complex64)
+    assert a.shape == (4, 3, 5) and a.dtype == np.complex64 and a.flags['C_CONTIGUOUS'] and pool.allocated == 1
+    addr_a = a.ctypes.data
+    a[...] = 1 + 2j
+    b = pool.take((4, 3, 5), np.complex64)                 # `a` is alive: a second buffer
+    assert b.ctypes.data != addr_a and pool.allocated == 2
+    view = a[1:3, :, ::2]                                  # a view keeps the buffer out of the pool after `a` itself is dropped
+    del a
+    gc.collect()
+    assert pool.idle_bytes == 0
+    c = pool.take((4, 3, 5), np.complex64)
+    assert c.ctypes.data not in (addr_a, b.ctypes.data) and pool.allocated == 3
+    assert np.all(view == 1 + 2j)                          # nobody overwrote what the view still shows
+    del view
+    gc.collect()
+    assert pool.idle_bytes == 4 * 3 * 5 * 8 and pool.reused == 0
+    d = pool.take((60,), np.complex64)                     # same byte count, another shape: the recycled buffer
+    assert d.ctypes.data == addr_a and pool.reused == 1 and pool.allocated == 3 and pool.idle_bytes == 0
+    e = pool.take((7,), np.float32)                        # another size allocates
+    assert pool.allocated == 4
+    big = pool.take((1 << 18,), np.complex64)              # 2 MiB > the idle cap: dropped on release, not kept
+    del big, b, c, d, e
+    gc.collect()
+    assert pool.idle_bytes <= 1 << 20 and pool.idle_bytes == 3 * 480 + 28          # b, c, d (480 B each) and e; `big` was dropped
+    pool.clear()
+    assert pool.idle_bytes == 0
+    assert len(made) == 5
+
+
+def test_engine_objects_hold_no_reference_cycle(pkg):
+    """A CsiEngine must be freed by its last reference (the suites create hundreds; device memory held until a gc pass would pile
+    up): its members may not point back at it.  Checked on the class without a device: every attribute __init__ sets that could hold
+    a callable is built from a weak reference."""
+    import inspect
+    from dl_channel_estimation_mamimo_amd import engine
+    src = inspect.getsource(engine.CsiEngine.__init__)
+    assert 'PinnedPool(self.' not in src and 'weakref.ref(self)' in src
+    # and the pool itself keeps nothing alive but idle buffers
+    import gc
+    import weakref
+
+    class Owner:
+        def __init__(self):
+            me = weakref.ref(self)
+            self.pool = engine.PinnedPool(lambda n: me().alloc(n))
+
+        def alloc(self, n):
+            return bytearray(n)
+
+    o = Owner()
+    a = o.pool.take((8,), np.float32)
+    w = weakref.ref(o)
+    gc.disable()
+    try:
+        del o
+        assert w() is None                              # freed by reference counting alone, with an array of its pool still alive
+    finally:
+        gc.enable()
+    assert a.shape == (8,)
