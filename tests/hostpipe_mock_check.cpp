@@ -1,0 +1,301 @@
+// hostpipe_mock_check.cpp - the host pipeline of the host-buffer entry points (csrc/csi_hostpipe.hpp: hp_run with its stager / drainer
+// threads, two pinned + two device slots, three streams chained by events) executed WITHOUT a GPU against a small model of the HIP
+// stream semantics, so that ThreadSanitizer can see every hand-over of a buffer:
+//   * a stream is a FIFO of work items run by its own thread; hipMemcpyAsync and the "kernels" are items on it;
+//   * hipEventRecord marks a position, hipStreamWaitEvent makes a stream wait for the position recorded at call time,
+//     hipEventSynchronize / hipStreamSynchronize block the caller - the happens-before edges HIP guarantees and no others;
+//   * "device memory" is host memory, csi_predict_device / csi_ls_estimate_device are stand-ins that enqueue a simple arithmetic map
+//     on the context's stream (what the pipeline needs from them: stream order, input -> output).
+// A dependency the pipeline forgets (a slot reused before its download ended, a staging buffer rewritten under a running upload) is a
+// data race here, and a wrong result.  The definitions below take precedence over libamdhip64's at link time; nothing of the real
+// runtime is called.  This is test scaffolding for OUR host code - it is not a stand-in for anything of the reference.
+//   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -pthread [-Xarch_host -fsanitize=thread] tests/hostpipe_mock_check.cpp -o /tmp/hpmock && /tmp/hpmock
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <set>
+#include <thread>
+#include <vector>
+
+#include "../dl-channel-estimation-mamimo_amd/csrc/csi_hostpipe.hpp"
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+namespace mock {
+
+struct Stream {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    uint64_t submitted = 0, completed = 0;
+    bool stop = false;
+    std::thread th;
+    Stream() : th([this] { run(); }) {}
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                f = std::move(q.front());
+                q.pop_front();
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++completed;
+            }
+            cv.notify_all();
+        }
+    }
+    void push(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(std::move(f));
+            ++submitted;
+        }
+        cv.notify_all();
+    }
+    void sync() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t want = submitted;
+        cv.wait(lk, [&] { return completed >= want; });
+    }
+    ~Stream() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
+
+struct Event {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t recorded = 0, done = 0;
+};
+
+std::mutex g_mu;
+std::set<Stream*> g_streams;
+std::set<const void*> g_pinned;
+std::atomic<long> g_copies{0}, g_waits{0};
+
+Stream* S(hipStream_t s) { return reinterpret_cast<Stream*>(s); }
+Event* E(hipEvent_t e) { return reinterpret_cast<Event*>(e); }
+
+}  // namespace mock
+
+extern "C" {
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "mock"; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+    auto* p = new mock::Stream();
+    std::lock_guard<std::mutex> lk(mock::g_mu);
+    mock::g_streams.insert(p);
+    *s = reinterpret_cast<hipStream_t>(p);
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(mock::g_mu);
+        mock::g_streams.erase(mock::S(s));
+    }
+    delete mock::S(s);
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {
+    mock::S(s)->sync();
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize(void) {
+    std::vector<mock::Stream*> all;
+    {
+        std::lock_guard<std::mutex> lk(mock::g_mu);
+        all.assign(mock::g_streams.begin(), mock::g_streams.end());
+    }
+    for (auto* s : all) s->sync();
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
+    *e = reinterpret_cast<hipEvent_t>(new mock::Event());
+    return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+    delete mock::E(e);
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    mock::Event* ev = mock::E(e);
+    uint64_t g;
+    {
+        std::lock_guard<std::mutex> lk(ev->mu);
+        g = ++ev->recorded;
+    }
+    mock::S(s)->push([ev, g] {
+        std::lock_guard<std::mutex> lk(ev->mu);      // (notified under the lock: whoever sees `done` may destroy the event at once, as HIP allows)
+        if (ev->done < g) ev->done = g;
+        ev->cv.notify_all();
+    });
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    mock::Event* ev = mock::E(e);
+    std::unique_lock<std::mutex> lk(ev->mu);
+    const uint64_t g = ev->recorded;
+    ev->cv.wait(lk, [&] { return ev->done >= g; });
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+    mock::Event* ev = mock::E(e);
+    uint64_t g;
+    {
+        std::lock_guard<std::mutex> lk(ev->mu);
+        g = ev->recorded;
+    }
+    ++mock::g_waits;
+    if (g)
+        mock::S(s)->push([ev, g] {
+            std::unique_lock<std::mutex> lk(ev->mu);
+            ev->cv.wait(lk, [&] { return ev->done >= g; });
+        });
+    return hipSuccess;
+}
+hipError_t hipMalloc(void** p, size_t n) {
+    *p = std::aligned_alloc(256, (n + 255) / 256 * 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+    *p = std::aligned_alloc(4096, (n + 4095) / 4096 * 4096);
+    if (!*p) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> lk(mock::g_mu);
+    mock::g_pinned.insert(*p);
+    return hipSuccess;
+}
+hipError_t hipHostFree(void* p) {
+    {
+        std::lock_guard<std::mutex> lk(mock::g_mu);
+        mock::g_pinned.erase(p);
+    }
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+    std::lock_guard<std::mutex> lk(mock::g_mu);
+    if (!mock::g_pinned.count(p)) return hipErrorInvalidValue;
+    std::memset(a, 0, sizeof *a);
+    a->type = hipMemoryTypeHost;
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
+    ++mock::g_copies;
+    mock::S(st)->push([d, s, n] { std::memcpy(d, s, n); });
+    return hipSuccess;
+}
+
+// the two device entry points the pipeline calls, as stream-ordered arithmetic maps (input chunk -> output planes)
+static inline float dnn_map(const float* x, size_t len, int t, int k) { return x[(size_t)(t * 7 + k) % len] * 0.5f + (float)t; }
+int csi_predict_device(csi_ctx* c, const float* d_re, const float* d_im, int64_t np, float* o_re, float* o_im) {
+    const csi_config cf = c->cfg;
+    mock::S(c->stream)->push([=] {
+        const size_t len = (size_t)cf.len_ltf;
+        for (int64_t p = 0; p < np; ++p)
+            for (int r = 0; r < cf.nr; ++r)
+                for (int t = 0; t < cf.nt; ++t)
+                    for (int k = 0; k < cf.n_out; ++k) {
+                        const size_t o = (((size_t)p * cf.nr + r) * cf.nt + t) * cf.n_out + k, i = ((size_t)p * cf.nr + r) * len;
+                        o_re[o] = dnn_map(d_re + i, len, t, k);
+                        o_im[o] = dnn_map(d_im + i, len, t, k) - 3.f;
+                    }
+    });
+    return CSI_OK;
+}
+int csi_ls_estimate_device(csi_ctx* c, const float* d_re, const float* d_im, int64_t np, float* h_re, float* h_im) {
+    const csi_config cf = c->cfg;
+    mock::S(c->stream)->push([=] {
+        const size_t len = (size_t)cf.len_ltf;
+        for (int64_t p = 0; p < np; ++p)
+            for (int r = 0; r < cf.nr; ++r)
+                for (int t = 0; t < cf.nt; ++t)
+                    for (int k = 0; k < LS_NDATA; ++k) {
+                        const size_t o = (((size_t)p * cf.nr + r) * cf.nt + t) * LS_NDATA + k, i = ((size_t)p * cf.nr + r) * len + (size_t)(k + 11 * t) % len;
+                        h_re[o] = d_re[i] - d_im[i];
+                        h_im[o] = d_re[i] + 2.f * d_im[i];
+                    }
+    });
+    return CSI_OK;
+}
+}  // extern "C"
+
+int main() {
+    int bad = 0;
+    csi_ctx* c = new csi_ctx();
+    c->cfg.nt = 2; c->cfg.nr = 2; c->cfg.len_ltf = 640; c->cfg.n_out = 52; c->cfg.device = 0;
+    hipStreamCreateWithFlags(&c->stream, 0);
+    const int64_t npkt = 203;
+    const size_t in_n = (size_t)c->cfg.nr * c->cfg.len_ltf, dnn_n = (size_t)c->cfg.nr * c->cfg.nt * c->cfg.n_out, ls_n = (size_t)c->cfg.nr * c->cfg.nt * LS_NDATA;
+    std::vector<double> x(2 * in_n * npkt);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (double)((i * 2654435761u) % 100003) / 97.0 - 500.0;
+    // what the call has to return, straight from the input
+    std::vector<float> re(in_n * npkt), im(in_n * npkt), want_dnn(2 * dnn_n * npkt), want_ls(2 * ls_n * npkt);
+    for (size_t i = 0; i < in_n * npkt; ++i) { re[i] = (float)x[2 * i]; im[i] = (float)x[2 * i + 1]; }
+    for (int64_t p = 0; p < npkt; ++p)
+        for (int r = 0; r < c->cfg.nr; ++r)
+            for (int t = 0; t < c->cfg.nt; ++t) {
+                const size_t i = ((size_t)p * c->cfg.nr + r) * c->cfg.len_ltf, len = (size_t)c->cfg.len_ltf;
+                for (int k = 0; k < c->cfg.n_out; ++k) {
+                    const size_t o = (((size_t)p * c->cfg.nr + r) * c->cfg.nt + t) * c->cfg.n_out + k;
+                    want_dnn[2 * o] = dnn_map(re.data() + i, len, t, k);
+                    want_dnn[2 * o + 1] = dnn_map(im.data() + i, len, t, k) - 3.f;
+                }
+                for (int k = 0; k < LS_NDATA; ++k) {
+                    const size_t o = (((size_t)p * c->cfg.nr + r) * c->cfg.nt + t) * LS_NDATA + k, j = i + (size_t)(k + 11 * t) % len;
+                    want_ls[2 * o] = re[j] - im[j];
+                    want_ls[2 * o + 1] = re[j] + 2.f * im[j];
+                }
+            }
+    std::vector<float> dnn(2 * dnn_n * npkt), ls(2 * ls_n * npkt);
+    int calls = 0;
+    for (int side : {1, 0})
+        for (int threads : {0, 3, 6})
+            for (int chunk : {0, 7, 32, 50, 203, 500}) {
+                if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }      // (what csi_set_option "host_threads" does)
+                c->hp_side_threads = side;
+                c->host_threads = threads;
+                c->hp_chunk_packets = chunk;
+                for (int what = 0; what < 3; ++what) {                               // both estimators, DNN alone, LS alone
+                    std::fill(dnn.begin(), dnn.end(), -7.f);
+                    std::fill(ls.begin(), ls.end(), -7.f);
+                    const int rc = hp_estimate_c128(c, x.data(), npkt, what != 2 ? dnn.data() : nullptr, what != 1 ? ls.data() : nullptr);
+                    ++calls;
+                    if (rc) { ++bad; std::printf("side %d threads %d chunk %d what %d: rc %d (%s)\n", side, threads, chunk, what, rc, c->err.c_str()); continue; }
+                    if (what != 2 && std::memcmp(dnn.data(), want_dnn.data(), dnn.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: DNN result differs\n", side, threads, chunk, what); }
+                    if (what != 1 && std::memcmp(ls.data(), want_ls.data(), ls.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: LS result differs\n", side, threads, chunk, what); }
+                }
+                // the plane entry points' pipeline (hp_packets) on the same model: DNN planes
+                std::vector<float> o_re(dnn_n * npkt, -7.f), o_im(dnn_n * npkt, -7.f);
+                const int rc = hp_packets(c, re.data(), im.data(), npkt, o_re.data(), o_im.data(), c->cfg.n_out,
+                                          [c](const float* a, const float* b, int64_t np, float* p, float* q) { return csi_predict_device(c, a, b, np, p, q); });
+                ++calls;
+                bool same = rc == 0;
+                for (size_t i = 0; same && i < dnn_n * npkt; ++i) same = o_re[i] == want_dnn[2 * i] && o_im[i] == want_dnn[2 * i + 1];
+                if (!same) { ++bad; std::printf("side %d threads %d chunk %d: plane pipeline rc %d or result differs\n", side, threads, chunk, rc); }
+            }
+    std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits\n", calls, mock::g_copies.load(), mock::g_waits.load());
+    std::printf(bad ? "FAILED (%d)\n" : "hostpipe_mock_check: ok\n", bad);
+    return bad ? 1 : 0;
+}
+#else
+int main() { return 0; }
+#endif

@@ -289,3 +289,19 @@ def test_engine_objects_hold_no_reference_cycle(pkg):
     finally:
         gc.enable()
     assert a.shape == (8,)
+
+
+def test_host_pipeline_on_a_model_of_the_stream_semantics(tmp_path):
+    """tests/hostpipe_mock_check.cpp: hp_run (stager / drainer threads, two pinned + two device slots, three streams chained by
+    events) and both host pipelines on top of it run 144 calls - side threads and inline, several thread counts, slot sizes from 7
+    packets to one chunk, both estimators / either alone - against a small model of the HIP stream semantics (FIFO streams on their own
+    threads, events as positions) with arithmetic stand-ins for the kernels: every result exact.  (Under -fsanitize=thread the same
+    binary shows no race, and a pipeline with one event dependency removed shows races and 11 wrong results: tools/sanitize_host.sh.)"""
+    exe = str(tmp_path / 'hostpipe_mock_check')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-Wno-unused-value', '-pthread',
+                          os.path.join(REPO, 'tests', 'hostpipe_mock_check.cpp'), '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    for _ in range(2):
+        run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+        assert run.returncode == 0 and 'hostpipe_mock_check: ok' in run.stdout and '144 pipelined calls' in run.stdout, run.stdout[-3000:]
