@@ -204,6 +204,29 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
     return hipSuccess;
 }
 
+// the one kernel the pipeline launches itself: weave_c64_kernel (result arrays in pinned memory) - args (re, im, out, n) - as a stream item.
+// The launch configuration calls are kept away from the real runtime as well.
+static thread_local struct { dim3 g, b; size_t sh; hipStream_t st; } g_cfg;
+hipError_t __hipPushCallConfiguration(dim3 g, dim3 b, size_t sh, hipStream_t st) {
+    g_cfg.g = g; g_cfg.b = b; g_cfg.sh = sh; g_cfg.st = st;
+    return hipSuccess;
+}
+hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* sh, hipStream_t* st) {
+    *g = g_cfg.g; *b = g_cfg.b; *sh = g_cfg.sh; *st = g_cfg.st;
+    return hipSuccess;
+}
+std::atomic<long> g_launches{0};
+hipError_t hipLaunchKernel(const void* fn, dim3, dim3, void** args, size_t, hipStream_t st) {
+    if (fn != reinterpret_cast<const void*>(&csi::weave_c64_kernel)) return hipErrorInvalidDeviceFunction;
+    const float* re = *static_cast<const float**>(args[0]);
+    const float* im = *static_cast<const float**>(args[1]);
+    float* out = reinterpret_cast<float*>(*static_cast<float2**>(args[2]));
+    const size_t n = *static_cast<size_t*>(args[3]);
+    ++g_launches;
+    mock::S(st)->push([=] { for (size_t i = 0; i < n; ++i) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; } });
+    return hipSuccess;
+}
+
 // the two device entry points the pipeline calls, as stream-ordered arithmetic maps (input chunk -> output planes)
 static inline float dnn_map(const float* x, size_t len, int t, int k) { return x[(size_t)(t * 7 + k) % len] * 0.5f + (float)t; }
 int csi_predict_device(csi_ctx* c, const float* d_re, const float* d_im, int64_t np, float* o_re, float* o_im) {
@@ -283,6 +306,24 @@ int main() {
                     if (what != 2 && std::memcmp(dnn.data(), want_dnn.data(), dnn.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: DNN result differs\n", side, threads, chunk, what); }
                     if (what != 1 && std::memcmp(ls.data(), want_ls.data(), ls.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: LS result differs\n", side, threads, chunk, what); }
                 }
+                // result arrays in "pinned" memory: complex64 assembled by the launched kernel, downloads into the arrays themselves
+                {
+                    float *pd = nullptr, *pl = nullptr;
+                    hipHostMalloc(reinterpret_cast<void**>(&pd), dnn.size() * 4, 0);
+                    hipHostMalloc(reinterpret_cast<void**>(&pl), ls.size() * 4, 0);
+                    for (int what = 0; what < 3; ++what) {
+                        std::fill(pd, pd + dnn.size(), -7.f);
+                        std::fill(pl, pl + ls.size(), -7.f);
+                        const int64_t before = c->hp_direct_out_calls;
+                        const int rc = hp_estimate_c128(c, x.data(), npkt, what != 2 ? pd : nullptr, what != 1 ? pl : nullptr);
+                        ++calls;
+                        if (rc || c->hp_direct_out_calls != before + 1) { ++bad; std::printf("side %d threads %d chunk %d what %d pinned: rc %d (%s), direct %lld\n", side, threads, chunk, what, rc, c->err.c_str(), (long long)(c->hp_direct_out_calls - before)); continue; }
+                        if (what != 2 && std::memcmp(pd, want_dnn.data(), dnn.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: pinned DNN result differs\n", side, threads, chunk, what); }
+                        if (what != 1 && std::memcmp(pl, want_ls.data(), ls.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: pinned LS result differs\n", side, threads, chunk, what); }
+                    }
+                    hipHostFree(pd);
+                    hipHostFree(pl);
+                }
                 // the plane entry points' pipeline (hp_packets) on the same model: DNN planes
                 std::vector<float> o_re(dnn_n * npkt, -7.f), o_im(dnn_n * npkt, -7.f);
                 const int rc = hp_packets(c, re.data(), im.data(), npkt, o_re.data(), o_im.data(), c->cfg.n_out,
@@ -292,7 +333,7 @@ int main() {
                 for (size_t i = 0; same && i < dnn_n * npkt; ++i) same = o_re[i] == want_dnn[2 * i] && o_im[i] == want_dnn[2 * i + 1];
                 if (!same) { ++bad; std::printf("side %d threads %d chunk %d: plane pipeline rc %d or result differs\n", side, threads, chunk, rc); }
             }
-    std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits\n", calls, mock::g_copies.load(), mock::g_waits.load());
+    std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits, %ld kernel launches\n", calls, mock::g_copies.load(), mock::g_waits.load(), g_launches.load());
     std::printf(bad ? "FAILED (%d)\n" : "hostpipe_mock_check: ok\n", bad);
     return bad ? 1 : 0;
 }
