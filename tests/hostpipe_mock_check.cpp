@@ -333,6 +333,42 @@ int main() {
                 for (size_t i = 0; same && i < dnn_n * npkt; ++i) same = o_re[i] == want_dnn[2 * i] && o_im[i] == want_dnn[2 * i + 1];
                 if (!same) { ++bad; std::printf("side %d threads %d chunk %d: plane pipeline rc %d or result differs\n", side, threads, chunk, rc); }
             }
+    // the plane pipeline over several chunks (its slots are >= 8 MiB of input): pageable and "pinned" caller buffers, both arrangements
+    {
+        if (c->hostpipe) { delete c->hostpipe; c->hostpipe = nullptr; }
+        c->cfg.nt = 16; c->cfg.nr = 8; c->cfg.len_ltf = 512; c->cfg.n_out = 20;
+        c->host_threads = 4;
+        const int64_t np2 = 1700;                                                    // 512-packet slots: 128 | 512 | 512 | 420 | 128
+        const size_t in2 = (size_t)c->cfg.nr * c->cfg.len_ltf * np2, out2 = (size_t)c->cfg.nr * c->cfg.nt * c->cfg.n_out * np2;
+        float *bufs[4];
+        for (int pinned = 0; pinned < 2; ++pinned) {
+            for (int k = 0; k < 4; ++k) {
+                const size_t bytes = (k < 2 ? in2 : out2) * 4;
+                if (pinned) hipHostMalloc(reinterpret_cast<void**>(&bufs[k]), bytes, 0);
+                else bufs[k] = static_cast<float*>(std::malloc(bytes));
+            }
+            for (size_t i = 0; i < in2; ++i) { bufs[0][i] = (float)((i * 40503u) % 8191) * 0.25f - 1000.f; bufs[1][i] = (float)((i * 12289u) % 4093) - 2000.f; }
+            for (int side : {1, 0}) {
+                c->hp_side_threads = side;
+                std::fill(bufs[2], bufs[2] + out2, -7.f);
+                std::fill(bufs[3], bufs[3] + out2, -7.f);
+                const int rc = hp_packets(c, bufs[0], bufs[1], np2, bufs[2], bufs[3], c->cfg.n_out,
+                                          [c](const float* a, const float* b, int64_t np, float* p, float* q) { return csi_predict_device(c, a, b, np, p, q); });
+                ++calls;
+                size_t wrong = rc ? 1 : 0;
+                const size_t len = (size_t)c->cfg.len_ltf;
+                for (int64_t p = 0; p < np2 && !wrong; ++p)
+                    for (int r = 0; r < c->cfg.nr && !wrong; ++r)
+                        for (int t = 0; t < c->cfg.nt && !wrong; ++t)
+                            for (int k = 0; k < c->cfg.n_out; ++k) {
+                                const size_t o = (((size_t)p * c->cfg.nr + r) * c->cfg.nt + t) * c->cfg.n_out + k, i = ((size_t)p * c->cfg.nr + r) * len;
+                                if (bufs[2][o] != dnn_map(bufs[0] + i, len, t, k) || bufs[3][o] != dnn_map(bufs[1] + i, len, t, k) - 3.f) { ++wrong; break; }
+                            }
+                if (wrong) { ++bad; std::printf("plane pipeline, %s buffers, side %d: rc %d or a result differs\n", pinned ? "pinned" : "pageable", side, rc); }
+            }
+            for (int k = 0; k < 4; ++k) { if (pinned) hipHostFree(bufs[k]); else std::free(bufs[k]); }
+        }
+    }
     std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits, %ld kernel launches\n", calls, mock::g_copies.load(), mock::g_waits.load(), g_launches.load());
     std::printf(bad ? "FAILED (%d)\n" : "hostpipe_mock_check: ok\n", bad);
     return bad ? 1 : 0;
