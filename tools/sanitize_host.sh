@@ -2,6 +2,7 @@
 # Build container (no GPU): the host side of the library under the sanitizers.
 #   1. tests/hostpool_check.cpp (thread pools, staging loops) under -fsanitize=thread and -fsanitize=address
 #   1b. tests/hostpipe_mock_check.cpp (hp_run on a model of the HIP stream semantics) under -fsanitize=thread
+#   1c. tests/comm_mock_check.cpp (csi_broadcast_weights by N rank threads on the HIP + RCCL models) under -fsanitize=thread
 #   2. libcsi_mamimo.so rebuilt with -Xarch_host -fsanitize=address / undefined, swapped in for the CPU tests that call host-only entry
 #      points (csi_pilot_classify, csi_crc32c, the RCCL-not-found path, the symbol table), sanitizer run-time preloaded into python;
 #      the product library is put back (and compared) afterwards
@@ -18,6 +19,9 @@ done
 # the whole host pipeline (hp_run: stager / drainer threads, slots, events) on the stream model of tests/hostpipe_mock_check.cpp
 hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wno-unused-value -pthread -Xarch_host -fsanitize=thread tests/hostpipe_mock_check.cpp -o /tmp/hpmock_tsan 2>/dev/null || { echo "build failed (hostpipe mock)"; exit 1; }
 for i in 1 2 3; do TSAN_OPTIONS=halt_on_error=0 /tmp/hpmock_tsan > /tmp/hpmock_tsan.log 2>&1; echo "hostpipe_mock_check [thread] run $i: $(grep -c '^WARNING: ThreadSanitizer' /tmp/hpmock_tsan.log) races; $(tail -1 /tmp/hpmock_tsan.log)"; done
+# csi_broadcast_weights by 2 / 4 / 8 rank threads on the HIP + RCCL models of tests/comm_mock_check.cpp (the whole library TU)
+hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wno-unused-value -pthread -Xarch_host -fsanitize=thread tests/comm_mock_check.cpp -o /tmp/comm_tsan 2>/dev/null || { echo "build failed (comm mock)"; exit 1; }
+TSAN_OPTIONS=halt_on_error=0 /tmp/comm_tsan > /tmp/comm_tsan.log 2>&1; echo "comm_mock_check [thread]: $(grep -c '^WARNING: ThreadSanitizer' /tmp/comm_tsan.log) races; $(tail -1 /tmp/comm_tsan.log)"
 cp -p $SO /tmp/libcsi_product.so
 for san in address undefined; do
   extra=""; [ $san = undefined ] && extra="-Xarch_host -fno-sanitize=vptr,function"
