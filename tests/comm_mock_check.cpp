@@ -8,6 +8,8 @@
 //   * a receiver whose csi_config differs: IT gets CSI_ERR_INVALID_ARG with the reason, EVERY other rank gets the "another rank
 //     refused" error, nobody hangs, the refusing receiver holds nothing, the root keeps its model, and a second broadcast among
 //     well-configured contexts on the same communicators then succeeds (the group was closed, the communicator is usable);
+//   * a receiver whose device allocation fails part-way: CSI_ERR_NOMEM there, the refusal everywhere else, and the SAME contexts and
+//     communicators complete the next broadcast;
 //   * a root with nothing loaded: receivers end empty, rc 0.
 // The kernels do not run here (launches are dropped), so a "loaded" model's re-laid-out buffers hold allocation patterns instead of
 // weights - which is all the transfer protocol needs: distinct bytes on the root that must arrive unchanged.
@@ -188,7 +190,8 @@ int bad = 0;
 #define EXPECT(cond, ...) do { if (!(cond)) { ++bad; std::printf("FAILED %s:%d: %s  ", __FILE__, __LINE__, #cond); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
 // one broadcast over `world` rank threads; shapes[r] is rank r's csi_config; returns the rcs; contexts stay alive in `ctx`
-std::vector<int> run_world(int world, int root, const std::vector<Shape>& shapes, bool root_loaded, std::vector<csi_ctx*>& ctx, bool reuse) {
+std::vector<int> run_world(int world, int root, const std::vector<Shape>& shapes, bool root_loaded, std::vector<csi_ctx*>& ctx, bool reuse,
+                           int oom_rank = -1, long oom_at = 0) {
     std::vector<int> rcs(world, -99);
     char uid[CSI_UNIQUE_ID_BYTES];
     if (!reuse) {
@@ -207,7 +210,9 @@ std::vector<int> run_world(int world, int root, const std::vector<Shape>& shapes
                     if (rc) { std::printf("rank %d load: %s\n", r, csi_last_error(ctx[r])); rcs[r] = rc; return; }
                 }
             }
+            if (r == oom_rank) mock::fail_alloc_in = oom_at;                    // this rank's oom_at-th device allocation inside the call fails
             rcs[r] = csi_broadcast_weights(ctx[r], root);
+            mock::fail_alloc_in = -1;
         });
     for (auto& t : th) t.join();
     return rcs;
@@ -285,6 +290,26 @@ int main() {
         for (csi_ctx* c : ctx) if (c) csi_destroy(c);
         for (csi_ctx* c : ctx2) csi_destroy(c);
     }
+    // ---- a receiver that runs out of device memory in the middle of its allocations: the same agreement, nothing leaks into a later call
+    for (long at : {1L, 7L, 19L}) {
+        std::vector<csi_ctx*> ctx;
+        std::vector<int> rcs = run_world(4, 0, std::vector<Shape>(4, base), true, ctx, false, 2, at);
+        ++scenarios;
+        for (int r = 0; r < 4; ++r) {
+            const std::string why = csi_last_error(ctx[r]);
+            if (r == 2) EXPECT(rcs[r] == CSI_ERR_NOMEM && why.find("device allocation") != std::string::npos && held(ctx[r]).empty(), "out of memory at %ld: rank 2 rc %d (%s)", at, rcs[r], why.c_str());
+            else EXPECT(rcs[r] == CSI_ERR_INVALID_ARG && why.find("another rank refused") != std::string::npos, "out of memory at %ld: rank %d rc %d (%s)", at, r, rcs[r], why.c_str());
+        }
+        rcs = run_world(4, 0, std::vector<Shape>(4, base), true, ctx, true);          // the same contexts and communicators, memory back
+        const auto want = held(ctx[0]);
+        for (int r = 0; r < 4; ++r) {
+            EXPECT(rcs[r] == CSI_OK, "after the failed allocation, rank %d: rc %d (%s)", r, rcs[r], csi_last_error(ctx[r]));
+            const auto got = held(ctx[r]);
+            EXPECT(got.size() == want.size(), "after the failed allocation, rank %d: buffer count", r);
+            for (size_t i = 0; i < got.size() && i < want.size(); ++i) EXPECT(!std::memcmp(got[i].first, want[i].first, want[i].second), "after the failed allocation, rank %d buffer %zu", r, i);
+        }
+        for (csi_ctx* c : ctx) csi_destroy(c);
+    }
     // ---- a second broadcast on the SAME communicators (the receivers are replaced wholesale), then a root with nothing loaded
     {
         std::vector<csi_ctx*> ctx;
@@ -319,6 +344,8 @@ int main() {
     }
     finished = true;
     watchdog.join();
+    for (auto& kv : mnccl::g_groups) delete kv.second;              // (the model's own rendezvous objects: a leak check then shows the library's leaks only)
+    mnccl::g_groups.clear();
     std::printf("%d broadcast scenarios, %d collectives on the RCCL model, %ld copies and %ld dropped kernel launches on the HIP model\n", scenarios, mnccl::g_collectives.load(),
                 mock::g_copies.load(), mock::g_launches.load());
     std::printf(bad ? "FAILED (%d)\n" : "comm_mock_check: ok\n", bad);

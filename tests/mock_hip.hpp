@@ -89,6 +89,7 @@ inline std::set<Stream*> g_streams;
 inline std::map<const char*, size_t> g_pinned;          // base -> bytes
 inline std::atomic<long> g_copies{0}, g_waits{0}, g_launches{0}, g_allocs{0};
 inline int n_devices = 8;
+inline thread_local long fail_alloc_in = -1;        // > 0: the n-th hipMalloc of THIS thread from now on fails (out of memory), once
 inline std::function<hipError_t(const void* fn, void** args, hipStream_t st)> launch_hook;
 
 inline Stream* null_stream() {
@@ -202,6 +203,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
     return hipSuccess;
 }
 hipError_t hipMalloc(void** p, size_t n) {
+    if (mock::fail_alloc_in > 0 && --mock::fail_alloc_in == 0) { mock::fail_alloc_in = -1; *p = nullptr; return hipErrorOutOfMemory; }
     const size_t bytes = (n + 255) / 256 * 256;
     *p = std::aligned_alloc(256, bytes ? bytes : 256);
     if (!*p) return hipErrorOutOfMemory;

@@ -22,6 +22,8 @@ for i in 1 2 3; do TSAN_OPTIONS=halt_on_error=0 /tmp/hpmock_tsan > /tmp/hpmock_t
 # csi_broadcast_weights by 2 / 4 / 8 rank threads on the HIP + RCCL models of tests/comm_mock_check.cpp (the whole library TU)
 hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wno-unused-value -pthread -Xarch_host -fsanitize=thread tests/comm_mock_check.cpp -o /tmp/comm_tsan 2>/dev/null || { echo "build failed (comm mock)"; exit 1; }
 TSAN_OPTIONS=halt_on_error=0 /tmp/comm_tsan > /tmp/comm_tsan.log 2>&1; echo "comm_mock_check [thread]: $(grep -c '^WARNING: ThreadSanitizer' /tmp/comm_tsan.log) races; $(tail -1 /tmp/comm_tsan.log)"
+hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wno-unused-value -pthread -Xarch_host -fsanitize=address tests/comm_mock_check.cpp -o /tmp/comm_asan 2>/dev/null || { echo "build failed (comm mock, address)"; exit 1; }
+ASAN_OPTIONS=detect_leaks=1 /tmp/comm_asan > /tmp/comm_asan.log 2>&1; echo "comm_mock_check [address + leak]: $(grep -c 'ERROR: \(Address\|Leak\)Sanitizer' /tmp/comm_asan.log) reports; $(tail -1 /tmp/comm_asan.log)"
 cp -p $SO /tmp/libcsi_product.so
 for san in address undefined; do
   extra=""; [ $san = undefined ] && extra="-Xarch_host -fno-sanitize=vptr,function"
