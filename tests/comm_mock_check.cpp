@@ -331,6 +331,21 @@ int main() {
         for (int r = 0; r < 2; ++r) EXPECT(rcs[r] == CSI_OK && held(empty[r]).empty() && !empty[r]->model[0].loaded, "empty root, rank %d: rc %d", r, rcs[r]);
         for (csi_ctx* c : empty) csi_destroy(c);
     }
+    // ---- the in-process transport of the same protocol, ACROSS devices (hipMemcpyPeerAsync): csi_clone_weights(dst on device 3, src on device 0)
+    {
+        csi_ctx *src = make_ctx(base, 0), *dst = make_ctx(base, 3), *other = make_ctx(Shape{8, 2, 64, 128, 52, 1, CSI_DTYPE_F32}, 1);
+        EXPECT(load(src, base, 5u) == CSI_OK, "clone: load (%s)", csi_last_error(src));
+        const long peer_before = mock::g_peer_copies.load();
+        EXPECT(csi_clone_weights(dst, src) == CSI_OK, "clone across devices: %s", csi_last_error(dst));
+        ++scenarios;
+        const auto want = held(src), got = held(dst);
+        EXPECT(got.size() == want.size() && !want.empty() && mock::g_peer_copies.load() - peer_before == (long)want.size(), "clone: %zu buffers, source %zu, %ld peer copies", got.size(), want.size(), mock::g_peer_copies.load() - peer_before);
+        for (size_t i = 0; i < got.size() && i < want.size(); ++i) EXPECT(got[i].first != want[i].first && !std::memcmp(got[i].first, want[i].first, want[i].second), "clone: buffer %zu", i);
+        EXPECT(csi_clone_weights(other, src) == CSI_ERR_INVALID_ARG && std::string(csi_last_error(other)).find("n_out 234") != std::string::npos && held(other).empty(), "clone into another network: %s", csi_last_error(other));
+        EXPECT(csi_clone_weights(dst, dst) == CSI_ERR_INVALID_ARG && csi_clone_weights(dst, nullptr) == CSI_ERR_INVALID_ARG, "clone: argument checks");
+        EXPECT(held(dst).size() == want.size(), "a refused argument emptied the destination");
+        csi_destroy(src); csi_destroy(dst); csi_destroy(other);
+    }
     // ---- arguments
     {
         csi_ctx* c = make_ctx(base, 0);

@@ -87,7 +87,7 @@ struct Event {
 inline std::mutex g_mu;
 inline std::set<Stream*> g_streams;
 inline std::map<const char*, size_t> g_pinned;          // base -> bytes
-inline std::atomic<long> g_copies{0}, g_waits{0}, g_launches{0}, g_allocs{0};
+inline std::atomic<long> g_copies{0}, g_peer_copies{0}, g_waits{0}, g_launches{0}, g_allocs{0};
 inline int n_devices = 8;
 inline thread_local long fail_alloc_in = -1;        // > 0: the n-th hipMalloc of THIS thread from now on fails (out of memory), once
 inline std::function<hipError_t(const void* fn, void** args, hipStream_t st)> launch_hook;
@@ -257,6 +257,7 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hip
 }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t st) {
     ++mock::g_copies;
+    ++mock::g_peer_copies;
     mock::S(st)->push([d, s, n] { std::memcpy(d, s, n); });
     return hipSuccess;
 }

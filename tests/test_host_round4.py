@@ -313,11 +313,11 @@ def test_weight_broadcast_by_n_ranks_on_the_stream_and_rccl_models(tmp_path):
     in call order; a rank that skips a collective its peers enter is reported as a hang).  Every receiver ends with the root's device
     buffers byte for byte (root 0 and root != 0, three network shapes incl. bf16); a receiver built for another network is refused
     THERE with the reason and reported on EVERY other rank, nobody waits, the root keeps its model; a second broadcast on the same
-    communicators; a root with nothing loaded; argument checks.  21 scenarios, ~3000 collectives."""
+    communicators; a root with nothing loaded; argument checks.  22 scenarios, ~3000 collectives."""
     exe = str(tmp_path / 'comm_mock_check')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-Wno-unused-value', '-pthread',
                           os.path.join(REPO, 'tests', 'comm_mock_check.cpp'), '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     assert res.returncode == 0, res.stdout[-3000:]
     run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=400, env=dict(os.environ, COMM_MOCK_WATCHDOG_S='120'))
-    assert run.returncode == 0 and 'comm_mock_check: ok' in run.stdout and '21 broadcast scenarios' in run.stdout, run.stdout[-3000:]
+    assert run.returncode == 0 and 'comm_mock_check: ok' in run.stdout and '22 broadcast scenarios' in run.stdout, run.stdout[-3000:]
