@@ -7,226 +7,21 @@
 //   * "device memory" is host memory, csi_predict_device / csi_ls_estimate_device are stand-ins that enqueue a simple arithmetic map
 //     on the context's stream (what the pipeline needs from them: stream order, input -> output).
 // A dependency the pipeline forgets (a slot reused before its download ended, a staging buffer rewritten under a running upload) is a
-// data race here, and a wrong result.  The definitions below take precedence over libamdhip64's at link time; nothing of the real
-// runtime is called.  This is test scaffolding for OUR host code - it is not a stand-in for anything of the reference.
+// data race here, and a wrong result.  The model is tests/mock_hip.hpp (its definitions take precedence over libamdhip64's at link
+// time; nothing of the real runtime is called).  This is test scaffolding for OUR host code - it is not a stand-in for anything of the
+// reference.
 //   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -pthread [-Xarch_host -fsanitize=thread] tests/hostpipe_mock_check.cpp -o /tmp/hpmock && /tmp/hpmock
-#include <atomic>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
-#include <functional>
-#include <mutex>
-#include <set>
-#include <thread>
 #include <vector>
 
 #include "../dl-channel-estimation-mamimo_amd/csrc/csi_hostpipe.hpp"
 
+#include "mock_hip.hpp"          // the model of the HIP runtime (streams as FIFO threads, events as positions, "device" memory on the host)
+
 #if !defined(__HIP_DEVICE_COMPILE__)
-namespace mock {
-
-struct Stream {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::function<void()>> q;
-    uint64_t submitted = 0, completed = 0;
-    bool stop = false;
-    std::thread th;
-    Stream() : th([this] { run(); }) {}
-    void run() {
-        for (;;) {
-            std::function<void()> f;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !q.empty(); });
-                if (q.empty()) return;
-                f = std::move(q.front());
-                q.pop_front();
-            }
-            f();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                ++completed;
-            }
-            cv.notify_all();
-        }
-    }
-    void push(std::function<void()> f) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            q.push_back(std::move(f));
-            ++submitted;
-        }
-        cv.notify_all();
-    }
-    void sync() {
-        std::unique_lock<std::mutex> lk(mu);
-        const uint64_t want = submitted;
-        cv.wait(lk, [&] { return completed >= want; });
-    }
-    ~Stream() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_all();
-        th.join();
-    }
-};
-
-struct Event {
-    std::mutex mu;
-    std::condition_variable cv;
-    uint64_t recorded = 0, done = 0;
-};
-
-std::mutex g_mu;
-std::set<Stream*> g_streams;
-std::set<const void*> g_pinned;
-std::atomic<long> g_copies{0}, g_waits{0};
-
-Stream* S(hipStream_t s) { return reinterpret_cast<Stream*>(s); }
-Event* E(hipEvent_t e) { return reinterpret_cast<Event*>(e); }
-
-}  // namespace mock
-
 extern "C" {
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetLastError(void) { return hipSuccess; }
-const char* hipGetErrorString(hipError_t) { return "mock"; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
-    auto* p = new mock::Stream();
-    std::lock_guard<std::mutex> lk(mock::g_mu);
-    mock::g_streams.insert(p);
-    *s = reinterpret_cast<hipStream_t>(p);
-    return hipSuccess;
-}
-hipError_t hipStreamDestroy(hipStream_t s) {
-    {
-        std::lock_guard<std::mutex> lk(mock::g_mu);
-        mock::g_streams.erase(mock::S(s));
-    }
-    delete mock::S(s);
-    return hipSuccess;
-}
-hipError_t hipStreamSynchronize(hipStream_t s) {
-    mock::S(s)->sync();
-    return hipSuccess;
-}
-hipError_t hipDeviceSynchronize(void) {
-    std::vector<mock::Stream*> all;
-    {
-        std::lock_guard<std::mutex> lk(mock::g_mu);
-        all.assign(mock::g_streams.begin(), mock::g_streams.end());
-    }
-    for (auto* s : all) s->sync();
-    return hipSuccess;
-}
-hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
-    *e = reinterpret_cast<hipEvent_t>(new mock::Event());
-    return hipSuccess;
-}
-hipError_t hipEventDestroy(hipEvent_t e) {
-    delete mock::E(e);
-    return hipSuccess;
-}
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
-    mock::Event* ev = mock::E(e);
-    uint64_t g;
-    {
-        std::lock_guard<std::mutex> lk(ev->mu);
-        g = ++ev->recorded;
-    }
-    mock::S(s)->push([ev, g] {
-        std::lock_guard<std::mutex> lk(ev->mu);      // (notified under the lock: whoever sees `done` may destroy the event at once, as HIP allows)
-        if (ev->done < g) ev->done = g;
-        ev->cv.notify_all();
-    });
-    return hipSuccess;
-}
-hipError_t hipEventSynchronize(hipEvent_t e) {
-    mock::Event* ev = mock::E(e);
-    std::unique_lock<std::mutex> lk(ev->mu);
-    const uint64_t g = ev->recorded;
-    ev->cv.wait(lk, [&] { return ev->done >= g; });
-    return hipSuccess;
-}
-hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
-    mock::Event* ev = mock::E(e);
-    uint64_t g;
-    {
-        std::lock_guard<std::mutex> lk(ev->mu);
-        g = ev->recorded;
-    }
-    ++mock::g_waits;
-    if (g)
-        mock::S(s)->push([ev, g] {
-            std::unique_lock<std::mutex> lk(ev->mu);
-            ev->cv.wait(lk, [&] { return ev->done >= g; });
-        });
-    return hipSuccess;
-}
-hipError_t hipMalloc(void** p, size_t n) {
-    *p = std::aligned_alloc(256, (n + 255) / 256 * 256);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
-}
-hipError_t hipFree(void* p) {
-    std::free(p);
-    return hipSuccess;
-}
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
-    *p = std::aligned_alloc(4096, (n + 4095) / 4096 * 4096);
-    if (!*p) return hipErrorOutOfMemory;
-    std::lock_guard<std::mutex> lk(mock::g_mu);
-    mock::g_pinned.insert(*p);
-    return hipSuccess;
-}
-hipError_t hipHostFree(void* p) {
-    {
-        std::lock_guard<std::mutex> lk(mock::g_mu);
-        mock::g_pinned.erase(p);
-    }
-    std::free(p);
-    return hipSuccess;
-}
-hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
-    std::lock_guard<std::mutex> lk(mock::g_mu);
-    if (!mock::g_pinned.count(p)) return hipErrorInvalidValue;
-    std::memset(a, 0, sizeof *a);
-    a->type = hipMemoryTypeHost;
-    return hipSuccess;
-}
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
-    ++mock::g_copies;
-    mock::S(st)->push([d, s, n] { std::memcpy(d, s, n); });
-    return hipSuccess;
-}
-
-// the one kernel the pipeline launches itself: weave_c64_kernel (result arrays in pinned memory) - args (re, im, out, n) - as a stream item.
-// The launch configuration calls are kept away from the real runtime as well.
-static thread_local struct { dim3 g, b; size_t sh; hipStream_t st; } g_cfg;
-hipError_t __hipPushCallConfiguration(dim3 g, dim3 b, size_t sh, hipStream_t st) {
-    g_cfg.g = g; g_cfg.b = b; g_cfg.sh = sh; g_cfg.st = st;
-    return hipSuccess;
-}
-hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* sh, hipStream_t* st) {
-    *g = g_cfg.g; *b = g_cfg.b; *sh = g_cfg.sh; *st = g_cfg.st;
-    return hipSuccess;
-}
-std::atomic<long> g_launches{0};
-hipError_t hipLaunchKernel(const void* fn, dim3, dim3, void** args, size_t, hipStream_t st) {
-    if (fn != reinterpret_cast<const void*>(&csi::weave_c64_kernel)) return hipErrorInvalidDeviceFunction;
-    const float* re = *static_cast<const float**>(args[0]);
-    const float* im = *static_cast<const float**>(args[1]);
-    float* out = reinterpret_cast<float*>(*static_cast<float2**>(args[2]));
-    const size_t n = *static_cast<size_t*>(args[3]);
-    ++g_launches;
-    mock::S(st)->push([=] { for (size_t i = 0; i < n; ++i) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; } });
-    return hipSuccess;
-}
-
 // the two device entry points the pipeline calls, as stream-ordered arithmetic maps (input chunk -> output planes)
 static inline float dnn_map(const float* x, size_t len, int t, int k) { return x[(size_t)(t * 7 + k) % len] * 0.5f + (float)t; }
 int csi_predict_device(csi_ctx* c, const float* d_re, const float* d_im, int64_t np, float* o_re, float* o_im) {
@@ -261,8 +56,20 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_re, const float* d_im, int
 }
 }  // extern "C"
 
+// the one kernel the pipeline launches itself: weave_c64_kernel (result arrays in pinned memory) - args (re, im, out, n) - as a stream item
+static hipError_t weave_launch(const void* fn, void** args, hipStream_t st) {
+    if (fn != reinterpret_cast<const void*>(&csi::weave_c64_kernel)) return hipErrorInvalidDeviceFunction;
+    const float* re = *static_cast<const float**>(args[0]);
+    const float* im = *static_cast<const float**>(args[1]);
+    float* out = reinterpret_cast<float*>(*static_cast<float2**>(args[2]));
+    const size_t n = *static_cast<size_t*>(args[3]);
+    mock::S(st)->push([=] { for (size_t i = 0; i < n; ++i) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; } });
+    return hipSuccess;
+}
+
 int main() {
     int bad = 0;
+    mock::launch_hook = weave_launch;
     csi_ctx* c = new csi_ctx();
     c->cfg.nt = 2; c->cfg.nr = 2; c->cfg.len_ltf = 640; c->cfg.n_out = 52; c->cfg.device = 0;
     hipStreamCreateWithFlags(&c->stream, 0);
@@ -369,7 +176,7 @@ int main() {
             for (int k = 0; k < 4; ++k) { if (pinned) hipHostFree(bufs[k]); else std::free(bufs[k]); }
         }
     }
-    std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits, %ld kernel launches\n", calls, mock::g_copies.load(), mock::g_waits.load(), g_launches.load());
+    std::printf("%d pipelined calls on the stream model, %ld copies, %ld stream waits, %ld kernel launches\n", calls, mock::g_copies.load(), mock::g_waits.load(), mock::g_launches.load());
     std::printf(bad ? "FAILED (%d)\n" : "hostpipe_mock_check: ok\n", bad);
     return bad ? 1 : 0;
 }
