@@ -267,7 +267,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         the LDS-DMA ring, fp32 matrix-core despread, 7: generic P, despread on the bf16 matrix
  *                         cores with every fp32 value cut exactly into three bf16 pieces (one of the two is chosen
  *                         automatically for any other P, 16 <= Nt <= 128); a choice the kernel cannot serve falls back
- *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 16)
+ *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 33: where it runs one workgroup per CU;
+ *                         below, kernel 6 serves - DESIGN.md 4.2)
  *   get only: "ls_mode" (the kernel the next LS call runs), "ls_pilot_pieces" (bf16 pieces the entries of P need: 1 - 3)
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
  *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor as ONE kernel, h2 in registers (generated
@@ -279,10 +280,23 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "hs_vm_cast", "hs_vm_pair"  vector-memory schedule of the split-f16 layer-0 / first per-pair kernel: 0 builtin LDS-DMA
  *                         with one drain per sub-tile, 1 hand-counted waits, 2 + one more sub-tile of look-ahead (default for
  *                         layer 0), 3 + one load and one 24-MFMA segment per sub-tile (default for the pair layer); same
- *                         results bit for bit, for A/B runs (tools/vm_ab.sh) */
+ *                         results bit for bit, for A/B runs (tools/vm_ab.sh)
+ *   "ls_fast_perm"     1 (default): a pilot matrix that is a signed row / column permutation of the Sylvester Hadamard matrix
+ *                         takes the Walsh-Hadamard LS kernel through permutation tables; 0: the generic kernels (A/B runs)
+ *   "ls_overlap_cus", "ls_overlap_stride"  csi_estimate_device: run the LS kernel on a side stream masked to this many CUs beside
+ *                         the DNN kernels (0 = default: in front of them on the one stream; measured slower, kept for the record)
+ *   "hp_side_threads"  host-buffer entry points: 1 (default) input staging and result staging on their own threads beside the
+ *                         caller's enqueue loop; 0: inline on the calling thread, in turn (A/B runs)
+ *   "hp_chunk_packets" packets per pipeline slot of csi_estimate_c128 (0 = automatic)
+ *   "hp_device_weave"  1 (default): csi_estimate_c128 with pinned result arrays assembles the complex64 values on the device
+ *   "ls_debug"         development switches of the LS kernels (tools/ls_race_*.py); write-only, 0 in production */
 int  csi_set_option(csi_ctx* ctx, const char* name, int64_t value);
-/* Current value of an option, or of the read-only counters "hs_launches" (split-engine GEMMs launched)
- * and "hs_range_fallbacks" (csi_predict calls repeated on the fp32 MFMA kernels). */
+/* Current value of an option, or of the read-only values: "hs_launches" (split-engine GEMMs launched), "hs_range_fallbacks"
+ * (csi_predict calls repeated on the fp32 MFMA kernels), "hs_weight_pins" / "hs_weight_err_e12" (layers pinned to the fp32 kernels
+ * at load because their split copies were not fp32-grade; worst relative error x 1e12), "band_available" (the assembly band kernel
+ * is embedded in this build), "graph_replays", "ls_pilot_fast" (0 generic / 1 Sylvester / 2 permuted pilot), "comm_world",
+ * "comm_rank", "comm_blobs", "comm_bytes" (communicator and last broadcast), "hp_direct_out_calls", and where the last pipelined
+ * host-buffer call spent its time in microseconds: "hp_total_us", "hp_stage_us", "hp_wait_stage_us", "hp_wait_out_us", "hp_weave_us". */
 int  csi_get_option(csi_ctx* ctx, const char* name, int64_t* value);
 
 /* Device-memory plumbing so that a host program needs no other GPU runtime. */

@@ -321,3 +321,22 @@ def test_weight_broadcast_by_n_ranks_on_the_stream_and_rccl_models(tmp_path):
     assert res.returncode == 0, res.stdout[-3000:]
     run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=400, env=dict(os.environ, COMM_MOCK_WATCHDOG_S='120'))
     assert run.returncode == 0 and 'comm_mock_check: ok' in run.stdout and '22 broadcast scenarios' in run.stdout, run.stdout[-3000:]
+
+
+def test_every_option_of_the_library_is_documented_in_the_header():
+    """Every name csi_set_option / csi_get_option accept appears (quoted) in include/csi_mamimo.h, and everything that can be set can be
+    read back (the write-only development switch "ls_debug" aside) - the option surface and its documentation cannot drift apart."""
+    import re
+    with open(os.path.join(REPO, 'dl-channel-estimation-mamimo_amd', 'csrc', 'csi_mamimo.hip')) as f:
+        src = f.read()
+    with open(os.path.join(REPO, 'include', 'csi_mamimo.h')) as f:
+        documented = set(re.findall(r'"([a-z0-9_]+)"', f.read()))
+
+    def names(fn):
+        i = src.index('int %s(' % fn)
+        return set(re.findall(r'n == "([a-z0-9_]+)"', src[i:src.index('\n}\n', i)]))
+
+    settable, gettable = names('csi_set_option'), names('csi_get_option')
+    assert len(settable) >= 20 and len(gettable) >= 40
+    assert settable - gettable == {'ls_debug'}
+    assert (settable | gettable) - documented == set(), sorted((settable | gettable) - documented)
