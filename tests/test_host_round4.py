@@ -340,3 +340,60 @@ def test_every_option_of_the_library_is_documented_in_the_header():
     assert len(settable) >= 20 and len(gettable) >= 40
     assert settable - gettable == {'ls_debug'}
     assert (settable | gettable) - documented == set(), sorted((settable | gettable) - documented)
+
+
+def test_python_engine_on_the_mock_runtime_pinned_result_pool(tmp_path):
+    """The Python layer on a machine without a GPU: tests/mock_library.cpp (the library's translation unit on the model of the HIP
+    runtime; kernels dropped) loaded in place of the product library in a child process.  CsiEngine.estimate(pinned_results=True) takes
+    its result arrays from the recycling pool of pinned buffers (csi_host_malloc), the library downloads straight into them
+    (hp_direct_out_calls), a collected result's buffer is reused by the next call, mixing pinned and pageable arrays falls back to the
+    host weave, close() leaves nothing behind."""
+    so = str(tmp_path / 'libcsi_mock.so')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', '-pthread',
+                          os.path.join(REPO, 'tests', 'mock_library.cpp'), '-o', so], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    script = r'''
+import gc, sys
+import numpy as np
+sys.path.insert(0, %r)
+import dl_channel_estimation_mamimo_amd as pkg
+from dl_channel_estimation_mamimo_amd import _lib
+_lib._SO = %r
+nt, nr, hidden, npkt = 8, 2, (64, 64), 50
+e = pkg.CsiEngine(nt, nr, hidden=hidden)
+rng = np.random.default_rng(0)
+w = pkg.synth.make_weights(rng, nt, hidden)
+e.load_weights('real', w); e.load_weights('imag', w); e.set_pilot(pkg.synth.hadamard(nt))
+x = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+a, b = e.estimate(x)
+assert a.shape == b.shape == (npkt, nr, nt, 234) and a.dtype == np.complex64 and e.get_option('hp_direct_out_calls') == 0
+c, d = e.estimate(x, pinned_results=True)
+assert c.shape == a.shape and c.dtype == np.complex64 and c.flags['C_CONTIGUOUS']
+assert e.get_option('hp_direct_out_calls') == 1 and (e.result_pool.allocated, e.result_pool.reused) == (2, 0)
+addr = {c.ctypes.data, d.ctypes.data}
+c2, d2 = e.estimate(x, pinned_results=True)                      # the first results are alive: fresh buffers
+assert {c2.ctypes.data, d2.ctypes.data}.isdisjoint(addr) and e.result_pool.allocated == 4
+del c, d
+gc.collect()
+assert e.result_pool.idle_bytes == 2 * c2.nbytes
+c3, _ = e.estimate(x, ls=False, pinned_results=True)             # a collected result's buffer serves the next call
+assert c3.ctypes.data in addr and e.result_pool.reused == 1 and e.get_option('hp_direct_out_calls') == 3
+mixed = (e.pinned_empty(a.shape, np.complex64), np.empty(a.shape, np.complex64))
+e.estimate(x, out=mixed)
+assert e.get_option('hp_direct_out_calls') == 3                    # one pageable array: host weave for both
+e.set_option('hp_device_weave', 0)
+e.estimate(x, pinned_results=True)
+assert e.get_option('hp_direct_out_calls') == 3
+try:
+    e.estimate(x[:, :1])
+    raise SystemExit('a wrong shape was accepted')
+except pkg.CsiError:
+    pass
+arr = e.to_device(np.arange(6, dtype=np.float32))
+e.close()
+assert arr.ptr == 0 and e.result_pool.idle_bytes == 0
+print('mock-runtime engine: ok')
+''' % (REPO, so)
+    run = subprocess.run([sys.executable, '-c', script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert run.returncode == 0 and 'mock-runtime engine: ok' in run.stdout, run.stdout[-3000:]
