@@ -186,7 +186,7 @@ hipError_t hipEventSynchronize(hipEvent_t e) {
     ev->cv.wait(lk, [&] { return ev->done >= g; });
     return hipSuccess;
 }
-hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.25f; return hipSuccess; }      // (a fixed, non-zero "duration": callers divide by it)
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
     mock::Event* ev = mock::E(e);
     uint64_t g;

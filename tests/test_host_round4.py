@@ -342,17 +342,24 @@ def test_every_option_of_the_library_is_documented_in_the_header():
     assert (settable | gettable) - documented == set(), sorted((settable | gettable) - documented)
 
 
-def test_python_engine_on_the_mock_runtime_pinned_result_pool(tmp_path):
+@pytest.fixture(scope='module')
+def mock_so(tmp_path_factory):
+    """tests/mock_library.cpp built once: the library's translation unit on the model of the HIP runtime (kernels dropped)."""
+    so = str(tmp_path_factory.mktemp('mocklib') / 'libcsi_mock.so')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', '-pthread',
+                          os.path.join(REPO, 'tests', 'mock_library.cpp'), '-o', so], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    return so
+
+
+def test_python_engine_on_the_mock_runtime_pinned_result_pool(mock_so):
     """The Python layer on a machine without a GPU: tests/mock_library.cpp (the library's translation unit on the model of the HIP
     runtime; kernels dropped) loaded in place of the product library in a child process.  CsiEngine.estimate(pinned_results=True) takes
     its result arrays from the recycling pool of pinned buffers (csi_host_malloc), the library downloads straight into them
     (hp_direct_out_calls), a collected result's buffer is reused by the next call, mixing pinned and pageable arrays falls back to the
     host weave, close() leaves nothing behind."""
-    so = str(tmp_path / 'libcsi_mock.so')
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', '-pthread',
-                          os.path.join(REPO, 'tests', 'mock_library.cpp'), '-o', so], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
-    assert res.returncode == 0, res.stdout[-3000:]
+    so = mock_so
     script = r'''
 import gc, sys
 import numpy as np
@@ -397,3 +404,32 @@ print('mock-runtime engine: ok')
 ''' % (REPO, so)
     run = subprocess.run([sys.executable, '-c', script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert run.returncode == 0 and 'mock-runtime engine: ok' in run.stdout, run.stdout[-3000:]
+
+
+def test_bench_script_runs_end_to_end_on_the_mock_runtime(mock_so):
+    """bench.py itself, every leg a one-GPU run has except the fresh-process side configs - warm-up, timed region with kernel events,
+    the steps again without them, host path incl. the pinned-result leg and the link probe, oracle check, CPU baseline, latency loop,
+    practical peak, next rows - on the mock runtime in a child process: the numbers mean nothing (kernels are dropped), but every line of
+    the script executes, the contract's keys are there and no side measurement reports an exception."""
+    runner = ("import sys, runpy; sys.path.insert(0, %r); from dl_channel_estimation_mamimo_amd import _lib; _lib._SO = %r; "
+              "sys.argv = ['bench.py'] + sys.argv[1:]; runpy.run_path(%r, run_name='__main__')") % (REPO, mock_so, os.path.join(REPO, 'bench.py'))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', runner, '--packets', '64', '--steps', '2', '--warmup', '1', '--host-path', '64', '--no-other-configs',
+                        '--cpu-budget-s', '2'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+                'roofline', 'cpu_baseline', 'kernels', 'parity_check', 'host_path_pcie_inclusive', 'next_rows', 'bench_wall_s'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['warmup'] == 1 and line['config']['pairs_per_step'] == 64 * 128
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in line['roofline'], key
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in line['cpu_baseline'], key
+    c128 = line['host_path_pcie_inclusive']['python_c128_to_c64']
+    assert 'dnn_only_pinned_result' in c128 and c128['dnn_only_pinned_result']['direct_downloads'] == 4, c128.keys()
+    text = json.dumps(line)
+    assert '_error' not in text and '"error"' not in text, [k for k in ('_error', '"error"') if k in text]
