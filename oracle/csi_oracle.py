@@ -94,6 +94,10 @@ def ofdm_demod(ltf, nt):
     :453 of the python file shifts both axes, which is a bug in dead code); keep the 234
     data bins (generate_maMIMO_LTF.m:98-102)."""
     ltf = np.asarray(ltf)
+    if ltf.dtype != np.complex128:
+        # the oracle computes in double, as MATLAB does: numpy >= 2 would transform a complex64 preamble in SINGLE precision
+        # (~1e-7 relative; found by the plain-C statement of this file, oracle/csi_oracle_c.c, which disagreed at that level)
+        ltf = ltf.astype(np.complex128)
     assert ltf.shape[-1] == SYM_LEN * nt
     sym = ltf.reshape(ltf.shape[:-1] + (nt, SYM_LEN))          # [..., s, n]
     win = sym[..., CP_LEN:CP_LEN + FFT_LEN]
