@@ -10,7 +10,7 @@
  * arithmetic are restated from helperMIMOChannelEstimate.m:8-41 and massiveMIMO_CSI_prediction_DNN.py:176-234 (MATLAB / TensorFlow
  * are not in this image: PARITY UNPINNED for those two, checked by identities and against the numpy statement).
  *
- * Paths in the comments are relative to the reference repository.  Build: gcc -O2 -std=c99 -shared -fPIC csi_oracle_c.c -lm
+ * Paths in the comments are relative to the reference repository.  Build: gcc -O3 -std=c99 -shared -fPIC csi_oracle_c.c -lm
  */
 #include <math.h>
 #include <stdlib.h>
@@ -144,39 +144,44 @@ int oc_fc_forward(const double* x, long n_rows, int d_in, int n_hidden, const in
                   const double* const* biases, const double* const* bn, double bn_eps, const double* w_reg, const double* b_reg,
                   int n_out, double* y)
 {
-    int wmax = d_in;
+    enum { RB = 8 };                     /* rows taken together, so that a kernel row is read once per RB samples; every
+                                            output is still one plain sum over k in ascending order */
+    int wmax = d_in > n_out ? d_in : n_out;
     for (int i = 0; i < n_hidden; ++i) if (widths[i] > wmax) wmax = widths[i];
-    double* a = (double*)malloc((size_t)wmax * sizeof(double));
-    double* b = (double*)malloc((size_t)wmax * sizeof(double));
+    double* a = (double*)malloc((size_t)RB * wmax * sizeof(double));
+    double* b = (double*)malloc((size_t)RB * wmax * sizeof(double));
     if (!a || !b) { free(a); free(b); return -1; }
-    for (long r = 0; r < n_rows; ++r) {
+    for (long r0 = 0; r0 < n_rows; r0 += RB) {
+        const int nr = n_rows - r0 < RB ? (int)(n_rows - r0) : RB;
         int din = d_in;
-        memcpy(a, x + (size_t)r * d_in, (size_t)d_in * sizeof(double));
-        for (int l = 0; l < n_hidden; ++l) {
-            const int dout = widths[l];
-            for (int o = 0; o < dout; ++o) b[o] = 0.0;
+        for (int r = 0; r < nr; ++r) memcpy(a + (size_t)r * wmax, x + (size_t)(r0 + r) * d_in, (size_t)d_in * sizeof(double));
+        for (int l = 0; l <= n_hidden; ++l) {                             /* l == n_hidden: the linear regressor (:227) */
+            const int last = l == n_hidden;
+            const int dout = last ? n_out : widths[l];
+            const double* W = last ? w_reg : kernels[l];
+            const double* bias = last ? b_reg : biases[l];
+            for (int r = 0; r < nr; ++r) for (int o = 0; o < dout; ++o) b[(size_t)r * wmax + o] = 0.0;
             for (int k = 0; k < din; ++k) {                               /* row k of the kernel is contiguous */
-                const double ak = a[k];
-                const double* wk = kernels[l] + (size_t)k * dout;
-                if (ak != 0.0) for (int o = 0; o < dout; ++o) b[o] += ak * wk[o];
+                const double* wk = W + (size_t)k * dout;
+                for (int r = 0; r < nr; ++r) {
+                    const double ak = a[(size_t)r * wmax + k];
+                    double* br = b + (size_t)r * wmax;
+                    for (int o = 0; o < dout; ++o) br[o] += ak * wk[o];
+                }
             }
-            for (int o = 0; o < dout; ++o) {
-                double v = b[o] + biases[l][o];
-                v = v > 0.0 ? v : 0.0;
-                if (bn) v = (v - bn[4 * l + 2][o]) / sqrt(bn[4 * l + 3][o] + bn_eps) * bn[4 * l + 0][o] + bn[4 * l + 1][o];
-                b[o] = v;
-            }
+            for (int r = 0; r < nr; ++r)
+                for (int o = 0; o < dout; ++o) {
+                    double v = b[(size_t)r * wmax + o] + bias[o];
+                    if (!last) {
+                        v = v > 0.0 ? v : 0.0;                            /* relu (:211-214), THEN BatchNormalization (:215-219) */
+                        if (bn) v = (v - bn[4 * l + 2][o]) / sqrt(bn[4 * l + 3][o] + bn_eps) * bn[4 * l + 0][o] + bn[4 * l + 1][o];
+                    }
+                    b[(size_t)r * wmax + o] = v;
+                }
             double* t = a; a = b; b = t;
             din = dout;
         }
-        double* yr = y + (size_t)r * n_out;
-        for (int o = 0; o < n_out; ++o) yr[o] = 0.0;
-        for (int k = 0; k < din; ++k) {
-            const double ak = a[k];
-            const double* wk = w_reg + (size_t)k * n_out;
-            for (int o = 0; o < n_out; ++o) yr[o] += ak * wk[o];
-        }
-        for (int o = 0; o < n_out; ++o) yr[o] += b_reg[o];
+        for (int r = 0; r < nr; ++r) memcpy(y + (size_t)(r0 + r) * n_out, a + (size_t)r * wmax, (size_t)n_out * sizeof(double));
     }
     free(a); free(b);
     return 0;

@@ -20,10 +20,10 @@ _lib = None
 
 
 def build(force=False):
-    """gcc -O2 -std=c99 -shared -fPIC csi_oracle_c.c -lm -> libcsi_oracle_c.so (rebuilt when the source is newer)."""
+    """gcc -O3 -std=c99 -shared -fPIC csi_oracle_c.c -lm -> libcsi_oracle_c.so (rebuilt when the source is newer)."""
     if force or not os.path.exists(LIBRARY) or os.path.getmtime(LIBRARY) < os.path.getmtime(SOURCE):
         tmp = LIBRARY + '.%d.tmp' % os.getpid()
-        subprocess.check_call(['gcc', '-O2', '-std=c99', '-Wall', '-Werror', '-shared', '-fPIC', SOURCE, '-o', tmp, '-lm'])
+        subprocess.check_call(['gcc', '-O3', '-std=c99', '-Wall', '-Werror', '-shared', '-fPIC', SOURCE, '-o', tmp, '-lm'])
         os.replace(tmp, LIBRARY)
     return LIBRARY
 

@@ -452,3 +452,26 @@ def test_estimate_c128_into_pinned_result_arrays(pkg, oracle):
     k = 3
     r_re, r_im = oracle.predict_packets(ltf[:k].astype(np.complex64), P, w_re, w_im, np.float64, pkt_batch=k)
     assert rel_rows(ref[0][:k].real, r_re) < TOL and rel_rows(ref[0][:k].imag, r_im) < TOL
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(4, 2, 3, (64, 64)), (8, 2, 4, (128, 256)), (32, 4, 2, (1024, 1024))])
+def test_hip_path_against_the_c_statement_of_the_oracle(pkg, oracle, nt, nr, npkt, hidden):
+    """The HIP path against the SECOND statement of the oracle (oracle/csi_oracle_c.c: plain C in double precision, its own DFT and
+    dot products - tests/test_oracle_c.py ties it to the reference-recorded vectors and to the numpy statement on CPU): LS and both
+    component models at the 1e-5 contract, the last case with the shipped 1024 x 1024 widths (band kernel's shape)."""
+    from oracle import csi_oracle_c as oc
+    rng = np.random.default_rng(400 + nt)
+    H = oracle.hadamard(nt)
+    P = (H[rng.permutation(nt)] * rng.choice([-1.0, 1.0], nt)[:, None]).astype(np.float64)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=5.0)[0].astype(np.complex64)
+    w_re, w_im = _weights(oracle, 40 + nt, nt, hidden)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden)
+    e.load_weights('real', w_re)
+    e.load_weights('imag', w_im)
+    e.set_pilot(P)
+    h = e.ls_estimate(ltf)
+    ref = oc.ls_estimate(ltf.astype(np.complex128), P)
+    assert rel_rows(np.concatenate([h.real, h.imag], -1), np.concatenate([ref.real, ref.imag], -1)) < TOL
+    o_re, o_im = e.predict(ltf)
+    r_re, r_im = oc.predict_packets(ltf.astype(np.complex128), P, w_re, w_im)
+    assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
