@@ -201,3 +201,74 @@ void oc_samples_from_packets(const double* part, long n_pkt, int nr, int nt, int
                 memcpy(row + len_ltf, P + (size_t)t * nt, (size_t)nt * sizeof(double));
             }
 }
+
+/* f-3: LMMSE_ce.m:23-39, one link.  h_tilde [np] (the link's LS estimate, re / im), h [n_h] the vector the reference passes as
+   "channel impulse response" (generate_maMIMO_LTF.m:342 hands it the scatterer delays), snr_db scalar.  out [nfft].
+   Rpp x = H_tilde is solved by Gaussian elimination with partial pivoting instead of forming inv(Rpp) (:39) - the same product
+   up to the conditioning of Rpp.  Returns 0, -1 when out of memory, -2 for a singular Rpp. */
+#include <complex.h>
+int oc_lmmse_ce(const double* ht_re, const double* ht_im, int nfft, int np, int nps, const double* h_re, const double* h_im, int n_h,
+                double snr_db, double* out_re, double* out_im)
+{
+    const double snr = pow(10.0, snr_db * 0.1);                                    /* :23 */
+    double hh = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < n_h; ++k) {                                                 /* :27-29, k = 0 .. length(h) - 1 */
+        const double m2 = h_re[k] * h_re[k] + (h_im ? h_im[k] * h_im[k] : 0.0);
+        hh += m2; s1 += m2 * k; s2 += m2 * (double)k * k;
+    }
+    const double r = s1 / hh, r2 = s2 / hh;
+    const double tau_rms = sqrt(r2 - r * r);                                        /* :30 */
+    const double df = 1.0 / nfft;                                                   /* :31 */
+    const double complex j2 = I * (2.0 * 3.14159265358979323846 * tau_rms * df);    /* :32 */
+    double complex* A = (double complex*)malloc((size_t)np * np * sizeof(double complex));
+    double complex* x = (double complex*)malloc((size_t)np * sizeof(double complex));
+    if (!A || !x) { free(A); free(x); return -1; }
+    for (int a = 0; a < np; ++a) {
+        for (int b = 0; b < np; ++b)                                                /* :35-36, :38 */
+            A[(size_t)a * np + b] = 1.0 / (1.0 + j2 * (double)(nps * (a - b))) + (a == b ? 1.0 / snr : 0.0);
+        x[a] = ht_re[a] + I * ht_im[a];
+    }
+    for (int c = 0; c < np; ++c) {
+        int piv = c;
+        for (int a = c + 1; a < np; ++a) if (cabs(A[(size_t)a * np + c]) > cabs(A[(size_t)piv * np + c])) piv = a;
+        if (cabs(A[(size_t)piv * np + c]) == 0.0) { free(A); free(x); return -2; }
+        if (piv != c) {
+            for (int b = 0; b < np; ++b) { double complex t = A[(size_t)c * np + b]; A[(size_t)c * np + b] = A[(size_t)piv * np + b]; A[(size_t)piv * np + b] = t; }
+            double complex t = x[c]; x[c] = x[piv]; x[piv] = t;
+        }
+        for (int a = c + 1; a < np; ++a) {
+            const double complex f = A[(size_t)a * np + c] / A[(size_t)c * np + c];
+            for (int b = c; b < np; ++b) A[(size_t)a * np + b] -= f * A[(size_t)c * np + b];
+            x[a] -= f * x[c];
+        }
+    }
+    for (int a = np - 1; a >= 0; --a) {
+        double complex s = x[a];
+        for (int b = a + 1; b < np; ++b) s -= A[(size_t)a * np + b] * x[b];
+        x[a] = s / A[(size_t)a * np + a];
+    }
+    for (int k1 = 0; k1 < nfft; ++k1) {                                             /* :33-34, :39 */
+        double complex s = 0.0;
+        for (int k2 = 0; k2 < np; ++k2) s += x[k2] / (1.0 + j2 * (double)(k1 - k2 * nps));
+        out_re[k1] = creal(s); out_im[k1] = cimag(s);
+    }
+    free(A); free(x);
+    return 0;
+}
+
+/* a-12: NMSE_subk, BER_test_maMIMO_LTF.m:675-686 - per link ||ref - est||^2 / ||ref||^2 over the 234 bins, mean over the links */
+double oc_nmse_subk(const double* ref_re, const double* ref_im, const double* est_re, const double* est_im, long n_links, int n_bins)
+{
+    double acc = 0.0;
+    for (long l = 0; l < n_links; ++l) {
+        double num = 0.0, den = 0.0;
+        for (int k = 0; k < n_bins; ++k) {
+            const size_t i = (size_t)l * n_bins + k;
+            const double dr = ref_re[i] - est_re[i], di = ref_im[i] - est_im[i];
+            num += dr * dr + di * di;
+            den += ref_re[i] * ref_re[i] + ref_im[i] * ref_im[i];
+        }
+        acc += num / den;
+    }
+    return acc / (double)n_links;
+}

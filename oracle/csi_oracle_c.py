@@ -45,6 +45,9 @@ def load():
         lib.oc_fc_forward.restype = ctypes.c_int
         lib.oc_samples_from_packets.argtypes = [dp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp]
         lib.oc_samples_from_packets.restype = None
+        lib.oc_lmmse_ce.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int, ctypes.c_double, dp, dp]
+        lib.oc_lmmse_ce.restype = ctypes.c_int
+        lib.oc_nmse_subk.argtypes, lib.oc_nmse_subk.restype = [dp, dp, dp, dp, ctypes.c_long, ctypes.c_int], ctypes.c_double
         _lib = lib
     return _lib
 
@@ -152,3 +155,38 @@ def predict_packets(ltf, P, w_real, w_imag):
         y = fc_forward(samples_from_packets(ltf, P, d), w)
         outs.append(y.reshape(npkt, nr, nt, -1))
     return outs[0], outs[1]
+
+
+def lmmse_ce(h_tilde, nfft, np_, nps, h, snr_db):
+    """LMMSE_ce.m:23-39 for one link, as csi_oracle.lmmse_ce"""
+    lib = load()
+    ht = np.asarray(h_tilde, dtype=np.complex128).reshape(-1)
+    h = np.asarray(h, dtype=np.complex128).reshape(-1)
+    t_re, t_im, h_re, h_im = _d(ht.real), _d(ht.imag), _d(h.real), _d(h.imag)
+    o_re, o_im = np.empty(nfft), np.empty(nfft)
+    rc = lib.oc_lmmse_ce(_p(t_re), _p(t_im), nfft, np_, nps, _p(h_re), _p(h_im), h.size, float(snr_db), _p(o_re), _p(o_im))
+    if rc:
+        raise RuntimeError('oc_lmmse_ce: %d' % rc)
+    return o_re + 1j * o_im
+
+
+def lmmse_estimate(h_ls, h, snr_db):
+    """helperMIMOChannelEstimate.m:33-39 with isMMSE, as csi_oracle.lmmse_estimate"""
+    h_ls = np.asarray(h_ls)
+    npkt, nr, nt, n = h_ls.shape
+    out = np.empty(h_ls.shape, dtype=np.complex128)
+    for p in range(npkt):
+        for i in range(nr):
+            for j in range(nt):
+                out[p, i, j] = lmmse_ce(h_ls[p, i, j], n, n, 1, h[p], snr_db[p, i])
+    return out
+
+
+def nmse_subk(h_ref, h_est):
+    """NMSE_subk (BER_test_maMIMO_LTF.m:675-686), as csi_oracle.nmse_subk"""
+    lib = load()
+    r = np.asarray(h_ref, dtype=np.complex128)
+    e = np.asarray(h_est, dtype=np.complex128)
+    n_bins = r.shape[-1]
+    r_re, r_im, e_re, e_im = _d(r.real), _d(r.imag), _d(e.real), _d(e.imag)
+    return float(lib.oc_nmse_subk(_p(r_re), _p(r_im), _p(e_re), _p(e_im), r.size // n_bins, n_bins))

@@ -133,3 +133,28 @@ def test_c_network_against_torch_functional(oc, oracle):
     want = F.linear(h, t(w['fc_regressor.kernel']).T, t(w['fc_regressor.bias'])).numpy()
     got = oc.fc_forward(x, w)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('snr_db', [-5.0, 0.0, 10.0, 25.0])
+def test_c_lmmse_equals_numpy_lmmse(oc, oracle, snr_db):
+    """LMMSE_ce.m:23-39 in the two statements (the numpy one forms inv(Rpp) as :39 does, the C one eliminates): one link at the
+    reference's sizes Nfft = Np = 234, Nps = 1 (helperMIMOChannelEstimate.m:37-39), and the per-link loop over a small packet."""
+    rng = np.random.default_rng(int(snr_db) + 50)
+    h_tilde = rng.standard_normal(234) + 1j * rng.standard_normal(234)
+    h = np.abs(rng.standard_normal(6)) * 3.0                                       # "h_tau": a few positive delays
+    want = oracle.lmmse_ce(h_tilde, 234, 234, 1, h, snr_db)
+    got = oc.lmmse_ce(h_tilde, 234, 234, 1, h, snr_db)
+    assert np.linalg.norm(got - want) < 1e-9 * np.linalg.norm(want)
+    h_ls = rng.standard_normal((2, 2, 1, 234)) + 1j * rng.standard_normal((2, 2, 1, 234))
+    hs = np.abs(rng.standard_normal((2, 5))) * 2.0
+    snr = np.full((2, 2), snr_db) + rng.standard_normal((2, 2))
+    a, b = oc.lmmse_estimate(h_ls, hs, snr), oracle.lmmse_estimate(h_ls, hs, snr)
+    assert np.linalg.norm(a - b) < 1e-9 * np.linalg.norm(b)
+
+
+def test_c_nmse_equals_numpy_nmse(oc, oracle):
+    rng = np.random.default_rng(3)
+    ref = rng.standard_normal((5, 2, 4, 234)) + 1j * rng.standard_normal((5, 2, 4, 234))
+    est = ref + 0.1 * (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape))
+    assert abs(oc.nmse_subk(ref, est) - oracle.nmse_subk(ref, est)) < 1e-14
+    assert oc.nmse_subk(ref, ref) == 0.0 and abs(oc.nmse_subk(ref, 0.9 * ref) - 0.01) < 1e-12
