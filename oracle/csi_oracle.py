@@ -439,9 +439,10 @@ def lmmse_estimate(h_ls, h, snr_db):
 def nmse_subk(h_ref, h_est):
     """h_* complex [..., Nr, Nt, 234] (or any [..., link, 234]): per link
     ||ref-est||^2 / ||ref||^2 over the bins, mean over all links."""
-    diff = np.asarray(h_ref) - np.asarray(h_est)
+    h_ref = np.asarray(h_ref, dtype=np.complex128)          # double, whatever the caller holds (complex64 sums would be single)
+    diff = h_ref - np.asarray(h_est, dtype=np.complex128)
     num = np.sum(np.abs(diff) ** 2, axis=-1)
-    den = np.sum(np.abs(np.asarray(h_ref)) ** 2, axis=-1)
+    den = np.sum(np.abs(h_ref) ** 2, axis=-1)
     return float(np.mean(num / den))
 
 
