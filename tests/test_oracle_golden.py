@@ -270,3 +270,24 @@ def test_split_f16_operands_are_fp32_grade(oracle):
         e_split = oracle.row_rel_err(got, ref)
         assert e_split < 5e-7, (gain, e_split)
         assert e_split < 3 * max(oracle.row_rel_err(f32, ref), 1e-7)       # no worse than plain fp32 evaluation
+
+
+def test_oracle_computes_in_double_whatever_it_is_handed(oracle):
+    """The checker's results must not depend on the precision of the arrays a test hands it: numpy >= 2 transforms complex64 input in
+    single precision (the LS oracle did just that until the C statement, oracle/csi_oracle_c.c, disagreed with it at 1e-7)."""
+    rng = np.random.default_rng(77)
+    nt, nr = 8, 2
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, 3, nr, P, snr_db=0.0)[0].astype(np.complex64)
+    wide = ltf.astype(np.complex128)
+    a, b = oracle.ls_estimate(ltf, P), oracle.ls_estimate(wide, P)
+    assert a.dtype == np.complex128 and np.array_equal(a, b)
+    assert oracle.ofdm_demod(ltf, nt).dtype == np.complex128
+    w_re = oracle.make_weights(rng, 321 * nt, [32, 16], 234)
+    w_im = oracle.make_weights(rng, 321 * nt, [32, 16], 234)
+    for fn in (oracle.predict_packets, oracle.predict_packets_shared):
+        x, y = fn(ltf, P, w_re, w_im, np.float64), fn(wide, P, w_re, w_im, np.float64)
+        assert x[0].dtype == np.float64 and np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    h = a.astype(np.complex64)
+    est = (h * np.complex64(0.97)).astype(np.complex64)
+    assert oracle.nmse_subk(h, est) == oracle.nmse_subk(h.astype(np.complex128), est.astype(np.complex128))
