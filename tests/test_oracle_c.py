@@ -161,3 +161,19 @@ def test_c_nmse_equals_numpy_nmse(oc, oracle):
     est = ref + 0.1 * (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape))
     assert abs(oc.nmse_subk(ref, est) - oracle.nmse_subk(ref, est)) < 1e-14
     assert oc.nmse_subk(ref, ref) == 0.0 and abs(oc.nmse_subk(ref, 0.9 * ref) - 0.01) < 1e-12
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(128, 2, 1, (64, 64)), (12, 3, 2, (40,)), (64, 1, 2, (32, 48, 16))])
+def test_c_literal_network_equals_numpy_shared_layer0_form(oc, oracle, nt, nr, npkt, hidden):
+    """The algebra the HIP path rests on (the first layer's product with the preamble is shared by the Nt pairs of an rx
+    antenna, the pilot rows become a constant table) is what csi_oracle.predict_packets_shared computes - the checker of the Nt = 128
+    GPU tests.  Here it is held against the C statement's LITERAL network (every sample row through the whole first layer)."""
+    rng = np.random.default_rng(nt + len(hidden))
+    P = rng.choice([-1.0, 1.0], (nt, nt))
+    ltf = rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))
+    w_re = oracle.make_weights(rng, 321 * nt, list(hidden), 234)
+    w_im = oracle.make_weights(rng, 321 * nt, list(hidden), 234)
+    got = oc.predict_packets(ltf, P, w_re, w_im)
+    want = oracle.predict_packets_shared(ltf, P, w_re, w_im, np.float64)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-11 * np.abs(b).max())
