@@ -111,6 +111,7 @@ def main():
                          '(csi_comm_init / csi_broadcast_weights: ncclBroadcast inside the C-ABI); torch = dist.broadcast_weights '
                          '(torch.distributed, host round trip).  CSI_DIST_BACKEND=gloo implies torch.')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the "next_rows" legs (LMMSE smoother, one training step, LS on a non-Sylvester pilot) measured after the timed region')
+    ap.add_argument('--no-regimes', action='store_true', help='skip the "regimes" leg (1 / 8 / 64 / 500-packet calls with their bounds) measured after the timed region')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()

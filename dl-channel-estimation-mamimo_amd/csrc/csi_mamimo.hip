@@ -48,7 +48,17 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
         r.nw = W; nstg = NS; r.per_cu = MB; nf = DB ? 2 : 1;                                                       \
     }
     // shapes as measured (profiles/r03_ls_probe_generic.txt); "ls_v2" = 1 selects the runner-up for A/B runs
+    // one antenna tile (Nt <= 32).  Round 5: the product build runs this shape ONE workgroup per CU.  Its two-workgroups-per-CU form
+    // (round 3's choice, 4 % faster) showed rare wrong first items on some parts of the pool (profiles/r04_ls_ringb_variants.txt: lanes
+    // 48-63 of one packed add beside ANOTHER workgroup's bf16 MFMAs on the same SIMD; never with one workgroup per CU, whose barriers
+    // keep the two waves of a SIMD in the same phase) and was never root-caused, so the shipped library cannot select it by any option:
+    // it is compiled only into the hunt build (CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS).  The shape is padded to > 80 KiB of LDS below so
+    // that the dispatcher cannot co-locate two of these workgroups either.
+#ifdef CSI_LS_RACE_VARIANTS
     if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 2, false) else LS_RB(1, 4, 1, 2, false) }
+#else
+    if (jt == 1) { if (c->ls_v2 == 1) LS_RB(1, 4, 2, 1, false) else LS_RB(1, 4, 1, 1, false) }
+#endif
     else if (jt == 2) { if (c->ls_v2 == 1) LS_RB(2, 8, 1, 1, false) else LS_RB(2, 8, 1, 1, true) }
     else if (jt == 3) { if (c->ls_v2 == 1) LS_RB(3, 8, 2, 1, false) else LS_RB(3, 8, 1, 1, true) }
     else { if (c->ls_v2 == 1) LS_RB(4, 8, 1, 1, false) else LS_RB(4, 8, 1, 1, true) }
@@ -65,6 +75,9 @@ LsRingB ls_ringb_shape(const csi_ctx* c) {
 #undef LS_RB
     r.lds = (size_t)(2 * LSC_NTW + nf * 16 * 2 * LSC_ROW + nstg * 16 * 2 * LS_FFT) * sizeof(float) + (size_t)(nstg + 1) * npp * jt * LSB_BLOCK * 2;
     if (r.lds > 160 * 1024) r.fn = nullptr;
+#ifndef CSI_LS_RACE_VARIANTS
+    if (jt == 1) r.lds = std::max(r.lds, (size_t)(81 * 1024));      // one workgroup per CU by construction (see above)
+#endif
     r.per_cu = std::max(1, std::min(r.per_cu, (int)((160 * 1024) / r.lds)));
     return r;
 }
@@ -1172,6 +1185,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "ls_ringb_min") *value = c->ls_ringb_min;
     else if (n == "ls_pilot_pieces") *value = c->p_pieces;
     else if (n == "ls_mode") *value = ls_plan(c).mode;
+    else if (n == "ls_per_cu") *value = ls_plan(c).per_cu;                    // read-only: resident workgroups per CU of the kernel the next LS call runs
     else if (n == "hp_stage_us") *value = c->hostpipe ? (int64_t)c->hostpipe->us_stage : 0;           // read-only: where the last csi_estimate_c128 spent its time
     else if (n == "hp_wait_stage_us") *value = c->hostpipe ? c->hostpipe->us_wait_stage : 0;
     else if (n == "hp_wait_out_us") *value = c->hostpipe ? c->hostpipe->us_wait_out : 0;
@@ -1267,6 +1281,14 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         (n == "hs_vm_cast" ? c->hs_vm_cast : c->hs_vm_pair) = (int)value;
     } else if (n == "ls_overlap_cus" || n == "ls_overlap_stride") {
         if (value < 0 || value > 255) return fail(c, CSI_ERR_INVALID_ARG, "%s must be 0 (LS in front of the DNN kernels on one stream) .. 255", name);
+#ifndef CSI_LS_RACE_VARIANTS
+        // measured slower than the serial order and it puts LS workgroups beside other kernels' MFMA waves - the one
+        // condition under which a packed add of the LS transform was ever seen wrong.  Not part of the shipped library.
+        if (n == "ls_overlap_cus" && value > 0)
+            return fail(c, CSI_ERR_INVALID_ARG, "ls_overlap_cus > 0 (the LS kernel on a CU-masked side stream beside the matrix kernels) is an experiment that "
+                                                "measured slower than the serial order and is not part of the product build; "
+                                                "rebuild with CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS to run it");
+#endif
         drop_graphs(c);
         (n == "ls_overlap_cus" ? c->ls_overlap_cus : c->ls_overlap_stride) = (int)value;
     } else if (n == "hp_side_threads") {

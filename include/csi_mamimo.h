@@ -267,9 +267,12 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         the LDS-DMA ring, fp32 matrix-core despread, 7: generic P, despread on the bf16 matrix
  *                         cores with every fp32 value cut exactly into three bf16 pieces (one of the two is chosen
  *                         automatically for any other P, 16 <= Nt <= 128); a choice the kernel cannot serve falls back
- *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 33: where it runs one workgroup per CU;
- *                         below, kernel 6 serves - DESIGN.md 4.2)
- *   get only: "ls_mode" (the kernel the next LS call runs), "ls_pilot_pieces" (bf16 pieces the entries of P need: 1 - 3)
+ *   "ls_ringb_min"     the smallest Nt at which a non-Hadamard P takes kernel 7 (default 33; below, kernel 6 serves - DESIGN.md 4.2).
+ *                         Kernel 7 runs ONE workgroup per CU at every Nt in the shipped library: its two-workgroups-per-CU form at
+ *                         Nt <= 32 (rare wrong first items on some parts, never root-caused) exists only in the hunt build
+ *                         (CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS) and no option of the product build selects it
+ *   get only: "ls_mode" (the kernel the next LS call runs), "ls_per_cu" (its resident workgroups per CU),
+ *                         "ls_pilot_pieces" (bf16 pieces the entries of P need: 1 - 3)
  *   "ls_v2"            1: the runner-up shape (chunk length / ring depth) of kernels 5 and 6, for A/B runs
  *   "hs_band"          1 (default): two hidden layers -> first per-pair layer + regressor as ONE kernel, h2 in registers (generated
  *                         gfx950 assembly, csrc/band_kernel_gen.py): the split engine of fp32 contexts (the form that streams the
@@ -284,7 +287,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "ls_fast_perm"     1 (default): a pilot matrix that is a signed row / column permutation of the Sylvester Hadamard matrix
  *                         takes the Walsh-Hadamard LS kernel through permutation tables; 0: the generic kernels (A/B runs)
  *   "ls_overlap_cus", "ls_overlap_stride"  csi_estimate_device: run the LS kernel on a side stream masked to this many CUs beside
- *                         the DNN kernels (0 = default: in front of them on the one stream; measured slower, kept for the record)
+ *                         the DNN kernels.  An experiment that measured slower than the serial order: the product
+ *                         build REFUSES "ls_overlap_cus" > 0 (CSI_ERR_INVALID_ARG with text); the hunt build
+ *                         (CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS) accepts it
  *   "hp_side_threads"  host-buffer entry points: 1 (default) input staging and result staging on their own threads beside the
  *                         caller's enqueue loop; 0: inline on the calling thread, in turn (A/B runs)
  *   "hp_chunk_packets" packets per pipeline slot of csi_estimate_c128 (0 = automatic)
