@@ -52,20 +52,34 @@ SPLIT_PRODUCTS = 3                  # f16 MFMAs per fp32-grade multiply on the s
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without torchrun: start N ranks of this script (one process per GPU,
-    LOCAL_RANK i -> device i) with a private rendezvous on 127.0.0.1, forward rank 0's line."""
+    LOCAL_RANK i -> device i) with a private rendezvous on 127.0.0.1, forward rank 0's line.  The port is found by
+    bind-and-close, which another process can win before rank 0 binds it again: a launch whose rank 0 dies WITHOUT having
+    printed a line and with an address-in-use / connection text on stderr is started once more on a fresh port, the
+    first failure going to stderr (it is the launcher that retries a rendezvous, never a measurement)."""
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    import uuid
+    for attempt in range(3):
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        token = uuid.uuid4().hex                    # per-launch: dist.exchange_unique_id never takes a leftover of another launch
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', CSI_RCCL_ID_TOKEN=token)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None))
+        out, err = procs[0].communicate()
+        rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        err = err.decode(errors='replace')
+        sys.stderr.write(err)
+        rendezvous_failed = any(rcs) and not out.strip() and any(t in err for t in ('EADDRINUSE', 'ddress already in use', 'Connection refused', 'connect() timed out', 'The server socket has failed'))
+        if rendezvous_failed and attempt < 2:
+            print('bench.py: rendezvous on 127.0.0.1:%d failed (rank exit codes %s); starting the ranks again on a fresh port' % (port, rcs), file=sys.stderr)
+            continue
+        break
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     if any(rcs):
@@ -111,6 +125,8 @@ def main():
                          '(csi_comm_init / csi_broadcast_weights: ncclBroadcast inside the C-ABI); torch = dist.broadcast_weights '
                          '(torch.distributed, host round trip).  CSI_DIST_BACKEND=gloo implies torch.')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the "next_rows" legs (LMMSE smoother, one training step, LS on a non-Sylvester pilot) measured after the timed region')
+    ap.add_argument('--legs-packets', default='', metavar='A,B',
+                    help='N > 1 only: total packets of the configs[3] / configs[4] legs (default 50000,100000 = BASELINE.json; the CPU tests shrink them)')
     ap.add_argument('--no-regimes', action='store_true', help='skip the "regimes" leg (1 / 8 / 64 / 500-packet calls with their bounds) measured after the timed region')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
@@ -136,6 +152,8 @@ def main():
         pkg.dist.barrier()
         if rank == 0:
             print(json.dumps({'rendezvous_only': True, 'n_gpus': n_gpus, 'ranks_seen': int(seen), 'requested': args.gpus,
+                              'other_configs_scheduled': [dict(config=n_, flags=' '.join(f_), fits=fit_, per_rank_gb=round(gb_, 1))
+                                                          for n_, _, f_, fit_, gb_ in multi_gpu_legs(args, world)] if world > 1 and default_headline(args) else [],
                               'packets_per_step': int(pkts), 'scaling': args.scaling, 'backend': backend if world > 1 else None,
                               'ranks_ms': [i['ms_per_step'] for i in infos], 'devices': [i['device'] for i in infos], 'ranks': infos}))
         return
@@ -484,25 +502,43 @@ def main():
             ts.append(time.perf_counter() - t1)
         latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6), 'what': 'LS + DNN(real) + DNN(imag) of one packet, device-resident, median of 30 calls'}
 
+    # N > 1: BASELINE.json's two multi-GPU configurations, by ALL ranks, each as a fresh N-rank job of this script (round-4 verdict,
+    # next 4): configs[3] Nt=64 Nr=8 50000 packets sharded, configs[4] Nt=128 Nr=16 100000 packets, one hipGraph per step
+    legs = None
+    if world > 1 and default_headline(args) and not args.no_other_configs and not args.graph and not args.option:
+        del d_re, d_im, d_ore, d_oim, d_hre, d_him
+        try:
+            eng.comm_destroy()
+        except Exception:                           # noqa: BLE001
+            pass
+        eng.close()
+        legs = run_multi_gpu_legs(pkg, args, rank, world, local)
     if rank != 0:
         return
 
-    # HBM traffic per launch comes from the committed rocprofv3 PMC summary of this same command
-    # (profiles/rNN_traffic.json, written by tools/profile_summarize.py); it cannot be measured
-    # from inside the process.
-    traffic = {}
+    # HBM traffic per launch comes from the committed rocprofv3 PMC summary of this same command ON THIS WORKLOAD
+    # (profiles/rNN_<workload>_traffic.json, written by tools/profile_config.sh + tools/profile_summarize.py; the newest round that
+    # has one); it cannot be measured from inside the process.  The line names the files its fractions can be recomputed from.
+    workload_tag = 'nt%d_nr%d_%s' % (nt, nr, args.dtype)
+    traffic, prof_files = {}, {}
     pdir = os.path.join(REPO, 'profiles')
     if os.path.isdir(pdir):
-        files = sorted(f for f in os.listdir(pdir) if f.endswith('_traffic.json'))
-        if files:
-            with open(os.path.join(pdir, files[-1])) as f:
+        for kind in ('traffic.json', 'kernel_stats.txt', 'pmc.txt'):
+            files = sorted(f for f in os.listdir(pdir) if f.endswith('_%s_%s' % (workload_tag, kind)))
+            if not files and workload_tag == 'nt32_nr4_f32':     # rounds 1-4 named the headline's summaries rNN_<kind>
+                files = sorted(f for f in os.listdir(pdir) if len(f) == len('r00_' + kind) and f.endswith('_' + kind))
+            if files:
+                prof_files[kind.split('.')[0]] = 'profiles/' + files[-1]
+        if 'traffic' in prof_files:
+            with open(os.path.join(REPO, prof_files['traffic'])) as f:
                 traffic = json.load(f)
-            traffic['_file'] = 'profiles/' + files[-1]
+            traffic['_file'] = prof_files['traffic']
 
-    def hbm_per_launch(prefix):
-        for k, v in traffic.items():
-            if k.startswith(prefix):
-                return v.get('hbm_bytes_per_launch')
+    def hbm_per_launch(*prefixes):
+        for pre in prefixes:
+            for k, v in traffic.items():
+                if k.startswith(pre):
+                    return v.get('hbm_bytes_per_launch')
         return None
 
     dom = prof['pair_dense_gemm']
@@ -566,8 +602,10 @@ def main():
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
-                     'traffic': hbm_per_launch(('csi_band8' if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32' else None, 'traffic_unit': 'HBM bytes per launch (PMC)',
-                     'traffic_source': traffic.get('_file'), 'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
+                     'traffic': (hbm_per_launch(('csi_band8' if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32'
+                                 else hbm_per_launch('csi_band8_bf16' if band_any else 'gemm_bf16_pp_pair_kernel<1')), 'traffic_unit': 'HBM bytes per launch (PMC)',
+                     'traffic_source': traffic.get('_file'), 'profile_files': prof_files or None,
+                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                      'avg_launch_ms': dom_ms, 'flops_per_launch': dom['flops'] / max(dom['launches'], 1),
                      'practical_peak': (practical['skeleton_executed_tflops'] / SPLIT_PRODUCTS) if practical and 'error' not in practical else None,
                      'frac_of_practical': (achieved / (practical['skeleton_executed_tflops'] / SPLIT_PRODUCTS)) if practical and 'error' not in practical else None,
@@ -594,22 +632,26 @@ def main():
     if host_path:
         out['host_path_pcie_inclusive'] = host_path
     if 'ls_estimate' in kernels:
-        p = prof['ls_estimate']
-        gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
-        out['roofline_ls'] = {'bound': 'hbm', 'kernel': 'ls_estimate', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': gbs / HBM_PEAK_GBS, 'traffic': hbm_per_launch('ls_estimate_'),
-                              'algorithmic_bytes_per_launch': p['bytes'] / max(p['launches'], 1),
-                              'traffic_note': 'algorithmic = 2560 B in + 1872 B out per pair (SURVEY 8d); the kernel never fetches the 64-sample '
-                                              'cyclic prefix of a symbol (20 % of the input), so its measured HBM traffic is below that figure'}
+        out['roofline_ls'] = ls_roofline(prof['ls_estimate'], hbm_per_launch('ls_estimate_'), traffic.get('_file'))
 
     if cpu_baseline:
         out['cpu_baseline'] = cpu_baseline
+    if world == 1 and not args.no_regimes and args.dtype == 'f32' and not args.graph and not args.option and (nt, nr, tuple(hidden)) == (32, 4, (1024, 1024)):
+        try:
+            out['regimes'] = regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt, ls=not args.no_ls)
+            big = [r for r in out['regimes'] if r['packets'] == 500]
+            if big:
+                big[0]['rate_vs_headline'] = round(big[0]['pairs_per_s'] / value, 4)
+        except Exception as e:                      # side measurements never take the headline down
+            out['regimes'] = {'error': repr(e)}
     if world == 1 and not args.no_next_rows and args.dtype == 'f32' and nt > 0:
         try:
             out['next_rows'] = next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, min(npkt, 1000))
         except Exception as e:                      # side measurements never take the headline down
             out['next_rows'] = {'error': repr(e)}
-    default_run = (nt, nr, args.packets, args.dtype, tuple(hidden), args.engine) == (32, 4, 4000, 'f32', (1024, 1024), 'auto')
+    default_run = default_headline(args)
+    if legs is not None:
+        out['other_configs'] = legs
     if world == 1 and default_run and not args.no_other_configs and not args.graph and not args.option:
         del d_re, d_im, d_ore, d_oim, d_hre, d_him
         out['other_configs'] = other_configs()
@@ -619,9 +661,97 @@ def main():
     print(json.dumps(out))
 
 
+def ls_roofline(p, traffic_bytes, traffic_file):
+    """HBM roofline of the LS kernel.  `achieved` = bytes the kernel MOVES (PMC: FETCH_SIZE / WRITE_SIZE of the committed counter
+    pass of this workload, gfx950 correction) over the launch time measured here; the kernel never fetches the 64-sample cyclic
+    prefix of a symbol, so that is less than SURVEY 8d's 2560 B in + 1872 B out per pair, which stays on the line as the labelled
+    `algorithmic_gbs` / `algorithmic_frac` (round-4 verdict, weak 4).  Without a counter file for the workload `achieved` falls back
+    to the bytes the kernel is known to move by construction: 2048 B in (no prefix) + 1872 B out per pair."""
+    ms = p['ms'] / max(p['launches'], 1)
+    algo = p['bytes'] / max(p['launches'], 1)
+    moved = traffic_bytes if traffic_bytes else algo * (2048.0 + 1872.0) / (2560.0 + 1872.0)
+    gbs = moved / max(ms, 1e-9) / 1e6
+    return {'bound': 'hbm', 'kernel': 'ls_estimate', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'achieved_is': ('PMC bytes per launch (%s) / launch time by HIP events in this run' % traffic_file) if traffic_bytes
+                           else 'bytes moved by construction (2048 B in without the cyclic prefixes + 1872 B out per pair) / launch time; no counter file for this workload',
+            'traffic': traffic_bytes, 'traffic_source': traffic_file, 'avg_launch_ms': ms,
+            'algorithmic_bytes_per_launch': algo, 'algorithmic_gbs': algo / max(ms, 1e-9) / 1e6, 'algorithmic_frac': algo / max(ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+            'algorithmic_note': 'SURVEY 8d: 2560 B in + 1872 B out per pair - counts the cyclic prefixes the kernel leaves in HBM; a speed figure, not the roofline fraction',
+            'achievable_note': 'a plain float4 copy reaches 6.29 TB/s on this part (MI355X_MICROARCH.md): frac / 0.786 = fraction of the achievable rate'}
+
+
+def regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt_resident, ls=True):
+    """Batch-size regimes of the SAME context, device-resident, outside the timed region (round-4 verdict, next 3): 1 packet
+    (DNN.py:339-346 predicts one packet per step), 8, 64, and 500 packets (what full_pipeline_maMIMO_DNNEst.sh:44-48 hands one
+    `--test` run per SNR level).  Per size: `latency_us` = one call + csi_synchronize, median; `pipelined_us` = per call when 20
+    calls are queued back to back (a serving loop that does not wait between calls); pairs/s from the latter; the bound that applies
+    and the fraction of it reached.  Bounds: up to 8 packets the call streams both component models' weights once (HBM at 8 TB/s;
+    they also fit the 256 MiB Infinity Cache, so a loop of calls may read them from there: `weights_from`); from 64 packets the
+    executed flops of the shared-layer-0 network (6 463 488 per pair) at the ceiling of the engine that serves the size -
+    2500 / 3 TFLOP/s where the split-f16 engine runs (`hs_launches` moved), 157.3 TFLOP/s on the fp32 MFMA kernels - plus the LS
+    kernel's 4432 B per pair at 8 TB/s."""
+    h1, h2 = hidden[0], hidden[-1]
+    w_bytes = 2 * 4.0 * (320 * nt * h1 + (h1 * h2 if len(hidden) > 1 else 0) + h2 * 234)
+    flops_pair = 4.0 * 320 * h1 + 4.0 * ((h1 * h2 if len(hidden) > 1 else 0) + h2 * 234)
+    res = []
+    for n in (1, 8, 64, 500):
+        if n > npkt_resident:
+            continue
+        o = [eng.empty((n, nr, nt, 234)) for _ in range(4)]
+
+        def call():
+            if ls:
+                eng.ls_estimate_device(d_re, d_im, n, o[2], o[3])
+            eng.predict_device(d_re, d_im, n, o[0], o[1])
+        for _ in range(5):
+            call()
+        eng.synchronize()
+        hs0 = eng.get_option('hs_launches')
+        lat = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            call()
+            eng.synchronize()
+            lat.append(time.perf_counter() - t0)
+        pip = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(20):
+                call()
+            eng.synchronize()
+            pip.append((time.perf_counter() - t0) / 20)
+        split = eng.get_option('hs_launches') > hs0
+        eng.profile_enable(True); eng.profile_reset()
+        call(); eng.synchronize()
+        prof = {k: round(v['ms'] * 1e3, 1) for k, v in eng.profile().items() if v['launches']}
+        eng.profile_enable(False)
+        pairs = n * nr * nt
+        t_w = w_bytes / (HBM_PEAK_GBS * 1e9)
+        t_f = pairs * flops_pair / ((BF16_MATRIX_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MATRIX_PEAK_TFLOPS) * 1e12)
+        t_ls = pairs * 4432.0 / (HBM_PEAK_GBS * 1e9) if ls else 0.0
+        if t_w >= t_f:
+            bound, t_b = 'hbm: both models\' weights (%.1f MB) streamed once at 8 TB/s' % (w_bytes / 1e6), t_w + t_ls
+        else:
+            bound, t_b = 'mfma: executed flops at %s' % ('2500/3 TFLOP/s (split-f16 engine)' if split else '157.3 TFLOP/s (fp32 MFMA kernels)'), t_f + t_ls
+        t_lat, t_pip = float(np.median(lat)), float(np.median(pip))
+        res.append({'packets': n, 'pairs': pairs, 'latency_us': round(t_lat * 1e6, 1), 'pipelined_us': round(t_pip * 1e6, 1),
+                    'pairs_per_s': pairs / t_pip, 'engine': 'split-f16' if split else 'fp32 MFMA',
+                    'bound': bound, 'bound_us': round(t_b * 1e6, 2), 'frac_of_bound': round(t_b / t_pip, 4), 'frac_of_bound_latency': round(t_b / t_lat, 4),
+                    'kernels_us_one_call_with_events': prof})
+        del o
+    return res
+
+
 FP64_VECTOR_PEAK_TFLOPS = 78.6        # MI355X datasheet (fp64 vector = fp64 matrix); the microarchitecture guide has no fp64 row
 
 P_VHT4 = [[1, -1, 1, 1], [1, 1, -1, 1], [1, 1, 1, -1], [-1, 1, 1, 1]]
+
+
+def newest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (None if there is none): the file a fraction on the line can be recomputed from"""
+    pdir = os.path.join(REPO, 'profiles')
+    files = sorted(f for f in os.listdir(pdir) if f.endswith('_' + suffix)) if os.path.isdir(pdir) else []
+    return 'profiles/' + files[-1] if files else None
 
 
 def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
@@ -648,13 +778,12 @@ def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
         eng.synchronize()
         p = eng.profile()['ls_estimate']
         eng.profile_enable(False)
-        gbs = p['bytes'] / max(p['ms'], 1e-9) / 1e6
         ltf = d_re.download(0, 2) + 1j * d_im.download(0, 2)
         ref = o.ls_estimate(ltf, Pv)
         got = h_re.download(0, 2) + 1j * h_im.download(0, 2)
         res['ls_vht_pilot'] = {'pilot': 'kron(H_%d, P_VHT4): Hadamard, not Sylvester-ordered' % (nt // 4), 'ls_mode': eng.get_option('ls_mode'),
                                'pilot_class': eng.get_option('ls_pilot_fast'), 'packets': npkt, 'ms_per_launch': p['ms'] / p['launches'],
-                               'roofline_ls': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS},
+                               'roofline_ls': ls_roofline(p, None, None),
                                'ls_rel_err': max(o.row_rel_err(got.real, ref.real), o.row_rel_err(got.imag, ref.imag))}
         eng.set_pilot(P0)
     # ---- LMMSE smoother of the LS estimate (fp64 Levinson solves)
@@ -680,7 +809,10 @@ def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
     res['lmmse'] = {'what': 'LMMSE_ce.m:23-39 per link as one Hermitian-Toeplitz Levinson solve per (packet, rx) in fp64 (csrc/lmmse.hip.h)',
                     'packets': npkt, 'ms_per_launch': ms, 'links_per_s': npkt * nr * nt / (ms * 1e-3),
                     'roofline': {'bound': 'fp64 vector FMA', 'achieved': tf, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_VECTOR_PEAK_TFLOPS},
-                    'rel_err_vs_oracle': max(o.row_rel_err(got.real, ref.real), o.row_rel_err(got.imag, ref.imag)), 'checked_packets': k}
+                    'rel_err_vs_oracle': max(o.row_rel_err(got.real, ref.real), o.row_rel_err(got.imag, ref.imag)), 'checked_packets': k,
+                    'tuning': 'a "next" row (SURVEY 8f-3): correct and measured, not tuned - one Levinson recursion per (packet, rx) is a serial chain of 234 steps',
+                    'profile_files': {'kernel_stats': newest_profile('next_rows_kernel_stats.txt'), 'pmc': newest_profile('next_rows_pmc.txt'),
+                                      'kernel': 'lmmse_levinson_kernel'}}
     # ---- one training step of the shipped model (B = 256), resident dataset, against the fp64 oracle's loss
     B, n_rows = 256, 64
     table = (rng.standard_normal((n_rows, 320 * nt)) * 0.1).astype(np.float32)
@@ -716,7 +848,82 @@ def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
                          'train_gemm_ms_per_step': g['ms'] / 5, 'train_gemm_tflops': g['flops'] / max(g['ms'], 1e-9) / 1e9,
                          'train_gemm_frac_of_fp32_mfma_peak': g['flops'] / max(g['ms'], 1e-9) / 1e9 / FP32_MATRIX_PEAK_TFLOPS,
                          'elementwise_ms_per_step': pr['train_elementwise']['ms'] / 5,
-                         'first_step_loss': loss0, 'first_step_loss_oracle_fp64': rloss, 'loss_rel_err': abs(loss0 - rloss) / max(abs(rloss), 1e-30)}
+                         'first_step_loss': loss0, 'first_step_loss_oracle_fp64': rloss, 'loss_rel_err': abs(loss0 - rloss) / max(abs(rloss), 1e-30),
+                         'tuning': 'a "next" row (SURVEY 8f-4): correct and measured, not tuned - B = 256 rows fill a quarter of the chip\'s fp32 MFMA tiles',
+                         'profile_files': {'kernel_stats': newest_profile('next_rows_kernel_stats.txt'), 'kernels': 'gemm_f32_kernel<*> launches of grid <= 256 workgroups'}}
+    return res
+
+
+def default_headline(args):
+    """the driver's command: config 2 with nothing overridden (the side configurations are measured only beside that)"""
+    return (args.nt, args.nr, args.packets, args.dtype, tuple(args.hidden), args.engine, args.scaling) == (32, 4, 4000, 'f32', (1024, 1024), 'auto', 'weak')
+
+
+HBM_BYTES_PER_GPU = 288e9
+
+
+def multi_gpu_legs(args, world):
+    """BASELINE.json configs[3] / configs[4] as N-rank jobs: (name, workload, flags, fits, GB resident per rank)."""
+    tot = [int(x) for x in args.legs_packets.split(',')] if args.legs_packets else [50000, 100000]
+    legs = []
+    for name, nt, nr, total, extra in (('configs[3]', 64, 8, tot[0], []), ('configs[4]', 128, 16, tot[1], ['--graph'])):
+        per_rank = -(-total // world)
+        gb = per_rank * nr * (2 * 320 * nt + 4 * nt * 234) * 4 / 1e9           # preamble planes + DNN and LS result planes
+        flags = ['--scaling', 'strong', '--nt', str(nt), '--nr', str(nr), '--packets', str(total), '--input', 'white',
+                 '--steps', '5', '--warmup', '4' if extra else '2'] + extra
+        what = 'Nt=%d Nr=%d, %d packets sharded over %d GPUs (contiguous packet ranges, weights broadcast once over RCCL)%s' % (
+            nt, nr, total, world, ', one hipGraph per step and rank' if extra else '')
+        legs.append((name, what, flags, gb < 0.8 * HBM_BYTES_PER_GPU / 1e9, gb))
+    return legs
+
+
+def run_multi_gpu_legs(pkg, args, rank, world, local):
+    """Every rank of the running job starts ONE child per leg with its own RANK / LOCAL_RANK and a fresh rendezvous port that rank 0
+    found and broadcast: a fresh N-rank job of this script per configuration (own engines, weights broadcast through the library,
+    own shard, rank 0 of it checks packets of its shard against the oracle).  Rank 0 returns the parsed lines."""
+    import socket
+    import subprocess
+    import torch.distributed as tdist
+    res = []
+    for name, what, flags, fits, gb in multi_gpu_legs(args, world):
+        if not fits:
+            res.append({'config': name, 'workload': what, 'skipped': '%.0f GB per rank do not fit %d GPUs of %.0f GB' % (gb, world, HBM_BYTES_PER_GPU / 1e9)})
+            continue
+        box = [None]
+        if rank == 0:
+            with socket.socket() as so:
+                so.bind(('127.0.0.1', 0))
+                box[0] = so.getsockname()[1]
+        tdist.broadcast_object_list(box, src=0)
+        env = dict(os.environ, MASTER_PORT=str(box[0]), CSI_RCCL_ID_TOKEN='leg-%s-%d' % (name, box[0]))
+        for k in [k for k in env if k.startswith('TORCHELASTIC_')]:      # under torchrun: the child job's rank 0 serves its own store
+            env.pop(k)                                                     # (TORCHELASTIC_USE_AGENT_STORE would make it look for the agent's)
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--no-other-configs', '--no-cpu-baseline', '--no-latency',
+               '--host-path', '0', '--check', '4', '--no-next-rows', '--no-regimes', '--weights-via', args.weights_via] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1500)
+            rc, so_, se_ = r.returncode, r.stdout, r.stderr
+        except Exception as e:                       # noqa: BLE001 - a failed side measurement never takes the headline down
+            rc, so_, se_ = -1, '', repr(e)
+        rcs = pkg.dist.gather_objects(rc)
+        pkg.dist.barrier()
+        if rank != 0:
+            continue
+        lines = [ln for ln in so_.splitlines() if ln.startswith('{')]
+        if any(rcs) or not lines:
+            res.append({'config': name, 'workload': what, 'flags': ' '.join(flags), 'error': 'rank exit codes %s: %s' % (rcs, se_[-400:])})
+            continue
+        j = json.loads(lines[-1])
+        res.append({'config': name, 'workload': what, 'flags': ' '.join(flags), 'n_gpus': j['n_gpus'], 'value': j['value'], 'unit': j['unit'],
+                    'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'scaling': j['scaling'], 'dtype': j['dtype'], 'launch': j['launch'],
+                    'pairs_per_step': j['config']['pairs_per_step'], 'input': j['input'], 'ranks_ms': j['ranks_ms'],
+                    'devices': [d.get('ordinal') for d in j['devices']], 'packets_per_rank': [r_['packets'] for r_ in j['ranks']],
+                    'rccl_ranks': j['config']['world_size_checked'], 'weights_via': j['config']['weights_via'], 'sharding': j['config']['sharding'],
+                    'roofline': {k: j['roofline'][k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms')},
+                    'roofline_ls_frac': (j.get('roofline_ls') or {}).get('frac'),
+                    'parity_check_rank0_shard': j['parity_check'], 'split_engine_range_guard': j.get('split_engine_range_guard'),
+                    'wall_s': round(time.perf_counter() - t0, 1)})
     return res
 
 
@@ -750,8 +957,10 @@ def other_configs():
             res.append({'config': name, 'workload': what, 'flags': ' '.join(flags), 'value': j['value'], 'unit': j['unit'],
                         'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'dtype': j['dtype'], 'launch': j['launch'],
                         'pairs_per_step': j['config']['pairs_per_step'], 'input': j['input'],
-                        'roofline': {k: j['roofline'][k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms')},
-                        'roofline_ls_frac': (j.get('roofline_ls') or {}).get('frac'),
+                        'roofline': {k: j['roofline'].get(k) for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'flops_per_launch',
+                                                                         'traffic', 'traffic_source', 'algorithmic_bytes_per_launch', 'profile_files')},
+                        'kernels': j['kernels'],
+                        'roofline_ls': {k: (j.get('roofline_ls') or {}).get(k) for k in ('achieved', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms', 'algorithmic_frac', 'achieved_is')},
                         'parity_check': j['parity_check'], 'split_engine_range_guard': j.get('split_engine_range_guard'),
                         'wall_s': round(time.perf_counter() - t0, 1)})
         except Exception as e:                      # a failed side measurement must never take the headline line down

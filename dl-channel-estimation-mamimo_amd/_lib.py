@@ -177,9 +177,13 @@ def build_library(force=False, verbose=False):
 
 def load_library():
     """dlopen the HIP library and attach prototypes.  Raises CsiError if it is not built."""
-    global _lib
+    global _lib, _SO
     if _lib is not None:
         return _lib
+    # test hook (multi-rank dry runs on a machine without a GPU, tests/mock_library.cpp): another build of the SAME translation unit.
+    # Honoured only together with CSI_DEBUG_HOOKS=1, like the code-object hooks of the library itself.
+    if os.environ.get('CSI_DEBUG_HOOKS') == '1' and os.environ.get('CSI_LIBRARY_PATH'):
+        _SO = os.environ['CSI_LIBRARY_PATH']
     if not os.path.exists(_SO):
         raise CsiError(-4, f'{_SO} not found: build it with __graft_entry__.build() '
                            f'(hipcc --offload-arch=gfx950); there is no CPU fallback')

@@ -346,6 +346,9 @@ class Role:
         for par in range(2):
             for p in range(4):
                 b.e('v_pk_max_i16 %s, %s, 0' % (vreg(V_AHI[par] + p), vreg(V_AHI[par] + p)))
+                if self.bf:                                  # bf16: both register quads are k-steps of one relu output
+                    b.e('v_pk_max_i16 %s, %s, 0' % (vreg(V_ALO[par] + p), vreg(V_ALO[par] + p)))
+                    continue
                 b.e('v_pk_min_u16 %s, %s, %s' % (vreg(V_T + 2), vreg(V_AHI[par] + p), vreg(V_T + 1)))
                 b.e('v_pk_mul_f16 %s, %s, %s' % (vreg(V_ALO[par] + p), vreg(V_ALO[par] + p), vreg(V_T + 2)))
 
@@ -1033,6 +1036,9 @@ VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_
             ('csi_band8_noaside_rnd', ('noconv', 'noreq', 'rnd')), ('csi_band8_p2first', ('p2first',)), ('csi_band8_prio1', ('prio1',)), ('csi_band8_prio0', ('prio0',)), ('csi_band8_p2first_noaside', ('p2first', 'noconv', 'noreq')),
             ('csi_band8_nobarrier', ('nobarrier',)), ('csi_band8_stagger', ('stagger',)), ('csi_band8_nointerleave', ('nointerleave',)), ('csi_band8_ownpieces', ('ownpieces',)), ('csi_band8_nodma', ('nodma',)), ('csi_band8_noread', ('noread',)),
             ('csi_band8_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band8_noaside_noread', ('noconv', 'noreq', 'noread')), ('csi_band8_exit0', ('exit0',)), ('csi_band8_exit1', ('exit1',)),
+            ('csi_band8_bf16_nobarrier', ('bf16', 'nobarrier')), ('csi_band8_bf16_noread', ('bf16', 'noread')), ('csi_band8_bf16_nodma', ('bf16', 'nodma')),
+            ('csi_band8_bf16_skeleton_nobarrier', ('bf16', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band8_bf16_skeleton_rnd', ('bf16', 'noconv', 'noreq', 'nodma', 'noread', 'rnd')),
+            ('csi_band8_bf16_noaside_noread', ('bf16', 'noconv', 'noreq', 'noread')), ('csi_band8_bf16_noaside_nodma', ('bf16', 'noconv', 'noreq', 'nodma')),
             ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
 
 

@@ -9,7 +9,10 @@ Process order matters on ROCm: call ``init_process_group`` (which imports torch 
 BEFORE the first ``CsiEngine`` is created - see ``_lib.load_library`` for why; with WORLD_SIZE > 1
 in the environment ``load_library`` enforces it."""
 import os
+import time
 import numpy as np
+
+_T_PROCESS_START = time.time()        # (module import: early in the life of a rank) - freshness reference of exchange_unique_id
 
 
 def env_rank_world():
@@ -77,8 +80,7 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
     """The RCCL unique id of the library's own communicator (engine.get_unique_id) from rank 0 to every rank.  With
     ``torch.distributed`` initialised it rides on its object broadcast; without it, through a file (``CSI_RCCL_ID_FILE``,
     default <XDG_RUNTIME_DIR or /tmp>/csi_rccl_<uid>/id_<hash of the launch token>, mode 0600) that rank 0 writes atomically
-    and removes at exit - no torch in the process at all."""
-    import time
+    and removes at exit (if it is still its own) - no torch in the process at all."""
     from .engine import get_unique_id
     try:
         import torch.distributed as tdist
@@ -89,14 +91,19 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
         box = [get_unique_id() if rank == 0 else None]
         tdist.broadcast_object_list(box, src=0)
         return box[0]
-    # The file carries a launch token in front of the 128 id bytes: a reader accepts it only with ITS launch's token, so a
-    # leftover of a crashed launch (any age) is never taken for the id of this one and a late rank (slow import, first-use
-    # build) is never rejected for being late.  Token: CSI_RCCL_ID_TOKEN, else torchrun's TORCHELASTIC_RUN_ID, else the
-    # rendezvous triple.  Default location: a directory of this user (mode 0700), the file itself mode 0600.
-    token = (os.environ.get('CSI_RCCL_ID_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID') or
-             '%s:%s:%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world)).encode()
+    # The file carries, in front of the 128 id bytes, a 32-byte tag of the launch token and the wall time rank 0 wrote it at.
+    # Token: CSI_RCCL_ID_TOKEN (bench.py's own launcher sets a fresh one per launch), else torchrun's TORCHELASTIC_RUN_ID, else -
+    # a hand-rolled launch - the rendezvous triple plus the launcher's pid.  Only the first two are unique per launch; with the
+    # fallback a file left by a KILLED launch (atexit does not run on SIGKILL) can carry the same tag, so there a reader also wants
+    # the file to be younger than its own process start minus CSI_RCCL_ID_MAX_AGE_S (default 120 s: ranks of one launch start
+    # within that; a rank that is later than that must be given a token) and keeps polling until rank 0 has replaced it.
+    # Default location: a directory of this user (mode 0700), the file itself mode 0600.
     import hashlib
-    tag = hashlib.sha256(token).digest()                       # 32 bytes in front of the id
+    import struct
+    strong = os.environ.get('CSI_RCCL_ID_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID')
+    token = (strong or '%s:%s:%d:%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world, os.getppid())).encode()
+    tag = hashlib.sha256(token).digest()                       # 32 bytes in front of the stamp and the id
+    max_age = float(os.environ.get('CSI_RCCL_ID_MAX_AGE_S', '120'))
     path = os.environ.get('CSI_RCCL_ID_FILE')
     if not path:
         base = os.path.join(os.environ.get('XDG_RUNTIME_DIR') or '/tmp', 'csi_rccl_%d' % os.getuid())
@@ -110,25 +117,37 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
         except FileNotFoundError:
             pass
         uid = get_unique_id()
+        blob = tag + struct.pack('<d', time.time()) + uid
         tmp = '%s.%d' % (path, os.getpid())
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
         with os.fdopen(fd, 'wb') as f:
-            f.write(tag + uid)
+            f.write(blob)
         os.replace(tmp, path)
+
+        def _remove_own():                                     # only what THIS launch wrote: a later launch may own the path by now
+            try:
+                with open(path, 'rb') as f:
+                    if f.read() != blob:
+                        return
+                os.remove(path)
+            except OSError:
+                pass
         import atexit
-        atexit.register(lambda: os.path.exists(path) and os.remove(path))
+        atexit.register(_remove_own)
         return uid
     t0 = time.time()
     while time.time() - t0 < timeout_s:
         try:
             with open(path, 'rb') as f:
                 blob = f.read()
-            if len(blob) == 32 + 128 and blob[:32] == tag:
-                return blob[32:]
+            if len(blob) == 32 + 8 + 128 and blob[:32] == tag:
+                if strong or struct.unpack('<d', blob[32:40])[0] >= _T_PROCESS_START - max_age:
+                    return blob[40:]
         except FileNotFoundError:
             pass
         time.sleep(0.05)
-    raise RuntimeError('no RCCL unique id of this launch at %s after %.0f s' % (path, timeout_s))
+    raise RuntimeError('no RCCL unique id of this launch at %s after %.0f s%s' % (
+        path, timeout_s, '' if strong else ' (no per-launch token: set CSI_RCCL_ID_TOKEN to the same fresh value on every rank)'))
 
 
 def local_device_count():

@@ -55,9 +55,11 @@ struct Stream {
             cv.notify_all();
         }
     }
+    std::vector<std::function<void()>>* capture = nullptr;      // stream capture (hipStreamBeginCapture): items are recorded, not run
     void push(std::function<void()> f) {
         {
             std::lock_guard<std::mutex> lk(mu);
+            if (capture) { capture->push_back(std::move(f)); return; }
             q.push_back(std::move(f));
             ++submitted;
         }
@@ -301,12 +303,34 @@ hipError_t hipLaunchKernel(const void* fn, dim3, dim3, void** args, size_t, hipS
     ++mock::g_launches;
     return mock::launch_hook ? mock::launch_hook(fn, args, st) : hipSuccess;
 }
-// stream capture / graphs: not modelled (the harnesses leave use_graph off)
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
-hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
-hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorNotSupported; }
-hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// stream capture / graphs, as far as csi_estimate_device + "use_graph" needs them: while a stream captures, what is pushed onto it
+// (kernel launches are dropped anyway; memsets, copies, event records) is recorded into the graph instead of run; an instantiated
+// graph is that list, a launch pushes its items onto the stream in order.  One capturing stream at a time per graph, no cross-stream
+// joins (the library captures single-stream sequences only: csi_context.hpp, in_graph_call).
+hipError_t hipStreamBeginCapture(hipStream_t st, hipStreamCaptureMode) {
+    mock::Stream* s = mock::S(st);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->capture) return hipErrorIllegalState;
+    s->capture = new std::vector<std::function<void()>>();
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t st, hipGraph_t* g) {
+    mock::Stream* s = mock::S(st);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->capture) return hipErrorIllegalState;
+    *g = reinterpret_cast<hipGraph_t>(s->capture);
+    s->capture = nullptr;
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) {
+    *e = reinterpret_cast<hipGraphExec_t>(new std::vector<std::function<void()>>(*reinterpret_cast<std::vector<std::function<void()>>*>(g)));
+    return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t st) {
+    for (auto& f : *reinterpret_cast<std::vector<std::function<void()>>*>(e)) mock::S(st)->push(f);
+    return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) { delete reinterpret_cast<std::vector<std::function<void()>>*>(g); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete reinterpret_cast<std::vector<std::function<void()>>*>(e); return hipSuccess; }
 }  // extern "C"
 #endif

@@ -116,21 +116,21 @@ def test_bench_gpus_8_rendezvous_only():
     env = dict(os.environ, CSI_DIST_BACKEND='gloo', PYTHONPATH=REPO)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    first = ''
-    for attempt in range(2):        # (one unexplained failure of a local multi-process rendezvous in ~10 suite runs: retried once, both reported)
-        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--rendezvous-only'], env=env, cwd=REPO,
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
-        if r.returncode == 0:
-            break
-        first = first or r.stdout[-2000:]
-    assert r.returncode == 0, 'first attempt:\n%s\nsecond attempt:\n%s' % (first, r.stdout[-2000:])
-    if first:
-        print('8-rank rendezvous: first attempt failed, second passed:\n' + first)
+    # (round 5: no retry here any more - the launcher itself starts the ranks again on a fresh port when the rendezvous fails, and says so)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--rendezvous-only'], env=env, cwd=REPO,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
     import json
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert out['rendezvous_only'] and out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['requested'] == 8
     assert [rk['rank'] for rk in out['ranks']] == list(range(8)) and len({rk['pid'] for rk in out['ranks']}) == 8
     assert out['scaling'] == 'weak' and out['packets_per_step'] == 8 * out['ranks'][0]['packets']
+    # round-4 verdict, next 4: an 8-rank run of the driver's command also schedules BASELINE.json's two 8-GPU configurations
+    legs = {l['config']: l for l in out['other_configs_scheduled']}
+    assert set(legs) == {'configs[3]', 'configs[4]'} and all(l['fits'] for l in legs.values())
+    assert '--scaling strong --nt 64 --nr 8 --packets 50000 --input white' in legs['configs[3]']['flags']
+    assert '--nt 128 --nr 16 --packets 100000' in legs['configs[4]']['flags'] and '--graph' in legs['configs[4]']['flags']
+    assert 150 < legs['configs[4]']['per_rank_gb'] < 0.8 * 288          # one GPU's share of configs[4] is resident in its 288 GB
 
 
 def test_native_crc32c_matches_the_table_walk_and_known_answers(pkg):
@@ -155,13 +155,17 @@ def test_unique_id_file_carries_the_launch_token(pkg, tmp_path, monkeypatch):
     a leftover of another launch is ignored however fresh it is, and the file is private (0600)."""
     import hashlib
     import stat
+    import struct
     from dl_channel_estimation_mamimo_amd import dist, engine
     path = tmp_path / 'id'
     monkeypatch.setenv('CSI_RCCL_ID_FILE', str(path))
     monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-A')
+    monkeypatch.delenv('TORCHELASTIC_RUN_ID', raising=False)
     monkeypatch.setattr(engine, 'get_unique_id', lambda: bytes(range(128)))
     uid = dist.exchange_unique_id(0, 2)
-    assert uid == bytes(range(128)) and path.read_bytes() == hashlib.sha256(b'launch-A').digest() + uid
+    blob = path.read_bytes()
+    assert uid == bytes(range(128)) and blob[:32] == hashlib.sha256(b'launch-A').digest() and blob[40:] == uid and len(blob) == 168
+    assert abs(struct.unpack('<d', blob[32:40])[0] - __import__('time').time()) < 60
     assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
     assert dist.exchange_unique_id(1, 2, timeout_s=1.0) == uid
     monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-B')                            # another launch finds launch A's file
@@ -170,6 +174,56 @@ def test_unique_id_file_carries_the_launch_token(pkg, tmp_path, monkeypatch):
     os.utime(path, (1, 1))                                                           # an OLD file of the right launch is fine (late rank)
     monkeypatch.setenv('CSI_RCCL_ID_TOKEN', 'launch-A')
     assert dist.exchange_unique_id(3, 4, timeout_s=1.0) == uid
+
+
+def test_unique_id_file_without_a_launch_token_wants_a_fresh_file(pkg, tmp_path, monkeypatch):
+    """without CSI_RCCL_ID_TOKEN / TORCHELASTIC_RUN_ID the tag is the rendezvous triple (+ the launcher's
+    pid), the same for every launch from one shell - a file left by a KILLED launch (atexit never ran) has a matching tag.  Such a
+    leftover must not be handed to a non-root rank: it is refused by its age (the time rank 0 stamped INTO the file - not the mtime),
+    the reader keeps polling and takes the file rank 0 of its own launch writes meanwhile.  Rank 0's exit handler removes only what
+    it wrote itself."""
+    import hashlib
+    import struct
+    import threading
+    import time
+    from dl_channel_estimation_mamimo_amd import dist, engine
+    path = tmp_path / 'id'
+    monkeypatch.setenv('CSI_RCCL_ID_FILE', str(path))
+    for k in ('CSI_RCCL_ID_TOKEN', 'TORCHELASTIC_RUN_ID'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29511')
+    tag = hashlib.sha256(('127.0.0.1:29511:2:%d' % os.getppid()).encode()).digest()
+    stale = bytes([7]) * 128
+    path.write_bytes(tag + struct.pack('<d', time.time() - 3600.0) + stale)         # an hour-old leftover with the RIGHT tag, fresh mtime
+    with pytest.raises(RuntimeError, match='CSI_RCCL_ID_TOKEN'):
+        dist.exchange_unique_id(1, 2, timeout_s=0.4)
+    # the same leftover, and rank 0 of this launch arrives half a second later: the reader returns rank 0's id, never the stale one
+    fresh = bytes(range(128))
+    monkeypatch.setattr(engine, 'get_unique_id', lambda: fresh)
+    got = {}
+    t = threading.Thread(target=lambda: got.update(uid=dist.exchange_unique_id(1, 2, timeout_s=10.0)))
+    t.start()
+    time.sleep(0.5)
+    assert dist.exchange_unique_id(0, 2) == fresh
+    t.join(20)
+    assert got.get('uid') == fresh
+    # a file that carries only the old layout (tag + id, no stamp) is never accepted
+    path.write_bytes(tag + fresh)
+    with pytest.raises(RuntimeError):
+        dist.exchange_unique_id(1, 2, timeout_s=0.3)
+    # rank 0's exit handler leaves a file alone that is no longer its own
+    import atexit
+    calls = []
+    monkeypatch.setattr(atexit, 'register', lambda fn: calls.append(fn))
+    dist.exchange_unique_id(0, 2)
+    other = tag + struct.pack('<d', time.time()) + bytes([9]) * 128
+    path.write_bytes(other)                                                          # a later launch owns the path now
+    calls[-1]()
+    assert path.read_bytes() == other
+    dist.exchange_unique_id(0, 2)
+    calls[-1]()
+    assert not path.exists()
 
 
 def test_integration_doc_indexes_every_entry_point_of_the_header():
@@ -422,8 +476,11 @@ def test_bench_script_runs_end_to_end_on_the_mock_runtime(mock_so):
     import json
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
-                'roofline', 'cpu_baseline', 'kernels', 'parity_check', 'host_path_pcie_inclusive', 'next_rows', 'bench_wall_s'):
+                'roofline', 'cpu_baseline', 'kernels', 'parity_check', 'host_path_pcie_inclusive', 'next_rows', 'regimes', 'bench_wall_s'):
         assert key in line, key
+    # round-4 verdict, next 3: the batch-size regimes that fit the resident batch (64 packets here), each with its bound
+    assert [r['packets'] for r in line['regimes']] == [1, 8, 64] and all(r['bound_us'] > 0 and 'bound' in r and r['pipelined_us'] > 0 for r in line['regimes'])
+    assert line['roofline_ls']['achieved_is'] and 'algorithmic_frac' in line['roofline_ls']
     assert line['n_gpus'] == 1 and line['steps'] == 2 and line['warmup'] == 1 and line['config']['pairs_per_step'] == 64 * 128
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in line['roofline'], key
@@ -477,3 +534,29 @@ print('ringb gating: ok')
 ''' % (REPO, mock_so)
     run = subprocess.run([sys.executable, '-c', script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert run.returncode == 0 and 'ringb gating: ok' in run.stdout, run.stdout[-3000:]
+
+
+def test_two_rank_bench_runs_the_multi_gpu_legs_on_the_mock_runtime(mock_so):
+    """`bench.py --gpus 2` end to end without a GPU (gloo, the library's translation unit on the mock runtime): the weak-scaled config-2
+    headline by two ranks AND - round-4 verdict, next 4 - the configs[3] / configs[4] legs as fresh two-rank jobs started by the
+    running ranks (shrunken packet counts; configs[4] as one hipGraph per step and rank).  Numbers mean nothing here (kernels are
+    dropped); what is asserted is that the first N > 1 run of the driver records the right workloads with per-rank evidence."""
+    env = dict(os.environ, CSI_DIST_BACKEND='gloo', CSI_DEBUG_HOOKS='1', CSI_LIBRARY_PATH=mock_so, PYTHONPATH=REPO)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--check', '0',
+                        '--legs-packets', '24,6', '--input', 'white'], env=env, cwd=REPO,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['pairs_per_step'] == 2 * 4000 * 128
+    legs = {l['config']: l for l in line['other_configs']}
+    assert set(legs) == {'configs[3]', 'configs[4]'}, line['other_configs']
+    for name, (nt, nr, total) in {'configs[3]': (64, 8, 24), 'configs[4]': (128, 16, 6)}.items():
+        l = legs[name]
+        assert 'error' not in l and 'skipped' not in l, l
+        assert l['n_gpus'] == 2 and l['scaling'] == 'strong' and l['pairs_per_step'] == total * nt * nr
+        assert l['packets_per_rank'] == [total // 2, total // 2] and len(l['ranks_ms']) == 2 and len(l['devices']) == 2
+        assert 'weights_via' in l and 'sharding' in l and 'roofline' in l and l['ms_per_step'] > 0
+    assert 'hipGraph' in legs['configs[4]']['launch'] and 'eager' in legs['configs[3]']['launch']

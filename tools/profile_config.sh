@@ -14,7 +14,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-COMMON="--no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs --no-next-rows --no-regimes"
+# NEXT_ROWS=1 keeps the "next_rows" legs (LMMSE, training step, LS on the 802.11 pilot) in the profiled command
+NR_FLAG="--no-next-rows"; [ "${NEXT_ROWS:-0}" = 1 ] && NR_FLAG=""
+COMMON="--no-cpu-baseline --check 0 --no-latency --host-path 0 --no-other-configs $NR_FLAG --no-regimes"
 BENCH="python bench.py --steps 3 --warmup 1 $COMMON $*"
 BENCH_KT="python bench.py --steps ${KT_STEPS:-20} --warmup ${KT_WARMUP:-5} $COMMON $*"
 echo "$BENCH_KT" > $OUT/cmd.txt
