@@ -403,6 +403,32 @@ def main():
             del pc
         except Exception as e:                      # a side measurement never takes the line down
             host_path['python_c128_to_c64']['dnn_only_pinned_result_error'] = repr(e)
+        # the same surface for a caller that holds its batch as complex64 in pinned memory (csi_estimate_c64, round-4 verdict next 7):
+        # no host pass on either side - the chunk is uploaded as it is and split on the device, the result assembled there
+        try:
+            x64 = eng.pinned_empty(x128.shape, np.complex64)
+            x64[...] = x128
+            pc = eng.pinned_empty(bufs[0].shape, np.complex64)
+            pc[...] = 0
+            eng.estimate(x64, ls=False, out=(pc, None))
+            t5s = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                eng.estimate(x64, ls=False, out=(pc, None))
+                t5s.append(time.perf_counter() - t0)
+            t5 = sorted(t5s)[1]
+            ref64 = np.empty(bufs[0].shape, np.complex64)
+            eng.estimate(x64.astype(np.complex128), ls=False, out=(ref64, None))
+            host_path['c64_pinned_in_and_out'] = {
+                'dnn_only': {'pairs_per_s': k * nr * nt / t5, 'ms': t5 * 1e3, 'ms_all': [round(t * 1e3, 2) for t in t5s],
+                             'bit_identical_with_c128_call_on_the_same_values': bool(np.array_equal(pc, ref64)),
+                             'where_us': {n: eng.get_option(n) for n in ('hp_total_us', 'hp_stage_us', 'hp_wait_stage_us', 'hp_wait_out_us', 'hp_weave_us')}},
+                'note': 'CsiEngine.estimate(complex64 array from pinned_empty, ls=False, out=(pinned complex64, None)) = csi_estimate_c64: the interleaved '
+                        'chunk is DMA\'d from the caller\'s array, split_c64_kernel + kernels + weave_c64_kernel on the device, one download per chunk into the '
+                        'caller\'s array.  Same bytes over the link as the complex128 call (8 B per sample after its host-side split), no host pass'}
+            del x64, pc, ref64
+        except Exception as e:                      # a side measurement never takes the line down
+            host_path['c64_error'] = repr(e)
         try:
             host_path['host_cpu_quota'] = open('/sys/fs/cgroup/cpu.max').read().strip() + ' (cgroup cpu.max: quota / period us); os.cpu_count() = %d' % os.cpu_count()
         except OSError:
@@ -422,6 +448,10 @@ def main():
                     pr_ = host_path['python_c128_to_c64']['dnn_only_pinned_result']
                     pr_['pcie_bound_ms'] = round(ab, 3)
                     pr_['frac_of_pcie_bound'] = round(ab / pr_['ms'], 3)
+                if key == 'dnn_only' and 'c64_pinned_in_and_out' in host_path:
+                    c64_ = host_path['c64_pinned_in_and_out']['dnn_only']
+                    c64_['pcie_bound_ms'] = round(ab, 3)
+                    c64_['frac_of_pcie_bound'] = round(ab / c64_['ms'], 3)
                 if key == 'dnn_only' and 'pinned_planes_dnn' in host_path:
                     host_path['pinned_planes_dnn']['pcie_bound_ms'] = round(ab, 3)
                     host_path['pinned_planes_dnn']['frac_of_pcie_bound'] = round(ab / host_path['pinned_planes_dnn']['ms'], 3)
@@ -496,11 +526,13 @@ def main():
             eng.synchronize()
             t1 = time.perf_counter()
             if not args.no_ls:
-                eng.ls_estimate_device(d_re, d_im, 1, d_hre, d_him)
-            eng.predict_device(d_re, d_im, 1, d_ore, d_oim)
+                eng.estimate_device(d_re, d_im, 1, d_ore, d_oim, d_hre, d_him)
+            else:
+                eng.predict_device(d_re, d_im, 1, d_ore, d_oim)
             eng.synchronize()
             ts.append(time.perf_counter() - t1)
-        latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6), 'what': 'LS + DNN(real) + DNN(imag) of one packet, device-resident, median of 30 calls'}
+        latency = {'one_packet_us': float(np.median(ts[10:]) * 1e6),
+                   'what': 'LS + DNN(real) + DNN(imag) of one packet as one csi_estimate_device call + csi_synchronize, device-resident, median of 30 calls'}
 
     # N > 1: BASELINE.json's two multi-GPU configurations, by ALL ranks, each as a fresh N-rank job of this script (round-4 verdict,
     # next 4): configs[3] Nt=64 Nr=8 50000 packets sharded, configs[4] Nt=128 Nr=16 100000 packets, one hipGraph per step
@@ -699,10 +731,11 @@ def regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt_resident, ls=True):
             continue
         o = [eng.empty((n, nr, nt, 234)) for _ in range(4)]
 
-        def call():
+        def call():                       # LS + DNN as ONE call (csi_estimate_device), as a serving loop would issue it
             if ls:
-                eng.ls_estimate_device(d_re, d_im, n, o[2], o[3])
-            eng.predict_device(d_re, d_im, n, o[0], o[1])
+                eng.estimate_device(d_re, d_im, n, o[0], o[1], o[2], o[3])
+            else:
+                eng.predict_device(d_re, d_im, n, o[0], o[1])
         for _ in range(5):
             call()
         eng.synchronize()

@@ -63,6 +63,7 @@ SYMBOLS = {
     'csi_ls_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, _fp]),
     'csi_ls_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     'csi_estimate_c128': (ctypes.c_int, [_ctx, _vp, ctypes.c_int64, _vp, _vp]),
+    'csi_estimate_c64': (ctypes.c_int, [_ctx, _vp, ctypes.c_int64, _vp, _vp]),
     'csi_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     'csi_lmmse_estimate': (ctypes.c_int, [_ctx, _fp, _fp, ctypes.c_int64, _fp, ctypes.c_int, _fp, _fp, _fp]),
     'csi_lmmse_estimate_device': (ctypes.c_int, [_ctx, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp]),

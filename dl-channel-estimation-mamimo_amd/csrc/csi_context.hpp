@@ -153,6 +153,11 @@ struct csi_ctx {
     char *aux_ws = nullptr, *aux_l0skinny = nullptr, *aux_skbuf = nullptr, *aux_fuse_ws = nullptr;
     size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0, aux_fuse_ws_bytes = 0;
     int small_call_overlap = 1;  // "small_call_overlap" option
+    // the one-packet regime (csi_dnn_small.hpp): both models of a call of <= 8 rx preambles in 1 + n_hidden launches
+    int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
+    int64_t small_calls = 0;     // "small_calls": calls that took it
+    char* small_ws = nullptr;    // its scratch: L0 of both models + ping-pong activations
+    size_t small_ws_bytes = 0;
     // "ls_overlap_cus" = n > 0: inside csi_estimate_device the LS kernel runs on its own stream, restricted to n compute units
     // (hipExtStreamCreateWithCUMask), BESIDE the DNN kernels of the same packets instead of in front of them: it is HBM-bound and
     // draws little power, the matrix kernels are bound by the power budget and by one workgroup per CU - a few CUs lent to it cost

@@ -1,0 +1,97 @@
+// csi_dnn_small.hpp - host side of the one-packet regime (small_call.hip.h): both component models of a call of at most 8 rx
+// preambles in 1 + n_hidden launches on the context's stream - layer 0 as one weight-streaming kernel, every layer behind it as
+// 16 x 16 MFMA tiles over the whole K - instead of six launches per model on two streams.  Same arithmetic class as the fp32 MFMA
+// kernels of gemm_f32.hip.h (exact fp32 products, fp32 accumulation); the reference call this serves is the literal per-packet
+// predict of massiveMIMO_CSI_prediction_DNN.py:339-346.
+#pragma once
+#include "csi_context.hpp"
+#include "small_call.hip.h"
+
+namespace {
+
+// which calls take it: fp32 contexts with a pilot input, both models loaded, at most SC_MAX_ROWS0 preambles and - so that a layer
+// is at most a few tiles per SIMD - at most 1024 pair rows; "small_fused" = 0 restores the general kernels (A/B runs, tests)
+bool small_call_ok(const csi_ctx* c, int64_t npkt) {
+    const csi_config& cf = c->cfg;
+    if (!c->small_fused || cf.dtype != CSI_DTYPE_F32 || cf.nt < 1 || c->force_pair_tile) return false;
+    if (c->f32_engine == 1) return false;        // "f32_engine" = 1 asks for the split-f16 engine wherever the shapes allow
+    if (npkt * cf.nr > SC_MAX_ROWS0 || npkt * cf.nr * cf.nt > 1024) return false;
+    for (int d = 0; d < 2; ++d)
+        if (!c->model[d].loaded || !c->model[d].table_ok || !c->model[d].layers[0].Wt) return false;
+    return true;
+}
+
+int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_out_re, float* d_out_im) {
+    const csi_config& cf = c->cfg;
+    const int nt = cf.nt, h1 = cf.hidden[0], nh = cf.n_hidden;
+    const int M1 = (int)(npkt * cf.nr), M2 = M1 * nt;
+    int maxh = 0;
+    for (int i = 1; i < nh; ++i) maxh = std::max(maxh, cf.hidden[i]);
+    // scratch: the per-pair layer's input rows of both models, then two ping-pong activation buffers per model
+    const size_t h1_floats = (size_t)M2 * h1, act_floats = (size_t)M2 * maxh;
+    int rc = ensure_bytes(c, &c->small_ws, &c->small_ws_bytes, (2 * h1_floats + 4 * act_floats) * sizeof(float));
+    if (rc) return rc;
+    float* h1buf = reinterpret_cast<float*>(c->small_ws);
+    float* act = h1buf + 2 * h1_floats;         // [buffer][model][M2][maxh]
+    Model* md[2] = {&c->model[0], &c->model[1]};
+    {
+        SmallL0Args a{};
+        a.x[0] = d_ltf_re; a.x[1] = d_ltf_im;
+        for (int d = 0; d < 2; ++d) {
+            const Model& m = *md[d];
+            // BatchNormalization shifts live in the next layer's bias where csi_load_weights folded them (Layer::bias_hs)
+            const bool fold = m.layers[1].bias_hs != nullptr;
+            a.Wt[d] = m.layers[0].Wt; a.T[d] = m.T; a.s0[d] = m.layers[0].scale; a.t0[d] = fold ? c->hs_zero : m.layers[0].shift;
+            a.h1out[d] = h1buf + d * h1_floats;
+        }
+        a.M = M1; a.K = cf.len_ltf; a.lda = cf.len_ltf; a.ldw = md[0]->layers[0].ldw; a.h1 = h1; a.nt = nt;
+        ProfScope ps(c, K_LAYER0_LTF, 2.0 * 2.0 * M1 * h1 * cf.len_ltf, 2.0 * 4.0 * ((double)cf.len_ltf * h1 + (double)M1 * cf.len_ltf + (double)(nt + M2) * h1));
+        const dim3 grid((unsigned)((h1 + SC_GEMV_COLS - 1) / SC_GEMV_COLS), 2);
+        if (M1 <= 4) hipLaunchKernelGGL((small_l0_gemv_kernel<4>), grid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((small_l0_gemv_kernel<8>), grid, dim3(256), 0, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+    }
+    float* out[2] = {d_out_re, d_out_im};
+    int cur = 0;
+    for (int li = 1; li <= nh; ++li) {
+        SmallGemmArgs g{};
+        const bool last = li == nh;
+        for (int d = 0; d < 2; ++d) {
+            const Model& m = *md[d];
+            const Layer& l = m.layers[li];
+            const bool fold = m.layers[1].bias_hs != nullptr;
+            g.A[d] = li == 1 ? h1buf + d * h1_floats : act + ((size_t)cur * 2 + d) * act_floats;
+            g.Bt[d] = l.Wt;
+            g.bias[d] = fold ? l.bias_hs : l.bias;
+            g.scale[d] = l.scale;
+            g.shift[d] = fold ? c->hs_zero : l.shift;
+            g.C[d] = last ? out[d] : act + ((size_t)(cur ^ 1) * 2 + d) * act_floats;
+        }
+        const Layer& l = md[0]->layers[li];
+        g.M = M2; g.N = l.out; g.K = l.in; g.ldb = l.ldw;
+        g.lda = li == 1 ? h1 : l.in;
+        g.ldc = last ? cf.n_out : l.out;
+        // row tiles per workgroup: as few as still leave ~256 workgroups (the k split inside the workgroup grows as RG shrinks)
+        const int tiles_n = (g.N + 15) / 16, tiles_m = (M2 + 15) / 16;
+        int rg = 4;
+        while (rg > 1 && (long)tiles_n * ((tiles_m + rg - 1) / rg) * 2 < 200) rg >>= 1;
+        const dim3 grid((unsigned)tiles_n, (unsigned)((tiles_m + rg - 1) / rg), 2);
+        ProfScope ps(c, last ? K_REGRESSOR : (li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN), 2.0 * 2.0 * (double)M2 * g.N * g.K,
+                     2.0 * 4.0 * ((double)g.N * g.K + (double)M2 * g.N + (double)M2 * g.K));
+#define SC_LAUNCH(EPIV)                                                                                                             \
+    do {                                                                                                                             \
+        if (rg == 4) hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 4>), grid, dim3(1024), 0, c->stream, g);                       \
+        else if (rg == 2) hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 2>), grid, dim3(1024), 0, c->stream, g);                  \
+        else hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 1>), grid, dim3(1024), 0, c->stream, g);                               \
+    } while (0)
+        if (last) SC_LAUNCH(EPI_BIAS);
+        else SC_LAUNCH(EPI_BIAS_RELU_AFFINE);
+#undef SC_LAUNCH
+        HIP_TRY(c, hipGetLastError());
+        cur ^= 1;
+    }
+    ++c->small_calls;
+    return CSI_OK;
+}
+
+}  // namespace

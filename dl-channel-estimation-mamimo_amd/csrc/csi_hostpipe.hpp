@@ -393,9 +393,10 @@ int hp_get(csi_ctx* c, csi_hostpipe** out) {
     return CSI_OK;
 }
 
-int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, bool need_pin_in, bool need_pin_out) {
+// dev_extra: bytes of device staging beyond the in + out regions (csi_estimate_c64: the interleaved chunk as it was uploaded)
+int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, bool need_pin_in, bool need_pin_out, size_t dev_extra = 0) {
     if ((!need_pin_in || h->pin_in_bytes >= in_bytes) && (!need_pin_out || h->pin_out_bytes >= out_bytes) &&
-        h->dev_bytes >= in_bytes + out_bytes)
+        h->dev_bytes >= in_bytes + out_bytes + dev_extra)
         return CSI_OK;                                    // every call ends drained: nothing in flight uses the slots
     HIP_TRY(c, hipStreamSynchronize(h->s_in));
     HIP_TRY(c, hipStreamSynchronize(h->s_out));
@@ -411,16 +412,16 @@ int hp_reserve(csi_ctx* c, csi_hostpipe* h, size_t in_bytes, size_t out_bytes, b
             h->pin_out[s] = nullptr;
             HIP_TRY(c, hipHostMalloc((void**)&h->pin_out[s], out_bytes, hipHostMallocDefault));
         }
-        if (h->dev_bytes < in_bytes + out_bytes) {
+        if (h->dev_bytes < in_bytes + out_bytes + dev_extra) {
             if (h->dev[s]) hipFree(h->dev[s]);
             h->dev[s] = nullptr;
-            if (hipMalloc((void**)&h->dev[s], in_bytes + out_bytes + 1024) != hipSuccess)
+            if (hipMalloc((void**)&h->dev[s], in_bytes + out_bytes + dev_extra + 1024) != hipSuccess)
                 return fail(c, CSI_ERR_NOMEM, "host pipeline: device staging allocation failed");
         }
     }
     if (need_pin_in) h->pin_in_bytes = std::max(h->pin_in_bytes, in_bytes);
     if (need_pin_out) h->pin_out_bytes = std::max(h->pin_out_bytes, out_bytes);
-    h->dev_bytes = std::max(h->dev_bytes, in_bytes + out_bytes);
+    h->dev_bytes = std::max(h->dev_bytes, in_bytes + out_bytes + dev_extra);
     return CSI_OK;
 }
 
@@ -709,7 +710,13 @@ int hp_packets_impl(csi_ctx* c, csi_hostpipe* h, const float* re, const float* i
 // of the pipeline (host threads, chunk by chunk, beside the uploads / kernels / downloads of the neighbouring
 // chunks) instead of as whole-array numpy passes in front of and behind the call.  One upload serves both
 // estimators: dnn_c64 and / or ls_c64 may be null.
-int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t npkt, float* dnn_c64, float* ls_c64) {
+//
+// in_c64 (csi_estimate_c64): the batch arrives as complex64 - half the bytes to read on the host and nothing to convert there.  The
+// interleaved chunk is uploaded AS IT IS (straight from the caller's array when that is pinned host memory, else through a plain copy
+// into the pinned slot) and split into the two planes on the device (split_c64_kernel, HBM-bound, in front of the chunk's kernels).
+int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const void* in_any, bool in_c64, int64_t npkt, float* dnn_c64, float* ls_c64) {
+    const double* in = static_cast<const double*>(in_any);
+    const float* in32 = static_cast<const float*>(in_any);
     const csi_config& cf = c->cfg;
     int rc = CSI_OK;
     const size_t in_n = (size_t)cf.nr * cf.len_ltf;                     // samples per packet
@@ -725,7 +732,10 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     // staging buffer, no host pass on the result side ("hp_device_weave" = 0: the host threads weave as for pageable arrays).
     const bool direct_out = c->hp_device_weave != 0 && (!dnn_c64 || hp_is_pinned(dnn_c64)) && (!ls_c64 || hp_is_pinned(ls_c64));
     // device[s]: in re | in im | result planes (dnn re | dnn im | ls re | ls im) | direct_out only: dnn complex64 | ls complex64
-    rc = hp_reserve(c, h, 2 * in_pkt * chunk, (direct_out ? 4 : 2) * out_pkt * chunk, true, !direct_out);
+    //            | in_c64 only: the chunk's interleaved (re, im) samples as uploaded
+    const bool in_pinned = in_c64 && hp_is_pinned(in_any);
+    const size_t raw_off = 2 * in_pkt * chunk + (direct_out ? 4 : 2) * out_pkt * chunk;
+    rc = hp_reserve(c, h, 2 * in_pkt * chunk, (direct_out ? 4 : 2) * out_pkt * chunk, !in_pinned, !direct_out, in_c64 ? 2 * in_pkt * chunk : 0);
     if (rc) return rc;
     if (direct_out) ++c->hp_direct_out_calls;
     std::vector<int64_t> first_of, size_of;
@@ -734,6 +744,15 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
     auto np_of = [&](int64_t i) { return size_of[(size_t)i]; };
     HpPipe p;
     p.nchunks = nchunks;
+    if (in_c64 && !in_pinned)
+        p.stage = [&](int64_t i, int s) {                                // complex64, pageable: a plain copy into pinned_in[s]
+            const float* src = in32 + (size_t)first_of[(size_t)i] * in_n * 2;
+            const auto cp = [&](size_t b, size_t e) { hp_stream_copy(h->pin_in[s] + b, reinterpret_cast<const char*>(src) + b, e - b); };
+            const size_t bytes = (size_t)np_of(i) * in_n * 2 * sizeof(float);
+            if (direct_out && c->hp_side_threads != 0) hp_parallel_range2(h->pool_in, h->pool_out, bytes, (size_t)1 << 18, 64, cp);
+            else h->pool_in.parallel_range(bytes, (size_t)1 << 18, cp);
+        };
+    if (!in_c64)
     p.stage = [&](int64_t i, int s) {                                    // complex128 -> two float32 planes in pinned_in[s]
         const double* src = in + (size_t)first_of[(size_t)i] * in_n * 2;
         float* p_re = reinterpret_cast<float*>(h->pin_in[s]);
@@ -745,6 +764,11 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         else h->pool_in.parallel_range((size_t)np_of(i) * in_n, (size_t)1 << 16, split);
     };
     p.enqueue_in = [&](int64_t i, int s) -> int {
+        if (in_c64) {                                                    // ONE upload of the interleaved chunk
+            const void* src = in_pinned ? static_cast<const void*>(in32 + (size_t)first_of[(size_t)i] * in_n * 2) : static_cast<const void*>(h->pin_in[s]);
+            HIP_TRY(c, hipMemcpyAsync(h->dev[s] + raw_off, src, 2 * in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
+            return CSI_OK;
+        }
         HIP_TRY(c, hipMemcpyAsync(h->dev[s], h->pin_in[s], in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
         HIP_TRY(c, hipMemcpyAsync(h->dev[s] + in_pkt * chunk, h->pin_in[s] + in_pkt * chunk, in_pkt * np_of(i), hipMemcpyHostToDevice, h->s_in));
         return CSI_OK;
@@ -755,6 +779,12 @@ int hp_estimate_c128_impl(csi_ctx* c, csi_hostpipe* h, const double* in, int64_t
         float* d_im = reinterpret_cast<float*>(h->dev[s] + in_pkt * chunk);
         float* d_out = reinterpret_cast<float*>(h->dev[s] + 2 * in_pkt * chunk);
         int r = CSI_OK;
+        if (in_c64) {                                                    // interleaved chunk -> the two planes, same stream, in front of the kernels
+            const size_t n = (size_t)np_of(i) * in_n;
+            const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+            hipLaunchKernelGGL(split_c64_kernel, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const float2*>(h->dev[s] + raw_off), d_re, d_im, n);
+            HIP_TRY(c, hipGetLastError());
+        }
         if (ls_c64) r = csi_ls_estimate_device(c, d_re, d_im, np_of(i), d_out + 2 * dnn_n * chunk, d_out + 2 * dnn_n * chunk + ls_n * chunk);
         if (!r && dnn_c64) r = csi_predict_device(c, d_re, d_im, np_of(i), d_out, d_out + dnn_n * chunk);
         if (!r && direct_out) {                                          // planes -> complex64 behind them, same stream
@@ -856,11 +886,11 @@ int hp_pcie_probe(csi_ctx* c, int64_t up, int64_t down, double* ms_up, double* m
     return CSI_OK;
 }
 
-int hp_estimate_c128(csi_ctx* c, const double* in, int64_t npkt, float* dnn_c64, float* ls_c64) {
+int hp_estimate_c128(csi_ctx* c, const void* in, bool in_c64, int64_t npkt, float* dnn_c64, float* ls_c64) {
     csi_hostpipe* h = nullptr;
     int rc = hp_get(c, &h);
     if (rc) return rc;
-    rc = hp_estimate_c128_impl(c, h, in, npkt, dnn_c64, ls_c64);
+    rc = hp_estimate_c128_impl(c, h, in, in_c64, npkt, dnn_c64, ls_c64);
     if (rc) {
         const std::string keep = c->err;
         hipStreamSynchronize(h->s_in);

@@ -13,6 +13,7 @@
 #include "csi_context.hpp"
 #include "csi_dnn_hs.hpp"
 #include "csi_dnn_f32.hpp"
+#include "csi_dnn_small.hpp"
 #include "csi_dnn_bf16.hpp"
 #include "csi_train.hpp"
 #include "csi_hostpipe.hpp"
@@ -504,6 +505,7 @@ void csi_destroy(csi_ctx* c) {
     if (c->hs_peak) hipFree(c->hs_peak);
     if (c->hs_zero) hipFree(c->hs_zero);
     if (c->fuse_ws) hipFree(c->fuse_ws);
+    if (c->small_ws) hipFree(c->small_ws);
     if (c->Ppad) hipFree(c->Ppad);
     if (c->Pbf) hipFree(c->Pbf);
     if (c->p_tables) hipFree(c->p_tables);
@@ -921,6 +923,8 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
             if (r) return r;
             return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
         }
+        // the one-packet regime: both models in 1 + n_hidden launches on this stream (csi_dnn_small.hpp)
+        if (small_call_ok(c, npkt)) return predict_small(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
         // small call: the two component models are independent and each is a chain of short,
         // launch-latency-bound kernels - run the imag model on a second stream with its own scratch
         const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call &&
@@ -985,6 +989,25 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
                 if (e != hipSuccess && !r) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: joining the LS stream failed: %s", hipGetErrorString(e));
             }
             if (!r) r = r2;
+        } else if (!g && !c->prof_on && c->small_call_overlap && small_call_ok(c, npkt)) {
+            // the one-packet regime: the LS kernel (a few workgroups, ~8 us with its boundary) on the second stream beside the three
+            // DNN launches instead of in front of them; forked and joined inside this call, so the caller's stream order holds
+            if (!c->aux_stream) {
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+            }
+            HIP_TRY(c, hipEventRecord(c->aux_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+            std::swap(c->stream, c->aux_stream);
+            r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
+            const hipError_t e = hipEventRecord(c->aux_join, c->stream);
+            std::swap(c->stream, c->aux_stream);
+            if (!r && e != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: recording the LS stream's event failed: %s", hipGetErrorString(e));
+            const int r2 = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+            const hipError_t e2 = hipStreamWaitEvent(c->stream, c->aux_join, 0);      // also on an error: the forked stream is always joined
+            if (!r) r = r2;
+            if (!r && e2 != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: joining the LS stream failed: %s", hipGetErrorString(e2));
         } else {
             r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
             if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
@@ -1166,6 +1189,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "xcd_order") *value = c->xcd_order;
     else if (n == "ls_fft_first_max") *value = c->ls_fft_first_max;
     else if (n == "small_call_overlap") *value = c->small_call_overlap;
+    else if (n == "small_fused") *value = c->small_fused;
+    else if (n == "small_calls") *value = c->small_calls;
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band_launches") *value = c->band_launches;
@@ -1244,6 +1269,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         return ls_prepare(c);
     } else if (n == "small_call_overlap") {
         c->small_call_overlap = value == 2 ? 2 : (value != 0);
+    } else if (n == "small_fused") {
+        drop_graphs(c);
+        c->small_fused = value != 0;
     } else if (n == "f32_engine") {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);
@@ -1692,10 +1720,22 @@ int csi_estimate_c128(csi_ctx* c, const double* ltf_c128, int64_t npkt, float* d
         return fail(c, CSI_ERR_INVALID_ARG, "csi_estimate_c128: bad argument");
     if (npkt == 0) return CSI_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    rc = hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, ls_c64);
+    rc = hp_estimate_c128(c, ltf_c128, false, npkt, dnn_c64, ls_c64);
     if (rc || !dnn_c64) return rc;
     // range guard of the split-f16 engine, as in csi_predict: repeat the DNN on the fp32 MFMA kernels
-    return range_guard_retry(c, [&] { return hp_estimate_c128(c, ltf_c128, npkt, dnn_c64, nullptr); });
+    return range_guard_retry(c, [&] { return hp_estimate_c128(c, ltf_c128, false, npkt, dnn_c64, nullptr); });
+}
+
+int csi_estimate_c64(csi_ctx* c, const float* ltf_c64, int64_t npkt, float* dnn_c64, float* ls_c64) {
+    int rc = check_ready(c, dnn_c64 != nullptr);
+    if (rc) return rc;
+    if (npkt < 0 || (npkt > 0 && (!ltf_c64 || (!dnn_c64 && !ls_c64))))
+        return fail(c, CSI_ERR_INVALID_ARG, "csi_estimate_c64: bad argument");
+    if (npkt == 0) return CSI_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    rc = hp_estimate_c128(c, ltf_c64, true, npkt, dnn_c64, ls_c64);
+    if (rc || !dnn_c64) return rc;
+    return range_guard_retry(c, [&] { return hp_estimate_c128(c, ltf_c64, true, npkt, dnn_c64, nullptr); });
 }
 
 int csi_ls_estimate(csi_ctx* c, const float* ltf_re, const float* ltf_im, int64_t npkt, float* h_re, float* h_im) {

@@ -1,0 +1,204 @@
+// small_call.hip.h - the one-packet regime: a call of a handful of rx preambles (massiveMIMO_CSI_prediction_DNN.py:339-346 predicts
+// ONE packet per step: Nt*Nr = 128 rows) through BOTH component models in three launches.
+//
+// Such a call is bound by two things: streaming the weights once (2 x 47 MB at Nt = 32: ~12 us of HBM time) and kernel boundaries
+// (each ~5 us on this part).  The general kernels (gemm_f32.hip.h) spend six launches per component model on it - layer 0 as K slabs
+// + their sum, split-K GEMM + epilogue for the per-pair layer and again for the regressor - on two streams.  Here:
+//
+//   small_l0_gemv_kernel     layer 0 of both models (blockIdx.y): L0[m][n] = sum_k x[m][k] Wt[n][k] for m < 8 preambles.  A workgroup owns
+//                            4 output columns = 4 contiguous rows of the K-major weights and walks ALL of K: 16-byte loads, every lane its
+//                            own k positions, fully coalesced, ~40 loads in flight per lane; the 256 partial sums of a column are combined
+//                            in LDS in a fixed order.  No slabs, no second kernel, no atomics: the result is run-to-run identical.
+//                            It then writes its 4 columns of the per-pair layer's input for all M * nt pair rows.
+//   small_tile_gemm_kernel   every layer behind it, both models (blockIdx.z), on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32
+//                            accumulate: the arithmetic of gemm_f32.hip.h) in 16 x 16 output tiles - a one-packet layer of the shipped
+//                            model is 1024 of them, one per SIMD of the chip.  A workgroup of 16 waves owns RG row tiles of one column
+//                            tile and ALL of K: the waves of a row tile split K between them and add their partial tiles in LDS in k
+//                            order - nothing leaves the workgroup half-summed, no slabs, no second kernel.  Operands go
+//                            global -> registers directly (16 bytes per lane and operand feed four MFMA k-steps: lane (i, q) holds
+//                            k = 16 j + 4 q + e in step e for BOTH operands, so the k order inside a group of 16 is permuted the same
+//                            way on both sides), 8 groups in flight; bias, relu and the BatchNormalization affine (after the relu)
+//                            are fused behind the last MFMA.  The first per-pair layer's input rows
+//                            h1 = relu(L0[row / nt] + T[row % nt]) * s0 + t0 (DNN.py:211-219, shared layer 0) are written by the
+//                            layer-0 kernel itself - they are element-wise in the column a workgroup of that kernel owns.
+//
+// Two accumulators per wave (even / odd k groups, added at the end in a fixed order) cover the 40-cycle dependent latency of the
+// 32-cycle MFMA.  Reference lines: Dense + relu DNN.py:211-214, BatchNormalization DNN.py:215-219, regressor DNN.py:227.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_f32.hip.h"
+
+namespace csi {
+
+constexpr int SC_MAX_ROWS0 = 8;          // preambles (packet, rx) a small call may hold
+constexpr int SC_GEMV_COLS = 4;          // output columns per workgroup of the layer-0 kernel
+
+struct SmallL0Args {
+    const float* x[2];       // [M][lda] one plane of the preambles per component model
+    const float* Wt[2];      // [h1][ldw] K-major layer-0 weights (LTF columns)
+    const float* T[2];       // [nt][h1] pilot table incl. the layer-0 bias
+    const float* s0[2];      // [h1] BatchNormalization scale of layer 0 (1 without BN)
+    const float* t0[2];      // [h1] its shift (a zero vector when the shift lives in the next layer's bias)
+    float* h1out[2];         // [M * nt][h1]: the first per-pair layer's input rows relu(L0[m] + T[t]) * s0 + t0, row m * nt + t
+    int M, K, lda, ldw, h1, nt;
+};
+
+// grid (ceil(h1 / 4), 2), 256 threads
+template <int MR>
+__global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
+    __shared__ float red[4][64][MR * SC_GEMV_COLS + 1];
+    __shared__ float part[4][MR * SC_GEMV_COLS];
+    const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * SC_GEMV_COLS;
+    const float* __restrict__ x = a.x[z];
+    const float* __restrict__ W = a.Wt[z];
+    f32x4 acc[MR][SC_GEMV_COLS];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < SC_GEMV_COLS; ++c) acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight rows beyond h1 are clamped (their sums are never stored)
+    const float* wrow[SC_GEMV_COLS];
+#pragma unroll
+    for (int c = 0; c < SC_GEMV_COLS; ++c) wrow[c] = W + (size_t)min(n0 + c, a.h1 - 1) * a.ldw;
+    constexpr int UN = 4;                                       // k steps of 1024 whose loads are in flight together
+    for (int k0 = 4 * tid; k0 < a.K; k0 += 1024 * UN) {
+        f32x4 w[UN][SC_GEMV_COLS], xv[UN][MR];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + 1024 * u;
+            const bool ok = k < a.K;                              // K % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+            for (int c = 0; c < SC_GEMV_COLS; ++c) w[u][c] = ok ? *reinterpret_cast<const f32x4*>(wrow[c] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                xv[u][m] = (ok && m < a.M) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * a.lda + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int c = 0; c < SC_GEMV_COLS; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][c][e] = fmaf(xv[u][m][e], w[u][c][e], acc[m][c][e]);
+    }
+    // fixed-order combination: lane's four k phases, then the 64 lanes of a wave (one thread per value), then the 4 waves
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < SC_GEMV_COLS; ++c)
+            red[wave][lane][m * SC_GEMV_COLS + c] = (acc[m][c][0] + acc[m][c][1]) + (acc[m][c][2] + acc[m][c][3]);
+    __syncthreads();
+    if (tid < 4 * MR * SC_GEMV_COLS) {
+        const int w = tid / (MR * SC_GEMV_COLS), v = tid - w * (MR * SC_GEMV_COLS);
+        float s = 0.f;
+        for (int l = 0; l < 64; ++l) s += red[w][l][v];
+        part[w][v] = s;
+    }
+    __syncthreads();
+    // The layer-0 sum of a column is complete inside this workgroup, and the first per-pair layer's input is element-wise in the
+    // column: h1[(m, t)][n] = relu(L0[m][n] + T[t][n]) * s0[n] + t0[n] (DNN.py:211-219 on the shared layer 0).  So the workgroup writes
+    // its 4 columns of all M * nt pair rows itself - 16 bytes per row - and the per-pair layer reads a plain matrix: generated inside
+    // that layer's tiles instead, every one of its 64 column tiles fetched L0, T and both BatchNormalization vectors again (4 x the
+    // operand traffic through the vector memory path: 31 us per one-packet layer against 17 for this whole kernel).
+    __shared__ float l0s[MR][SC_GEMV_COLS];
+    if (tid < MR * SC_GEMV_COLS) l0s[tid / SC_GEMV_COLS][tid % SC_GEMV_COLS] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+    const int rows = a.M * a.nt;
+    if (n0 + SC_GEMV_COLS <= a.h1) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.s0[z] + n0), sh = *reinterpret_cast<const f32x4*>(a.t0[z] + n0);
+        for (int r = tid; r < rows; r += 256) {
+            const int m = r / a.nt, t = r - m * a.nt;
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(a.T[z] + (size_t)t * a.h1 + n0);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(l0s[m][e] + tv[e], 0.f), sc[e], sh[e]);
+            *reinterpret_cast<f32x4*>(a.h1out[z] + (size_t)r * a.h1 + n0) = v;
+        }
+    } else {                                    // (h1 % 4 == 0 by csi_create: kept for safety)
+        for (int r = tid; r < rows; r += 256) {
+            const int m = r / a.nt, t = r - m * a.nt;
+            for (int e = 0; e < SC_GEMV_COLS && n0 + e < a.h1; ++e)
+                a.h1out[z][(size_t)r * a.h1 + n0 + e] = fmaf(fmaxf(l0s[m][e] + a.T[z][(size_t)t * a.h1 + n0 + e], 0.f), a.s0[z][n0 + e], a.t0[z][n0 + e]);
+        }
+    }
+}
+
+struct SmallGemmArgs {
+    const float* A[2];       // [M][lda] (the first per-pair layer reads the rows small_l0_gemv_kernel wrote)
+    const float* Bt[2];      // [N][ldb] K-major weights, zero padded in K to a multiple of 32
+    const float* bias[2];    // [N]
+    const float* scale[2];   // [N] EPI_BIAS_RELU_AFFINE
+    const float* shift[2];   // [N]
+    float* C[2];             // [M][ldc]
+    int M, N, K, lda, ldb, ldc;
+};
+
+// grid (ceil(N / 16), ceil(M / (16 RG)), 2), 1024 threads = 16 waves: wave w -> row group w % RG (16 rows), k part w / RG of KS = 16 / RG.
+// Every wave walks its part of K with its loads for several groups of 16 k in flight; four waves share a SIMD, so one wave's MFMAs run
+// under the others' load latency (a single wave per tile over the whole K measured 32 us per one-packet layer: each batch of loads was a
+// full L2 / HBM round trip with nothing beside it).  The KS partial tiles of a row group meet in LDS and are added in k order by the
+// wave that holds part 0 - inside the workgroup, in a fixed order, no global slabs.  RG is chosen by the host so that a layer is
+// ~256 workgroups: 4 for the 64 column tiles of the shipped per-pair layer, 1 for the regressor's 15.
+template <int EPI, int RG>
+__global__ __launch_bounds__(1024) void small_tile_gemm_kernel(SmallGemmArgs g) {
+    constexpr int KS = 16 / RG;
+    __shared__ f32x4 part[16][64];
+    const int z = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = wave % RG, kq = wave / RG;
+    const int i = lane & 15, q = lane >> 4;
+    const int row0 = ((int)blockIdx.y * RG + rg) * 16;
+    const int m = min(row0 + i, g.M - 1);                                        // this lane's A row (clamped; clamped rows are never stored)
+    const int n = min((int)blockIdx.x * 16 + i, g.N - 1);                        // this lane's B column
+    const float* __restrict__ bp = g.Bt[z] + (size_t)n * g.ldb + 4 * q;
+    const float* __restrict__ ap = g.A[z] + (size_t)m * g.lda + 4 * q;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;                       // groups of 16 k in flight per wave (<= 128 registers: four waves per SIMD)
+    const int ngroups = (g.K + 15) >> 4;        // the K tail multiplies zero-padded weight columns; A-side buffers carry zeroed slack
+    const int per = (ngroups + KS - 1) / KS;
+    const int jb = kq * per, je = min(ngroups, jb + per);
+    if (row0 < g.M) {                           // (a wave without rows still meets the barrier below)
+        for (int j0 = jb; j0 < je; j0 += UN) {
+            f32x4 a[UN], b[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int j = min(j0 + u, je - 1);                 // (a repeated last group is masked below)
+                b[u] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
+                a[u] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (j0 + u < je) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc0, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    part[wave][lane] = acc0 + acc1;
+    __syncthreads();
+    if (kq != 0 || row0 >= g.M) return;
+    f32x4 sum = part[rg][lane];
+#pragma unroll
+    for (int k = 1; k < KS; ++k) sum += part[k * RG + rg][lane];                  // k order: fixed
+    // C/D layout: column = lane & 15, row = 4 (lane >> 4) + r
+    const int col = (int)blockIdx.x * 16 + i;
+    if (col >= g.N) return;
+    const float bias = g.bias[z][col];
+    float sc = 1.f, sh = 0.f;
+    if constexpr (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[z][col]; sh = g.shift[z][col]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * q + r;
+        if (row >= g.M) continue;
+        float v = sum[r] + bias;
+        if constexpr (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v, 0.f), sc, sh);
+        g.C[z][(size_t)row * g.ldc + col] = v;
+    }
+}
+
+}  // namespace csi

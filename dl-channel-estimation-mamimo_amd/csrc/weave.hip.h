@@ -18,4 +18,15 @@ __global__ __launch_bounds__(256) void weave_c64_kernel(const float* __restrict_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = make_float2(re[i], im[i]);
 }
 
+// The other direction, for csi_estimate_c64: a complex64 batch as the caller holds it - interleaved (re, im) floats - into the two float32
+// planes every kernel of the path reads (X.real / X.imag, inference.py:29-30).  One 8-byte load per lane, 4-byte stores to each plane.
+__global__ __launch_bounds__(256) void split_c64_kernel(const float2* __restrict__ in, float* __restrict__ re, float* __restrict__ im, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float2 v = in[i];
+        re[i] = v.x;
+        im[i] = v.y;
+    }
+}
+
 }  // namespace csi

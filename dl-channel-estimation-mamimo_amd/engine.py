@@ -423,8 +423,11 @@ class CsiEngine:
         staging copies (csi_estimate_c128).  Returns (dnn, ls); an estimator that was not asked for is None.
         ``out=(dnn_buf, ls_buf)`` reuses complex64 arrays; arrays from ``pinned_empty(shape, np.complex64)`` receive the
         downloads directly (complex values assembled on the device, no host pass on the result side; same bits).
-        ``pinned_results=True`` takes the result arrays from ``self.result_pool``: fresh arrays over recycled pinned buffers."""
-        ltf = np.ascontiguousarray(ltf, dtype=np.complex128)
+        ``pinned_results=True`` takes the result arrays from ``self.result_pool``: fresh arrays over recycled pinned buffers.
+        A complex64 ``ltf`` is NOT widened: it goes through csi_estimate_c64 (uploaded as it is - straight from the array when it
+        came from ``pinned_empty(shape, np.complex64)`` - and split on the device); same bits as the complex128 call on such values."""
+        c64_in = isinstance(ltf, np.ndarray) and ltf.dtype == np.complex64
+        ltf = np.ascontiguousarray(ltf, dtype=np.complex64 if c64_in else np.complex128)
         if ltf.ndim != 3 or ltf.shape[1:] != (self.nr, self.len_ltf):
             raise CsiError(-1, f'preambles must be [npkt,{self.nr},{self.len_ltf}], got {ltf.shape}')
         npkt = ltf.shape[0]
@@ -441,7 +444,7 @@ class CsiEngine:
             bufs.append(given)
         if bufs[0] is None and bufs[1] is None:
             raise CsiError(-1, 'estimate: nothing asked for')
-        self._check(self._lib.csi_estimate_c128(self._ctx, ltf.ctypes.data, npkt,
+        self._check((self._lib.csi_estimate_c64 if c64_in else self._lib.csi_estimate_c128)(self._ctx, ltf.ctypes.data, npkt,
                                                 bufs[0].ctypes.data if bufs[0] is not None else None,
                                                 bufs[1].ctypes.data if bufs[1] is not None else None))
         return bufs[0], bufs[1]

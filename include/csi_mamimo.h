@@ -13,7 +13,7 @@
  *   Model.predict(generator) over packets, batch = nTX*nRX
  *        DNN.py:339-346 + sample assembly dataGenerator.py:299-316  csi_predict[_device]
  *   CSIPredictor.inference: X.real / X.imag -> predict x2 ->
- *        real + 1j*imag on complex128 batches    inference.py:24-32  csi_estimate_c128
+ *        real + 1j*imag on complex128 batches    inference.py:24-32  csi_estimate_c128 (complex64 batches: csi_estimate_c64)
  *   Model.predict(x, batch_size=bs)              inference.py:29-30
  *        / DNN.py:434,470  (arbitrary rows [B, lenLTF+Nt])          csi_predict_samples
  *   ofdmdemod + helperMIMOChannelEstimate
@@ -153,6 +153,14 @@ int  csi_estimate_device(csi_ctx* ctx, const float* d_ltf_re, const float* d_ltf
  * "hp_direct_out_calls"); same bits either way. */
 int  csi_estimate_c128(csi_ctx* ctx, const double* ltf_c128, int64_t npkt, float* dnn_c64, float* ls_c64);
 
+/* The same call for a batch the caller already holds as complex64 (an addition: inference.py:39-43 insists on complex128, and
+ * CSIPredictor.inference keeps that contract; a pipeline that produces its preambles in single precision need not widen them
+ * first).  ltf_c64 [npkt][nr][len_ltf] as interleaved (re, im) floats; results as csi_estimate_c128.  Half the bytes to read on
+ * the host and no conversion pass there: the interleaved chunk is uploaded as it is - straight from the caller's array when
+ * that is pinned host memory (csi_host_malloc) - and split into the two float32 planes on the device (csrc/weave.hip.h).
+ * Bit-identical with csi_estimate_c128 on a batch whose values are representable in single precision. */
+int  csi_estimate_c64(csi_ctx* ctx, const float* ltf_c64, int64_t npkt, float* dnn_c64, float* ls_c64);
+
 /* LMMSE smoothing of an LS estimate (the 'hDmmse' output of helperMIMOChannelEstimate.m:37-39,
  * LMMSE_ce.m:23-39 with Nfft = Np = 234, Nps = 1).  h_re / h_im: LS estimate [npkt][nr][nt][234];
  * hvec [npkt][L]: the vector the reference passes as LMMSE_ce's 'h' (generate_maMIMO_LTF.m:342
@@ -235,6 +243,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 15, max 64)
  *   "small_call_overlap" 1 (default): calls of at most 64 rx preambles run the real and the imag model on
  *                         two streams side by side (they are launch-latency bound); 0: one after the other
+ *   "small_fused"      1 (default): a call of at most 8 rx preambles (and at most 1024 pair rows) - the reference's literal
+ *                         one-packet predict, DNN.py:339-346 - runs BOTH component models in 1 + n_hidden launches: layer 0 as one
+ *                         weight-streaming kernel, every layer behind it as 16 x 16 fp32-MFMA tiles over the whole K, no split-K slabs
+ *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it)
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
  *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,

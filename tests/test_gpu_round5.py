@@ -1,0 +1,144 @@
+"""GPU tests added in round 5 (-m gpu): every call goes through the C-ABI of libcsi_mamimo.so and is checked against the numpy oracle on
+identical seeded inputs at the 1e-5 norm-relative contract (BASELINE.json north_star), nothing loosened per test.
+
+  * the one-packet regime (csrc/small_call.hip.h): both component models of a call of at most 8 rx preambles in 1 + n_hidden launches,
+  * the 500-packet call of full_pipeline_maMIMO_DNNEst.sh:44-48 (one `--test` run per SNR level),
+  * csi_estimate_c64 (complex64 batch in)."""
+import numpy as np
+import pytest
+
+from conftest import rel_rows
+from test_gpu_parity import _engine, _pilot, _weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+SMALL_CASES = [
+    # nt, nr, npkt, hidden, use_bn, n_out
+    (32, 4, 1, (1024, 1024), True, 234),     # DNN.py:339-346: one packet of the shipped model = 128 rows
+    (32, 4, 2, (1024, 1024), True, 234),     # 8 preambles: the largest call the path takes at Nr = 4
+    (8, 2, 1, (64, 64), True, 234),          # 16 pair rows: one row tile, three of its four waves without rows
+    (8, 2, 4, (64, 64), False, 234),         # --useBN off
+    (4, 1, 7, (32, 48, 40), True, 234),      # three hidden layers (ping-pong buffers), K = 1280: the k loop's tail
+    (8, 2, 3, (100, 36), True, 234),         # widths that are not multiples of 16: K tail of the tiles over zero-padded weights
+    (8, 2, 2, (64,), True, 52),              # single hidden layer: the per-pair layer IS the regressor; 52 outputs (inference.py:58)
+    (12, 2, 3, (40, 24), True, 234),         # Nt not a power of two: pair rows straddle (packet, rx) boundaries inside a tile
+    (64, 2, 1, (96, 64), True, 234),         # Nt = 64
+    (128, 1, 1, (64, 64), True, 234),        # Nt = 128: 128 pair rows from ONE preamble
+    (8, 2, 3, (512, 320), True, 234),        # ("small_fused" = 0 leg: the split-K latency path of every general kernel, K >= 256)
+    (8, 2, 1, (256,), False, 234),           # one packet, single hidden layer, no BN (general kernels: split-K regressor)
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden,use_bn,n_out', SMALL_CASES)
+def test_small_call_path_matches_oracle_and_general_kernels(pkg, oracle, nt, nr, npkt, hidden, use_bn, n_out):
+    """small_l0_gemv_kernel + small_tile_gemm_kernel (PAIR / plain, both epilogues) against the fp64 oracle on the same packets, against
+    the general kernels ("small_fused" = 0) to rounding, and run-to-run bit-identical (no atomics, fixed summation order)."""
+    rng = np.random.default_rng(5000 + nt * 10 + npkt)
+    w_re, w_im = _weights(oracle, 4321 + nt, nt, hidden, use_bn, n_out)
+    P = _pilot(rng, nt, orthogonal=False)
+    ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn, n_out)
+    assert e.get_option('small_fused') == 1
+    n0 = e.get_option('small_calls')
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('small_calls') == n0 + 1, 'a call of %d preambles must take the one-packet path' % (npkt * nr)
+    assert o_re.shape == (npkt, nr, nt, n_out) and o_re.dtype == np.float32
+    r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+    assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL
+    p_re, p_im = e.predict(ltf)
+    assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im), 'run-to-run identical'
+    e.set_option('small_fused', 0)
+    g_re, g_im = e.predict(ltf)
+    assert e.get_option('small_calls') == n0 + 2
+    assert rel_rows(g_re, r_re) < TOL and rel_rows(g_im, r_im) < TOL
+    assert rel_rows(o_re, g_re) < 5e-6 and rel_rows(o_im, g_im) < 5e-6
+
+
+def test_small_call_limits_and_the_literal_predict(pkg, oracle):
+    """9 preambles (or more than 1024 pair rows) take the general kernels; the small path equals the literal un-shared network
+    (csi_predict_samples: Keras Model.predict semantics, DNN.py:346) on the same packet; device-resident calls and a replayed hipGraph of
+    the one-packet call give the same bits as the host call."""
+    nt, nr, hidden = 32, 4, (256, 128)
+    rng = np.random.default_rng(77)
+    w_re, w_im = _weights(oracle, 99, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, 3, nr, P, snr_db=0.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    n0 = e.get_option('small_calls')
+    e.predict(ltf[:3])                                        # 12 preambles
+    assert e.get_option('small_calls') == n0
+    o_re, o_im = e.predict(ltf[:1])
+    assert e.get_option('small_calls') == n0 + 1
+    # literal network on the assembled samples [LTF ; P_t] of packet 0 (gen.py:299-316 order)
+    y_re = e.predict_samples('real', oracle.samples_from_packets(ltf[:1], P, 'real').astype(np.float32))
+    y_im = e.predict_samples('imag', oracle.samples_from_packets(ltf[:1], P, 'imag').astype(np.float32))
+    assert rel_rows(o_re.reshape(-1, 234), y_re) < 5e-6 and rel_rows(o_im.reshape(-1, 234), y_im) < 5e-6
+    # device-resident + graph replay
+    d_re, d_im = e.to_device(np.ascontiguousarray(ltf[:1].real)), e.to_device(np.ascontiguousarray(ltf[:1].imag))
+    q_re, q_im = e.empty((1, nr, nt, 234)), e.empty((1, nr, nt, 234))
+    e.set_option('use_graph', 1)
+    g0 = e.get_option('graph_replays')
+    for _ in range(4):
+        e.predict_device(d_re, d_im, 1, q_re, q_im)
+        e.synchronize()
+        assert np.array_equal(q_re.download(), o_re) and np.array_equal(q_im.download(), o_im)
+    assert e.get_option('graph_replays') >= g0 + 2
+    e.set_option('use_graph', 0)
+
+
+def test_500_packet_call_of_the_pipeline(pkg, oracle):
+    """full_pipeline_maMIMO_DNNEst.sh:44-48 hands `--test` the 500 packets of ONE SNR level: that call (64 000 pair rows, the split-f16
+    engine + band kernel) against the fp64 oracle on packets spread over the batch, at the lowest and the highest SNR of setenv.sh."""
+    nt, nr, hidden, npkt = 32, 4, (1024, 1024), 500
+    w_re, w_im = _weights(oracle, 1234, nt, hidden)
+    P = oracle.hadamard(nt)
+    for snr in (-25.0, 10.0):
+        rng = np.random.default_rng(int(2000 + snr))
+        ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=snr)[0].astype(np.complex64)
+        e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+        o_re, o_im = e.predict(ltf)
+        assert e.get_option('hs_launches') > 0 and e.get_option('hs_range_fallbacks') == 0 and e.get_option('band_launches') > 0
+        sel = [0, 123, 250, 377, 499]
+        r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+        assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL
+        h = e.ls_estimate(ltf)
+        r_ls = oracle.ls_estimate(ltf[sel], P)
+        assert rel_rows(np.concatenate([h[sel].real, h[sel].imag], -1), np.concatenate([r_ls.real, r_ls.imag], -1)) < TOL
+        e.close()
+
+
+def test_estimate_c64_is_bit_identical_with_the_c128_call(pkg, oracle):
+    """csi_estimate_c64 (round-4 verdict, next 7): a complex64 batch uploaded as it is and split on the device.  On values that single
+    precision represents it must return the bits of csi_estimate_c128 - pageable and pinned input, pageable and pinned result arrays,
+    either estimator alone, several pipeline slot sizes (short first / last chunks) - and both agree with the fp64 oracle."""
+    nt, nr, hidden, npkt = 8, 2, (64, 64), 150
+    rng = np.random.default_rng(64)
+    w_re, w_im = _weights(oracle, 640, nt, hidden)
+    P = oracle.hadamard(nt)
+    x64 = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=3.0)[0].astype(np.complex64)
+    x128 = x64.astype(np.complex128)                                   # the same values, widened
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    r_re, r_im = oracle.predict_packets(x64[:3], P, w_re, w_im, np.float64, pkt_batch=3)
+    xp = e.pinned_empty(x64.shape, np.complex64)
+    xp[...] = x64
+    for chunk in (0, 7, 64, 149):
+        e.set_option('hp_chunk_packets', chunk)
+        # the complex128 call on the same schedule (a chunk's size picks its kernels - split-K factors, the one-packet path - so the bits
+        # of two schedules differ by rounding; the two ENTRY POINTS on one schedule must not differ at all)
+        ref_dnn, ref_ls = e.estimate(x128)
+        assert rel_rows(ref_dnn[:3].real, r_re) < TOL and rel_rows(ref_dnn[:3].imag, r_im) < TOL
+        for src in (x64, xp):
+            dnn, ls = e.estimate(src)
+            assert dnn.dtype == np.complex64 and np.array_equal(dnn, ref_dnn) and np.array_equal(ls, ref_ls), (chunk, src is xp)
+            dnn, ls = e.estimate(src, pinned_results=True)
+            assert np.array_equal(dnn, ref_dnn) and np.array_equal(ls, ref_ls), (chunk, src is xp, 'pinned results')
+            only, none = e.estimate(src, ls=False)
+            assert none is None and np.array_equal(only, ref_dnn)
+            none, only = e.estimate(src, dnn=False)
+            assert none is None and np.array_equal(only, ref_ls)
+    e.set_option('hp_chunk_packets', 0)
+    with pytest.raises(pkg.CsiError):
+        e.estimate(x64[:, :1])                                          # wrong shape
+    # the reference's wrapper keeps its complex128 contract (inference.py:39-43)
+    assert e.estimate(x128[:2])[0].dtype == np.complex64

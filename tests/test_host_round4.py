@@ -451,6 +451,20 @@ try:
     raise SystemExit('a wrong shape was accepted')
 except pkg.CsiError:
     pass
+# round 5: a complex64 batch is not widened - csi_estimate_c64 (pageable: staged by a plain copy; pinned: DMA'd as it is)
+x64 = x.astype(np.complex64)
+e.set_option('hp_device_weave', 1)
+n_direct = e.get_option('hp_direct_out_calls')
+a64, b64 = e.estimate(x64)
+assert a64.shape == a.shape and a64.dtype == np.complex64 and b64.shape == b.shape
+xp = e.pinned_empty(x64.shape, np.complex64); xp[...] = x64
+c64, _ = e.estimate(xp, ls=False, pinned_results=True)
+assert c64.shape == a.shape and e.get_option('hp_direct_out_calls') == n_direct + 1
+try:
+    e.estimate(x64[:, :1])
+    raise SystemExit('a wrong complex64 shape was accepted')
+except pkg.CsiError:
+    pass
 arr = e.to_device(np.arange(6, dtype=np.float32))
 e.close()
 assert arr.ptr == 0 and e.result_pool.idle_bytes == 0
