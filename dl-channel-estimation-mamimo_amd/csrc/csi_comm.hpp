@@ -90,6 +90,7 @@ struct WireMeta {
     // the sender's csi_config, as far as it shapes the buffers: a receiver built for anything else refuses the record
     int32_t cfg_nt, cfg_len_ltf, cfg_n_out, cfg_dtype, cfg_use_bn, cfg_hidden[CSI_MAX_HIDDEN];
     int32_t loaded[2], has_W0p[2], has_W0rm[2], hs_repr_ok[2];
+    double hs_repr_err[2];                             // the sender's load-time measurement behind hs_repr_ok ("hs_weight_err_e12" reads the same on every rank)
     int32_t pilot_ok, p_sylvester, p_pieces;
     int32_t p_fast_ok, p_perm[2][CSI_WIRE_MAX_NT];     // Hadamard-equivalent pilot: output row / symbol permutation with signs (csi_set_pilot)
     WireLayer layer[2][CSI_MAX_HIDDEN + 1];
@@ -148,6 +149,7 @@ void wire_fill(const csi_ctx* c, WireMeta& w) {
         w.loaded[d] = m.loaded && (int)m.layers.size() == cf.n_hidden + 1;
         if (!w.loaded[d]) continue;
         w.hs_repr_ok[d] = m.hs_repr_ok;
+        w.hs_repr_err[d] = m.hs_repr_err;
         w.has_W0p[d] = m.W0p != nullptr;
         w.has_W0rm[d] = m.W0rm != nullptr;
         for (int i = 0; i <= cf.n_hidden; ++i) {
@@ -250,6 +252,8 @@ int wire_finish(csi_ctx* c, const WireMeta& w) {
         Model& m = c->model[d];
         m.loaded = w.loaded[d] != 0;
         m.hs_repr_ok = !m.loaded || w.hs_repr_ok[d] != 0;
+        m.hs_repr_err = m.loaded ? w.hs_repr_err[d] : 0.0;
+        if (m.loaded && !m.hs_repr_ok) ++c->hs_weight_pins;      // a receiver counts a pinned model like the context that loaded it
         m.table_ok = false;
         if (m.loaded && c->pilot_ok) {
             int rc = build_pilot_table(c, m);

@@ -274,9 +274,13 @@ int band_skeleton_time(csi_ctx* c, int64_t rows, int iters, double* ms_per_launc
     size_t sz = sizeof(a8);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     const unsigned grid = (unsigned)((M2 + BAND_ROWS - 1) / BAND_ROWS);
-    hipEvent_t e0, e1;
-    HIP_TRY(c, hipEventCreate(&e0));
-    HIP_TRY(c, hipEventCreate(&e1));
+    struct Events {                                    // destroyed on every return path (an early HIP_TRY return leaked them)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    } ev;
+    HIP_TRY(c, hipEventCreate(&ev.a));
+    HIP_TRY(c, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     for (int i = 0; i < 2; ++i) HIP_TRY(c, hipModuleLaunchKernel(sk, grid, 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) HIP_TRY(c, hipModuleLaunchKernel(sk, grid, 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
@@ -284,8 +288,6 @@ int band_skeleton_time(csi_ctx* c, int64_t rows, int iters, double* ms_per_launc
     HIP_TRY(c, hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     if (ms_per_launch) *ms_per_launch = (double)ms / iters;
     // executed f16 flop: 3 products, the padded 256-column regressor tile included (what the pipe really does)
     if (executed_flops) *executed_flops = 3.0 * (2.0 * (double)grid * BAND_ROWS * l1.out * h1 + 2.0 * (double)grid * BAND_ROWS * 256.0 * l1.out);

@@ -71,22 +71,42 @@ int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int6
         g.M = M2; g.N = l.out; g.K = l.in; g.ldb = l.ldw;
         g.lda = li == 1 ? h1 : l.in;
         g.ldc = last ? cf.n_out : l.out;
-        // row tiles per workgroup: as few as still leave ~256 workgroups (the k split inside the workgroup grows as RG shrinks)
-        const int tiles_n = (g.N + 15) / 16, tiles_m = (M2 + 15) / 16;
+        bool force16 = false;                     // A/B runs: CSI_DEBUG_HOOKS=1 CSI_SMALL_TILE16=1 keeps every layer on the 16 x 16 tiles
+        if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_SMALL_TILE16")) force16 = d[0] == '1';
+        ProfScope ps(c, last ? K_REGRESSOR : (li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN), 2.0 * 2.0 * (double)M2 * g.N * g.K,
+                     2.0 * 4.0 * ((double)g.N * g.K + (double)M2 * g.N + (double)M2 * g.K));
+        // 32 x 32 tiles (half the operand traffic per flop) where they still make ~256 workgroups, 16 x 16 tiles where the layer is
+        // too narrow for that (the regressor's 234 columns); row tiles per workgroup: as few as leave that many workgroups - the k
+        // split inside the workgroup grows as RG shrinks
+        const int tn32 = (g.N + 31) / 32, tm32 = (M2 + 31) / 32;
+        const bool t32 = (long)tn32 * tm32 * 2 >= 200 && !force16;
+        const int tsz = t32 ? 32 : 16;
+        const int tiles_n = (g.N + tsz - 1) / tsz, tiles_m = (M2 + tsz - 1) / tsz;
         int rg = 4;
         while (rg > 1 && (long)tiles_n * ((tiles_m + rg - 1) / rg) * 2 < 200) rg >>= 1;
         const dim3 grid((unsigned)tiles_n, (unsigned)((tiles_m + rg - 1) / rg), 2);
-        ProfScope ps(c, last ? K_REGRESSOR : (li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN), 2.0 * 2.0 * (double)M2 * g.N * g.K,
-                     2.0 * 4.0 * ((double)g.N * g.K + (double)M2 * g.N + (double)M2 * g.K));
-#define SC_LAUNCH(EPIV)                                                                                                             \
-    do {                                                                                                                             \
-        if (rg == 4) hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 4>), grid, dim3(1024), 0, c->stream, g);                       \
-        else if (rg == 2) hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 2>), grid, dim3(1024), 0, c->stream, g);                  \
-        else hipLaunchKernelGGL((small_tile_gemm_kernel<EPIV, 1>), grid, dim3(1024), 0, c->stream, g);                               \
+        // groups of 32 k a wave owns -> groups whose loads it requests at once
+        const int per_wave = (((g.K + 31) >> 5) + (16 / rg) - 1) / (16 / rg);
+        const int ub = t32 ? (per_wave >= 2 ? 2 : 1) : (per_wave >= 4 ? 4 : (per_wave >= 2 ? 2 : 1));
+#define SC_K(KERNEL, EPIV, RGV, UBV) hipLaunchKernelGGL((KERNEL<EPIV, RGV, UBV>), grid, dim3(1024), 0, c->stream, g)
+#define SC_LAUNCH3(EPIV, RGV)                                                                        \
+    do {                                                                                             \
+        if (t32) { if (ub == 2) SC_K(small_tile32_gemm_kernel, EPIV, RGV, 2); else SC_K(small_tile32_gemm_kernel, EPIV, RGV, 1); }        \
+        else if (ub == 4) SC_K(small_tile_gemm_kernel, EPIV, RGV, 4);                                \
+        else if (ub == 2) SC_K(small_tile_gemm_kernel, EPIV, RGV, 2);                                \
+        else SC_K(small_tile_gemm_kernel, EPIV, RGV, 1);                                             \
+    } while (0)
+#define SC_LAUNCH(EPIV)                                                                              \
+    do {                                                                                             \
+        if (rg == 4) SC_LAUNCH3(EPIV, 4);                                                            \
+        else if (rg == 2) SC_LAUNCH3(EPIV, 2);                                                       \
+        else SC_LAUNCH3(EPIV, 1);                                                                    \
     } while (0)
         if (last) SC_LAUNCH(EPI_BIAS);
         else SC_LAUNCH(EPI_BIAS_RELU_AFFINE);
 #undef SC_LAUNCH
+#undef SC_LAUNCH3
+#undef SC_K
         HIP_TRY(c, hipGetLastError());
         cur ^= 1;
     }

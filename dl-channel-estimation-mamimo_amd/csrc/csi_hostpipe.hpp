@@ -459,7 +459,10 @@ struct HpSide {
     hipError_t err = hipSuccess;
 
     // stager: needs_release_of(i) = i - 2 (the upload that frees its slot); drainer: = i (its own download)
-    void start(int device, int64_t nchunks, int lag, hipEvent_t* ev, std::atomic<int64_t>* busy_us, const std::function<void(int64_t, int)>& work) {
+    // false: no thread to be had (pids limit, EAGAIN) - the caller falls back to the inline arrangement for this call (ADVICE round 4:
+    // the std::system_error used to leave through the extern "C" entry point and end in std::terminate)
+    bool start(int device, int64_t nchunks, int lag, hipEvent_t* ev, std::atomic<int64_t>* busy_us, const std::function<void(int64_t, int)>& work) {
+      try {
         th = std::thread([this, device, nchunks, lag, ev, busy_us, work] {
             (void)hipSetDevice(device);
             for (int64_t i = 0; i < nchunks; ++i) {
@@ -489,6 +492,10 @@ struct HpSide {
                 cv.notify_all();
             }
         });
+      } catch (const std::system_error&) {
+        return false;
+      }
+      return true;
     }
     bool wait_done(int64_t n) {               // until chunks 0 .. n - 1 are through this side
         std::unique_lock<std::mutex> lk(mu);
@@ -528,9 +535,12 @@ int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
     h->clock_reset();
     const int64_t t_begin = csi_hostpipe::now_us();
     HpSide stager, drainer;                            // their destructors stop and join them on every return path
-    const bool threads = c->hp_side_threads != 0;      // 0: stage / weave inline on the calling thread, in turn (the round-3 arrangement; A/B)
-    if (threads && p.stage) stager.start(dev, p.nchunks, 2, h->ev_in, &h->us_stage, p.stage);
-    if (threads && p.weave) drainer.start(dev, p.nchunks, 0, h->ev_out, &h->us_weave_thread, p.weave);
+    bool threads = c->hp_side_threads != 0;            // 0: stage / weave inline on the calling thread, in turn (the round-3 arrangement; A/B)
+    if (threads && p.stage && !stager.start(dev, p.nchunks, 2, h->ev_in, &h->us_stage, p.stage)) threads = false;
+    if (threads && p.weave && !drainer.start(dev, p.nchunks, 0, h->ev_out, &h->us_weave_thread, p.weave)) {
+        stager.cancel();                               // (it has not been released a chunk yet: it stops at its first wait, or after chunks 0 / 1, which the inline path stages again)
+        threads = false;
+    }
     auto inline_stage = [&](int64_t i, int s) -> int {
         if (i >= 2) HIP_TRY(c, hipEventSynchronize(h->ev_in[s]));
         const int64_t t0 = csi_hostpipe::now_us();

@@ -15,14 +15,14 @@
 //                            model is 1024 of them, one per SIMD of the chip.  A workgroup of 16 waves owns RG row tiles of one column
 //                            tile and ALL of K: the waves of a row tile split K between them and add their partial tiles in LDS in k
 //                            order - nothing leaves the workgroup half-summed, no slabs, no second kernel.  Operands go
-//                            global -> registers directly (16 bytes per lane and operand feed four MFMA k-steps: lane (i, q) holds
-//                            k = 16 j + 4 q + e in step e for BOTH operands, so the k order inside a group of 16 is permuted the same
-//                            way on both sides), 8 groups in flight; bias, relu and the BatchNormalization affine (after the relu)
-//                            are fused behind the last MFMA.  The first per-pair layer's input rows
+//                            global -> registers directly (32 bytes per lane and operand feed eight MFMA k-steps: lane (i, q) holds
+//                            k = 32 j + 8 q + e in step e for BOTH operands, so the k order inside a group of 32 is permuted the same
+//                            way on both sides), a batch of groups in flight; bias, relu and the BatchNormalization affine (after the
+//                            relu) are fused behind the last MFMA.  The first per-pair layer's input rows
 //                            h1 = relu(L0[row / nt] + T[row % nt]) * s0 + t0 (DNN.py:211-219, shared layer 0) are written by the
 //                            layer-0 kernel itself - they are element-wise in the column a workgroup of that kernel owns.
 //
-// Two accumulators per wave (even / odd k groups, added at the end in a fixed order) cover the 40-cycle dependent latency of the
+// Two accumulators per wave (alternating k-steps, added at the end in a fixed order) cover the 40-cycle dependent latency of the
 // 32-cycle MFMA.  Reference lines: Dense + relu DNN.py:211-214, BatchNormalization DNN.py:215-219, regressor DNN.py:227.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -64,16 +64,22 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
     constexpr int UN = 4;                                       // k steps of 1024 whose loads are in flight together
     for (int k0 = 4 * tid; k0 < a.K; k0 += 1024 * UN) {
         f32x4 w[UN][SC_GEMV_COLS], xv[UN][MR];
+        float okfs[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+            // branch-free: a quad beyond K (K % 4 == 0: inside or outside as a whole) is fetched from k = 0 and multiplied by 0;
+            // rows beyond M repeat row M - 1 (their sums are never stored)
             const int k = k0 + 1024 * u;
-            const bool ok = k < a.K;                              // K % 4 == 0: a float4 is inside or outside as a whole
+            const bool ok = k < a.K;
+            const int kc = ok ? k : 0;
+            const float okf = ok ? 1.f : 0.f;
 #pragma unroll
-            for (int c = 0; c < SC_GEMV_COLS; ++c) w[u][c] = ok ? *reinterpret_cast<const f32x4*>(wrow[c] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < SC_GEMV_COLS; ++c) w[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + kc);      // (non-temporal loads measured 20.1 us against 17.0)
+            okfs[u] = okf;
 #pragma unroll
-            for (int m = 0; m < MR; ++m)
-                xv[u][m] = (ok && m < a.M) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * a.lda + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MR; ++m) xv[u][m] = *reinterpret_cast<const f32x4*>(x + (size_t)min(m, a.M - 1) * a.lda + kc);
         }
+        __builtin_amdgcn_sched_barrier(0);      // all UN * (4 + MR) loads are requested before the first fma (the scheduler otherwise sinks each to its use)
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
 #pragma unroll
                 for (int c = 0; c < SC_GEMV_COLS; ++c)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][c][e] = fmaf(xv[u][m][e], w[u][c][e], acc[m][c][e]);
+                    for (int e = 0; e < 4; ++e) acc[m][c][e] = fmaf(xv[u][m][e] * okfs[u], w[u][c][e], acc[m][c][e]);
     }
     // fixed-order combination: lane's four k phases, then the 64 lanes of a wave (one thread per value), then the 4 waves
 #pragma unroll
@@ -141,42 +147,68 @@ struct SmallGemmArgs {
 // full L2 / HBM round trip with nothing beside it).  The KS partial tiles of a row group meet in LDS and are added in k order by the
 // wave that holds part 0 - inside the workgroup, in a fixed order, no global slabs.  RG is chosen by the host so that a layer is
 // ~256 workgroups: 4 for the 64 column tiles of the shipped per-pair layer, 1 for the regressor's 15.
-template <int EPI, int RG>
+template <int EPI, int RG, int UB>
 __global__ __launch_bounds__(1024) void small_tile_gemm_kernel(SmallGemmArgs g) {
     constexpr int KS = 16 / RG;
     __shared__ f32x4 part[16][64];
-    const int z = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: scalar k offsets below)
     const int rg = wave % RG, kq = wave / RG;
     const int i = lane & 15, q = lane >> 4;
     const int row0 = ((int)blockIdx.y * RG + rg) * 16;
     const int m = min(row0 + i, g.M - 1);                                        // this lane's A row (clamped; clamped rows are never stored)
     const int n = min((int)blockIdx.x * 16 + i, g.N - 1);                        // this lane's B column
-    const float* __restrict__ bp = g.Bt[z] + (size_t)n * g.ldb + 4 * q;
-    const float* __restrict__ ap = g.A[z] + (size_t)m * g.lda + 4 * q;
+    // k layout: groups of 32 k; lane (i, q) owns the 8 consecutive k = 32 j + 8 q .. + 7 of its row / column (two 16-byte loads per operand
+    // and group) and supplies element e of them in MFMA step e - the same permutation on both operands, so every k meets its partner.
+    // The four q lanes of a row read 128 contiguous bytes: whole cache lines per request (with 16-k groups a request took 64 bytes of
+    // each of 16 lines and left the other halves to a later iteration, by when 16 waves' worth of requests had evicted them).
+    const float* __restrict__ bp = g.Bt[z] + (size_t)n * g.ldb + 8 * q;
+    const float* __restrict__ ap = g.A[z] + (size_t)m * g.lda + 8 * q;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;                       // groups of 16 k in flight per wave (<= 128 registers: four waves per SIMD)
-    const int ngroups = (g.K + 15) >> 4;        // the K tail multiplies zero-padded weight columns; A-side buffers carry zeroed slack
+    // A batch = UB groups: all of its 4 UB loads are requested before its first MFMA (no branch inside a batch), 8 UB MFMAs follow;
+    // four waves share a SIMD, so one wave's MFMAs run under the others' round trips.  The host picks UB = 4 / 2 / 1 from the groups a
+    // wave owns; the few groups behind the last whole batch go one at a time.
+    const int ngroups = (g.K + 31) >> 5;        // the K tail multiplies zero-padded weight columns (ldb % 32 == 0); A-side buffers carry zeroed slack
     const int per = (ngroups + KS - 1) / KS;
     const int jb = kq * per, je = min(ngroups, jb + per);
+    auto steps = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc0, 0, 0, 0);
+        }
+    };
     if (row0 < g.M) {                           // (a wave without rows still meets the barrier below)
-        for (int j0 = jb; j0 < je; j0 += UN) {
-            f32x4 a[UN], b[UN];
+        int j0 = jb;
+        for (; j0 + UB <= je; j0 += UB) {
+            const float* __restrict__ bq = bp + 32 * j0;
+            const float* __restrict__ aq = ap + 32 * j0;
+            f32x4 a[UB][2], b[UB][2];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int j = min(j0 + u, je - 1);                 // (a repeated last group is masked below)
-                b[u] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
-                a[u] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+            for (int u = 0; u < UB; ++u) {
+                b[u][0] = *reinterpret_cast<const f32x4*>(bq + 32 * u);
+                b[u][1] = *reinterpret_cast<const f32x4*>(bq + 32 * u + 4);
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                if (j0 + u < je) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc0, 0, 0, 0);
-                    }
-                }
+            for (int u = 0; u < UB; ++u) {
+                a[u][0] = *reinterpret_cast<const f32x4*>(aq + 32 * u);
+                a[u][1] = *reinterpret_cast<const f32x4*>(aq + 32 * u + 4);
             }
+            // nothing crosses: without it the scheduler sinks every load to just in front of its MFMAs (34 registers, two loads in
+            // flight, a vmcnt wait per four MFMAs) - the opposite of what a latency-bound wave needs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) steps(a[u][0], a[u][1], b[u][0], b[u][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; j0 < je; ++j0) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + 32 * j0), b1 = *reinterpret_cast<const f32x4*>(bp + 32 * j0 + 4);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + 32 * j0), a1 = *reinterpret_cast<const f32x4*>(ap + 32 * j0 + 4);
+            steps(a0, a1, b0, b1);
         }
     }
     part[wave][lane] = acc0 + acc1;
@@ -196,6 +228,86 @@ __global__ __launch_bounds__(1024) void small_tile_gemm_kernel(SmallGemmArgs g) 
         const int row = row0 + 4 * q + r;
         if (row >= g.M) continue;
         float v = sum[r] + bias;
+        if constexpr (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v, 0.f), sc, sh);
+        g.C[z][(size_t)row * g.ldc + col] = v;
+    }
+}
+
+// The same scheme on 32 x 32 output tiles (v_mfma_f32_32x32x2_f32): twice the flops per operand byte.  The 16 x 16 form of a one-packet
+// per-pair layer moves 512 KB per CU from the L2 (every activation row is fetched by all 64 column tiles, every weight row by both row
+// halves) and measures 17 us, of which 6 each are the A and the B loads and none the MFMAs (CSI_SMALL_DBG ablation) -
+// it is bound by the L2 -> CU path at ~13 TB/s for the chip.  Here: grid (ceil(N / 32), ceil(M / (32 RG)), 2), 1024 threads; wave w ->
+// row tile w % RG, k part w / RG of KS = 16 / RG; groups of 32 k, lane (i, q) owns k = 32 j + 16 q .. + 15 of its row / column (four
+// 16-byte loads per operand: the two q lanes of a row read 128 contiguous bytes) and supplies element e in MFMA step e of 16.  The KS
+// partial tiles meet in LDS (64 KB) and every wave of a row tile adds and finishes 16 / KS of its 16 accumulator registers, k order fixed.
+template <int EPI, int RG, int UB>
+__global__ __launch_bounds__(1024) void small_tile32_gemm_kernel(SmallGemmArgs g) {
+    constexpr int KS = 16 / RG;
+    __shared__ float part[16][16][64];
+    const int z = blockIdx.z, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave % RG, kq = wave / RG;
+    const int i = lane & 31, q = lane >> 5;
+    const int row0 = ((int)blockIdx.y * RG + rg) * 32;
+    const int m = min(row0 + i, g.M - 1);
+    const int n = min((int)blockIdx.x * 32 + i, g.N - 1);
+    const float* __restrict__ bp = g.Bt[z] + (size_t)n * g.ldb + 16 * q;
+    const float* __restrict__ ap = g.A[z] + (size_t)m * g.lda + 16 * q;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ngroups = (g.K + 31) >> 5;
+    const int per = (ngroups + KS - 1) / KS;
+    const int jb = kq * per, je = min(ngroups, jb + per);
+    auto steps = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v][e], b[v][e], acc, 0, 0, 0);
+    };
+    if (row0 < g.M) {
+        int j0 = jb;
+        for (; j0 + UB <= je; j0 += UB) {
+            f32x4 a[UB][4], b[UB][4];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) b[u][v] = *reinterpret_cast<const f32x4*>(bp + 32 * (j0 + u) + 4 * v);
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a[u][v] = *reinterpret_cast<const f32x4*>(ap + 32 * (j0 + u) + 4 * v);
+            __builtin_amdgcn_sched_barrier(0);          // every load of the batch is requested before its first MFMA (see the 16 x 16 form)
+#pragma unroll
+            for (int u = 0; u < UB; ++u) steps(a[u], b[u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; j0 < je; ++j0) {
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { b[v] = *reinterpret_cast<const f32x4*>(bp + 32 * j0 + 4 * v); a[v] = *reinterpret_cast<const f32x4*>(ap + 32 * j0 + 4 * v); }
+            steps(a, b);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (row0 >= g.M) return;
+    // C/D layout of the 32 x 32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  This wave finishes registers
+    // kq * RG .. + RG - 1 of its row tile.
+    const int col = (int)blockIdx.x * 32 + i;
+    if (col >= g.N) return;
+    const float bias = g.bias[z][col];
+    float sc = 1.f, sh = 0.f;
+    if constexpr (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[z][col]; sh = g.shift[z][col]; }
+#pragma unroll
+    for (int t = 0; t < RG; ++t) {
+        const int r = kq * RG + t;
+        float sum = part[rg][r][lane];
+#pragma unroll
+        for (int k = 1; k < KS; ++k) sum += part[k * RG + rg][r][lane];          // k order: fixed
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        if (row >= g.M) continue;
+        float v = sum + bias;
         if constexpr (EPI == EPI_BIAS_RELU_AFFINE) v = fmaf(fmaxf(v, 0.f), sc, sh);
         g.C[z][(size_t)row * g.ldc + col] = v;
     }

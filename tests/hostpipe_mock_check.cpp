@@ -56,8 +56,17 @@ int csi_ls_estimate_device(csi_ctx* c, const float* d_re, const float* d_im, int
 }
 }  // extern "C"
 
-// the one kernel the pipeline launches itself: weave_c64_kernel (result arrays in pinned memory) - args (re, im, out, n) - as a stream item
+// the kernels the pipeline launches itself, as stream items: weave_c64_kernel (result arrays in pinned memory) - args (re, im, out, n) -
+// and, round 5, split_c64_kernel (csi_estimate_c64: the interleaved chunk as uploaded -> the two planes) - args (in, re, im, n)
 static hipError_t weave_launch(const void* fn, void** args, hipStream_t st) {
+    if (fn == reinterpret_cast<const void*>(&csi::split_c64_kernel)) {
+        const float* in = reinterpret_cast<const float*>(*static_cast<const float2**>(args[0]));
+        float* re = *static_cast<float**>(args[1]);
+        float* im = *static_cast<float**>(args[2]);
+        const size_t n = *static_cast<size_t*>(args[3]);
+        mock::S(st)->push([=] { for (size_t i = 0; i < n; ++i) { re[i] = in[2 * i]; im[i] = in[2 * i + 1]; } });
+        return hipSuccess;
+    }
     if (fn != reinterpret_cast<const void*>(&csi::weave_c64_kernel)) return hipErrorInvalidDeviceFunction;
     const float* re = *static_cast<const float**>(args[0]);
     const float* im = *static_cast<const float**>(args[1]);
@@ -80,6 +89,8 @@ int main() {
     // what the call has to return, straight from the input
     std::vector<float> re(in_n * npkt), im(in_n * npkt), want_dnn(2 * dnn_n * npkt), want_ls(2 * ls_n * npkt);
     for (size_t i = 0; i < in_n * npkt; ++i) { re[i] = (float)x[2 * i]; im[i] = (float)x[2 * i + 1]; }
+    std::vector<float> x32(x.size());                     // the batch as complex64: the values the complex128 call converts to
+    for (size_t i = 0; i < x.size(); ++i) x32[i] = (float)x[i];
     for (int64_t p = 0; p < npkt; ++p)
         for (int r = 0; r < c->cfg.nr; ++r)
             for (int t = 0; t < c->cfg.nt; ++t) {
@@ -107,7 +118,7 @@ int main() {
                 for (int what = 0; what < 3; ++what) {                               // both estimators, DNN alone, LS alone
                     std::fill(dnn.begin(), dnn.end(), -7.f);
                     std::fill(ls.begin(), ls.end(), -7.f);
-                    const int rc = hp_estimate_c128(c, x.data(), npkt, what != 2 ? dnn.data() : nullptr, what != 1 ? ls.data() : nullptr);
+                    const int rc = hp_estimate_c128(c, x.data(), false, npkt, what != 2 ? dnn.data() : nullptr, what != 1 ? ls.data() : nullptr);
                     ++calls;
                     if (rc) { ++bad; std::printf("side %d threads %d chunk %d what %d: rc %d (%s)\n", side, threads, chunk, what, rc, c->err.c_str()); continue; }
                     if (what != 2 && std::memcmp(dnn.data(), want_dnn.data(), dnn.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: DNN result differs\n", side, threads, chunk, what); }
@@ -122,12 +133,30 @@ int main() {
                         std::fill(pd, pd + dnn.size(), -7.f);
                         std::fill(pl, pl + ls.size(), -7.f);
                         const int64_t before = c->hp_direct_out_calls;
-                        const int rc = hp_estimate_c128(c, x.data(), npkt, what != 2 ? pd : nullptr, what != 1 ? pl : nullptr);
+                        const int rc = hp_estimate_c128(c, x.data(), false, npkt, what != 2 ? pd : nullptr, what != 1 ? pl : nullptr);
                         ++calls;
                         if (rc || c->hp_direct_out_calls != before + 1) { ++bad; std::printf("side %d threads %d chunk %d what %d pinned: rc %d (%s), direct %lld\n", side, threads, chunk, what, rc, c->err.c_str(), (long long)(c->hp_direct_out_calls - before)); continue; }
                         if (what != 2 && std::memcmp(pd, want_dnn.data(), dnn.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: pinned DNN result differs\n", side, threads, chunk, what); }
                         if (what != 1 && std::memcmp(pl, want_ls.data(), ls.size() * 4)) { ++bad; std::printf("side %d threads %d chunk %d what %d: pinned LS result differs\n", side, threads, chunk, what); }
                     }
+                    // round 5, csi_estimate_c64: the same batch as complex64 - from pageable memory (staged by a plain copy) and from
+                    // "pinned" memory (uploaded from the caller's array itself), into pageable and into pinned result arrays
+                    float* px = nullptr;
+                    hipHostMalloc(reinterpret_cast<void**>(&px), x32.size() * 4, 0);
+                    std::memcpy(px, x32.data(), x32.size() * 4);
+                    for (int src = 0; src < 2; ++src)
+                        for (int what = 0; what < 3; ++what) {
+                            std::fill(pd, pd + dnn.size(), -7.f); std::fill(pl, pl + ls.size(), -7.f);
+                            std::fill(dnn.begin(), dnn.end(), -7.f); std::fill(ls.begin(), ls.end(), -7.f);
+                            const float* in64 = src ? px : x32.data();
+                            int rc = hp_estimate_c128(c, in64, true, npkt, what != 2 ? pd : nullptr, what != 1 ? pl : nullptr);
+                            if (!rc) rc = hp_estimate_c128(c, in64, true, npkt, what != 2 ? dnn.data() : nullptr, what != 1 ? ls.data() : nullptr);
+                            calls += 2;
+                            if (rc) { ++bad; std::printf("side %d threads %d chunk %d what %d c64 src %d: rc %d (%s)\n", side, threads, chunk, what, src, rc, c->err.c_str()); continue; }
+                            if (what != 2 && (std::memcmp(pd, want_dnn.data(), dnn.size() * 4) || std::memcmp(dnn.data(), want_dnn.data(), dnn.size() * 4))) { ++bad; std::printf("side %d threads %d chunk %d what %d c64 src %d: DNN result differs\n", side, threads, chunk, what, src); }
+                            if (what != 1 && (std::memcmp(pl, want_ls.data(), ls.size() * 4) || std::memcmp(ls.data(), want_ls.data(), ls.size() * 4))) { ++bad; std::printf("side %d threads %d chunk %d what %d c64 src %d: LS result differs\n", side, threads, chunk, what, src); }
+                        }
+                    hipHostFree(px);
                     hipHostFree(pd);
                     hipHostFree(pl);
                 }

@@ -25,6 +25,7 @@ SMALL_CASES = [
     (12, 2, 3, (40, 24), True, 234),         # Nt not a power of two: pair rows straddle (packet, rx) boundaries inside a tile
     (64, 2, 1, (96, 64), True, 234),         # Nt = 64
     (128, 1, 1, (64, 64), True, 234),        # Nt = 128: 128 pair rows from ONE preamble
+    (12, 2, 3, (72, 1100), True, 234),       # a wide per-pair layer on the 32 x 32 tiles: ragged rows (72) and columns (1100), K = 72 (3 groups for 16 k-parts); regressor K = 1100
     (8, 2, 3, (512, 320), True, 234),        # ("small_fused" = 0 leg: the split-K latency path of every general kernel, K >= 256)
     (8, 2, 1, (256,), False, 234),           # one packet, single hidden layer, no BN (general kernels: split-K regressor)
 ]
@@ -142,3 +143,49 @@ def test_estimate_c64_is_bit_identical_with_the_c128_call(pkg, oracle):
         e.estimate(x64[:, :1])                                          # wrong shape
     # the reference's wrapper keeps its complex128 contract (inference.py:39-43)
     assert e.estimate(x128[:2])[0].dtype == np.complex64
+
+
+def test_tensorflow_written_model_predicts_what_tensorflow_predicted(pkg):
+    """The GPU half of the f-1 landing test: once `tools/make_tf_fixture.py` has been run on a TensorFlow host and its
+    output committed under tests/golden/tf_written/, the HIP path loads TensorFlow's OWN checkpoint and SavedModel files and must reproduce
+    TensorFlow's OWN `Model.predict` on the recorded batch at the 1e-5 contract - the one place the Dense / BatchNormalization arithmetic
+    is pinned to the reference's framework instead of to the oracle's restatement of it.  Skips loudly until then."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'tf_written')
+    if not os.path.exists(os.path.join(d, 'expected.npz')):
+        pytest.skip('NO TensorFlow-written model files in tests/golden/tf_written/ (f-1 stays "partial"): run '
+                    '`python tools/make_tf_fixture.py tests/golden/tf_written` on a TensorFlow 2.x host and commit the output')
+    exp = np.load(os.path.join(d, 'expected.npz'))
+    x = np.concatenate([exp['x_sig'][:, :, 0], exp['x_p']], axis=1).astype(np.float32)       # [Flatten(seq_in), seq_p], DNN.py:207-208
+    nt = exp['x_p'].shape[1]
+    for comp in ('real', 'imag'):
+        for path in (os.path.join(d, comp + '_weights-improvement.hdf5'), os.path.join(d, comp + '_keras_model')):
+            w = pkg.load_weight_file(path)
+            hidden = tuple(int(w['fc_dense%d.bias' % i].shape[0]) for i in range(8) if 'fc_dense%d.bias' % i in w)
+            e = pkg.CsiEngine(nt, 1, hidden=hidden, n_out=int(w['fc_regressor.bias'].shape[0]), use_bn=True)
+            e.load_weights(comp, w)
+            y = e.predict_samples(comp, x)
+            assert rel_rows(y, exp[comp + '_y']) < TOL, (path, rel_rows(y, exp[comp + '_y']))
+            e.close()
+
+
+def test_a_receiver_counts_a_pinned_model_and_success_leaves_no_error_text(pkg, oracle):
+    """csi_load_weights used to leave an explanatory text in csi_last_error while returning CSI_OK when it pinned a model
+    to the fp32 MFMA kernels, and a context that RECEIVED such a model (csi_clone_weights = the receiver side of csi_broadcast_weights)
+    read 0 for "hs_weight_pins" / "hs_weight_err_e12".  Now: no text after a successful load, and the receiver's counters equal the
+    sender's."""
+    nt, nr, hidden = 32, 2, (64, 64)
+    w_re, w_im = _weights(oracle, 5, nt, hidden)
+    bad = {k: np.array(v, copy=True) for k, v in w_im.items()}
+    bad['fc_dense1.kernel'] *= 2.0 ** -22
+    bad['fc_dense1.kernel'][3, 5] = 1.0                     # one entry 2^22 above the rest: the split copies are not fp32-grade
+    e = _engine(pkg, nt, nr, hidden, w_re, bad, oracle.hadamard(nt))
+    assert e.get_option('hs_weight_pins') == 1 and e.get_option('hs_weight_err_e12') > 1e6
+    assert (e._lib.csi_last_error(e._ctx) or b'') == b'', 'a successful csi_load_weights leaves no error text'
+    r = pkg.CsiEngine(nt, nr, hidden=hidden)
+    r.clone_weights_from(e)
+    assert r.get_option('hs_weight_pins') == 1 and r.get_option('hs_weight_err_e12') == e.get_option('hs_weight_err_e12')
+    rng = np.random.default_rng(1)
+    ltf = oracle.make_structured_packets(rng, 40, nr, oracle.hadamard(nt), snr_db=5.0)[0].astype(np.complex64)
+    a, b = e.predict(ltf), r.predict(ltf)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build container (no GPU): what tools/pkadd_probe_box_short.sh / _cold.sh expect to find prebuilt, so that the GPU box compiles nothing.
+# Build container (no GPU): what tools/ls_race_box.sh pkadd-cold expects to find prebuilt, so that the GPU box compiles nothing.
 #   tools/pkadd_probe.bin               hipcc of tools/pkadd_mfma_probe.hip
 #   tools/_variants/libcsi_mamimo.so    the library with the race-hunt instantiations of the LS kernel (CSI_BUILD_DEFINES=CSI_LS_RACE_VARIANTS);
 #                                       the in-tree product library is put back afterwards, untouched

@@ -9,6 +9,7 @@ import dl_channel_estimation_mamimo_amd as pkg
 n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 fused = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mode = sys.argv[3] if len(sys.argv) > 3 else 'estimate'
+graph = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 nt, nr, hidden = 32, 4, (1024, 1024)
 rng = np.random.default_rng(0)
 eng = pkg.CsiEngine(nt, nr, hidden=hidden)
@@ -16,6 +17,7 @@ eng.load_weights('real', pkg.synth.make_weights(rng, nt, hidden))
 eng.load_weights('imag', pkg.synth.make_weights(rng, nt, hidden))
 eng.set_pilot(pkg.synth.hadamard(nt))
 eng.set_option('small_fused', fused)
+eng.set_option('use_graph', graph)
 d_re, d_im = eng.empty((1, nr, eng.len_ltf)), eng.empty((1, nr, eng.len_ltf))
 eng.synth_white(1, 0, 1, d_re, d_im)
 o = [eng.empty((1, nr, nt, 234)) for _ in range(4)]
@@ -43,4 +45,5 @@ for _ in range(n_calls):
     call()
 eng.synchronize()
 pip = (time.perf_counter() - t0) / n_calls
+print('use_graph=%d ' % graph, end='')
 print('small_fused=%d mode=%s: latency median %.1f us (min %.1f), pipelined %.1f us per call' % (fused, mode, np.median(lat) * 1e6, min(lat) * 1e6, pip * 1e6))
