@@ -155,6 +155,10 @@ struct csi_ctx {
     int small_call_overlap = 1;  // "small_call_overlap" option
     // the one-packet regime (csi_dnn_small.hpp): both models of a call of <= 8 rx preambles in 1 + n_hidden launches
     int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
+    int small_rows = 1024;       // "small_rows": pair rows up to which a call takes it (and at most 64 preambles).  Measured (profiles/r05_regime_probe.txt):
+                                 // 4 packets 117 us against 143 on the general kernels, 8 packets 162 / 170, 12 packets 251 / 246, 16 packets 283 / 252
+    bool in_host_pipeline = false;   // a chunk of a host-buffer entry point is being enqueued: no second-stream fork inside (measured: the
+                                 // two-stream arrangement costs the PCIe-bound pipeline 6 % - profiles/r05_regime_probe.txt)
     int64_t small_calls = 0;     // "small_calls": calls that took it
     char* small_ws = nullptr;    // its scratch: L0 of both models + ping-pong activations
     size_t small_ws_bytes = 0;
@@ -206,8 +210,9 @@ struct csi_ctx {
     hipFunction_t band_fn_ns = nullptr;        // split-f16 form without them (nt outside 16 .. 128)
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;
-    int hs_min_blocks = 80;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
-                                 // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024: 40 packets); layer 0 from max(this, 128)
+    int hs_min_blocks = 48;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
+                                 // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024 with the two component models on two
+                                 // streams: 24 packets - profiles/r05_regime_probe.txt; 80 = 40 packets before round 5); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats

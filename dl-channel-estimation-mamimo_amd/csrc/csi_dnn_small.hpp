@@ -15,7 +15,9 @@ bool small_call_ok(const csi_ctx* c, int64_t npkt) {
     const csi_config& cf = c->cfg;
     if (!c->small_fused || cf.dtype != CSI_DTYPE_F32 || cf.nt < 1 || c->force_pair_tile) return false;
     if (c->f32_engine == 1) return false;        // "f32_engine" = 1 asks for the split-f16 engine wherever the shapes allow
-    if (npkt * cf.nr > SC_MAX_ROWS0 || npkt * cf.nr * cf.nt > 1024) return false;
+    // up to 8 preambles layer 0 is the weight-streaming kernel; up to "small_rows" pair rows (default 2048: 16 packets of the shipped
+    // shape) it is the tile kernel with the EPI_H1 epilogue - beyond that the general kernels (from 24 packets the split-f16 engine) win
+    if (npkt * cf.nr * cf.nt > c->small_rows || npkt * cf.nr > 64) return false;
     for (int d = 0; d < 2; ++d)
         if (!c->model[d].loaded || !c->model[d].table_ok || !c->model[d].layers[0].Wt) return false;
     return true;
@@ -34,7 +36,27 @@ int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int6
     float* h1buf = reinterpret_cast<float*>(c->small_ws);
     float* act = h1buf + 2 * h1_floats;         // [buffer][model][M2][maxh]
     Model* md[2] = {&c->model[0], &c->model[1]};
-    {
+    if (M1 > SC_MAX_ROWS0) {
+        // 9 ... 64 preambles: layer 0 on the 16 x 16 tiles, the per-pair layer's input rows written by its epilogue (EPI_H1)
+        SmallGemmArgs g{};
+        g.A[0] = d_ltf_re; g.A[1] = d_ltf_im;
+        for (int d = 0; d < 2; ++d) {
+            const Model& m = *md[d];
+            const bool fold = m.layers[1].bias_hs != nullptr;
+            g.Bt[d] = m.layers[0].Wt; g.T[d] = m.T; g.s0[d] = m.layers[0].scale; g.t0[d] = fold ? c->hs_zero : m.layers[0].shift;
+            g.C[d] = h1buf + d * h1_floats;
+        }
+        g.M = M1; g.N = h1; g.K = cf.len_ltf; g.lda = cf.len_ltf; g.ldb = md[0]->layers[0].ldw; g.ldc = h1; g.nt = nt;
+        const int tiles_n = (h1 + 15) / 16, tiles_m = (M1 + 15) / 16;
+        int rg = 4;
+        while (rg > 1 && (long)tiles_n * ((tiles_m + rg - 1) / rg) * 2 < 200) rg >>= 1;
+        const dim3 grid((unsigned)tiles_n, (unsigned)((tiles_m + rg - 1) / rg), 2);
+        ProfScope ps(c, K_LAYER0_LTF, 2.0 * 2.0 * M1 * h1 * cf.len_ltf, 2.0 * 4.0 * ((double)cf.len_ltf * h1 + (double)M1 * cf.len_ltf + (double)(nt + M2) * h1));
+        if (rg == 4) hipLaunchKernelGGL((small_tile_gemm_kernel<EPI_H1, 4, 4>), grid, dim3(1024), 0, c->stream, g);
+        else if (rg == 2) hipLaunchKernelGGL((small_tile_gemm_kernel<EPI_H1, 2, 4>), grid, dim3(1024), 0, c->stream, g);
+        else hipLaunchKernelGGL((small_tile_gemm_kernel<EPI_H1, 1, 4>), grid, dim3(1024), 0, c->stream, g);
+        HIP_TRY(c, hipGetLastError());
+    } else {
         SmallL0Args a{};
         a.x[0] = d_ltf_re; a.x[1] = d_ltf_im;
         for (int d = 0; d < 2; ++d) {

@@ -577,7 +577,9 @@ int hp_run(csi_ctx* c, csi_hostpipe* h, const HpPipe& p) {
         // kernels: behind the upload, and behind the download of chunk i - 2 that releases device[s]'s output half
         HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_in[s], 0));
         if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, h->ev_out[s], 0));
+        c->in_host_pipeline = true;                    // (the chunk's kernels stay on the one stream: csi_predict_device's two-stream fork is for device-resident calls)
         rc = p.compute(i, s);
+        c->in_host_pipeline = false;
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(h->ev_comp[s], c->stream));
         // pinned_out[s] must have been handed to the user (chunk i - 2) before the next download lands in it

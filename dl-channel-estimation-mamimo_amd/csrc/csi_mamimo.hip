@@ -925,8 +925,12 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         if (small_call_ok(c, npkt)) return predict_small(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
         // small call: the two component models are independent and each is a chain of short,
         // launch-latency-bound kernels - run the imag model on a second stream with its own scratch
-        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call &&
-                             (npkt * c->cfg.nr <= 64 || c->small_call_overlap == 2);       // 2: any size (experiment: tails of one model's kernels under the other's)
+        // Round 5: up to 98 304 pair rows (768 bands of the fused kernel per model - three rounds of the chip), not 64 preambles: a
+        // component model's kernels of a mid-size call fill a fraction of the 256 CUs (64 packets = 64 bands), and the other model's
+        // fill the rest - 24 ... 128 packets 1.25-1.55x, 384 packets +16 %, 500 packets +1.4 % (profiles/r05_regime_probe.txt).  Beyond
+        // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).
+        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
+                             (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= 98304 || c->small_call_overlap == 2);
         if (!overlap) {
             int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
             if (r) return r;
@@ -1173,6 +1177,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "small_call_overlap") *value = c->small_call_overlap;
     else if (n == "small_fused") *value = c->small_fused;
     else if (n == "small_calls") *value = c->small_calls;
+    else if (n == "small_rows") *value = c->small_rows;
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band_launches") *value = c->band_launches;
@@ -1254,6 +1259,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "small_fused") {
         drop_graphs(c);
         c->small_fused = value != 0;
+    } else if (n == "small_rows") {
+        if (value < 0 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "small_rows must be 0..65536");
+        drop_graphs(c);
+        c->small_rows = (int)value;
     } else if (n == "f32_engine") {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);

@@ -137,9 +137,16 @@ struct SmallGemmArgs {
     const float* bias[2];    // [N]
     const float* scale[2];   // [N] EPI_BIAS_RELU_AFFINE
     const float* shift[2];   // [N]
-    float* C[2];             // [M][ldc]
+    float* C[2];             // [M][ldc]; EPI_H1: [M * nt][ldc]
     int M, N, K, lda, ldb, ldc;
+    // EPI_H1 (layer 0 of a call of 9 ... 64 preambles): the tile is the layer-0 LTF product L0[m][n]; what is written is the first
+    // per-pair layer's input, rows m * nt + t = relu(L0[m][n] + T[t][n]) * s0[n] + t0[n] for every tx antenna t (DNN.py:211-219)
+    const float* T[2];       // [nt][N] pilot table incl. the layer-0 bias
+    const float* s0[2];      // [N]
+    const float* t0[2];      // [N]
+    int nt;
 };
+constexpr int EPI_H1 = 3;
 
 // grid (ceil(N / 16), ceil(M / (16 RG)), 2), 1024 threads = 16 waves: wave w -> row group w % RG (16 rows), k part w / RG of KS = 16 / RG.
 // Every wave walks its part of K with its loads for several groups of 16 k in flight; four waves share a SIMD, so one wave's MFMAs run
@@ -220,6 +227,18 @@ __global__ __launch_bounds__(1024) void small_tile_gemm_kernel(SmallGemmArgs g) 
     // C/D layout: column = lane & 15, row = 4 (lane >> 4) + r
     const int col = (int)blockIdx.x * 16 + i;
     if (col >= g.N) return;
+    if constexpr (EPI == EPI_H1) {
+        const float sc = g.s0[z][col], sh = g.t0[z][col];
+        for (int t = 0; t < g.nt; ++t) {
+            const float tv = g.T[z][(size_t)t * g.N + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q + r;
+                if (row < g.M) g.C[z][((size_t)row * g.nt + t) * g.ldc + col] = fmaf(fmaxf(sum[r] + tv, 0.f), sc, sh);
+            }
+        }
+        return;
+    }
     const float bias = g.bias[z][col];
     float sc = 1.f, sh = 0.f;
     if constexpr (EPI == EPI_BIAS_RELU_AFFINE) { sc = g.scale[z][col]; sh = g.shift[z][col]; }

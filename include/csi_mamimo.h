@@ -241,11 +241,14 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 15, max 64)
- *   "small_call_overlap" 1 (default): calls of at most 64 rx preambles run the real and the imag model on
- *                         two streams side by side (they are launch-latency bound); 0: one after the other
- *   "small_fused"      1 (default): a call of at most 8 rx preambles (and at most 1024 pair rows) - the reference's literal
- *                         one-packet predict, DNN.py:339-346 - runs BOTH component models in 1 + n_hidden launches: layer 0 as one
- *                         weight-streaming kernel, every layer behind it as 16 x 16 fp32-MFMA tiles over the whole K, no split-K slabs
+ *   "small_call_overlap" 1 (default): calls of at most 98 304 pair rows (768 packets at Nt = 32, Nr = 4) run the real and the imag
+ *                         model on two streams side by side - a mid-size call's kernels fill a fraction of the chip (24 ... 128 packets:
+ *                         1.25-1.55x, 500 packets +1.4 %; device-pointer calls only: inside the host-buffer entry points' pipeline the
+ *                         chunks stay on one stream, where the fork measured 6 % slower); 0: one after the other; 2: any size (A/B runs)
+ *   "small_fused"      1 (default): a call of at most "small_rows" pair rows (default 1024 = 8 packets at Nt = 32, Nr = 4; and at most 64
+ *                         rx preambles) - the reference's literal one-packet predict, DNN.py:339-346, and its small multiples - runs BOTH
+ *                         component models in 1 + n_hidden launches: layer 0 as one weight-streaming kernel (up to 8 preambles) or on
+ *                         fp32-MFMA tiles, every layer behind it as 16 x 16 / 32 x 32 fp32-MFMA tiles over the whole K, no split-K slabs
  *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it)
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
  *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
@@ -259,7 +262,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         layer's kernel (its 256 x 256 tile of activations becomes the A operand of a second product
  *                         on the CU; only partial sums reach memory).  0 (default): measured slower than two kernels
  *   "hs_min_blocks"    automatic mode: the per-pair layers take the split engine from this many 256x256 workgroups
- *                         on (default 80), layer 0 from max(this, 128)
+ *                         on (default 48 = 24 packets of the shipped shape; 80 before the two-stream arrangement of round 5),
+ *                         layer 0 from max(this, 128)
  *   "hs_in_shift"      split engine: the preamble samples are carried times 2^shift.  99 (default): chosen per
  *                         launch on the device from a sampled maximum of the data, so that it lands at
  *                         2^13..2^14 (any input scaling is served); -8..14: fixed

@@ -26,6 +26,11 @@ SMALL_CASES = [
     (64, 2, 1, (96, 64), True, 234),         # Nt = 64
     (128, 1, 1, (64, 64), True, 234),        # Nt = 128: 128 pair rows from ONE preamble
     (12, 2, 3, (72, 1100), True, 234),       # a wide per-pair layer on the 32 x 32 tiles: ragged rows (72) and columns (1100), K = 72 (3 groups for 16 k-parts); regressor K = 1100
+    (32, 4, 8, (1024, 1024), True, 234),     # 8 packets of the shipped model: 32 preambles - layer 0 on the tiles, its epilogue writes the per-pair input (EPI_H1)
+    (32, 2, 16, (1024, 1024), True, 234),    # 16 packets of Nr = 2: 32 preambles, 1024 pair rows - the largest call the path takes by default
+    (8, 2, 12, (64, 64), True, 234),         # 24 preambles, ragged row tiles
+    (4, 1, 40, (32, 48, 40), False, 234),    # 40 preambles of Nt = 4, three hidden layers, no BN, K = 1280
+    (12, 2, 9, (40, 24), True, 52),          # 18 preambles, Nt = 12, 52 outputs
     (8, 2, 3, (512, 320), True, 234),        # ("small_fused" = 0 leg: the split-K latency path of every general kernel, K >= 256)
     (8, 2, 1, (256,), False, 234),           # one packet, single hidden layer, no BN (general kernels: split-K regressor)
 ]
@@ -57,7 +62,7 @@ def test_small_call_path_matches_oracle_and_general_kernels(pkg, oracle, nt, nr,
 
 
 def test_small_call_limits_and_the_literal_predict(pkg, oracle):
-    """9 preambles (or more than 1024 pair rows) take the general kernels; the small path equals the literal un-shared network
+    """More than "small_rows" pair rows (or more than 64 preambles) take the general kernels; the small path equals the literal un-shared network
     (csi_predict_samples: Keras Model.predict semantics, DNN.py:346) on the same packet; device-resident calls and a replayed hipGraph of
     the one-packet call give the same bits as the host call."""
     nt, nr, hidden = 32, 4, (256, 128)
@@ -67,7 +72,12 @@ def test_small_call_limits_and_the_literal_predict(pkg, oracle):
     ltf = oracle.make_structured_packets(rng, 3, nr, P, snr_db=0.0)[0].astype(np.complex64)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
     n0 = e.get_option('small_calls')
-    e.predict(ltf[:3])                                        # 12 preambles
+    e.set_option('small_rows', 256)
+    e.predict(ltf[:3])                                        # 384 pair rows > "small_rows"
+    assert e.get_option('small_calls') == n0
+    e.set_option('small_rows', 4096)
+    big = np.concatenate([ltf] * 6)[:17]                      # 17 packets = 68 preambles: beyond the path's 64 whatever "small_rows" says
+    e.predict(big)
     assert e.get_option('small_calls') == n0
     o_re, o_im = e.predict(ltf[:1])
     assert e.get_option('small_calls') == n0 + 1

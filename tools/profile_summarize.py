@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 CSVs written by tools/profile_round.sh into the committed summaries under
+"""Turn the rocprofv3 CSVs written by tools/profile_config.sh (rounds 1-4: tools/profile_round.sh, its headline-only predecessor) into the committed summaries under
 profiles/:  <tag>_kernel_stats.txt (from the kernel trace), <tag>_pmc.txt (per-kernel mean of every
 counter, one pass per counter group) and <tag>_traffic.json (HBM bytes per launch of each kernel,
 read by bench.py for roofline.traffic).
