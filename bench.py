@@ -126,7 +126,7 @@ def main():
                          '(torch.distributed, host round trip).  CSI_DIST_BACKEND=gloo implies torch.')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the "next_rows" legs (LMMSE smoother, one training step, LS on a non-Sylvester pilot) measured after the timed region')
     ap.add_argument('--legs-packets', default='', metavar='A,B',
-                    help='N > 1 only: total packets of the configs[3] / configs[4] legs (default 50000,100000 = BASELINE.json; the CPU tests shrink them)')
+                    help='N > 1 only: total packets of the configs[3] / configs[4] legs (default 50000,100000 = BASELINE.json; the CPU tests shrink them - and, given explicitly, the legs run beside any headline)')
     ap.add_argument('--no-regimes', action='store_true', help='skip the "regimes" leg (1 / 8 / 64 / 500-packet calls with their bounds) measured after the timed region')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
@@ -153,7 +153,7 @@ def main():
         if rank == 0:
             print(json.dumps({'rendezvous_only': True, 'n_gpus': n_gpus, 'ranks_seen': int(seen), 'requested': args.gpus,
                               'other_configs_scheduled': [dict(config=n_, flags=' '.join(f_), fits=fit_, per_rank_gb=round(gb_, 1))
-                                                          for n_, _, f_, fit_, gb_ in multi_gpu_legs(args, world)] if world > 1 and default_headline(args) else [],
+                                                          for n_, _, f_, fit_, gb_ in multi_gpu_legs(args, world)] if world > 1 and (default_headline(args) or args.legs_packets) else [],
                               'packets_per_step': int(pkts), 'scaling': args.scaling, 'backend': backend if world > 1 else None,
                               'ranks_ms': [i['ms_per_step'] for i in infos], 'devices': [i['device'] for i in infos], 'ranks': infos}))
         return
@@ -537,7 +537,7 @@ def main():
     # N > 1: BASELINE.json's two multi-GPU configurations, by ALL ranks, each as a fresh N-rank job of this script (round-4 verdict,
     # next 4): configs[3] Nt=64 Nr=8 50000 packets sharded, configs[4] Nt=128 Nr=16 100000 packets, one hipGraph per step
     legs = None
-    if world > 1 and default_headline(args) and not args.no_other_configs and not args.graph and not args.option:
+    if world > 1 and (default_headline(args) or args.legs_packets) and not args.no_other_configs and not args.graph and not args.option:
         del d_re, d_im, d_ore, d_oim, d_hre, d_him
         try:
             eng.comm_destroy()

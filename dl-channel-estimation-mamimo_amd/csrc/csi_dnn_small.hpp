@@ -68,9 +68,11 @@ int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int6
         }
         a.M = M1; a.K = cf.len_ltf; a.lda = cf.len_ltf; a.ldw = md[0]->layers[0].ldw; a.h1 = h1; a.nt = nt;
         ProfScope ps(c, K_LAYER0_LTF, 2.0 * 2.0 * M1 * h1 * cf.len_ltf, 2.0 * 4.0 * ((double)cf.len_ltf * h1 + (double)M1 * cf.len_ltf + (double)(nt + M2) * h1));
-        const dim3 grid((unsigned)((h1 + SC_GEMV_COLS - 1) / SC_GEMV_COLS), 2);
-        if (M1 <= 4) hipLaunchKernelGGL((small_l0_gemv_kernel<4>), grid, dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((small_l0_gemv_kernel<8>), grid, dim3(256), 0, c->stream, a);
+        // 4 columns per workgroup, 2 k steps of 1024 in flight: every shape tried (4 / 8 columns, 2 ... 5 steps) lands at 16.2-17.0 us
+        // for the 84 MB of the shipped model = 5.2 TB/s - the memory system's rate, not the kernel's (profiles/r05_small_call_trace.txt)
+        const dim3 grid((unsigned)((h1 + 3) / 4), 2);
+        if (M1 > 4) hipLaunchKernelGGL((small_l0_gemv_kernel<8, 4, 2>), grid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((small_l0_gemv_kernel<4, 4, 2>), grid, dim3(256), 0, c->stream, a);
         HIP_TRY(c, hipGetLastError());
     }
     float* out[2] = {d_out_re, d_out_im};

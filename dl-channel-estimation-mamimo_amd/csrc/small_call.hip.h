@@ -31,7 +31,6 @@
 namespace csi {
 
 constexpr int SC_MAX_ROWS0 = 8;          // preambles (packet, rx) a small call may hold
-constexpr int SC_GEMV_COLS = 4;          // output columns per workgroup of the layer-0 kernel
 
 struct SmallL0Args {
     const float* x[2];       // [M][lda] one plane of the preambles per component model
@@ -43,8 +42,8 @@ struct SmallL0Args {
     int M, K, lda, ldw, h1, nt;
 };
 
-// grid (ceil(h1 / 4), 2), 256 threads
-template <int MR>
+// grid (ceil(h1 / COLS), 2), 256 threads; COLS output columns per workgroup (a multiple of 4), UN k steps of 1024 in flight
+template <int MR, int SC_GEMV_COLS, int UN>
 __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
     __shared__ float red[4][64][MR * SC_GEMV_COLS + 1];
     __shared__ float part[4][MR * SC_GEMV_COLS];
@@ -61,7 +60,6 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
     const float* wrow[SC_GEMV_COLS];
 #pragma unroll
     for (int c = 0; c < SC_GEMV_COLS; ++c) wrow[c] = W + (size_t)min(n0 + c, a.h1 - 1) * a.ldw;
-    constexpr int UN = 4;                                       // k steps of 1024 whose loads are in flight together
     for (int k0 = 4 * tid; k0 < a.K; k0 += 1024 * UN) {
         f32x4 w[UN][SC_GEMV_COLS], xv[UN][MR];
         float okfs[UN];
@@ -96,8 +94,8 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
         for (int c = 0; c < SC_GEMV_COLS; ++c)
             red[wave][lane][m * SC_GEMV_COLS + c] = (acc[m][c][0] + acc[m][c][1]) + (acc[m][c][2] + acc[m][c][3]);
     __syncthreads();
-    if (tid < 4 * MR * SC_GEMV_COLS) {
-        const int w = tid / (MR * SC_GEMV_COLS), v = tid - w * (MR * SC_GEMV_COLS);
+    for (int idx = tid; idx < 4 * MR * SC_GEMV_COLS; idx += 256) {
+        const int w = idx / (MR * SC_GEMV_COLS), v = idx - w * (MR * SC_GEMV_COLS);
         float s = 0.f;
         for (int l = 0; l < 64; ++l) s += red[w][l][v];
         part[w][v] = s;
@@ -112,22 +110,17 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
     if (tid < MR * SC_GEMV_COLS) l0s[tid / SC_GEMV_COLS][tid % SC_GEMV_COLS] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     __syncthreads();
     const int rows = a.M * a.nt;
-    if (n0 + SC_GEMV_COLS <= a.h1) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.s0[z] + n0), sh = *reinterpret_cast<const f32x4*>(a.t0[z] + n0);
-        for (int r = tid; r < rows; r += 256) {
-            const int m = r / a.nt, t = r - m * a.nt;
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(a.T[z] + (size_t)t * a.h1 + n0);
-            f32x4 v;
+    constexpr int Q = SC_GEMV_COLS / 4;          // 16-byte quads per row of this workgroup's columns
+    for (int idx = tid; idx < rows * Q; idx += 256) {
+        const int r = idx / Q, qd = idx - r * Q, n = n0 + 4 * qd;
+        if (n >= a.h1) continue;                 // (h1 % 4 == 0 by csi_create: a quad is inside or outside as a whole)
+        const int m = r / a.nt, t = r - m * a.nt;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.s0[z] + n), sh = *reinterpret_cast<const f32x4*>(a.t0[z] + n);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(a.T[z] + (size_t)t * a.h1 + n);
+        f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(l0s[m][e] + tv[e], 0.f), sc[e], sh[e]);
-            *reinterpret_cast<f32x4*>(a.h1out[z] + (size_t)r * a.h1 + n0) = v;
-        }
-    } else {                                    // (h1 % 4 == 0 by csi_create: kept for safety)
-        for (int r = tid; r < rows; r += 256) {
-            const int m = r / a.nt, t = r - m * a.nt;
-            for (int e = 0; e < SC_GEMV_COLS && n0 + e < a.h1; ++e)
-                a.h1out[z][(size_t)r * a.h1 + n0 + e] = fmaf(fmaxf(l0s[m][e] + a.T[z][(size_t)t * a.h1 + n0 + e], 0.f), a.s0[z][n0 + e], a.t0[z][n0 + e]);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(l0s[m][4 * qd + e] + tv[e], 0.f), sc[e], sh[e]);
+        *reinterpret_cast<f32x4*>(a.h1out[z] + (size_t)r * a.h1 + n) = v;
     }
 }
 

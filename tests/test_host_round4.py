@@ -563,12 +563,12 @@ def test_two_rank_bench_runs_the_multi_gpu_legs_on_the_mock_runtime(mock_so):
     port = 29600 + os.getpid() % 300
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--check', '0',
-                        '--legs-packets', '24,6', '--input', 'white'], env=env, cwd=REPO,
+                        '--packets', '64', '--legs-packets', '24,6', '--input', 'white'], env=env, cwd=REPO,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     import json
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['pairs_per_step'] == 2 * 4000 * 128
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['pairs_per_step'] == 2 * 64 * 128      # (64 packets per rank: the mock's allocator fills every buffer)
     legs = {l['config']: l for l in line['other_configs']}
     assert set(legs) == {'configs[3]', 'configs[4]'}, line['other_configs']
     for name, (nt, nr, total) in {'configs[3]': (64, 8, 24), 'configs[4]': (128, 16, 6)}.items():
