@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     const bool timing = mode == "time" || mode == "stamps" || mode == "loop";
     const int nt = argc > 2 ? atoi(argv[2]) : 32;
     const int K = 1024, N = 1024, NO = 234;
-    const int M = timing ? 262144 : 1024 + 24;
+    const int M = getenv("BAND_M") ? atoi(getenv("BAND_M")) : (timing ? 262144 : 1024 + 24);      // BAND_M: rows of the timing runs (round 5: launch-tail experiment)
     const int M1 = (M + nt - 1) / nt;
     auto hW = rnd((size_t)N * K, 0.054f, false);
     auto hW2 = rnd((size_t)NO * N, 0.07f, false);
