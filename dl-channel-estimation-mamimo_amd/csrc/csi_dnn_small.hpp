@@ -1,6 +1,7 @@
-// csi_dnn_small.hpp - host side of the one-packet regime (small_call.hip.h): both component models of a call of at most 8 rx
-// preambles in 1 + n_hidden launches on the context's stream - layer 0 as one weight-streaming kernel, every layer behind it as
-// 16 x 16 MFMA tiles over the whole K - instead of six launches per model on two streams.  Same arithmetic class as the fp32 MFMA
+// csi_dnn_small.hpp - host side of the one-packet regime (small_call.hip.h): both component models of a small call (at most
+// "small_rows" = 1024 pair rows and 64 rx preambles) in 1 + n_hidden launches on the context's stream - layer 0 as one
+// weight-streaming kernel (up to 8 preambles) or on fp32-MFMA tiles, every layer behind it as 16 x 16 / 32 x 32 MFMA tiles over
+// the whole K - instead of six launches per model on two streams.  Same arithmetic class as the fp32 MFMA
 // kernels of gemm_f32.hip.h (exact fp32 products, fp32 accumulation); the reference call this serves is the literal per-packet
 // predict of massiveMIMO_CSI_prediction_DNN.py:339-346.
 #pragma once
@@ -9,13 +10,13 @@
 
 namespace {
 
-// which calls take it: fp32 contexts with a pilot input, both models loaded, at most SC_MAX_ROWS0 preambles and - so that a layer
-// is at most a few tiles per SIMD - at most 1024 pair rows; "small_fused" = 0 restores the general kernels (A/B runs, tests)
+// which calls take it: fp32 contexts with a pilot input, both models loaded, at most 64 preambles and "small_rows" pair rows;
+// "small_fused" = 0 restores the general kernels (A/B runs, tests)
 bool small_call_ok(const csi_ctx* c, int64_t npkt) {
     const csi_config& cf = c->cfg;
     if (!c->small_fused || cf.dtype != CSI_DTYPE_F32 || cf.nt < 1 || c->force_pair_tile) return false;
     if (c->f32_engine == 1) return false;        // "f32_engine" = 1 asks for the split-f16 engine wherever the shapes allow
-    // up to 8 preambles layer 0 is the weight-streaming kernel; up to "small_rows" pair rows (default 2048: 16 packets of the shipped
+    // up to 8 preambles layer 0 is the weight-streaming kernel; up to "small_rows" pair rows (default 1024: 8 packets of the shipped
     // shape) it is the tile kernel with the EPI_H1 epilogue - beyond that the general kernels (from 24 packets the split-f16 engine) win
     if (npkt * cf.nr * cf.nt > c->small_rows || npkt * cf.nr > 64) return false;
     for (int d = 0; d < 2; ++d)

@@ -199,3 +199,35 @@ def test_a_receiver_counts_a_pinned_model_and_success_leaves_no_error_text(pkg, 
     ltf = oracle.make_structured_packets(rng, 40, nr, oracle.hadamard(nt), snr_db=5.0)[0].astype(np.complex64)
     a, b = e.predict(ltf), r.predict(ltf)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_fuzz_small_call_shapes(pkg, oracle):
+    """Seeded, bounded fuzz of the one-packet path: random antenna counts, preamble counts (1 ... 64, at most 1024 pair rows), one to three
+    hidden layers of random widths (multiples of 4, not of the 16 / 32 tiles), with and without BatchNormalization, random output widths -
+    every case against the fp64 oracle and against the general kernels, and the path must have been taken."""
+    rng = np.random.default_rng(20250930)
+    done = 0
+    while done < 14:
+        nt = int(rng.choice([4, 8, 12, 16, 32, 64]))
+        nr = int(rng.integers(1, 5))
+        npkt = int(rng.integers(1, 17))
+        if npkt * nr > 64 or npkt * nr * nt > 1024:
+            continue
+        nh = int(rng.integers(1, 4))
+        hidden = tuple(int(4 * rng.integers(2, 76)) for _ in range(nh))
+        use_bn = bool(rng.integers(0, 2))
+        n_out = int(rng.choice([52, 234, 100]))
+        w_re, w_im = _weights(oracle, int(rng.integers(1 << 30)), nt, hidden, use_bn, n_out)
+        P = _pilot(rng, nt, orthogonal=False)
+        ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+        e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn, n_out)
+        o_re, o_im = e.predict(ltf)
+        case = (nt, nr, npkt, hidden, use_bn, n_out)
+        assert e.get_option('small_calls') == 1, case
+        r_re, r_im = oracle.predict_packets(ltf, P, w_re, w_im, np.float64, pkt_batch=npkt)
+        assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL, case
+        e.set_option('small_fused', 0)
+        g_re, g_im = e.predict(ltf)
+        assert rel_rows(o_re, g_re) < 5e-6 and rel_rows(o_im, g_im) < 5e-6, case
+        e.close()
+        done += 1
