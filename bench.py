@@ -544,7 +544,10 @@ def main():
         except Exception:                           # noqa: BLE001
             pass
         eng.close()
-        legs = run_multi_gpu_legs(pkg, args, rank, world, local)
+        try:
+            legs = run_multi_gpu_legs(pkg, args, rank, world, local)
+        except Exception as e:                      # noqa: BLE001 - the side legs never take the headline's line down
+            legs = [{'error': 'multi-GPU legs: ' + repr(e)}]
     if rank != 0:
         return
 
@@ -928,14 +931,14 @@ def run_multi_gpu_legs(pkg, args, rank, world, local):
                 so.bind(('127.0.0.1', 0))
                 box[0] = so.getsockname()[1]
         tdist.broadcast_object_list(box, src=0)
-        env = dict(os.environ, MASTER_PORT=str(box[0]), CSI_RCCL_ID_TOKEN='leg-%s-%d' % (name, box[0]))
+        env = dict(os.environ, MASTER_PORT=str(box[0]), CSI_RCCL_ID_TOKEN='leg-%s-%d' % (name, box[0]), CSI_DIST_TIMEOUT_S='180')
         for k in [k for k in env if k.startswith('TORCHELASTIC_')]:      # under torchrun: the child job's rank 0 serves its own store
             env.pop(k)                                                     # (TORCHELASTIC_USE_AGENT_STORE would make it look for the agent's)
         cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--no-other-configs', '--no-cpu-baseline', '--no-latency',
                '--host-path', '0', '--check', '4', '--no-next-rows', '--no-regimes', '--weights-via', args.weights_via] + flags
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1500)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=420)     # (one GPU's share takes 5 / 22 s of wall time)
             rc, so_, se_ = r.returncode, r.stdout, r.stderr
         except Exception as e:                       # noqa: BLE001 - a failed side measurement never takes the headline down
             rc, so_, se_ = -1, '', repr(e)

@@ -39,7 +39,13 @@ def init_process_group(backend=None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # CSI_DIST_TIMEOUT_S bounds the rendezvous and every later collective of the group (torch's default is 10-30 minutes): bench.py's
+    # N > 1 side legs set it, so that a leg whose ranks cannot meet costs two minutes and an error entry, not the headline's line
+    kw = {}
+    if os.environ.get('CSI_DIST_TIMEOUT_S'):
+        import datetime
+        kw['timeout'] = datetime.timedelta(seconds=float(os.environ['CSI_DIST_TIMEOUT_S']))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return dist
 
 
