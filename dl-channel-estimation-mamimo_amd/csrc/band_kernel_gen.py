@@ -45,6 +45,7 @@ RING_SLOT = 16384
 AX_OFF = 4 * RING_SLOT            # fragment exchange: [rg][parity][hi | lo][64 lanes x 16 B]
 BIAS1_OFF = AX_OFF + 16384        # out_scale * bias1 [N1], then bias2 [256]
 KARG_BYTES = 128
+KARG_BYTES_CS = 144                # column-split form: + the base of the partial outputs (8 bytes, padded to 16)
 MAX_N1 = 4096                     # static LDS: ring + exchange + bias tables for up to this many hidden features
 LDS_OLD = BIAS1_OFF + 4 * MAX_N1 + 1024
 # bf16 'staged' form: the L0 / T values of the stage-1 fragments come through LDS as well - per sub-step one slab of the pilot table
@@ -65,6 +66,7 @@ S_TRIP, S_COL, S_NCOL, S_NSUB1, S_DMA = 48, 49, 50, 51, 52
 S_T = 54                          # s54..s63 scratch
 S_ROWMASK, S_SAVE = 64, 66
 S_COLBYTES, S_BIAS2OFF, S_DMA2 = 68, 69, 70
+S_PART = 74                       # column-split form: s[74:75] = base of the partial outputs of splits 1 ..
 S_TSLABB, S_TCH = 72, 73        # staged bf16 form: bytes of a T slab (nt * 128), byte offset of this wave's 1-KiB chunk of it
 
 # vector registers (arch half: v0..v127)
@@ -711,6 +713,34 @@ def common_prologue(b, dbg=(), mode='hs'):
         b.e('s_endpgm')
     b.e('s_cmp_ge_i32 %s, %s' % (sreg(S_M0), sreg(S_M)))
     b.e('s_cbranch_scc1 L_end')
+    if 'colsplit' in dbg:
+        # column-split form (small calls: fewer bands than CUs): workgroup (x, y) computes band x over the N1 hidden features
+        # [y N1, (y + 1) N1) of a layer that is gridDim.y * N1 wide - the kernel's own arguments describe split 0, split y moves
+        # W1 by y N1 rows, bias1 by y N1 entries, the regressor weights by y N1 k-columns (4 bytes each: hi | lo), reads a zero bias2
+        # and writes its partial outputs to part + (y - 1) * M * ldo * 4; the host adds the partials to split 0's output in y order
+        b.e('s_load_dwordx2 %s, s[0:1], 0x80' % sreg(S_PART, 2))
+        b.e('s_waitcnt lgkmcnt(0)')
+        b.e('s_cmp_eq_u32 s3, 0')
+        b.e('s_cbranch_scc1 L_cs_done')
+        b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_T), sreg(S_N1)))
+        b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_T + 1), sreg(S_LDB1)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_T + 1)))            # bytes of the N1 weight rows of one split (host: < 2^31 / splits)
+        b.e('s_mul_i32 %s, %s, s3' % (sreg(S_T), sreg(S_T)))
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_W1), sreg(S_W1), sreg(S_T)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1 + 1), sreg(S_W1 + 1)))
+        b.e('s_mul_i32 %s, %s, s3' % (sreg(S_T), sreg(S_N1)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
+        for ptr in (S_B1, S_W2):
+            b.e('s_add_u32 %s, %s, %s' % (sreg(ptr), sreg(ptr), sreg(S_T)))
+            b.e('s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_M), sreg(S_LDO)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
+        b.e('s_sub_u32 %s, s3, 1' % sreg(S_T + 1))
+        b.e('s_mul_hi_u32 %s, %s, %s' % (sreg(S_T + 2), sreg(S_T), sreg(S_T + 1)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_T + 1)))
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_OUT), sreg(S_PART), sreg(S_T)))
+        b.e('s_addc_u32 %s, %s, %s' % (sreg(S_OUT + 1), sreg(S_PART + 1), sreg(S_T + 2)))
+        b.label('L_cs_done')
     if 'exit0' in dbg:
         b.e('s_branch L_end')
     stamp(b, 0, 0)
@@ -739,6 +769,10 @@ def common_prologue(b, dbg=(), mode='hs'):
     b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
     b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))
     b.e('v_cmp_gt_u32_e32 vcc, %s, v0' % sreg(S_N2))
+    if 'colsplit' in dbg:                                  # splits 1 .. carry no bias2 (the host adds their outputs to split 0's)
+        b.e('s_cmp_eq_u32 s3, 0')
+        b.e('s_cselect_b64 %s, -1, 0' % sreg(S_T, 2))
+        b.e('s_and_b64 vcc, vcc, %s' % sreg(S_T, 2))
     b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
     b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B2, 2)))
     b.e('s_waitcnt vmcnt(0)')
@@ -996,6 +1030,7 @@ DESCRIPTOR = '''
   .amdhsa_user_sgpr_count 2
   .amdhsa_user_sgpr_kernarg_segment_ptr 1
   .amdhsa_system_sgpr_workgroup_id_x 1
+  .amdhsa_system_sgpr_workgroup_id_y {idy}
   .amdhsa_system_vgpr_workitem_id 0
   .amdhsa_next_free_vgpr 256
   .amdhsa_next_free_sgpr 96
@@ -1029,7 +1064,7 @@ META_KERNEL = '''  - .name: {name}
         .value_kind: by_value
 '''
 
-VARIANTS = [('csi_band8', ()), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
+VARIANTS = [('csi_band8', ()), ('csi_band8_cs', ('colsplit',)), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')), ('csi_band8_skeleton_rnd_nobarrier', ('noconv', 'noreq', 'nodma', 'noread', 'rnd', 'nobarrier')),
@@ -1051,8 +1086,10 @@ def main():
         if only and name not in only:
             continue
         parts.append(kernel(name, dbg, 'bf16' if 'bf16' in dbg else 'hs'))
-        parts.append(DESCRIPTOR.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
-        meta.append(META_KERNEL.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
+        cs = 'colsplit' in dbg
+        karg = KARG_BYTES_CS if cs else KARG_BYTES
+        parts.append(DESCRIPTOR.format(name=name, karg=karg, lds=LDS_BYTES, idy=1 if cs else 0))
+        meta.append(META_KERNEL.format(name=name, karg=karg, lds=LDS_BYTES))
     parts.append('.amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.target: amdgcn-amd-amdhsa--gfx950\namdhsa.kernels:\n' + ''.join(meta) + '...\n.end_amdgpu_metadata\n')
     with open(path, 'w') as f:
         f.write('\n'.join(parts))

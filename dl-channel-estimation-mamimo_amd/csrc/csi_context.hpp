@@ -157,6 +157,8 @@ struct csi_ctx {
     int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
     int small_rows = 1024;       // "small_rows": pair rows up to which a call takes it (and at most 64 preambles).  Measured (profiles/r05_regime_probe.txt):
                                  // 4 packets 117 us against 143 on the general kernels, 8 packets 162 / 170, 12 packets 251 / 246, 16 packets 283 / 252
+    int small_rows_band = 512;   // "small_rows_band": the same limit where the column-split band kernel serves the model (csi_dnn_hs.hpp: the general
+                                 // path with it takes 136 us at 5 ... 8 packets against 155-161 here; at 4 packets 135 against 117)
     bool in_host_pipeline = false;   // a chunk of a host-buffer entry point is being enqueued: no second-stream fork inside (measured: the
                                  // two-stream arrangement costs the PCIe-bound pipeline 6 % - profiles/r05_regime_probe.txt)
     int64_t small_calls = 0;     // "small_calls": calls that took it
@@ -208,8 +210,14 @@ struct csi_ctx {
     hipFunction_t band_fn_bf16 = nullptr;
     hipFunction_t band_fn_bf16_ns = nullptr;   // bf16 form without the staged T / L0 streams (nt outside 32 .. 64)
     hipFunction_t band_fn_ns = nullptr;        // split-f16 form without them (nt outside 16 .. 128)
+    hipFunction_t band_fn_cs = nullptr;        // column-split form: grid (bands, splits), split y computes N1 / splits of the hidden features
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;
+    int band_split = -1;         // "band_split": calls with fewer bands than CUs split every band's hidden features over 2 / 4 workgroups (the
+                                 // regressor sums of the splits are added in split order by band_split_sum_kernel); -1 = automatic (as many
+                                 // splits as keep the workgroups of the models in flight within the 256 CUs), 0 / 1 = never, 2 / 4 = always
+    int64_t band_split_launches = 0;
+    int models_in_flight = 1;    // 2 while csi_predict_device runs the component models on two streams
     int hs_min_blocks = 48;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024 with the two component models on two
                                  // streams: 24 packets - profiles/r05_regime_probe.txt; 80 = 40 packets before round 5); layer 0 from max(this, 128)

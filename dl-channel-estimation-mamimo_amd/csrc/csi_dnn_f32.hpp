@@ -275,7 +275,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
 
         // first per-pair layer: h1 generated in the prologue from L0 + T
         float* out_chunk = d_out + (size_t)p0 * nr * nt * cf.n_out;
-        if (hs_ok && hs_tail_wanted(c, M2, m.layers[1].out)) {
+        if (hs_ok && (hs_tail_wanted(c, M2, m.layers[1].out) || band_split_static_ok(c, m))) {
             rc = hs_tail(c, m, l0, M2, hbuf[0], hbuf[1], out_chunk);
             if (rc) return rc;
             continue;

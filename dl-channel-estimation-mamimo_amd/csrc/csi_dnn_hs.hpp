@@ -223,10 +223,30 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             c->band_fn = c->band_fn_bf16 = c->band_fn_bf16_ns = c->band_fn_ns = nullptr;
             return CSI_OK;
         }
+        if (hipModuleGetFunction(&c->band_fn_cs, c->band_mod, "csi_band8_cs") != hipSuccess) {      // (an external code object may lack it)
+            (void)hipGetLastError();
+            c->band_fn_cs = nullptr;
+        }
     }
     *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : (staged ? c->band_fn : c->band_fn_ns);
 #endif
     return CSI_OK;
+}
+
+// Static part of "the column-split band kernel serves this model's per-pair layers" (band8_serves + band8_staged + band8_splits on
+// the shapes alone): with it a call of a few hundred pair rows is faster on the split engine than on the fp32 MFMA kernels -
+// 5 ... 20 packets of the shipped shape 136-142 us against 155-260 (profiles/r05_band_split_probe.txt)
+bool band_split_static_ok(csi_ctx* c, const Model& m) {
+    const csi_config& cf = c->cfg;
+    if (cf.n_hidden != 2 || !c->hs_band || c->hs_band == 3 || c->hs_fuse_regressor || c->band_split == 0 || c->band_split == 1 ||
+        c->force_pair_tile == 128)
+        return false;
+    if (m.layers.size() < 3 || !m.layers[2].Wh_p) return false;
+    const int h1 = cf.hidden[0], n1 = cf.hidden[1];
+    if (cf.nt < 16 || cf.nt > 128 || h1 < 128 || (h1 % 64) != 0 || (n1 % 512) != 0 || n1 > BAND8_MAX_N1 || cf.n_out < 1 || cf.n_out > 256) return false;
+    hipFunction_t fn = nullptr;
+    if (band8_function(c, &fn, false, true) != CSI_OK || !fn) return false;
+    return c->band_fn_cs != nullptr;
 }
 
 int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops, double bytes) {
@@ -236,6 +256,47 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
     size_t sz = sizeof(a8);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+    return CSI_OK;
+}
+
+// Column splits of a call of `bands` bands: a band is one workgroup's work for ~200 us, so a call with fewer bands than CUs leaves
+// CUs idle for that long - 2 or 4 workgroups per band, each over N1 / splits hidden features, fill them ("band_split";
+// profiles/r05_band_split_probe.txt: 24 packets 248 -> 149 us, 64 packets 299 -> 251 us)
+int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floats) {
+    if (!c->band_fn_cs || c->band_split == 0 || c->band_split == 1 || ba.stamps) return 1;
+    const long bands = (ba.M + BAND_ROWS - 1) / BAND_ROWS;
+    int S = 1;
+    if (c->band_split > 1) {
+        S = c->band_split;
+    } else {
+        const long in_flight = bands * std::max(c->models_in_flight, 1);
+        while (S < 4 && in_flight * (2 * S) <= 256) S *= 2;
+    }
+    while (S > 1 && (ba.N1 % (256 * S)) != 0) S >>= 1;
+    const unsigned long long part = (unsigned long long)(S - 1) * (unsigned long long)ba.M * (unsigned long long)ba.ldo;
+    if (S > 1 && (part > part_capacity_floats || part * 4ull >= 0xffffffffull || (unsigned long long)ba.N1 * ba.ldb1 * 2ull >= 0x7fffffffull)) return 1;
+    return S;
+}
+
+// the column-split launch: partial outputs of splits 1 .. in `part`, added to split 0's output in split order
+int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes) {
+    ++c->band_launches;
+    ++c->band_split_launches;
+    BandArgs one = ba;
+    one.N1 = ba.N1 / S;
+    Band8ArgsCs a{};
+    a.a = band8_args(one);
+    a.part = part;
+    size_t sz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    {
+        ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
+        HIP_TRY(c, hipModuleLaunchKernel(c->band_fn_cs, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+    }
+    const size_t n = (size_t)ba.M * ba.ldo;
+    ProfScope ps(c, K_SPLITK_REDUCE, (double)(S - 1) * n, 4.0 * (S + 1) * (double)n);
+    hipLaunchKernelGGL(band_split_sum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, ba.out, part, n, n, S - 1);
+    HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
 
@@ -363,6 +424,9 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
             ++c->hs_launches;
             const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
             const double bytes = 4.0 * ((double)M2 / cf.nt * h1 + (double)cf.nt * h1 + (double)l1.out * h1 + (double)cf.n_out * l1.out + (double)M2 * cf.n_out);
+            // (the band path leaves the activation buffers unused: hbuf0 - M2 x 1024 floats here - holds the partial outputs)
+            const int S = (fn == c->band_fn && staged && ba.ldo == ba.n2) ? band8_splits(c, ba, (size_t)M2 * l1.out) : 1;
+            if (S > 1) return band8_launch_split(c, ba, S, hbuf0, flops, bytes);
             return band8_launch(c, fn, ba, flops, bytes);
         }
     }

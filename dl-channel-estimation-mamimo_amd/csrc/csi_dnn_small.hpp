@@ -12,7 +12,7 @@ namespace {
 
 // which calls take it: fp32 contexts with a pilot input, both models loaded, at most 64 preambles and "small_rows" pair rows;
 // "small_fused" = 0 restores the general kernels (A/B runs, tests)
-bool small_call_ok(const csi_ctx* c, int64_t npkt) {
+bool small_call_ok(csi_ctx* c, int64_t npkt) {
     const csi_config& cf = c->cfg;
     if (!c->small_fused || cf.dtype != CSI_DTYPE_F32 || cf.nt < 1 || c->force_pair_tile) return false;
     if (c->f32_engine == 1) return false;        // "f32_engine" = 1 asks for the split-f16 engine wherever the shapes allow
@@ -21,6 +21,11 @@ bool small_call_ok(const csi_ctx* c, int64_t npkt) {
     if (npkt * cf.nr * cf.nt > c->small_rows || npkt * cf.nr > 64) return false;
     for (int d = 0; d < 2; ++d)
         if (!c->model[d].loaded || !c->model[d].table_ok || !c->model[d].layers[0].Wt) return false;
+    // where the column-split band kernel serves the model the general path wins from 5 packets of the shipped shape on (136 us against
+    // 155 here; 4 packets: 135 against 117 - profiles/r05_band_split_probe.txt): this path keeps the calls of at most "small_rows_band" rows
+    if (npkt * cf.nr * cf.nt > c->small_rows_band && c->f32_engine != 0 && hs_static_ok(c, c->model[0]) && hs_static_ok(c, c->model[1]) &&
+        band_split_static_ok(c, c->model[0]) && band_split_static_ok(c, c->model[1]))
+        return false;
     return true;
 }
 

@@ -951,12 +951,14 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
             std::swap(c->fuse_ws, c->aux_fuse_ws); std::swap(c->fuse_ws_bytes, c->aux_fuse_ws_bytes);
         };
         swap_scratch();                                   // imag model: aux stream, aux scratch
+        c->models_in_flight = 2;
         int r = predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
         hipError_t e = r ? hipSuccess : hipEventRecord(c->aux_join, c->stream);
         swap_scratch();
-        if (r) return r;
+        if (r) { c->models_in_flight = 1; return r; }
+        if (e == hipSuccess) r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        c->models_in_flight = 1;
         HIP_TRY(c, e);
-        r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
         if (r) return r;
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->aux_join, 0));
         return CSI_OK;
@@ -1178,9 +1180,12 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "small_fused") *value = c->small_fused;
     else if (n == "small_calls") *value = c->small_calls;
     else if (n == "small_rows") *value = c->small_rows;
+    else if (n == "small_rows_band") *value = c->small_rows_band;
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band_launches") *value = c->band_launches;
+    else if (n == "band_split") *value = c->band_split;
+    else if (n == "band_split_launches") *value = c->band_split_launches;
     else if (n == "comm_bytes") *value = c->comm ? c->comm->bytes_broadcast : 0;
     else if (n == "comm_blobs") *value = c->comm ? c->comm->blobs_broadcast : 0;
     else if (n == "comm_world") *value = c->comm ? c->comm->world : 0;
@@ -1263,6 +1268,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "small_rows must be 0..65536");
         drop_graphs(c);
         c->small_rows = (int)value;
+    } else if (n == "small_rows_band") {
+        if (value < 0 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "small_rows_band must be 0..65536");
+        drop_graphs(c);
+        c->small_rows_band = (int)value;
     } else if (n == "f32_engine") {
         if (value < -1 || value > 1) return fail(c, CSI_ERR_INVALID_ARG, "f32_engine must be -1 (automatic), 0 (fp32 MFMA) or 1 (split f16)");
         drop_graphs(c);
@@ -1279,6 +1288,11 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
                                                 "2 (bf16 contexts: also the form with per-lane loads, any nt) or 3 (fp32 contexts: only that form; A/B runs)");
         drop_graphs(c);
         c->hs_band = (int)value;
+    } else if (n == "band_split") {
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(c, CSI_ERR_INVALID_ARG, "band_split must be -1 (automatic), 0 / 1 (never) or 2 / 4 (column splits of every band)");
+        drop_graphs(c);
+        c->band_split = (int)value;
     } else if (n == "hs_min_blocks") {
         if (value < 1 || value > 65536) return fail(c, CSI_ERR_INVALID_ARG, "hs_min_blocks must be 1..65536");
         drop_graphs(c);

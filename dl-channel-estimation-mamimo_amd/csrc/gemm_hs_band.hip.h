@@ -56,6 +56,14 @@ struct Band8Args {
     unsigned nt_magic;           // floor(2^32 / nt): row -> (pair row, tx antenna) by multiplication
 };
 static_assert(sizeof(Band8Args) == 128, "Band8Args is read by s_load_dwordx16 x 2");
+// the column-split form ("csi_band8_cs", grid (bands, splits)): the same record describing split 0 - N1 = the hidden features ONE split
+// computes - followed by the base of the partial outputs of splits 1 .. ([splits - 1][M][ldo] fp32)
+struct Band8ArgsCs {
+    Band8Args a;
+    float* part;
+    unsigned long long pad;
+};
+static_assert(sizeof(Band8ArgsCs) == 144, "Band8ArgsCs: s_load_dwordx16 x 2 + s_load_dwordx2 at 0x80");
 constexpr int BAND8_THREADS = 512;
 constexpr int BAND8_MAX_N1 = 4096;
 
@@ -73,6 +81,15 @@ inline bool band8_serves(const BandArgs& g, bool bf16 = false) {
     return g.K1 >= (bf16 ? 256 : 128) && (g.K1 % (bf16 ? 128 : 64)) == 0 && g.N1 >= 256 && (g.N1 % 256) == 0 && g.N1 <= BAND8_MAX_N1 && g.n2 >= 1 && g.n2 <= 256 &&
            g.nt >= 1 && (unsigned long long)g.M * (unsigned long long)g.nt < 0xffffffffull && (unsigned long long)g.M * g.ldo * 4ull < 0xffffffffull &&
            (unsigned long long)((g.M + g.nt - 1) / g.nt) * g.ldl * 4ull < 0x7fffffffull;
+}
+
+// out[i] += part[0][i] + part[1][i] + ... in split order (the regressor sums of the column-split band kernel; split 0 wrote out with the bias)
+__global__ void band_split_sum_kernel(float* __restrict__ out, const float* __restrict__ part, size_t n, size_t stride, int extra) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = out[i];
+        for (int s = 0; s < extra; ++s) v += part[(size_t)s * stride + i];
+        out[i] = v;
+    }
 }
 
 // position p of a 16-k group of the permuted regressor weights holds original k-column hs_band_kperm(p)

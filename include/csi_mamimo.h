@@ -249,7 +249,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         rx preambles) - the reference's literal one-packet predict, DNN.py:339-346, and its small multiples - runs BOTH
  *                         component models in 1 + n_hidden launches: layer 0 as one weight-streaming kernel (up to 8 preambles) or on
  *                         fp32-MFMA tiles, every layer behind it as 16 x 16 / 32 x 32 fp32-MFMA tiles over the whole K, no split-K slabs
- *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it)
+ *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it).
+ *                         "small_rows_band" (default 512 = 4 packets of that shape): the limit where the column-split band kernel serves
+ *                         the model ("band_split": two hidden layers, 16 <= Nt <= 128, hidden[1] a multiple of 512) - from there
+ *                         on the general path with that kernel is the faster one
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
  *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
@@ -296,6 +299,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         32 <= nt <= 64 (streamed form); 0: the separate kernels (A/B runs); 2: bf16 contexts take the per-lane form
  *                         at any other nt as well (measured slower than the separate kernels); 3: only the per-lane forms (A/B runs).
  *                         Read-only: "band_launches".
+ *   "band_split"       -1 (default): a call with fewer bands of 128 pair rows than the part has CUs (24 ... 64 packets of the shipped
+ *                         shape) splits every band's hidden features over 2 or 4 workgroups ("csi_band8_cs") and adds their regressor
+ *                         sums in split order - same arithmetic, the final fp32 sums associate differently (1 ulp class);
+ *                         0 / 1: never; 2 / 4: always (A/B runs, tests).  Read-only: "band_split_launches".
  *   "hs_vm_cast", "hs_vm_pair"  vector-memory schedule of the split-f16 layer-0 / first per-pair kernel: 0 builtin LDS-DMA
  *                         with one drain per sub-tile, 1 hand-counted waits, 2 + one more sub-tile of look-ahead (default for
  *                         layer 0), 3 + one load and one 24-MFMA segment per sub-tile (default for the pair layer); same

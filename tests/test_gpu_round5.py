@@ -46,6 +46,7 @@ def test_small_call_path_matches_oracle_and_general_kernels(pkg, oracle, nt, nr,
     ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, use_bn, n_out)
     assert e.get_option('small_fused') == 1
+    e.set_option('small_rows_band', 65536)     # (the shipped model beyond 512 pair rows goes to the column-split band kernel by default: test below)
     n0 = e.get_option('small_calls')
     o_re, o_im = e.predict(ltf)
     assert e.get_option('small_calls') == n0 + 1, 'a call of %d preambles must take the one-packet path' % (npkt * nr)
@@ -117,6 +118,81 @@ def test_500_packet_call_of_the_pipeline(pkg, oracle):
         r_ls = oracle.ls_estimate(ltf[sel], P)
         assert rel_rows(np.concatenate([h[sel].real, h[sel].imag], -1), np.concatenate([r_ls.real, r_ls.imag], -1)) < TOL
         e.close()
+
+
+BAND_SPLIT_CASES = [
+    # nt, nr, npkt, hidden, forced engine
+    (32, 4, 24, (1024, 1024), 0),      # 24 bands per model: the automatic mode takes 4 splits
+    (32, 4, 64, (1024, 1024), 0),      # 64 bands: 2 splits (two models in flight fill the 256 CUs)
+    (24, 2, 37, (256, 1024), 1),       # 1776 rows = 13.9 bands (ragged last band), K1 = 256, pair rows straddle band boundaries
+    (16, 2, 9, (128, 512), 1),         # N1 = 512: 2 splits at most; K1 = 128 = the shortest stage 1 the kernel serves
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden,engine', BAND_SPLIT_CASES)
+def test_column_split_band_kernel(pkg, oracle, nt, nr, npkt, hidden, engine):
+    """"band_split" (csi_band8_cs + band_split_sum_kernel): every band's hidden features over 2 / 4 workgroups - against the fp64 oracle at
+    the contract, against the unsplit kernel to the rounding of the final fp32 sums, run-to-run bit-identical (the partial sums are
+    added in split order), and the automatic mode takes it exactly where the bands leave CUs idle."""
+    rng = np.random.default_rng(7000 + nt + npkt)
+    w_re, w_im = _weights(oracle, 99 + nt, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=5.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    if engine:
+        e.set_option('f32_engine', engine)
+    sel = sorted(set([0, npkt // 3, npkt - 1]))
+    r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    e.set_option('band_split', 0)
+    u_re, u_im = e.predict(ltf)
+    assert e.get_option('band_launches') > 0 and e.get_option('band_split_launches') == 0
+    assert rel_rows(u_re[sel], r_re) < TOL and rel_rows(u_im[sel], r_im) < TOL
+    for sp in (2, 4):
+        e.set_option('band_split', sp)
+        n0 = e.get_option('band_split_launches')
+        o_re, o_im = e.predict(ltf)
+        assert e.get_option('band_split_launches') == n0 + 2, 'both component models take the split kernel'
+        assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL
+        assert rel_rows(o_re, u_re) < 2e-6 and rel_rows(o_im, u_im) < 2e-6
+        p_re, p_im = e.predict(ltf)
+        assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im), 'run-to-run identical'
+    e.set_option('band_split', -1)
+    n0 = e.get_option('band_split_launches')
+    a_re, a_im = e.predict(ltf)
+    assert e.get_option('band_split_launches') > n0, 'at most 64 bands per model: CUs would idle without the split'
+    assert rel_rows(a_re[sel], r_re) < TOL and rel_rows(a_im[sel], r_im) < TOL
+    e.close()
+
+
+def test_default_routing_of_small_calls_of_the_shipped_model(pkg, oracle):
+    """Nt = 32, Nr = 4, FC 1024 x 1024: up to 4 packets (512 pair rows) the one-packet path, from 5 packets the general path with the
+    column-split band kernel (measured faster from there, profiles/r05_band_split_probe.txt) - each against the fp64 oracle."""
+    nt, nr, hidden = 32, 4, (1024, 1024)
+    w_re, w_im = _weights(oracle, 1234, nt, hidden)
+    P = oracle.hadamard(nt)
+    rng = np.random.default_rng(12)
+    ltf = oracle.make_structured_packets(rng, 8, nr, P, snr_db=0.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    for npkt, small in ((1, True), (4, True), (5, False), (8, False)):
+        s0, b0 = e.get_option('small_calls'), e.get_option('band_split_launches')
+        o_re, o_im = e.predict(ltf[:npkt])
+        assert (e.get_option('small_calls') == s0 + 1) == small and (e.get_option('band_split_launches') == b0 + 2) == (not small), npkt
+        r_re, r_im = oracle.predict_packets(ltf[:npkt], P, w_re, w_im, np.float64, pkt_batch=npkt)
+        assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL, npkt
+    e.close()
+
+
+def test_column_split_is_not_taken_by_full_size_calls(pkg, oracle):
+    """256 packets = 256 bands per model: no split (a split would only add the partial-sum pass)."""
+    nt, nr, hidden, npkt = 32, 4, (1024, 1024), 256
+    w_re, w_im = _weights(oracle, 1234, nt, hidden)
+    P = oracle.hadamard(nt)
+    rng = np.random.default_rng(11)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=0.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.predict(ltf)
+    assert e.get_option('band_launches') > 0 and e.get_option('band_split_launches') == 0
+    e.close()
 
 
 def test_estimate_c64_is_bit_identical_with_the_c128_call(pkg, oracle):
