@@ -743,6 +743,7 @@ def regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt_resident, ls=True):
             call()
         eng.synchronize()
         hs0 = eng.get_option('hs_launches')
+        ls0 = eng.get_option('l0_stream_launches')
         lat = []
         for _ in range(30):
             t0 = time.perf_counter()
@@ -759,7 +760,8 @@ def regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt_resident, ls=True):
         hs_per_call = (eng.get_option('hs_launches') - hs0) / 130.0
         split = hs_per_call > 0
         # 2 split-engine launches per call = the band kernel of each component model only: layer 0 ran on the fp32 MFMA kernels
-        mixed = split and len(hidden) == 2 and hs_per_call < 3
+        streamed = eng.get_option('l0_stream_launches') > ls0        # layer 0 on the weight-streaming split-f16 kernel
+        mixed = split and len(hidden) == 2 and hs_per_call < 3 and not streamed
         eng.profile_enable(True); eng.profile_reset()
         call(); eng.synchronize()
         prof = {k: round(v['ms'] * 1e3, 1) for k, v in eng.profile().items() if v['launches']}
@@ -779,7 +781,8 @@ def regimes(pkg, eng, nt, nr, hidden, d_re, d_im, npkt_resident, ls=True):
                                                          '2500/3 TFLOP/s (split-f16 engine)' if split else '157.3 TFLOP/s (fp32 MFMA kernels)'), t_f + t_ls
         t_lat, t_pip = float(np.median(lat)), float(np.median(pip))
         res.append({'packets': n, 'pairs': pairs, 'latency_us': round(t_lat * 1e6, 1), 'pipelined_us': round(t_pip * 1e6, 1),
-                    'pairs_per_s': pairs / t_pip, 'engine': 'fp32 MFMA layer 0 + split-f16 band kernel' if mixed else ('split-f16' if split else 'fp32 MFMA'),
+                    'pairs_per_s': pairs / t_pip, 'engine': 'fp32 MFMA layer 0 + split-f16 band kernel' if mixed else
+                    ('split-f16 (weight-streaming layer 0 + column-split band kernel)' if streamed else ('split-f16' if split else 'fp32 MFMA')),
                     'bound': bound, 'bound_us': round(t_b * 1e6, 2), 'frac_of_bound': round(t_b / t_pip, 4), 'frac_of_bound_latency': round(t_b / t_lat, 4),
                     'kernels_us_one_call_with_events': prof})
         del o

@@ -16,6 +16,7 @@
 #include "gemm_bf16.hip.h"
 #include "gemm_hs.hip.h"
 #include "gemm_hs_band.hip.h"
+#include "l0_hs_stream.hip.h"
 #include "ls_estimate.hip.h"
 #include "lmmse.hip.h"
 #include "metrics.hip.h"
@@ -84,6 +85,7 @@ struct Model {
     int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
     float* T_sw = nullptr;       // T (bf16 contexts) / T_hs (split engine) in the slab order of the staged band kernels (band_tsw_kernel); rebuilt with the table
     bool T_sw_ok = false;
+    float* l0_rowmax = nullptr;  // [256] row maxima of a mid-size call's preambles (l0_row_max_kernel -> l0_hs_stream_kernel)
     bool loaded = false;
     bool table_ok = false;
     // csi_load_weights measures how well the split-f16 copies represent the fp32 matrices: the weight scale comes from max |w| of a
@@ -157,8 +159,12 @@ struct csi_ctx {
     int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
     int small_rows = 1024;       // "small_rows": pair rows up to which a call takes it (and at most 64 preambles).  Measured (profiles/r05_regime_probe.txt):
                                  // 4 packets 117 us against 143 on the general kernels, 8 packets 162 / 170, 12 packets 251 / 246, 16 packets 283 / 252
-    int small_rows_band = 512;   // "small_rows_band": the same limit where the column-split band kernel serves the model (csi_dnn_hs.hpp: the general
-                                 // path with it takes 136 us at 5 ... 8 packets against 155-161 here; at 4 packets 135 against 117)
+    int l0_stream = 1;           // "l0_stream": layer 0 of a call of 9 ... 256 rx preambles on the weight-streaming split-f16 kernel (l0_hs_stream.hip.h)
+    int l0_stream_ks = 0;        // "l0_stream_ks": its k ranges (0 = automatic: ~256 workgroups per component model up to 64 preambles, ~128 beyond)
+    int64_t l0_stream_launches = 0;
+    int l0_stream_prepass_rows = 64;   // "l0_stream_prepass_rows": beyond this many preambles the row scales come from l0_row_max_kernel
+    int small_rows_band = 256;   // "small_rows_band": the same limit where the column-split band kernel serves the model (csi_dnn_hs.hpp): the general
+                                 // path with it and the weight-streaming layer 0 takes 102 us at 3 ... 5 packets against 117-121 here (2 packets: 111 / 61)
     bool in_host_pipeline = false;   // a chunk of a host-buffer entry point is being enqueued: no second-stream fork inside (measured: the
                                  // two-stream arrangement costs the PCIe-bound pipeline 6 % - profiles/r05_regime_probe.txt)
     int64_t small_calls = 0;     // "small_calls": calls that took it
@@ -191,7 +197,7 @@ struct csi_ctx {
     int hs_act_shift = HS_SHIFT_AUTO;        // split-f16: hidden activations are carried times 2^hs_act_shift (|h| < 65504 / 2^shift)
     float* hs_zero = nullptr;    // zeros, widest hidden layer: the BN shift the split-engine kernels see (it lives in the next layer's bias)
     unsigned* hs_peak = nullptr; // device word: range guard of the split engine (gemm_hs.hip.h), 0 = no operand came near the f16 limit
-    size_t hs_lds_attr[14] = {};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out) / pair + fused regressor
+    size_t hs_lds_attr[20] = {};   // dynamic-LDS limit already raised on this context's device: layer 0 / pair (hs out) / pair (fp32 out) / pair + fused regressor
     int64_t hs_launches = 0;     // split-engine GEMMs launched so far / at the last range check
     int64_t hs_checked = 0;
     int64_t hs_range_fallbacks = 0;
@@ -421,7 +427,8 @@ void free_model(Model& m) {
     if (m.T) hipFree(m.T);
     if (m.T_hs) hipFree(m.T_hs);
     if (m.T_sw) hipFree(m.T_sw);
-    m.W0p = m.T = m.T_hs = m.T_sw = nullptr;
+    if (m.l0_rowmax) hipFree(m.l0_rowmax);
+    m.W0p = m.T = m.T_hs = m.T_sw = m.l0_rowmax = nullptr;
     m.T_sw_ok = false;
     m.T_hs_shift = HS_SHIFT_AUTO;
     m.loaded = m.table_ok = false;

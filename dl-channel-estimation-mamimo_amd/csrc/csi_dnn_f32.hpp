@@ -190,6 +190,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         int kps_tmp;
         splits_max = choose_splits((int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp);
         if (hs_ok) splits_max = std::max(splits_max, hs_layer0_splits(c, (int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp));
+        if (hs_ok) splits_max = std::max(splits_max, l0_stream_splits(c, m, (int)std::min<int64_t>(chunk * nr, 1 << 30), h1, cf.len_ltf, &kps_tmp));
         const size_t need = ((size_t)nr * h1 * 4 * (splits_max > 1 ? splits_max + 1 : 1) + hid_pkt) * (size_t)chunk;
         if ((need <= budget && chunk <= max_rows) || chunk == 1) break;
         nchunks = std::max(nchunks + 1, (int64_t)((double)nchunks * (double)need / (double)budget));
@@ -200,6 +201,7 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
         if (tail > 0 && tail != chunk) {
             splits_max = std::max(splits_max, choose_splits((int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
             if (hs_ok) splits_max = std::max(splits_max, hs_layer0_splits(c, (int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
+            if (hs_ok) splits_max = std::max(splits_max, l0_stream_splits(c, m, (int)(tail * nr), h1, cf.len_ltf, &kps_tmp));
         }
     }
     const size_t slab_floats = (size_t)chunk * nr * h1;
@@ -243,13 +245,20 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
             l0 = sum;
         }
         int kps = 0;
+        // 9 ... 256 preambles: the weight-streaming kernel of the split engine (l0_hs_stream.hip.h), k ranges summed below
+        const int stream_splits = (hs_ok && !l0) ? l0_stream_splits(c, m, M1, h1, cf.len_ltf, &kps) : 0;
+        if (stream_splits) {
+            rc = l0_stream_launch(c, m, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps, stream_splits, slabs);
+            if (rc) return rc;
+            l0 = slabs;
+        }
         const int hs_splits = (hs_ok && !l0) ? hs_layer0_splits(c, M1, h1, cf.len_ltf, &kps) : 0;
         if (hs_splits) {
             rc = hs_launch_layer0(c, m, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps, hs_splits, slabs);
             if (rc) return rc;
             l0 = slabs;
         }
-        const int splits = hs_splits ? hs_splits : (l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps));
+        const int splits = stream_splits ? stream_splits : (hs_splits ? hs_splits : (l0 ? 1 : choose_splits(M1, h1, cf.len_ltf, &kps)));
         GemmArgs g{};
         g.A = d_ltf + (size_t)p0 * nr * cf.len_ltf;
         g.lda = cf.len_ltf;

@@ -81,6 +81,52 @@ int hs_dynamic_lds(csi_ctx* c, Kern kern, size_t bytes, size_t* have) {
     return CSI_OK;
 }
 
+// Layer 0 of a mid-size call on the weight-streaming kernel (l0_hs_stream.hip.h): the number of k ranges, 0 = the call is not its
+// (at most 8 preambles: layer0_skinny_kernel / the one-packet path; more than 256: the 256 x 256 kernels have enough row tiles)
+int l0_stream_splits(const csi_ctx* c, const Model& m, int M1, int h1, int K, int* k_per_split) {
+    if (c->hs_in_shift != HS_SHIFT_AUTO) return 0;        // a fixed input scale ("hs_in_shift") addresses the kernels that take one scale per launch
+    if (!c->l0_stream || M1 <= 8 || M1 > 256 || (K % L0S_KC) != 0 || K < 2 * L0S_KC || c->force_pair_tile || !m.layers[0].Wh) return 0;
+    const int groups = (h1 + L0S_COLS - 1) / L0S_COLS;
+    int ks = c->l0_stream_ks > 0 ? c->l0_stream_ks : std::max(1, (M1 <= 128 ? 256 : 128) / groups);
+    ks = std::max(1, std::min(ks, K / (2 * L0S_KC)));                 // at least two chunks per range
+    const int kps = ((K + ks - 1) / ks + L0S_KC - 1) / L0S_KC * L0S_KC;
+    *k_per_split = kps;
+    return (K + kps - 1) / kps;
+}
+
+int l0_stream_launch(csi_ctx* c, Model& m, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
+    const Layer& l0 = m.layers[0];
+    L0StreamArgs a{};
+    a.x = x; a.Wh = l0.Wh; a.slabs = slabs;
+    a.M = M1; a.N = h1; a.K = K; a.lda = ldx; a.ldwh = l0.ldwh; a.kps = kps; a.wshift = l0.wshift;
+    const int rt = (M1 + 31) / 32;
+    const dim3 grid((unsigned)((h1 + L0S_COLS - 1) / L0S_COLS), (unsigned)splits);
+    ++c->l0_stream_launches;
+    if (M1 > c->l0_stream_prepass_rows) {
+        // row maxima over the whole K by their own small kernel (beyond 64 preambles cheaper than the first pass of every workgroup)
+        if (!m.l0_rowmax && hipMalloc((void**)&m.l0_rowmax, 256 * sizeof(float)) != hipSuccess)
+            return fail(c, CSI_ERR_NOMEM, "device allocation of the row maxima failed");
+        hipLaunchKernelGGL(l0_row_max_kernel, dim3((unsigned)M1), dim3(256), 0, c->stream, x, ldx, K, m.l0_rowmax);
+        HIP_TRY(c, hipGetLastError());
+        a.row_max = m.l0_rowmax;
+    }
+    ProfScope ps(c, K_LAYER0_LTF, 2.0 * (double)M1 * h1 * K, 4.0 * ((double)M1 * K + (double)h1 * K + (double)M1 * h1 * splits));
+    auto go = [&](auto kern, int rtt, size_t* attr) {
+        const size_t lds = l0s_lds_bytes(rtt);
+        int rc = hs_dynamic_lds(c, kern, lds, attr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+        return (int)CSI_OK;
+    };
+    if (rt <= 1) return go(l0_hs_stream_kernel<1>, 1, &c->hs_lds_attr[14]);
+    if (rt <= 2) return go(l0_hs_stream_kernel<2>, 2, &c->hs_lds_attr[15]);
+    if (rt <= 3) return go(l0_hs_stream_kernel<3>, 3, &c->hs_lds_attr[16]);
+    if (rt <= 4) return go(l0_hs_stream_kernel<4>, 4, &c->hs_lds_attr[17]);
+    if (rt <= 6) return go(l0_hs_stream_kernel<6>, 6, &c->hs_lds_attr[18]);
+    return go(l0_hs_stream_kernel<8>, 8, &c->hs_lds_attr[19]);
+}
+
 // layer 0: slabs[z][M1][h1] = (X[M1][K] * W0[0:K, :]) over k range z, X converted inside the kernel
 int hs_launch_layer0(csi_ctx* c, const Model& m, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
     const Layer& l0 = m.layers[0];

@@ -21,8 +21,9 @@ bool small_call_ok(csi_ctx* c, int64_t npkt) {
     if (npkt * cf.nr * cf.nt > c->small_rows || npkt * cf.nr > 64) return false;
     for (int d = 0; d < 2; ++d)
         if (!c->model[d].loaded || !c->model[d].table_ok || !c->model[d].layers[0].Wt) return false;
-    // where the column-split band kernel serves the model the general path wins from 5 packets of the shipped shape on (136 us against
-    // 155 here; 4 packets: 135 against 117 - profiles/r05_band_split_probe.txt): this path keeps the calls of at most "small_rows_band" rows
+    // where the column-split band kernel serves the model the general path (weight-streaming layer 0 + that kernel) wins from 3 packets of
+    // the shipped shape on (102 us against 121 here; 2 packets: 111 against 61 - profiles/r05_band_split_probe.txt): this path keeps the
+    // calls of at most "small_rows_band" rows
     if (npkt * cf.nr * cf.nt > c->small_rows_band && c->f32_engine != 0 && hs_static_ok(c, c->model[0]) && hs_static_ok(c, c->model[1]) &&
         band_split_static_ok(c, c->model[0]) && band_split_static_ok(c, c->model[1]))
         return false;

@@ -1185,6 +1185,10 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band_launches") *value = c->band_launches;
     else if (n == "band_split") *value = c->band_split;
+    else if (n == "l0_stream") *value = c->l0_stream;
+    else if (n == "l0_stream_ks") *value = c->l0_stream_ks;
+    else if (n == "l0_stream_prepass_rows") *value = c->l0_stream_prepass_rows;
+    else if (n == "l0_stream_launches") *value = c->l0_stream_launches;
     else if (n == "band_split_launches") *value = c->band_split_launches;
     else if (n == "comm_bytes") *value = c->comm ? c->comm->bytes_broadcast : 0;
     else if (n == "comm_blobs") *value = c->comm ? c->comm->blobs_broadcast : 0;
@@ -1288,6 +1292,17 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
                                                 "2 (bf16 contexts: also the form with per-lane loads, any nt) or 3 (fp32 contexts: only that form; A/B runs)");
         drop_graphs(c);
         c->hs_band = (int)value;
+    } else if (n == "l0_stream") {
+        drop_graphs(c);
+        c->l0_stream = value != 0;
+    } else if (n == "l0_stream_prepass_rows") {
+        if (value < 0 || value > 256) return fail(c, CSI_ERR_INVALID_ARG, "l0_stream_prepass_rows must be 0..256");
+        drop_graphs(c);
+        c->l0_stream_prepass_rows = (int)value;
+    } else if (n == "l0_stream_ks") {
+        if (value < 0 || value > 256) return fail(c, CSI_ERR_INVALID_ARG, "l0_stream_ks must be 0 (automatic) .. 256");
+        drop_graphs(c);
+        c->l0_stream_ks = (int)value;
     } else if (n == "band_split") {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
             return fail(c, CSI_ERR_INVALID_ARG, "band_split must be -1 (automatic), 0 / 1 (never) or 2 / 4 (column splits of every band)");

@@ -250,9 +250,14 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         component models in 1 + n_hidden launches: layer 0 as one weight-streaming kernel (up to 8 preambles) or on
  *                         fp32-MFMA tiles, every layer behind it as 16 x 16 / 32 x 32 fp32-MFMA tiles over the whole K, no split-K slabs
  *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it).
- *                         "small_rows_band" (default 512 = 4 packets of that shape): the limit where the column-split band kernel serves
+ *                         "small_rows_band" (default 256 = 2 packets of that shape): the limit where the column-split band kernel serves
  *                         the model ("band_split": two hidden layers, 16 <= Nt <= 128, hidden[1] a multiple of 512) - from there
- *                         on the general path with that kernel is the faster one
+ *                         on the general path (weight-streaming layer 0 + that kernel) is the faster one
+ *   "l0_stream"        1 (default): layer 0 of a call of 9 ... 256 rx preambles runs on the weight-streaming split-f16 kernel
+ *                         (csrc/l0_hs_stream.hip.h: every preamble row scaled by its own power of two, no range guard needed);
+ *                         0: the general kernels.  "l0_stream_ks": its k ranges (0 = automatic); "l0_stream_prepass_rows": beyond
+ *                         this many preambles (default 64) the row maxima come from their own small kernel.
+ *                         Read-only: "l0_stream_launches"
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
  *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,

@@ -136,8 +136,12 @@ def test_column_split_band_kernel(pkg, oracle, nt, nr, npkt, hidden, engine):
     added in split order), and the automatic mode takes it exactly where the bands leave CUs idle."""
     rng = np.random.default_rng(7000 + nt + npkt)
     w_re, w_im = _weights(oracle, 99 + nt, nt, hidden)
-    P = oracle.hadamard(nt)
-    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=5.0)[0].astype(np.complex64)
+    if nt & (nt - 1):                              # Nt not a power of two: a general pilot matrix, white preambles
+        P = _pilot(rng, nt, orthogonal=False)
+        ltf = (rng.standard_normal((npkt, nr, 320 * nt)) + 1j * rng.standard_normal((npkt, nr, 320 * nt))).astype(np.complex64)
+    else:
+        P = oracle.hadamard(nt)
+        ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=5.0)[0].astype(np.complex64)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
     if engine:
         e.set_option('f32_engine', engine)
@@ -165,20 +169,67 @@ def test_column_split_band_kernel(pkg, oracle, nt, nr, npkt, hidden, engine):
 
 
 def test_default_routing_of_small_calls_of_the_shipped_model(pkg, oracle):
-    """Nt = 32, Nr = 4, FC 1024 x 1024: up to 4 packets (512 pair rows) the one-packet path, from 5 packets the general path with the
-    column-split band kernel (measured faster from there, profiles/r05_band_split_probe.txt) - each against the fp64 oracle."""
+    """Nt = 32, Nr = 4, FC 1024 x 1024: up to 2 packets (256 pair rows, 8 preambles) the one-packet path, from 3 packets the general path
+    with the weight-streaming layer 0 and the column-split band kernel (measured faster from there, profiles/r05_band_split_probe.txt) -
+    each against the fp64 oracle."""
     nt, nr, hidden = 32, 4, (1024, 1024)
     w_re, w_im = _weights(oracle, 1234, nt, hidden)
     P = oracle.hadamard(nt)
     rng = np.random.default_rng(12)
     ltf = oracle.make_structured_packets(rng, 8, nr, P, snr_db=0.0)[0].astype(np.complex64)
     e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
-    for npkt, small in ((1, True), (4, True), (5, False), (8, False)):
+    for npkt, small in ((1, True), (2, True), (3, False), (8, False)):
         s0, b0 = e.get_option('small_calls'), e.get_option('band_split_launches')
         o_re, o_im = e.predict(ltf[:npkt])
         assert (e.get_option('small_calls') == s0 + 1) == small and (e.get_option('band_split_launches') == b0 + 2) == (not small), npkt
         r_re, r_im = oracle.predict_packets(ltf[:npkt], P, w_re, w_im, np.float64, pkt_batch=npkt)
         assert rel_rows(o_re, r_re) < TOL and rel_rows(o_im, r_im) < TOL, npkt
+    e.close()
+
+
+L0_STREAM_CASES = [
+    # nt, nr, npkt, hidden: M1 = npkt * nr rx preambles
+    (32, 4, 3, (1024, 1024)),      # 12 preambles: one ragged row tile, the in-kernel first pass
+    (32, 4, 8, (1024, 1024)),      # 32: exactly one row tile
+    (32, 3, 11, (1024, 1024)),     # 33: two row tiles, the second one row
+    (32, 4, 24, (1024, 1024)),     # 96: three row tiles, row maxima from l0_row_max_kernel
+    (32, 4, 64, (1024, 1024)),     # 256: the largest call the kernel takes
+    (16, 2, 21, (208, 512)),       # K = 5120, N = 208: the second column group is ragged (80 columns), 42 preambles
+    (64, 1, 9, (128, 512)),        # Nt = 64: K = 20480
+]
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', L0_STREAM_CASES)
+def test_layer0_weight_streaming_kernel(pkg, oracle, nt, nr, npkt, hidden):
+    """l0_hs_stream_kernel (+ l0_row_max_kernel beyond 64 preambles): layer 0 of a mid-size call on the split-f16 path with per-row input
+    scales - against the fp64 oracle at the contract, against the general kernels ("l0_stream" = 0), run-to-run bit-identical; and with
+    rows of wildly different magnitude (1e-6 ... 1e6 in ONE call), which a single per-launch scale could not hold."""
+    rng = np.random.default_rng(8000 + nt + npkt)
+    w_re, w_im = _weights(oracle, 77 + nt, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=3.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    e.set_option('small_rows_band', 0)                  # (12 preambles of the shipped shape: the general path, not the one-packet one)
+    e.set_option('small_fused', 0)
+    sel = sorted(set([0, npkt // 2, npkt - 1]))
+    r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    n0 = e.get_option('l0_stream_launches')
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('l0_stream_launches') == n0 + 2, 'both component models take the kernel'
+    assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL
+    p_re, p_im = e.predict(ltf)
+    assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im), 'run-to-run identical'
+    e.set_option('l0_stream', 0)
+    g_re, g_im = e.predict(ltf)
+    assert e.get_option('l0_stream_launches') == n0 + 4
+    assert rel_rows(o_re, g_re) < 5e-6 and rel_rows(o_im, g_im) < 5e-6
+    e.set_option('l0_stream', 1)
+    # every (packet, rx) preamble at its own magnitude
+    mag = (10.0 ** rng.uniform(-6, 6, size=(npkt, nr, 1))).astype(np.float32)
+    wide = (ltf * mag).astype(np.complex64)
+    w_o_re, w_o_im = e.predict(wide)
+    rw_re, rw_im = oracle.predict_packets(wide[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    assert rel_rows(w_o_re[sel], rw_re) < TOL and rel_rows(w_o_im[sel], rw_im) < TOL
     e.close()
 
 
