@@ -85,7 +85,7 @@ struct Model {
     int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
     float* T_sw = nullptr;       // T (bf16 contexts) / T_hs (split engine) in the slab order of the staged band kernels (band_tsw_kernel); rebuilt with the table
     bool T_sw_ok = false;
-    float* l0_rowmax = nullptr;  // [256] row maxima of a mid-size call's preambles (l0_row_max_kernel -> l0_hs_stream_kernel)
+    float* l0_rowmax = nullptr;  // [4096] row maxima of a mid-size call's preambles (l0_row_max_kernel -> l0_hs_stream_kernel)
     bool loaded = false;
     bool table_ok = false;
     // csi_load_weights measures how well the split-f16 copies represent the fp32 matrices: the weight scale comes from max |w| of a
@@ -162,6 +162,8 @@ struct csi_ctx {
     int l0_stream = 1;           // "l0_stream": layer 0 of a call of 9 ... 256 rx preambles on the weight-streaming split-f16 kernel (l0_hs_stream.hip.h)
     int l0_stream_ks = 0;        // "l0_stream_ks": its k ranges (0 = automatic: ~256 workgroups per component model up to 64 preambles, ~128 beyond)
     int64_t l0_stream_launches = 0;
+    int l0_stream_max_rows = 1280;     // "l0_stream_max_rows": the largest call (rx preambles) the kernel takes (<= 4096), beyond 256 in row blocks (gridDim.z).
+                                       // Measured (profiles/r05_band_split_probe.txt): 128 packets 400 -> 323 us, 256: 693 -> 595, 320: 862 -> 790; 500 packets 1108 -> 1134 (not taken)
     int l0_stream_prepass_rows = 64;   // "l0_stream_prepass_rows": beyond this many preambles the row scales come from l0_row_max_kernel
     int small_rows_band = 256;   // "small_rows_band": the same limit where the column-split band kernel serves the model (csi_dnn_hs.hpp): the general
                                  // path with it and the weight-streaming layer 0 takes 102 us at 3 ... 5 packets against 117-121 here (2 packets: 111 / 61)

@@ -85,9 +85,10 @@ int hs_dynamic_lds(csi_ctx* c, Kern kern, size_t bytes, size_t* have) {
 // (at most 8 preambles: layer0_skinny_kernel / the one-packet path; more than 256: the 256 x 256 kernels have enough row tiles)
 int l0_stream_splits(const csi_ctx* c, const Model& m, int M1, int h1, int K, int* k_per_split) {
     if (c->hs_in_shift != HS_SHIFT_AUTO) return 0;        // a fixed input scale ("hs_in_shift") addresses the kernels that take one scale per launch
-    if (!c->l0_stream || M1 <= 8 || M1 > 256 || (K % L0S_KC) != 0 || K < 2 * L0S_KC || c->force_pair_tile || !m.layers[0].Wh) return 0;
+    if (!c->l0_stream || M1 <= 8 || M1 > c->l0_stream_max_rows || (K % L0S_KC) != 0 || K < 2 * L0S_KC || c->force_pair_tile || !m.layers[0].Wh) return 0;
     const int groups = (h1 + L0S_COLS - 1) / L0S_COLS;
-    int ks = c->l0_stream_ks > 0 ? c->l0_stream_ks : std::max(1, (M1 <= 128 ? 256 : 128) / groups);
+    const int blocks = (M1 + 255) / 256;                              // row blocks (gridDim.z)
+    int ks = c->l0_stream_ks > 0 ? c->l0_stream_ks : std::max(1, (M1 <= 128 ? 256 : 128) / (groups * blocks));
     ks = std::max(1, std::min(ks, K / (2 * L0S_KC)));                 // at least two chunks per range
     const int kps = ((K + ks - 1) / ks + L0S_KC - 1) / L0S_KC * L0S_KC;
     *k_per_split = kps;
@@ -99,12 +100,14 @@ int l0_stream_launch(csi_ctx* c, Model& m, const float* x, int ldx, int M1, int 
     L0StreamArgs a{};
     a.x = x; a.Wh = l0.Wh; a.slabs = slabs;
     a.M = M1; a.N = h1; a.K = K; a.lda = ldx; a.ldwh = l0.ldwh; a.kps = kps; a.wshift = l0.wshift;
-    const int rt = (M1 + 31) / 32;
-    const dim3 grid((unsigned)((h1 + L0S_COLS - 1) / L0S_COLS), (unsigned)splits);
+    const int blocks = (M1 + 255) / 256;
+    const int rt = ((M1 + 31) / 32 + blocks - 1) / blocks;           // row tiles per workgroup: the row blocks are (nearly) equal
+    const int rt_inst = rt <= 4 ? rt : (rt <= 6 ? 6 : 8);
+    const dim3 grid((unsigned)((h1 + L0S_COLS - 1) / L0S_COLS), (unsigned)splits, (unsigned)((M1 + 32 * rt_inst - 1) / (32 * rt_inst)));
     ++c->l0_stream_launches;
     if (M1 > c->l0_stream_prepass_rows) {
         // row maxima over the whole K by their own small kernel (beyond 64 preambles cheaper than the first pass of every workgroup)
-        if (!m.l0_rowmax && hipMalloc((void**)&m.l0_rowmax, 256 * sizeof(float)) != hipSuccess)
+        if (!m.l0_rowmax && hipMalloc((void**)&m.l0_rowmax, 4096 * sizeof(float)) != hipSuccess)
             return fail(c, CSI_ERR_NOMEM, "device allocation of the row maxima failed");
         hipLaunchKernelGGL(l0_row_max_kernel, dim3((unsigned)M1), dim3(256), 0, c->stream, x, ldx, K, m.l0_rowmax);
         HIP_TRY(c, hipGetLastError());

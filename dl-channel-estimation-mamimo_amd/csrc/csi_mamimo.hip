@@ -1188,6 +1188,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "l0_stream") *value = c->l0_stream;
     else if (n == "l0_stream_ks") *value = c->l0_stream_ks;
     else if (n == "l0_stream_prepass_rows") *value = c->l0_stream_prepass_rows;
+    else if (n == "l0_stream_max_rows") *value = c->l0_stream_max_rows;
     else if (n == "l0_stream_launches") *value = c->l0_stream_launches;
     else if (n == "band_split_launches") *value = c->band_split_launches;
     else if (n == "comm_bytes") *value = c->comm ? c->comm->bytes_broadcast : 0;
@@ -1295,6 +1296,10 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
     } else if (n == "l0_stream") {
         drop_graphs(c);
         c->l0_stream = value != 0;
+    } else if (n == "l0_stream_max_rows") {
+        if (value < 8 || value > 4096) return fail(c, CSI_ERR_INVALID_ARG, "l0_stream_max_rows must be 8..4096");
+        drop_graphs(c);
+        c->l0_stream_max_rows = (int)value;
     } else if (n == "l0_stream_prepass_rows") {
         if (value < 0 || value > 256) return fail(c, CSI_ERR_INVALID_ARG, "l0_stream_prepass_rows must be 0..256");
         drop_graphs(c);

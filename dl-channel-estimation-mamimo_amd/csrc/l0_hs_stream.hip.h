@@ -1,5 +1,5 @@
 // l0_hs_stream.hip.h - layer 0 (the shared LTF product, massiveMIMO_CSI_prediction_DNN.py:211-214 on the columns of the flattened
-// preamble) of a MID-SIZE call - 9 ... 256 rx preambles, i.e. 3 ... 64 packets of the shipped shape - as a weight-streaming kernel on
+// preamble) of a MID-SIZE call - 9 ... 1280 rx preambles, i.e. 3 ... 320 packets of the shipped shape - as a weight-streaming kernel on
 // the split-f16 matrix path.
 //
 // Such a call's layer 0 is bound by streaming the weights once (42 MB per component model at Nt = 32: ~8 us of HBM time); its
@@ -73,7 +73,7 @@ __device__ __forceinline__ int l0s_row_shift(float m) {
     return (bits == 0 || ex == 0xff) ? 0 : max(-100, min(100, 14 - (ex - 126)));      // frexp exponent e = ex - 126: m in [2^(e-1), 2^e)
 }
 
-// RT = row tiles of 32 (M <= 32 RT)
+// RT = row tiles of 32 per workgroup (M <= 32 RT gridDim.z)
 template <int RT>
 __global__ __launch_bounds__(256) void l0_hs_stream_kernel(L0StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char l0s_lds[];
@@ -86,6 +86,13 @@ __global__ __launch_bounds__(256) void l0_hs_stream_kernel(L0StreamArgs a) {
     const int klen = min(a.K, kbeg + a.kps) - kbeg;                                // a multiple of 32 (host)
     const int nchunk = klen / L0S_KC;
     const int n0 = (int)blockIdx.x * L0S_COLS + 32 * wave;
+    // row block blockIdx.z of 32 RT rows (calls of more than 256 preambles: the weights of a (column group, k range) are read once per
+    // row block, from the L2 after the first)
+    const int mrow0 = (int)blockIdx.z * 32 * RT;
+    a.x += (size_t)mrow0 * a.lda;
+    if (a.row_max) a.row_max += mrow0;
+    const int Mtot = a.M;
+    a.M = min(a.M - mrow0, 32 * RT);
 
     // ---- first pass: the largest magnitude of every row inside this k range -> the row's scale.  8 consecutive lanes own a row; the
     // loads of a batch (10 per lane: the 320 k of the shipped split) are all requested before the first is used
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256) void l0_hs_stream_kernel(L0StreamArgs a) {
     // ---- epilogue: D column = lane & 31 (this lane's weight column), D row = 8 (r >> 2) + 4 (lane >> 5) + (r & 3); undo the row's scale
     const int col = n0 + j;
     if (col >= a.N) return;
-    float* out = a.slabs + (size_t)blockIdx.y * a.M * a.N + col;
+    float* out = a.slabs + ((size_t)blockIdx.y * Mtot + mrow0) * a.N + col;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll

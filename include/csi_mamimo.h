@@ -253,7 +253,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         "small_rows_band" (default 256 = 2 packets of that shape): the limit where the column-split band kernel serves
  *                         the model ("band_split": two hidden layers, 16 <= Nt <= 128, hidden[1] a multiple of 512) - from there
  *                         on the general path (weight-streaming layer 0 + that kernel) is the faster one
- *   "l0_stream"        1 (default): layer 0 of a call of 9 ... 256 rx preambles runs on the weight-streaming split-f16 kernel
+ *   "l0_stream"        1 (default): layer 0 of a call of 9 ... "l0_stream_max_rows" (default 1280) rx preambles runs on the weight-streaming split-f16 kernel
  *                         (csrc/l0_hs_stream.hip.h: every preamble row scaled by its own power of two, no range guard needed);
  *                         0: the general kernels.  "l0_stream_ks": its k ranges (0 = automatic); "l0_stream_prepass_rows": beyond
  *                         this many preambles (default 64) the row maxima come from their own small kernel.

@@ -193,7 +193,9 @@ L0_STREAM_CASES = [
     (32, 4, 8, (1024, 1024)),      # 32: exactly one row tile
     (32, 3, 11, (1024, 1024)),     # 33: two row tiles, the second one row
     (32, 4, 24, (1024, 1024)),     # 96: three row tiles, row maxima from l0_row_max_kernel
-    (32, 4, 64, (1024, 1024)),     # 256: the largest call the kernel takes
+    (32, 4, 64, (1024, 1024)),     # 256: the largest call of one row block
+    (32, 4, 80, (1024, 1024)),     # 320: two row blocks of 6 row tiles (192 + 128 rows)
+    (16, 3, 183, (128, 512)),      # 549: three row blocks, the last one ragged (37 rows); K = 5120
     (16, 2, 21, (208, 512)),       # K = 5120, N = 208: the second column group is ragged (80 columns), 42 preambles
     (64, 1, 9, (128, 512)),        # Nt = 64: K = 20480
 ]
