@@ -320,6 +320,9 @@ int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floa
     } else {
         const long in_flight = bands * std::max(c->models_in_flight, 1);
         while (S < 4 && in_flight * (2 * S) <= 256) S *= 2;
+        // a second round of workgroups that is at most a quarter full (129 ... 160 packets of the shipped shape): half-size workgroups
+        // fill it better - 144 packets 502 -> 460 us, 160: 511 -> 476; from 192 packets on the split only costs (profiles/r05_band_split_probe.txt)
+        if (S == 1 && in_flight > 256 && in_flight <= 320) S = 2;
     }
     while (S > 1 && (ba.N1 % (256 * S)) != 0) S >>= 1;
     const unsigned long long part = (unsigned long long)(S - 1) * (unsigned long long)ba.M * (unsigned long long)ba.ldo;
