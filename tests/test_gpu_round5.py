@@ -360,3 +360,37 @@ def test_fuzz_small_call_shapes(pkg, oracle):
         assert rel_rows(o_re, g_re) < 5e-6 and rel_rows(o_im, g_im) < 5e-6, case
         e.close()
         done += 1
+
+
+def test_fuzz_mid_size_calls(pkg, oracle):
+    """Seeded, bounded fuzz of the mid-size routing: random antenna counts, 9 ... 600 rx preambles, hidden widths that do and do not admit
+    the band kernel / its column split - whatever combination of l0_hs_stream_kernel, csi_band8(_cs), the separate split-engine kernels
+    and the fp32 MFMA kernels serves the call, the result meets the contract against the fp64 oracle and repeats bit for bit."""
+    rng = np.random.default_rng(20251001)
+    done, streamed, split = 0, 0, 0
+    while done < 12:
+        nt = int(rng.choice([16, 32, 64]))
+        nr = int(rng.integers(1, 5))
+        npkt = int(rng.integers(3, 160))
+        if not 9 <= npkt * nr <= 600 or npkt * nr * nt > 40000:
+            continue
+        h1 = int(rng.choice([128, 192, 208, 256, 320]))
+        h2 = int(rng.choice([256, 512, 1024, 96]))
+        hidden = (h1, h2)
+        w_re, w_im = _weights(oracle, int(rng.integers(1 << 30)), nt, hidden)
+        P = oracle.hadamard(nt)
+        ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=float(rng.uniform(-10, 20)))[0].astype(np.complex64)
+        e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+        o_re, o_im = e.predict(ltf)
+        case = (nt, nr, npkt, hidden)
+        sel = sorted(set(int(i) for i in rng.integers(0, npkt, 3)) | {0, npkt - 1})
+        r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+        assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL, case
+        p_re, p_im = e.predict(ltf)
+        assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im), case
+        streamed += e.get_option('l0_stream_launches') > 0
+        split += e.get_option('band_split_launches') > 0
+        assert e.get_option('hs_range_fallbacks') == 0, case
+        e.close()
+        done += 1
+    assert streamed >= 6 and split >= 2, (streamed, split)
