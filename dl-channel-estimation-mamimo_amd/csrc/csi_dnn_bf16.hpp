@@ -54,6 +54,40 @@ int bf16_layer0_splits(int M1, int h1, int K) {
     return best;
 }
 
+// Layer 0 of a call of at most "l0_stream_max_rows" rx preambles on the weight-streaming kernel (l0_hs_stream.hip.h, bf16 form): k ranges, 0 = no
+int bf16_l0_stream_splits(const csi_ctx* c, int M1, int h1, int K, int* k_per_split) {
+    if (!c->l0_stream || M1 < 1 || M1 > c->l0_stream_max_rows || (K % L0S_KC) != 0 || K < 2 * L0S_KC || c->force_pair_tile) return 0;
+    const int groups = (h1 + L0S_COLS - 1) / L0S_COLS, blocks = (M1 + 255) / 256;
+    int ks = c->l0_stream_ks > 0 ? c->l0_stream_ks : std::max(1, (M1 <= 128 ? 256 : 128) / (groups * blocks));
+    ks = std::max(1, std::min(ks, K / (2 * L0S_KC)));
+    const int kps = ((K + ks - 1) / ks + L0S_KC - 1) / L0S_KC * L0S_KC;
+    *k_per_split = kps;
+    return (K + kps - 1) / kps;
+}
+
+int bf16_l0_stream_launch(csi_ctx* c, const Model& m, const float* x, int ldx, int M1, int h1, int K, int kps, int splits, float* slabs) {
+    L0StreamBf16Args a{};
+    a.x = x; a.Wb = m.layers[0].Wb; a.slabs = slabs;
+    a.M = M1; a.N = h1; a.K = K; a.lda = ldx; a.ldwb = m.layers[0].ldwb; a.kps = kps;
+    const int blocks = (M1 + 255) / 256;
+    const int rt = ((M1 + 31) / 32 + blocks - 1) / blocks;
+    const int rt_inst = rt <= 4 ? rt : (rt <= 6 ? 6 : 8);
+    const dim3 grid((unsigned)((h1 + L0S_COLS - 1) / L0S_COLS), (unsigned)splits, (unsigned)((M1 + 32 * rt_inst - 1) / (32 * rt_inst)));
+    ++c->l0_stream_launches;
+    ProfScope ps(c, K_LAYER0_LTF, 2.0 * (double)M1 * h1 * K, 4.0 * (double)M1 * K + 2.0 * (double)h1 * K + 4.0 * (double)M1 * h1 * splits);
+    auto go = [&](auto kern, int rtt) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), l0b_lds_bytes(rtt), c->stream, a);       // (at most 41 KB: below the default dynamic-LDS limit)
+        HIP_TRY(c, hipGetLastError());
+        return (int)CSI_OK;
+    };
+    if (rt <= 1) return go(l0_bf16_stream_kernel<1>, 1);
+    if (rt <= 2) return go(l0_bf16_stream_kernel<2>, 2);
+    if (rt <= 3) return go(l0_bf16_stream_kernel<3>, 3);
+    if (rt <= 4) return go(l0_bf16_stream_kernel<4>, 4);
+    if (rt <= 6) return go(l0_bf16_stream_kernel<6>, 6);
+    return go(l0_bf16_stream_kernel<8>, 8);
+}
+
 // first per-pair layer with h1 generated inside the GEMM (gemm_bf16_pp_pair_kernel); usable when the
 // grid is large, the reduction length fits the LDS copy of the bn0 vectors and rows are 16-byte aligned
 bool pair_fused_ok(const csi_ctx* c, int M, int N, int K, bool out_bf16, int ldc) {
@@ -165,7 +199,7 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     if (rc) return rc;
     char* base = c->ws;
     bf16_t* xb = reinterpret_cast<bf16_t*>(base);             base += (size_t)chunk * nr * cf.len_ltf * 2;
-    float* l0 = reinterpret_cast<float*>(base);               base += (size_t)chunk * nr * h1 * 4 * (BF16_L0_MAX_SPLITS + 1);
+    float* l0_ws = reinterpret_cast<float*>(base);            base += (size_t)chunk * nr * h1 * 4 * (BF16_L0_MAX_SPLITS + 1);
     bf16_t* h1b = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * h1 * 2;
     bf16_t* hb0 = reinterpret_cast<bf16_t*>(base);            base += (size_t)chunk * nr * nt * maxh * 2;
     bf16_t* hb1 = reinterpret_cast<bf16_t*>(base);
@@ -175,14 +209,24 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         GemmBf16Args g{};
         g.A = xb; g.lda = cf.len_ltf;
         g.Bt = m.layers[0].Wb; g.ldb = m.layers[0].ldwb;
-        g.C = l0; g.ldc = h1;
+        g.C = l0_ws; g.ldc = h1;
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
-        const int S = bf16_layer0_splits(M1, h1, cf.len_ltf);
+        int S = bf16_layer0_splits(M1, h1, cf.len_ltf);
         g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
+        float* l0 = l0_ws;
+        int kps_stream = 0;
+        const int stream_splits = bf16_l0_stream_splits(c, M1, h1, cf.len_ltf, &kps_stream);
         const long l0_tiles = (long)((M1 + PP_BM - 1) / PP_BM) * ((h1 + PP_BN - 1) / PP_BN) * S;
         const bool l0_fused = c->bf16_fused_h1 != 0 && c->force_pair_tile != 128 && (l0_tiles >= 256 || c->force_pair_tile == 256) &&
                               g.k_per_split / PP_BK >= 3 && (cf.len_ltf & 3) == 0;
-        if (l0_fused) {
+        if (stream_splits) {
+            // small and mid-size calls: the weight-streaming kernel, its k-range slabs in the split-K scratch of the context
+            rc = ensure_bytes(c, &c->skbuf, &c->skbuf_bytes, (size_t)(stream_splits + 1) * M1 * h1 * sizeof(float));
+            if (rc) return rc;
+            l0 = reinterpret_cast<float*>(c->skbuf);
+            S = stream_splits;
+            rc = bf16_l0_stream_launch(c, m, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, M1, h1, cf.len_ltf, kps_stream, stream_splits, l0);
+        } else if (l0_fused) {
             // the conversion happens inside the GEMM: no separate pass over the preambles
             rc = launch_layer0_cast_bf16(c, g, d_ltf + (size_t)p0 * nr * cf.len_ltf, cf.len_ltf, S);
         } else {

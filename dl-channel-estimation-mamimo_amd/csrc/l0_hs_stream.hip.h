@@ -239,4 +239,112 @@ __global__ __launch_bounds__(256) void l0_hs_stream_kernel(L0StreamArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel for bf16 contexts (csi_dtype = CSI_DTYPE_BF16, BASELINE configs[2]'s arithmetic: bf16 operands, fp32 accumulation):
+// one v_mfma_f32_32x32x16_bf16 per 16 k and row tile, the preambles rounded to bf16 exactly as f32_to_bf16_kernel rounds them, no input
+// scale (bf16 carries the fp32 exponent).  Before it a bf16 call of fewer than 256 row tiles of 256 x 256 ran layer 0 as eight
+// workgroups of the 128 x 128 kernel over the whole K: 223 us whatever the call's size (545 us per one-packet call at Nt = 64).
+struct L0StreamBf16Args {
+    const float* x;        // [M][lda] fp32
+    const bf16_t* Wb;      // [N][ldwb] bf16 layer-0 weights (LTF columns), K-major
+    float* slabs;          // [gridDim.y][M][N] fp32
+    int M, N, K, lda, ldwb;
+    int kps;               // k-columns per blockIdx.y, a multiple of 32
+};
+constexpr int L0B_ROWB = 80;       // LDS bytes per row and chunk: 32 bf16 | 16 bytes of padding (conflict-free 16-byte reads)
+inline size_t l0b_lds_bytes(int rt) { return (size_t)2 * 32 * rt * L0B_ROWB; }
+
+template <int RT>
+__global__ __launch_bounds__(256) void l0_bf16_stream_kernel(L0StreamBf16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char l0s_lds[];
+    unsigned char* xs = l0s_lds;                                                   // [2][32 RT][80]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, g = lane >> 5;
+    const int kbeg = (int)blockIdx.y * a.kps;
+    const int klen = min(a.K, kbeg + a.kps) - kbeg;
+    const int nchunk = klen / L0S_KC;
+    const int n0 = (int)blockIdx.x * L0S_COLS + 32 * wave;
+    const int mrow0 = (int)blockIdx.z * 32 * RT;
+    a.x += (size_t)mrow0 * a.lda;
+    const int Mtot = a.M;
+    a.M = min(a.M - mrow0, 32 * RT);
+
+    const int srow = tid >> 3, sq = tid & 7;
+    f32x4 xv[2][RT];
+    const float* xrow[RT];
+    float live[RT];                       // rows beyond M read row M - 1 and are staged as zeros (the chunk loop has no branch)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        xrow[t] = a.x + (size_t)min(32 * t + srow, a.M - 1) * a.lda + kbeg + 4 * sq;
+        live[t] = 32 * t + srow < a.M ? 1.f : 0.f;
+    }
+    auto load_x = [&](int c, f32x4 (&v)[RT]) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) v[t] = *reinterpret_cast<const f32x4*>(xrow[t] + L0S_KC * min(c, nchunk - 1));
+    };
+    auto store_x = [&](int buf, const f32x4 (&v)[RT]) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[t][0] * live[t]) | ((uint32_t)f2bf(v[t][1] * live[t]) << 16);
+            o.y = (uint32_t)f2bf(v[t][2] * live[t]) | ((uint32_t)f2bf(v[t][3] * live[t]) << 16);
+            *reinterpret_cast<uint2*>(xs + ((size_t)buf * 32 * RT + 32 * t + srow) * L0B_ROWB + 8 * sq) = o;
+        }
+    };
+    // B side: this lane's column, k half g of every 16-k group: two 16-byte loads per 32-k chunk
+    const bf16_t* wp = a.Wb + (size_t)min(n0 + j, a.N - 1) * a.ldwb + (size_t)kbeg + 8 * g;
+    uint4 wq[L0S_AHEAD][2];
+    auto load_w = [&](int c, uint4 (&w)[2]) {
+        const bf16_t* p = wp + (size_t)min(c, nchunk - 1) * 32;
+        w[0] = *reinterpret_cast<const uint4*>(p);
+        w[1] = *reinterpret_cast<const uint4*>(p + 16);
+    };
+    f32x16 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    load_x(0, xv[0]);
+    load_x(1, xv[1]);
+#pragma unroll
+    for (int u = 0; u < L0S_AHEAD; ++u) load_w(u, wq[u]);
+    store_x(0, xv[0]);
+    __syncthreads();
+    const unsigned char* arow = xs + (size_t)j * L0B_ROWB + 16 * g;
+    auto chunk = [&](int c, uint4 (&w)[2], f32x4 (&xc)[RT], const f32x4 (&xn)[RT]) {
+        const int buf = c & 1;
+        load_x(c + 2, xc);
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, w[grp]);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ((size_t)buf * 32 * RT + 32 * t) * L0B_ROWB + 32 * grp);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b, acc[t], 0, 0, 0);
+            }
+        }
+        load_w(c + L0S_AHEAD, w);
+        store_x(buf ^ 1, xn);
+        __syncthreads();
+    };
+    int c = 0;
+    for (; c + L0S_AHEAD <= nchunk; c += L0S_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < L0S_AHEAD; ++u) chunk(c + u, wq[u], xv[u & 1], xv[(u & 1) ^ 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < L0S_AHEAD - 1; ++u)
+        if (c + u < nchunk) chunk(c + u, wq[u], xv[u & 1], xv[(u & 1) ^ 1]);
+    const int col = n0 + j;
+    if (col >= a.N) return;
+    float* out = a.slabs + ((size_t)blockIdx.y * Mtot + mrow0) * a.N + col;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * t + 8 * (r >> 2) + 4 * g + (r & 3);
+            if (row < a.M) out[(size_t)row * a.N] = acc[t][r];
+        }
+}
+
 }  // namespace csi

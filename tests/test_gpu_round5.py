@@ -394,3 +394,33 @@ def test_fuzz_mid_size_calls(pkg, oracle):
         e.close()
         done += 1
     assert streamed >= 6 and split >= 2, (streamed, split)
+
+
+BF16_TOL_IMPL = 4e-3     # vs the bf16-operand emulation (tests/test_gpu_parity.py: the tolerance of every bf16 kernel)
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(64, 4, 1, (1024, 1024)),      # one packet of configs[2]'s shape: 4 preambles
+                                               (32, 3, 11, (208, 512)),       # 33 preambles: two row tiles; N = 208 (ragged column group)
+                                               (16, 2, 70, (128, 64)),        # 140 preambles, K = 5120
+                                               (8, 4, 90, (64, 64))])         # 360 preambles: two row blocks
+def test_bf16_layer0_weight_streaming_kernel(pkg, oracle, nt, nr, npkt, hidden):
+    """l0_bf16_stream_kernel: layer 0 of small and mid-size calls of a bf16 context - against the oracle's bf16-operand emulation at the
+    tolerance of every bf16 kernel, against the kernels it replaces, run-to-run bit-identical."""
+    rng = np.random.default_rng(9000 + nt + npkt)
+    w_re, w_im = _weights(oracle, 700 + nt, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=6.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    n0 = e.get_option('l0_stream_launches')
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('l0_stream_launches') == n0 + 2
+    sel = sorted(set([0, npkt // 2, npkt - 1]))
+    b_re, b_im = oracle.predict_packets_bf16(ltf[sel], P, w_re, w_im)
+    assert rel_rows(o_re[sel], b_re) < BF16_TOL_IMPL and rel_rows(o_im[sel], b_im) < BF16_TOL_IMPL
+    p_re, p_im = e.predict(ltf)
+    assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im)
+    e.set_option('l0_stream', 0)
+    g_re, g_im = e.predict(ltf)
+    assert e.get_option('l0_stream_launches') == n0 + 4
+    assert rel_rows(o_re, g_re) < BF16_TOL_IMPL and rel_rows(o_im, g_im) < BF16_TOL_IMPL
+    e.close()
