@@ -916,11 +916,8 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
     if (npkt == 0) return CSI_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     auto run = [&]() -> int {
-        if (c->cfg.dtype == CSI_DTYPE_BF16) {
-            int r = predict_plane_bf16(c, c->model[0], d_ltf_re, npkt, d_out_re);
-            if (r) return r;
-            return predict_plane_bf16(c, c->model[1], d_ltf_im, npkt, d_out_im);
-        }
+        const bool bf16 = c->cfg.dtype == CSI_DTYPE_BF16;
+        auto plane = [&](Model& m, const float* in, float* out) { return bf16 ? predict_plane_bf16(c, m, in, npkt, out) : predict_plane(c, m, in, npkt, out); };
         // the one-packet regime: both models in 1 + n_hidden launches on this stream (csi_dnn_small.hpp)
         if (small_call_ok(c, npkt)) return predict_small(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
         // small call: the two component models are independent and each is a chain of short,
@@ -928,13 +925,15 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         // Round 5: up to 98 304 pair rows (768 bands of the fused kernel per model - three rounds of the chip), not 64 preambles: a
         // component model's kernels of a mid-size call fill a fraction of the 256 CUs (64 packets = 64 bands), and the other model's
         // fill the rest - 24 ... 128 packets 1.25-1.55x, 384 packets +16 %, 500 packets +1.4 % (profiles/r05_regime_probe.txt).  Beyond
-        // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).
+        // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).  bf16 contexts (sequential until the
+        // end of round 5): up to 262 144 pair rows - Nt = 64: one packet 129 -> 95 us, 64 packets 271 -> 198, 500: 1478 -> 1196, 1000: 2380 -> 2096,
+        // 2000 packets equal (profiles/r05_band_split_probe.txt).
         const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
-                             (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= 98304 || c->small_call_overlap == 2);
+                             (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 98304) || c->small_call_overlap == 2);
         if (!overlap) {
-            int r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+            int r = plane(c->model[0], d_ltf_re, d_out_re);
             if (r) return r;
-            return predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+            return plane(c->model[1], d_ltf_im, d_out_im);
         }
         if (!c->aux_stream) {
             HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
@@ -952,11 +951,11 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         };
         swap_scratch();                                   // imag model: aux stream, aux scratch
         c->models_in_flight = 2;
-        int r = predict_plane(c, c->model[1], d_ltf_im, npkt, d_out_im);
+        int r = plane(c->model[1], d_ltf_im, d_out_im);
         hipError_t e = r ? hipSuccess : hipEventRecord(c->aux_join, c->stream);
         swap_scratch();
         if (r) { c->models_in_flight = 1; return r; }
-        if (e == hipSuccess) r = predict_plane(c, c->model[0], d_ltf_re, npkt, d_out_re);
+        if (e == hipSuccess) r = plane(c->model[0], d_ltf_re, d_out_re);
         c->models_in_flight = 1;
         HIP_TRY(c, e);
         if (r) return r;
