@@ -24,7 +24,8 @@ bool small_call_ok(csi_ctx* c, int64_t npkt) {
     // where the column-split band kernel serves the model the general path (weight-streaming layer 0 + that kernel) wins from 3 packets of
     // the shipped shape on (102 us against 121 here; 2 packets: 111 against 61 - profiles/r05_band_split_probe.txt): this path keeps the
     // calls of at most "small_rows_band" rows
-    if (npkt * cf.nr * cf.nt > c->small_rows_band && c->f32_engine != 0 && hs_static_ok(c, c->model[0]) && hs_static_ok(c, c->model[1]) &&
+    // (calls of at most 8 preambles - layer 0 on the weight-streaming gemv - stay here whatever their rows: Nt = 64, 2 packets = 512 rows 99 us against 128)
+    if (npkt * cf.nr * cf.nt > c->small_rows_band && npkt * cf.nr > SC_MAX_ROWS0 && c->f32_engine != 0 && hs_static_ok(c, c->model[0]) && hs_static_ok(c, c->model[1]) &&
         band_split_static_ok(c, c->model[0]) && band_split_static_ok(c, c->model[1]))
         return false;
     return true;

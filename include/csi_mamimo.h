@@ -250,7 +250,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         component models in 1 + n_hidden launches: layer 0 as one weight-streaming kernel (up to 8 preambles) or on
  *                         fp32-MFMA tiles, every layer behind it as 16 x 16 / 32 x 32 fp32-MFMA tiles over the whole K, no split-K slabs
  *                         (csrc/small_call.hip.h); 0: the general kernels (A/B runs).  Read-only: "small_calls" (calls that took it).
- *                         "small_rows_band" (default 256 = 2 packets of that shape): the limit where the column-split band kernel serves
+ *                         "small_rows_band" (default 256 = 2 packets of that shape; calls of at most 8 preambles are not subject to it): the limit where the column-split band kernel serves
  *                         the model ("band_split": two hidden layers, 16 <= Nt <= 128, hidden[1] a multiple of 512) - from there
  *                         on the general path (weight-streaming layer 0 + that kernel) is the faster one
  *   "l0_stream"        1 (default): layer 0 of a call of 9 ... "l0_stream_max_rows" (default 1280) rx preambles runs on the weight-streaming split-f16 kernel
