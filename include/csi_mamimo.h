@@ -261,7 +261,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "f32_engine"       fp32 contexts: -1 (default) large GEMMs - at least half a round of 256x256 tiles - run on
  *                         the f16 matrix cores with split operands (x = hi + lo halves, three MFMA per
  *                         product, fp32 accumulation: the same 1e-5 contract at ~2.6x the fp32 MFMA rate,
- *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels; 0: fp32 MFMA kernels only;
+ *                         gemm_hs.hip.h), small ones on the fp32 MFMA kernels - except that calls of 9 ... 1280 rx preambles run
+ *                         layer 0 on the engine's weight-streaming kernel ("l0_stream") and models the column-split band kernel
+ *                         serves ("band_split") run their per-pair layers on it at every size; 0: fp32 MFMA kernels only;
  *                         1: split engine wherever the layer shapes allow (hidden widths multiples of 16)
  *   "hs_blocked"       split engine: 1 (default) keeps the hidden activations between its layers in a blocked layout
  *                         ([16 rows][k-group of 16] = the 1 KiB one LDS-DMA piece of the next GEMM fetches, contiguous),
@@ -271,7 +273,8 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         on the CU; only partial sums reach memory).  0 (default): measured slower than two kernels
  *   "hs_min_blocks"    automatic mode: the per-pair layers take the split engine from this many 256x256 workgroups
  *                         on (default 48 = 24 packets of the shipped shape; 80 before the two-stream arrangement of round 5),
- *                         layer 0 from max(this, 128)
+ *                         layer 0 from max(this, 128).  (Models the column-split band kernel serves take the split engine's
+ *                         per-pair layers at every size - "band_split" - and are not subject to this threshold.)
  *   "hs_in_shift"      split engine: the preamble samples are carried times 2^shift.  99 (default): chosen per
  *                         launch on the device from a sampled maximum of the data, so that it lands at
  *                         2^13..2^14 (any input scaling is served); -8..14: fixed
