@@ -225,6 +225,8 @@ struct csi_ctx {
                                  // regressor sums of the splits are added in split order by band_split_sum_kernel); -1 = automatic (as many
                                  // splits as keep the workgroups of the models in flight within the 256 CUs), 0 / 1 = never, 2 / 4 = always
     int64_t band_split_launches = 0;
+    int aux_fork_early = 1;      // "aux_fork_early": csi_estimate_device forks the second stream of a two-stream call in front of its LS kernel
+    bool aux_preforked = false;
     int models_in_flight = 1;    // 2 while csi_predict_device runs the component models on two streams
     int hs_min_blocks = 48;      // automatic mode: the per-pair layers go to the split engine from this many 256x256 workgroups on
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024 with the two component models on two

@@ -907,6 +907,23 @@ int csi_set_pilot(csi_ctx* c, const float* P) {
     return CSI_OK;
 }
 
+namespace {
+// does csi_predict_device run the two component models of this call on two streams?
+bool two_stream_call(csi_ctx* c, int64_t npkt) {
+    const bool bf16 = c->cfg.dtype == CSI_DTYPE_BF16;
+    return c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
+           (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 98304) || c->small_call_overlap == 2);
+}
+int aux_stream_ensure(csi_ctx* c) {
+    if (!c->aux_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+    }
+    return CSI_OK;
+}
+}  // namespace
+
 int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_out_re,
                        float* d_out_im) {
     int rc = check_ready(c, true);
@@ -928,20 +945,18 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).  bf16 contexts (sequential until the
         // end of round 5): up to 262 144 pair rows - Nt = 64: one packet 129 -> 95 us, 64 packets 271 -> 198, 500: 1478 -> 1196, 1000: 2380 -> 2096,
         // 2000 packets equal (profiles/r05_band_split_probe.txt).
-        const bool overlap = c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
-                             (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 98304) || c->small_call_overlap == 2);
+        const bool overlap = two_stream_call(c, npkt);
         if (!overlap) {
             int r = plane(c->model[0], d_ltf_re, d_out_re);
             if (r) return r;
             return plane(c->model[1], d_ltf_im, d_out_im);
         }
-        if (!c->aux_stream) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+        if (int ra = aux_stream_ensure(c)) return ra;
+        if (!c->aux_preforked) {           // (csi_estimate_device forks in front of its LS kernel)
+            HIP_TRY(c, hipEventRecord(c->aux_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
         }
-        HIP_TRY(c, hipEventRecord(c->aux_fork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+        c->aux_preforked = false;
         auto swap_scratch = [&]() {
             std::swap(c->stream, c->aux_stream);
             std::swap(c->ws, c->aux_ws); std::swap(c->ws_bytes, c->aux_ws_bytes);
@@ -996,8 +1011,17 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
             // (one-packet calls, round 5: the LS kernel on a second stream beside the three DNN launches was built and measured -
             // 72.5 us per call against 64.2 in this order; the fork / join events cost more than the 8.7 us kernel hides, and it
             // runs 16.8 us beside the weight stream.  profiles/r05_small_call_trace.txt)
-            r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
+            // The second stream of a two-stream call is forked HERE, in front of the LS kernel: the imag model's chain needs the
+            // preambles, not the LS result, and the cross-queue wait (6-7 us before its first kernel starts) passes under the LS kernel
+            if (c->aux_fork_early && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
+                hipError_t e = hipEventRecord(c->aux_fork, c->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0);
+                if (e != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: forking the second stream failed: %s", hipGetErrorString(e));
+                else c->aux_preforked = true;
+            }
+            if (!r) r = csi_ls_estimate_device(c, d_ltf_re, d_ltf_im, npkt, d_h_re, d_h_im);
             if (!r) r = csi_predict_device(c, d_ltf_re, d_ltf_im, npkt, d_out_re, d_out_im);
+            c->aux_preforked = false;
         }
         c->use_graph = g;
         c->in_graph_call = false;
@@ -1184,6 +1208,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band_launches") *value = c->band_launches;
     else if (n == "band_split") *value = c->band_split;
+    else if (n == "aux_fork_early") *value = c->aux_fork_early;
     else if (n == "l0_stream") *value = c->l0_stream;
     else if (n == "l0_stream_ks") *value = c->l0_stream_ks;
     else if (n == "l0_stream_prepass_rows") *value = c->l0_stream_prepass_rows;
@@ -1307,6 +1332,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 256) return fail(c, CSI_ERR_INVALID_ARG, "l0_stream_ks must be 0 (automatic) .. 256");
         drop_graphs(c);
         c->l0_stream_ks = (int)value;
+    } else if (n == "aux_fork_early") {
+        drop_graphs(c);
+        c->aux_fork_early = value != 0;
     } else if (n == "band_split") {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4)
             return fail(c, CSI_ERR_INVALID_ARG, "band_split must be -1 (automatic), 0 / 1 (never) or 2 / 4 (column splits of every band)");

@@ -244,7 +244,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "small_call_overlap" 1 (default): calls of at most 98 304 pair rows (768 packets at Nt = 32, Nr = 4) run the real and the imag
  *                         model on two streams side by side - a mid-size call's kernels fill a fraction of the chip (24 ... 128 packets:
  *                         1.25-1.55x, 500 packets +1.4 %; device-pointer calls only: inside the host-buffer entry points' pipeline the
- *                         chunks stay on one stream, where the fork measured 6 % slower); 0: one after the other; 2: any size (A/B runs)
+ *                         chunks stay on one stream, where the fork measured 6 % slower); 0: one after the other; 2: any size (A/B runs).
+ *                         bf16 contexts: up to 262 144 pair rows.  "aux_fork_early" (default 1): csi_estimate_device forks the second
+ *                         stream in front of its LS kernel - the imag model's chain needs the preambles, not the LS result (3 ... 32
+ *                         packets 6 % faster); 0: behind it (A/B runs)
  *   "small_fused"      1 (default): a call of at most "small_rows" pair rows (default 1024 = 8 packets at Nt = 32, Nr = 4; and at most 64
  *                         rx preambles) - the reference's literal one-packet predict, DNN.py:339-346, and its small multiples - runs BOTH
  *                         component models in 1 + n_hidden launches: layer 0 as one weight-streaming kernel (up to 8 preambles) or on
