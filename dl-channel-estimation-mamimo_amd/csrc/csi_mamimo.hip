@@ -912,7 +912,7 @@ namespace {
 bool two_stream_call(csi_ctx* c, int64_t npkt) {
     const bool bf16 = c->cfg.dtype == CSI_DTYPE_BF16;
     return c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
-           (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 98304) || c->small_call_overlap == 2);
+           (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 131072) || c->small_call_overlap == 2);
 }
 int aux_stream_ensure(csi_ctx* c) {
     if (!c->aux_stream) {
@@ -942,7 +942,8 @@ int csi_predict_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im,
         // Round 5: up to 98 304 pair rows (768 bands of the fused kernel per model - three rounds of the chip), not 64 preambles: a
         // component model's kernels of a mid-size call fill a fraction of the 256 CUs (64 packets = 64 bands), and the other model's
         // fill the rest - 24 ... 128 packets 1.25-1.55x, 384 packets +16 %, 500 packets +1.4 % (profiles/r05_regime_probe.txt).  Beyond
-        // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).  bf16 contexts (sequential until the
+        // that the gain is below 1 % and not worth the second workspace; 2 = any size (A/B runs).  (With the fork in front of the LS kernel:
+        // 131 072 rows - 1000 packets +2.8 %, 2000 equal, 4000 packets 2.5 % slower.)  bf16 contexts (sequential until the
         // end of round 5): up to 262 144 pair rows - Nt = 64: one packet 129 -> 95 us, 64 packets 271 -> 198, 500: 1478 -> 1196, 1000: 2380 -> 2096,
         // 2000 packets equal (profiles/r05_band_split_probe.txt).
         const bool overlap = two_stream_call(c, npkt);
