@@ -122,7 +122,7 @@ def build_band_kernel(verbose=False):
     import tempfile
     csrc = os.path.join(_PKG_DIR, 'csrc')
     gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
-    names = ['csi_band8', 'csi_band8_cs', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd']
+    names = ['csi_band8', 'csi_band8_cs', 'csi_band8_bf16_cs', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd']
     tag = '// kernels: ' + ' '.join(names)
     if os.path.exists(inc) and os.path.getmtime(inc) >= os.path.getmtime(gen):
         with open(inc) as f:

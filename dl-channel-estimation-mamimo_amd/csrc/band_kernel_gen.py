@@ -729,9 +729,10 @@ def common_prologue(b, dbg=(), mode='hs'):
         b.e('s_add_u32 %s, %s, %s' % (sreg(S_W1), sreg(S_W1), sreg(S_T)))
         b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1 + 1), sreg(S_W1 + 1)))
         b.e('s_mul_i32 %s, %s, s3' % (sreg(S_T), sreg(S_N1)))
-        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
-        for ptr in (S_B1, S_W2):
-            b.e('s_add_u32 %s, %s, %s' % (sreg(ptr), sreg(ptr), sreg(S_T)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))                         # bias1: floats; regressor k-columns: hi | lo = 4 bytes (bf16: 2)
+        b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_T + 1), sreg(S_T), 1 if mode == 'bf16' else 0))
+        for ptr, off in ((S_B1, S_T), (S_W2, S_T + 1)):
+            b.e('s_add_u32 %s, %s, %s' % (sreg(ptr), sreg(ptr), sreg(off)))
             b.e('s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1)))
         b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_M), sreg(S_LDO)))
         b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
@@ -1064,7 +1065,7 @@ META_KERNEL = '''  - .name: {name}
         .value_kind: by_value
 '''
 
-VARIANTS = [('csi_band8', ()), ('csi_band8_cs', ('colsplit',)), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
+VARIANTS = [('csi_band8', ()), ('csi_band8_cs', ('colsplit',)), ('csi_band8_bf16_cs', ('bf16', 'colsplit')), ('csi_band8_nostage', ('nostage',)), ('csi_band8_nostage_noreq', ('nostage', 'noreq')), ('csi_band8_bf16', ('bf16',)), ('csi_band8_bf16_nostage', ('bf16', 'nostage')), ('csi_band8_bf16_nostage_noaside', ('bf16', 'nostage', 'noconv', 'noreq')), ('csi_band8_bf16_noconv', ('bf16', 'noconv')), ('csi_band8_bf16_noaside', ('bf16', 'noconv', 'noreq')),
             ('csi_band8_bf16_skeleton', ('bf16', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band8_bf16_nostagger', ('bf16', 'nostagger')), ('csi_band8_noconv', ('noconv',)), ('csi_band8_noreq', ('noreq',)),
             ('csi_band8_noaside', ('noconv', 'noreq')), ('csi_band8_skeleton', ('noconv', 'noreq', 'nodma', 'noread')),
             ('csi_band8_skeleton_rnd', ('noconv', 'noreq', 'nodma', 'noread', 'rnd')), ('csi_band8_skeleton_rnd_nobarrier', ('noconv', 'noreq', 'nodma', 'noread', 'rnd', 'nobarrier')),

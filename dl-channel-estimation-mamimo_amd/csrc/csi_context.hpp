@@ -218,6 +218,7 @@ struct csi_ctx {
     hipFunction_t band_fn_bf16 = nullptr;
     hipFunction_t band_fn_bf16_ns = nullptr;   // bf16 form without the staged T / L0 streams (nt outside 32 .. 64)
     hipFunction_t band_fn_ns = nullptr;        // split-f16 form without them (nt outside 16 .. 128)
+    hipFunction_t band_fn_bf16_cs = nullptr;   // ... of the bf16 form
     hipFunction_t band_fn_cs = nullptr;        // column-split form: grid (bands, splits), split y computes N1 / splits of the hidden features
     bool band_failed = false;                // the code object could not be loaded: separate kernels from then on
     int64_t band_launches = 0;

@@ -237,7 +237,13 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         if (rc) return rc;
         const Layer& l1 = m.layers[1];
         const bool regressor_first = cf.n_hidden == 1;
-        if (pair_fused_ok(c, M2, l1.out, h1, !regressor_first, l1.out)) {
+        const bool fused_ok = pair_fused_ok(c, M2, l1.out, h1, !regressor_first, l1.out);
+        // small calls (fewer row tiles than the fused pair kernel wants): the band kernel in its column-split launch serves them too
+        const bool band_small = !fused_ok && nh == 2 && c->hs_band && m.layers[nh].Wb_p && (c->band_split != 0 && c->band_split != 1) && c->force_pair_tile == 0 &&
+                                c->bf16_fused_h1 != 0 && (M2 + BAND_ROWS - 1) / BAND_ROWS * 2 <= 256 && nt >= 32 && nt <= 64 && h1 >= 256 && (h1 % 128) == 0 &&
+                                (l1.out % 256) == 0 && l1.out <= BAND8_MAX_N1 && cf.n_out <= 256 && l1.in == h1 && l1.ldwb == h1 && m.layers[nh].ldwb == l1.out;
+        bool done = false;
+        if (fused_ok || band_small) {
             // h1 is generated inside the first per-pair GEMM from the (slab-summed) layer-0 product
             float* l0sum = l0;
             if (S > 1) {
@@ -280,11 +286,19 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
             if (fn) {
                 const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
                 const double bytes = 4.0 * ((double)M2 / nt * h1 + (double)nt * h1) + 2.0 * ((double)l1.out * h1 + (double)cf.n_out * l1.out) + 4.0 * (double)M2 * cf.n_out;
-                rc = band8_launch(c, fn, ba, flops, bytes);
-            } else {
+                // small calls: the column-split launch (csi_dnn_hs.hpp); its partial outputs live in the h1 / activation buffers this path leaves unused
+                const bool staged_fn = fn == c->band_fn_bf16;
+                const int Sb = (staged_fn && ba.ldo == ba.n2 && (ba.N1 * (long)ba.ldb1 * 2 < 0x7fffffffL)) ?
+                                   band8_splits(c, ba, ((size_t)M2 * h1 + (size_t)M2 * maxh) / 2, true) : 1;
+                if (Sb > 1) rc = band8_launch_split(c, ba, Sb, reinterpret_cast<float*>(h1b), flops, bytes, true);
+                else if (fused_ok || Sb == 1) rc = band8_launch(c, fn, ba, flops, bytes);
+                done = true;
+            } else if (fused_ok) {
                 rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
+                done = true;
             }
-        } else {
+        }
+        if (!done) {
             {
                 ProfScope ps(c, K_PAIR_H1_BF16, 3.0 * M2 * h1, 2.0 * M2 * h1 + 4.0 * M1 * h1);
                 hipLaunchKernelGGL(pair_h1_bf16_kernel, dim3((unsigned)std::min(M1, 65536)), dim3(256), 0, c->stream, l0, S, (size_t)M1 * h1, m.T,

@@ -276,6 +276,10 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             (void)hipGetLastError();
             c->band_fn_cs = nullptr;
         }
+        if (hipModuleGetFunction(&c->band_fn_bf16_cs, c->band_mod, "csi_band8_bf16_cs") != hipSuccess) {
+            (void)hipGetLastError();
+            c->band_fn_bf16_cs = nullptr;
+        }
     }
     *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : (staged ? c->band_fn : c->band_fn_ns);
 #endif
@@ -311,8 +315,8 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
 // Column splits of a call of `bands` bands: a band is one workgroup's work for ~200 us, so a call with fewer bands than CUs leaves
 // CUs idle for that long - 2 or 4 workgroups per band, each over N1 / splits hidden features, fill them ("band_split";
 // profiles/r05_band_split_probe.txt: 24 packets 248 -> 149 us, 64 packets 299 -> 251 us)
-int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floats) {
-    if (!c->band_fn_cs || c->band_split == 0 || c->band_split == 1 || ba.stamps) return 1;
+int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floats, bool bf16 = false) {
+    if (!(bf16 ? c->band_fn_bf16_cs : c->band_fn_cs) || c->band_split == 0 || c->band_split == 1 || ba.stamps) return 1;
     const long bands = (ba.M + BAND_ROWS - 1) / BAND_ROWS;
     int S = 1;
     if (c->band_split > 1) {
@@ -331,7 +335,7 @@ int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floa
 }
 
 // the column-split launch: partial outputs of splits 1 .. in `part`, added to split 0's output in split order
-int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes) {
+int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes, bool bf16 = false) {
     ++c->band_launches;
     ++c->band_split_launches;
     BandArgs one = ba;
@@ -343,7 +347,7 @@ int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, doubl
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     {
         ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
-        HIP_TRY(c, hipModuleLaunchKernel(c->band_fn_cs, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+        HIP_TRY(c, hipModuleLaunchKernel(bf16 ? c->band_fn_bf16_cs : c->band_fn_cs, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
     }
     const size_t n = (size_t)ba.M * ba.ldo;
     ProfScope ps(c, K_SPLITK_REDUCE, (double)(S - 1) * n, 4.0 * (S + 1) * (double)n);

@@ -424,3 +424,33 @@ def test_bf16_layer0_weight_streaming_kernel(pkg, oracle, nt, nr, npkt, hidden):
     assert e.get_option('l0_stream_launches') == n0 + 4
     assert rel_rows(o_re, g_re) < BF16_TOL_IMPL and rel_rows(o_im, g_im) < BF16_TOL_IMPL
     e.close()
+
+
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(64, 4, 1, (1024, 1024)),      # one packet of configs[2]'s shape: 2 bands per model, 4 column splits
+                                               (32, 3, 13, (256, 512)),       # 1248 rows = 9.75 bands (ragged), N1 = 512: 2 splits at most
+                                               (64, 2, 24, (512, 1024))])     # 24 bands per model
+def test_bf16_column_split_band_kernel(pkg, oracle, nt, nr, npkt, hidden):
+    """csi_band8_bf16_cs: small calls of a bf16 context on the band kernel in its column-split launch (before: pair_h1 + two 128 x 128 GEMMs) -
+    against the bf16-operand emulation, against the kernels it replaces ("band_split" = 0), run-to-run bit-identical."""
+    rng = np.random.default_rng(9500 + nt + npkt)
+    w_re, w_im = _weights(oracle, 800 + nt, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=4.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    n0 = e.get_option('band_split_launches')
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('band_split_launches') == n0 + 2
+    sel = sorted(set([0, npkt // 2, npkt - 1]))
+    b_re, b_im = oracle.predict_packets_bf16(ltf[sel], P, w_re, w_im)
+    assert rel_rows(o_re[sel], b_re) < BF16_TOL_IMPL and rel_rows(o_im[sel], b_im) < BF16_TOL_IMPL
+    p_re, p_im = e.predict(ltf)
+    assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im)
+    e.set_option('band_split', 0)
+    g_re, g_im = e.predict(ltf)
+    assert e.get_option('band_split_launches') == n0 + 4
+    assert rel_rows(o_re, g_re) < BF16_TOL_IMPL and rel_rows(o_im, g_im) < BF16_TOL_IMPL
+    for sp in (2, 4):
+        e.set_option('band_split', sp)
+        s_re, s_im = e.predict(ltf)
+        assert rel_rows(s_re[sel], b_re) < BF16_TOL_IMPL and rel_rows(s_im[sel], b_im) < BF16_TOL_IMPL
+    e.close()
