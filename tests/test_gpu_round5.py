@@ -454,3 +454,44 @@ def test_bf16_column_split_band_kernel(pkg, oracle, nt, nr, npkt, hidden):
         s_re, s_im = e.predict(ltf)
         assert rel_rows(s_re[sel], b_re) < BF16_TOL_IMPL and rel_rows(s_im[sel], b_im) < BF16_TOL_IMPL
     e.close()
+
+
+def test_mid_size_call_under_a_small_workspace_and_under_graph_replay(pkg, oracle):
+    """The mid-size routing in the two situations that change its launch plan: a workspace budget that cuts the call into several packet
+    chunks (each chunk takes the streaming layer 0 with its own k ranges and the column-split band kernel) and a captured hipGraph of the
+    device call (one stream, so four column splits instead of two) - both against the fp64 oracle and the one-chunk eager call."""
+    nt, nr, hidden, npkt = 32, 2, (256, 512), 40
+    rng = np.random.default_rng(31)
+    w_re, w_im = _weights(oracle, 41, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=2.0)[0].astype(np.complex64)
+    sel = [0, 17, 39]
+    r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=len(sel))
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('l0_stream_launches') == 2 and e.get_option('band_split_launches') == 2
+    assert rel_rows(o_re[sel], r_re) < TOL and rel_rows(o_im[sel], r_im) < TOL
+    # ~13 packets per chunk: layer-0 slabs (33 k ranges of 26 preambles x 256) dominate the per-packet need
+    per_pkt = nr * 256 * 4 * 33 + nr * nt * 512 * 4
+    small = _engine(pkg, nt, nr, hidden, w_re, w_im, P, workspace_bytes=13 * per_pkt)
+    c_re, c_im = small.predict(ltf)
+    assert small.get_option('l0_stream_launches') >= 6, 'several chunks, each on the streaming kernel'
+    assert rel_rows(c_re[sel], r_re) < TOL and rel_rows(c_im[sel], r_im) < TOL
+    assert rel_rows(c_re, o_re) < 2e-6 and rel_rows(c_im, o_im) < 2e-6
+    small.close()
+    d_re, d_im = e.to_device(np.ascontiguousarray(ltf.real)), e.to_device(np.ascontiguousarray(ltf.imag))
+    q = [e.empty((npkt, nr, nt, 234)) for _ in range(4)]
+    e.estimate_device(d_re, d_im, npkt, *q); e.synchronize()
+    eager = [a.download() for a in q]
+    assert rel_rows(eager[0][sel], r_re) < TOL
+    e.set_option('use_graph', 1)
+    g0 = e.get_option('graph_replays')
+    for _ in range(4):
+        e.estimate_device(d_re, d_im, npkt, *q); e.synchronize()
+    assert e.get_option('graph_replays') >= g0 + 2
+    graph = [a.download() for a in q]
+    assert rel_rows(graph[0][sel], r_re) < TOL and rel_rows(graph[1][sel], r_im) < TOL
+    assert np.array_equal(graph[2], eager[2]) and np.array_equal(graph[3], eager[3]), 'LS planes: same kernel, same bits'
+    assert rel_rows(graph[0], eager[0]) < 2e-6 and rel_rows(graph[1], eager[1]) < 2e-6
+    e.set_option('use_graph', 0)
+    e.close()
