@@ -213,6 +213,18 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         g.M = M1; g.N = h1; g.K = cf.len_ltf;
         int S = bf16_layer0_splits(M1, h1, cf.len_ltf);
         g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
+        // between the streaming kernel's range and the fused 256 x 256 kernel's (fewer than 256 of its tiles): the 128 x 128 kernel, its K cut
+        // into as many ranges as fill the 256 CUs (384 packets at Nt = 64: 96 workgroups over the whole K took 320-360 us per model)
+        if (S == 1) {
+            const long tiles128 = (long)((M1 + 127) / 128) * ((h1 + 127) / 128);
+            int s2 = (int)std::min<long>(BF16_L0_MAX_SPLITS, (256 + tiles128 - 1) / tiles128);
+            while (s2 > 1 && cf.len_ltf / s2 < 1024) --s2;
+            const long tiles256 = (long)((M1 + PP_BM - 1) / PP_BM) * ((h1 + PP_BN - 1) / PP_BN);
+            if (s2 > 1 && tiles256 < 256) {
+                S = s2;
+                g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
+            }
+        }
         float* l0 = l0_ws;
         int kps_stream = 0;
         const int stream_splits = bf16_l0_stream_splits(c, M1, h1, cf.len_ltf, &kps_stream);
