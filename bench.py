@@ -128,6 +128,10 @@ def main():
     ap.add_argument('--legs-packets', default='', metavar='A,B',
                     help='N > 1 only: total packets of the configs[3] / configs[4] legs (default 50000,100000 = BASELINE.json; the CPU tests shrink them - and, given explicitly, the legs run beside any headline)')
     ap.add_argument('--no-regimes', action='store_true', help='skip the "regimes" leg (1 / 8 / 64 / 500-packet calls with their bounds) measured after the timed region')
+    ap.add_argument('--full-line', action='store_true',
+                    help='print the whole detail object as the line instead of the compact record (what the fresh-process legs of this script '
+                         'ask of their children; by hand: bench_detail.json holds the same object)')
+    ap.add_argument('--detail-file', default='', help='where the full detail object goes (default: bench_detail.json beside this script, and gpurun_out/ when that exists)')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='start the ranks, rendezvous, all-reduce a rank count and print it - no GPU work (checks the launch path on any host)')
     args = ap.parse_args()
@@ -488,13 +492,15 @@ def main():
         k = min(npkt, 256)
         ltf = (d_re.download(0, k) + 1j * d_im.download(0, k)).astype(np.complex64)
         r = cb.time_reference_loop(ltf, wts['P']['pilot'], wts['real'], wts['imag'], budget_s=args.cpu_budget_s)
+        granted, how = cpus_granted()
         cpu_baseline = {
-            'value': r['pairs_per_s'], 'unit': 'pair-channel estimates/s', 'cores': r['threads'], 'kind': 'port',
-            'sample': '%d packets one by one (batch = Nt*Nr rows, naive un-shared fp32 network, torch-CPU sgemm, '
-                      'real then imag model) + numpy LS; median per-packet latency; host cpu_count=%d'
-                      % (r['packets'], os.cpu_count()),
+            'value': r['pairs_per_s'], 'unit': 'pair-channel estimates/s', 'cores': granted, 'cores_is': how, 'threads': r['threads'],
+            'host_cpu_count': os.cpu_count(), 'kind': 'port',
+            'sample': '%d packets one by one, naive fp32 net (torch-CPU sgemm) real+imag + numpy LS; median per packet' % r['packets'],
+            'sample_detail': 'batch = Nt*Nr rows per packet (massiveMIMO_CSI_prediction_DNN.py:339-346), un-shared layer 0, real then imag model; '
+                             'threads = the torch intra-op count that was fastest on this box (oracle/cpu_baseline.py), cores = CPUs the container may use',
             'dnn_only': r['dnn_pairs_per_s'], 'ls_only': r['ls_pairs_per_s'], 'cpu_model': r['cpu_model'],
-            'dnn_one_large_batch': {'value': r['batched_dnn_pairs_per_s'], 'packets': r['batched_packets']},
+            'dnn_one_large_batch': r['batched_dnn_pairs_per_s'], 'dnn_one_large_batch_packets': r['batched_packets'],
             'gpu_over_cpu': value / r['pairs_per_s']}
 
     # the same steps on the fp32 MFMA kernels, for comparison (outside the headline timed region)
@@ -693,7 +699,135 @@ def main():
     # the whole process as rank 0 saw it (imports, input synthesis, warm-up, timed region, side measurements): what a clock around
     # the command should read, give or take the interpreter's start
     out['bench_wall_s'] = round(time.perf_counter() - t_process, 1)
-    print(json.dumps(out))
+    if args.full_line:
+        print(json.dumps(out))
+        return
+    detail_file = write_detail(out, args.detail_file)
+    print(compact_line(out, detail_file))
+
+LINE_LIMIT = 4096                     # bytes: the driver's capture lost round 5's 20 KB line (BENCH_r05.parsed = null)
+
+
+def _sig(x, n=6):
+    """floats to n significant digits (the line is a record, bench_detail.json keeps every digit)"""
+    if isinstance(x, float):
+        return float('%.*g' % (n, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def write_detail(out, path=''):
+    """The whole measurement object (every note, per-kernel table, host-path legs, regimes, next rows, per-rank records) goes to a
+    file, not to the line: bench_detail.json beside this script and, on a gpurun box, gpurun_out/bench_detail.json so that it
+    travels back.  Never to stderr: the driver's record keeps one 8 KB tail of stdout + stderr together and the line has to be in it."""
+    text = json.dumps(out, indent=1)
+    written = None
+    targets = [path] if path else [os.path.join(REPO, 'bench_detail.json')]
+    if not path and os.path.isdir(os.path.join(REPO, 'gpurun_out')):
+        targets.append(os.path.join(REPO, 'gpurun_out', 'bench_detail.json'))
+    for t in targets:
+        try:
+            with open(t, 'w') as f:
+                f.write(text)
+            written = written or os.path.relpath(t, REPO)
+        except OSError as e:
+            print('bench.py: cannot write %s (%s)' % (t, e), file=sys.stderr)
+    return written
+
+
+def compact_line(out, detail_file):
+    """The ONE line of the contract, below LINE_LIMIT bytes for any rank count: contract keys, `config`, `roofline` (dominant
+    kernel), `roofline_ls`, `cpu_baseline`, `parity_check` and one-number summaries of the side measurements (what the reference
+    itself reports is one figure per configuration, massiveMIMO_CSI_prediction_DNN.py:441-475).  Everything else is in `detail_file`."""
+    rf, cfg = out['roofline'], out['config']
+    line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                'vs_baseline', 'dtype', 'data')}
+    line['config'] = {'workload': cfg['workload'], 'pairs_per_step': cfg['pairs_per_step'], 'packets_per_s': cfg['packets_per_s'],
+                      'ranks': cfg['ranks'], 'weights_via': cfg['weights_via'].split(':')[0].split(' (')[0], 'ls_included': cfg['ls_included'],
+                      'launch': 'hipGraph' if out['launch'].startswith('one hipGraph') else 'eager'}
+    line['roofline'] = {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'flops_per_launch',
+                                               'algorithmic_bytes_per_launch', 'practical_peak', 'frac_of_practical')}
+    line['roofline']['kernel'] = rf['kernel'].split(' (')[-1].split(':')[0] if '(' in rf['kernel'] else rf['kernel']
+    line['roofline']['profile_files'] = sorted((rf.get('profile_files') or {}).values()) or None
+    if out.get('roofline_ls'):
+        line['roofline_ls'] = {k: out['roofline_ls'].get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')}
+    if out.get('cpu_baseline'):
+        cb = out['cpu_baseline']
+        line['cpu_baseline'] = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'cores_is', 'threads', 'host_cpu_count', 'cpu_model', 'kind', 'sample',
+                                                       'dnn_only', 'ls_only', 'dnn_one_large_batch', 'gpu_over_cpu')}
+    pc = dict(out.get('parity_check') or {})
+    if 'packets' in pc:
+        pc['packets'] = len(pc['packets'])
+    line['parity_check'] = pc
+    if out.get('latency'):
+        line['latency_us'] = out['latency']['one_packet_us']
+    line['ranks_ms'] = out['ranks_ms']
+    if out.get('split_engine_range_guard'):
+        line['hs_range_fallbacks'] = out['split_engine_range_guard']['hs_range_fallbacks']
+    if out.get('timed_region_events'):
+        line['ms_per_step_without_kernel_events'] = out['timed_region_events']['ms_per_step_without']
+    if out.get('native_fp32_engine'):
+        n = out['native_fp32_engine']
+        line['native_fp32_engine'] = {'value': n['value'], 'ms_per_step': n['ms_per_step'], 'frac_of_fp32_mfma_peak': n['frac_of_fp32_mfma_peak']}
+    hp = out.get('host_path_pcie_inclusive')
+    if hp:
+        c128 = (hp.get('python_c128_to_c64') or {}).get('dnn_only') or {}
+        c64 = (hp.get('c64_pinned_in_and_out') or {}).get('dnn_only') or {}
+        line['host_path'] = {'packets': hp.get('packets'), 'planes_pairs_per_s': hp.get('pairs_per_s'),
+                             'c128_dnn_only_pairs_per_s': c128.get('pairs_per_s'), 'c128_frac_of_pcie_bound': c128.get('frac_of_pcie_bound'),
+                             'c64_pinned_pairs_per_s': c64.get('pairs_per_s'), 'c64_frac_of_pcie_bound': c64.get('frac_of_pcie_bound')}
+    rg = out.get('regimes')
+    if isinstance(rg, list):
+        # packets -> [queued us per call, latency us, bound us]
+        line['regimes_us'] = {str(r['packets']): [r['pipelined_us'], r['latency_us'], r['bound_us']] for r in rg}
+        big = [r for r in rg if r['packets'] == 500 and 'rate_vs_headline' in r]
+        if big:
+            line['regime_500_rate_vs_headline'] = big[0]['rate_vs_headline']
+    elif rg:
+        line['regimes_us'] = rg
+    nx = out.get('next_rows')
+    if isinstance(nx, dict) and 'error' not in nx:
+        line['next_rows'] = {'lmmse_links_per_s': (nx.get('lmmse') or {}).get('links_per_s'), 'lmmse_frac_fp64': ((nx.get('lmmse') or {}).get('roofline') or {}).get('frac'),
+                             'train_ms_per_step': (nx.get('train_step') or {}).get('ms_per_step'), 'train_loss_rel_err': (nx.get('train_step') or {}).get('loss_rel_err'),
+                             'ls_vht_pilot_frac_hbm': ((nx.get('ls_vht_pilot') or {}).get('roofline_ls') or {}).get('frac')}
+    elif nx:
+        line['next_rows'] = nx
+    if out.get('other_configs') is not None:
+        oc = []
+        for c in out['other_configs']:
+            if 'error' in c or 'skipped' in c:
+                oc.append({'config': c.get('config'), 'error': (c.get('error') or c.get('skipped'))[:160]})
+                continue
+            pcheck = c.get('parity_check') or c.get('parity_check_rank0_shard') or {}
+            e = {'config': c['config'], 'value': c['value'], 'ms_per_step': c['ms_per_step'], 'dtype': c['dtype'],
+                 'frac': (c.get('roofline') or {}).get('frac'), 'dnn_rel_err': pcheck.get('dnn_rel_err')}
+            if 'dnn_rel_err_vs_bf16_emulation' in pcheck:
+                e['dnn_rel_err_vs_bf16_emulation'] = pcheck['dnn_rel_err_vs_bf16_emulation']
+            if 'n_gpus' in c:
+                e['n_gpus'] = c['n_gpus']
+                e['ranks_ms'] = c.get('ranks_ms')
+            oc.append(e)
+        line['other_configs'] = oc
+    line['detail_file'] = detail_file
+    line['bench_wall_s'] = out['bench_wall_s']
+    line = _sig(line)
+    line['value'], line['ms_per_step'] = out['value'], out['ms_per_step']          # the contract's two numbers keep every digit
+    text = json.dumps(line, separators=(',', ':'))
+    # a line that would not fit sheds its summaries, least important first, never a contract key (and says which in `dropped`)
+    dropped = []
+    for key in ('next_rows', 'host_path', 'native_fp32_engine', 'regimes_us', 'other_configs', 'ranks_ms'):
+        if len(text) < LINE_LIMIT:
+            break
+        if key in line:
+            line.pop(key)
+            dropped.append(key)
+            line['dropped'] = dropped
+            text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT, 'bench line of %d bytes' % len(text)
+    return text
 
 
 def ls_roofline(p, traffic_bytes, traffic_file):
@@ -901,6 +1035,28 @@ def next_rows(pkg, eng, nt, nr, hidden, wts, d_re, d_im, npkt):
     return res
 
 
+def cpus_granted():
+    """CPUs this process may actually use (north_star: core count stated): the cgroup v2 quota when there is one (cpu.max = quota /
+    period), else the affinity mask, else os.cpu_count() - on the GPU boxes os.cpu_count() says 256 while the container is granted 16."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            return round(int(quota) / int(period), 2), 'cgroup cpu.max %s/%s' % (quota, period)
+    except (OSError, ValueError):
+        pass
+    try:                                  # cgroup v1
+        quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if quota > 0 and period > 0:
+            return round(quota / period, 2), 'cgroup cpu.cfs_quota_us %d/%d' % (quota, period)
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0)), 'sched_getaffinity'
+    except (AttributeError, OSError):
+        return os.cpu_count(), 'os.cpu_count'
+
+
 def default_headline(args):
     """the driver's command: config 2 with nothing overridden (the side configurations are measured only beside that)"""
     return (args.nt, args.nr, args.packets, args.dtype, tuple(args.hidden), args.engine, args.scaling) == (32, 4, 4000, 'f32', (1024, 1024), 'auto', 'weak')
@@ -945,7 +1101,7 @@ def run_multi_gpu_legs(pkg, args, rank, world, local):
         env = dict(os.environ, MASTER_PORT=str(box[0]), CSI_RCCL_ID_TOKEN='leg-%s-%d' % (name, box[0]), CSI_DIST_TIMEOUT_S='180')
         for k in [k for k in env if k.startswith('TORCHELASTIC_')]:      # under torchrun: the child job's rank 0 serves its own store
             env.pop(k)                                                     # (TORCHELASTIC_USE_AGENT_STORE would make it look for the agent's)
-        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--no-other-configs', '--no-cpu-baseline', '--no-latency',
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--full-line', '--no-other-configs', '--no-cpu-baseline', '--no-latency',
                '--host-path', '0', '--check', '4', '--no-next-rows', '--no-regimes', '--weights-via', args.weights_via] + flags
         t0 = time.perf_counter()
         try:
@@ -991,7 +1147,7 @@ def other_configs():
     import subprocess
     res = []
     for name, what, flags in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-other-configs', '--no-cpu-baseline', '--no-latency',
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--full-line', '--no-other-configs', '--no-cpu-baseline', '--no-latency',
                '--host-path', '0', '--check', '4', '--no-next-rows'] + flags
         t0 = time.perf_counter()
         try:

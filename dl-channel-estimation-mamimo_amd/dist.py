@@ -99,7 +99,8 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
         return box[0]
     # The file carries, in front of the 128 id bytes, a 32-byte tag of the launch token and the wall time rank 0 wrote it at.
     # Token: CSI_RCCL_ID_TOKEN (bench.py's own launcher sets a fresh one per launch), else torchrun's TORCHELASTIC_RUN_ID, else -
-    # a hand-rolled launch - the rendezvous triple plus the launcher's pid.  Only the first two are unique per launch; with the
+    # a hand-rolled launch - the rendezvous triple (address, port, world size: what ranks started from separate shells, ssh sessions
+    # or service units still agree on; the launcher's pid is NOT part of it).  Only the first two are unique per launch; with the
     # fallback a file left by a KILLED launch (atexit does not run on SIGKILL) can carry the same tag, so there a reader also wants
     # the file to be younger than its own process start minus CSI_RCCL_ID_MAX_AGE_S (default 120 s: ranks of one launch start
     # within that; a rank that is later than that must be given a token) and keeps polling until rank 0 has replaced it.
@@ -107,7 +108,7 @@ def exchange_unique_id(rank, world, timeout_s=120.0):
     import hashlib
     import struct
     strong = os.environ.get('CSI_RCCL_ID_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID')
-    token = (strong or '%s:%s:%d:%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world, os.getppid())).encode()
+    token = (strong or '%s:%s:%d' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29500'), world)).encode()
     tag = hashlib.sha256(token).digest()                       # 32 bytes in front of the stamp and the id
     max_age = float(os.environ.get('CSI_RCCL_ID_MAX_AGE_S', '120'))
     path = os.environ.get('CSI_RCCL_ID_FILE')

@@ -177,8 +177,8 @@ def test_unique_id_file_carries_the_launch_token(pkg, tmp_path, monkeypatch):
 
 
 def test_unique_id_file_without_a_launch_token_wants_a_fresh_file(pkg, tmp_path, monkeypatch):
-    """without CSI_RCCL_ID_TOKEN / TORCHELASTIC_RUN_ID the tag is the rendezvous triple (+ the launcher's
-    pid), the same for every launch from one shell - a file left by a KILLED launch (atexit never ran) has a matching tag.  Such a
+    """without CSI_RCCL_ID_TOKEN / TORCHELASTIC_RUN_ID the tag is the rendezvous triple, the same for
+    every launch on one port - a file left by a KILLED launch (atexit never ran) has a matching tag.  Such a
     leftover must not be handed to a non-root rank: it is refused by its age (the time rank 0 stamped INTO the file - not the mtime),
     the reader keeps polling and takes the file rank 0 of its own launch writes meanwhile.  Rank 0's exit handler removes only what
     it wrote itself."""
@@ -193,7 +193,7 @@ def test_unique_id_file_without_a_launch_token_wants_a_fresh_file(pkg, tmp_path,
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
     monkeypatch.setenv('MASTER_PORT', '29511')
-    tag = hashlib.sha256(('127.0.0.1:29511:2:%d' % os.getppid()).encode()).digest()
+    tag = hashlib.sha256(b'127.0.0.1:29511:2').digest()
     stale = bytes([7]) * 128
     path.write_bytes(tag + struct.pack('<d', time.time() - 3600.0) + stale)         # an hour-old leftover with the RIGHT tag, fresh mtime
     with pytest.raises(RuntimeError, match='CSI_RCCL_ID_TOKEN'):
@@ -224,6 +224,31 @@ def test_unique_id_file_without_a_launch_token_wants_a_fresh_file(pkg, tmp_path,
     dist.exchange_unique_id(0, 2)
     calls[-1]()
     assert not path.exists()
+
+
+def test_unique_id_file_is_found_by_ranks_with_different_parents(tmp_path):
+    """ranks of a hand-rolled launch need not share a parent process (separate shells, ssh / docker exec
+    sessions, `bash -c` wrappers, service units).  Without a launch token, path and tag derive from the rendezvous triple alone, so
+    rank 1 - started here behind an extra `bash -c` + `sh -c`, i.e. with another parent than rank 0's - finds rank 0's file in the
+    DEFAULT location.  (Stale files are handled by the stamp inside the file: the test above.)"""
+    code = ("import sys, os; sys.path.insert(0, %r); import dl_channel_estimation_mamimo_amd as pkg; "
+            "from dl_channel_estimation_mamimo_amd import dist, engine; engine.get_unique_id = lambda: bytes(range(128)); "
+            "r = int(sys.argv[1]); uid = dist.exchange_unique_id(r, 2, timeout_s=30.0); "
+            "import time; time.sleep(1.5 if r == 0 else 0); print('rank', r, 'ppid', os.getppid(), uid.hex()[:16])") % REPO
+    env = dict(os.environ, XDG_RUNTIME_DIR=str(tmp_path), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29700 + os.getpid() % 200))
+    for k in ('CSI_RCCL_ID_TOKEN', 'TORCHELASTIC_RUN_ID', 'CSI_RCCL_ID_FILE', 'RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    script = tmp_path / 'rank.py'
+    script.write_text(code)
+    p1 = subprocess.Popen(['bash', '-c', 'sh -c "%s %s 1"; true' % (sys.executable, script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    p0 = subprocess.Popen([sys.executable, str(script), '0'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    o0, e0 = p0.communicate(timeout=120)
+    o1, e1 = p1.communicate(timeout=120)
+    assert p0.returncode == 0 and 'rank 0' in o0, e0[-2000:]
+    assert 'rank 1' in o1, (o1, e1[-2000:])
+    f0, f1 = o0.split(), o1.split()
+    assert f0[3] != f1[3], 'the two ranks were meant to have different parents'
+    assert f0[4] == f1[4] == bytes(range(128)).hex()[:16]
 
 
 def test_integration_doc_indexes_every_entry_point_of_the_header():
@@ -474,7 +499,7 @@ print('mock-runtime engine: ok')
     assert run.returncode == 0 and 'mock-runtime engine: ok' in run.stdout, run.stdout[-3000:]
 
 
-def test_bench_script_runs_end_to_end_on_the_mock_runtime(mock_so):
+def test_bench_script_runs_end_to_end_on_the_mock_runtime(mock_so, tmp_path):
     """bench.py itself, every leg a one-GPU run has except the fresh-process side configs - warm-up, timed region with kernel events,
     the steps again without them, host path incl. the pinned-result leg and the link probe, oracle check, CPU baseline, latency loop,
     practical peak, next rows - on the mock runtime in a child process: the numbers mean nothing (kernels are dropped), but every line of
@@ -485,24 +510,43 @@ def test_bench_script_runs_end_to_end_on_the_mock_runtime(mock_so):
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, '-c', runner, '--packets', '64', '--steps', '2', '--warmup', '1', '--host-path', '64', '--no-other-configs',
-                        '--cpu-budget-s', '2'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=REPO)
+                        '--cpu-budget-s', '2', '--detail-file', str(tmp_path / 'bench_detail_mock.json')], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     import json
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    raw = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    # round-5 verdict, next 1: the line is a record the driver can parse (BENCH_r05.parsed was null for a 20 KB line) - below 4 KB,
+    # stderr quiet enough to share an 8 KB tail with it, everything else in the detail file it names
+    assert len(raw) < 4096, len(raw)
+    assert len(raw) + len(r.stderr) < 8000, (len(raw), len(r.stderr), r.stderr[-2000:])
+    line = json.loads(raw)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
-                'roofline', 'cpu_baseline', 'kernels', 'parity_check', 'host_path_pcie_inclusive', 'next_rows', 'regimes', 'bench_wall_s'):
+                'roofline', 'roofline_ls', 'cpu_baseline', 'parity_check', 'latency_us', 'ranks_ms', 'host_path', 'next_rows', 'regimes_us', 'detail_file', 'bench_wall_s'):
         assert key in line, key
-    # round-4 verdict, next 3: the batch-size regimes that fit the resident batch (64 packets here), each with its bound
-    assert [r['packets'] for r in line['regimes']] == [1, 8, 64] and all(r['bound_us'] > 0 and 'bound' in r and r['pipelined_us'] > 0 for r in line['regimes'])
-    assert line['roofline_ls']['achieved_is'] and 'algorithmic_frac' in line['roofline_ls']
+    assert 'dropped' not in line
     assert line['n_gpus'] == 1 and line['steps'] == 2 and line['warmup'] == 1 and line['config']['pairs_per_step'] == 64 * 128
-    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    assert 'workload' in line['config'] and not any(k in line['config'] for k in ('model', 'global_batch', 'seq_len'))
+    for key in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'flops_per_launch', 'algorithmic_bytes_per_launch'):
         assert key in line['roofline'], key
-    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
-        assert key in line['cpu_baseline'], key
-    c128 = line['host_path_pcie_inclusive']['python_c128_to_c64']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in line['roofline_ls'], key
+    cb = line['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'threads', 'host_cpu_count', 'cpu_model', 'kind', 'sample'):
+        assert key in cb, key
+    # round-5 verdict, weak 6: `cores` = the CPUs the container grants, not torch's thread pick and not the host's count
+    assert 0 < cb['cores'] <= os.cpu_count() and cb['host_cpu_count'] == os.cpu_count() and cb['threads'] >= 1
+    assert sorted(line['regimes_us']) == ['1', '64', '8'] and all(len(v) == 3 and v[0] > 0 and v[2] > 0 for v in line['regimes_us'].values())
+    # the detail file: the whole object, with what the line left out
+    with open(os.path.join(REPO, line['detail_file'])) as f:
+        detail = json.load(f)
+    for key in ('kernels', 'host_path_pcie_inclusive', 'next_rows', 'regimes', 'ranks', 'devices', 'arithmetic', 'input', 'launch'):
+        assert key in detail, key
+    assert detail['value'] == line['value'] and detail['ms_per_step'] == line['ms_per_step']
+    # round-4 verdict, next 3: the batch-size regimes that fit the resident batch (64 packets here), each with its bound
+    assert [r_['packets'] for r_ in detail['regimes']] == [1, 8, 64] and all(r_['bound_us'] > 0 and 'bound' in r_ and r_['pipelined_us'] > 0 for r_ in detail['regimes'])
+    assert detail['roofline_ls']['achieved_is'] and 'algorithmic_frac' in detail['roofline_ls']
+    c128 = detail['host_path_pcie_inclusive']['python_c128_to_c64']
     assert 'dnn_only_pinned_result' in c128 and c128['dnn_only_pinned_result']['direct_downloads'] == 4, c128.keys()
-    text = json.dumps(line)
+    text = json.dumps(detail)
     assert '_error' not in text and '"error"' not in text, [k for k in ('_error', '"error"') if k in text]
 
 
@@ -550,7 +594,7 @@ print('ringb gating: ok')
     assert run.returncode == 0 and 'ringb gating: ok' in run.stdout, run.stdout[-3000:]
 
 
-def test_two_rank_bench_runs_the_multi_gpu_legs_on_the_mock_runtime(mock_so):
+def test_two_rank_bench_runs_the_multi_gpu_legs_on_the_mock_runtime(mock_so, tmp_path):
     """`torchrun ... bench.py --gpus 2` end to end without a GPU (gloo, the library's translation unit on the mock runtime): the weak-scaled config-2
     headline by two ranks AND - round-4 verdict, next 4 - the configs[3] / configs[4] legs as fresh two-rank jobs started by the
     running ranks (shrunken packet counts; configs[4] as one hipGraph per step and rank).  Numbers mean nothing here (kernels are
@@ -563,14 +607,28 @@ def test_two_rank_bench_runs_the_multi_gpu_legs_on_the_mock_runtime(mock_so):
     port = 29600 + os.getpid() % 300
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--check', '0',
-                        '--packets', '64', '--legs-packets', '24,6', '--input', 'white'], env=env, cwd=REPO,
+                        '--packets', '64', '--legs-packets', '24,6', '--input', 'white',
+                        '--detail-file', str(tmp_path / 'bench_detail_2rank.json')], env=env, cwd=REPO,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     import json
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    raw = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    line = json.loads(raw)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['pairs_per_step'] == 2 * 64 * 128      # (64 packets per rank: the mock's allocator fills every buffer)
-    legs = {l['config']: l for l in line['other_configs']}
-    assert set(legs) == {'configs[3]', 'configs[4]'}, line['other_configs']
+    # round-5 verdict, next 1: the N-rank line with both legs stays a record - below 4 KB at 2 ranks AND extrapolated to 8 (what grows
+    # with the rank count is `ranks_ms` of the headline and of each leg; everything per-rank beyond that lives in the detail file)
+    per_rank = (len(json.dumps(line['ranks_ms'])) + sum(len(json.dumps(l.get('ranks_ms'))) for l in line['other_configs'])) / 2.0
+    assert len(raw) < 4096 and len(raw) + 6 * (per_rank + 4) < 4096, (len(raw), per_rank)
+    assert 'dropped' not in line and len(line['ranks_ms']) == 2
+    for key in ('roofline', 'parity_check', 'detail_file', 'bench_wall_s'):
+        assert key in line, key
+    brief = {l['config']: l for l in line['other_configs']}
+    assert set(brief) == {'configs[3]', 'configs[4]'} and all(l['n_gpus'] == 2 and l['ms_per_step'] > 0 and len(l['ranks_ms']) == 2 for l in brief.values()), line['other_configs']
+    with open(os.path.join(REPO, line['detail_file'])) as f:
+        detail = json.load(f)
+    assert len(detail['ranks']) == 2 and len(detail['devices']) == 2
+    legs = {l['config']: l for l in detail['other_configs']}
+    assert set(legs) == {'configs[3]', 'configs[4]'}, detail['other_configs']
     for name, (nt, nr, total) in {'configs[3]': (64, 8, 24), 'configs[4]': (128, 16, 6)}.items():
         l = legs[name]
         assert 'error' not in l and 'skipped' not in l, l
