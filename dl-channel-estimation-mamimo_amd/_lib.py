@@ -117,14 +117,16 @@ def library_path():
 
 
 def build_band_kernel(verbose=False):
-    """csrc/band_kernel_gen.py -> gfx950 assembly -> code object -> csrc/band8_hsaco.inc (a C array the library embeds and
-    loads with hipModuleLoadData on first use).  clang / ld.lld of the ROCm LLVM; no GPU needed."""
+    """csrc/band_kernel_gen.py + csrc/band4_kernel_gen.py (the register-blocked bf16 form; its main() writes the kernels of both
+    generators into one file) -> gfx950 assembly -> code object -> csrc/band8_hsaco.inc (a C array the library embeds and loads
+    with hipModuleLoadData on first use).  clang / ld.lld of the ROCm LLVM; no GPU needed."""
     import tempfile
     csrc = os.path.join(_PKG_DIR, 'csrc')
-    gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
-    names = ['csi_band8', 'csi_band8_cs', 'csi_band8_bf16_cs', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd']
+    gen8, gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band4_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
+    names = ['csi_band8', 'csi_band8_cs', 'csi_band8_bf16_cs', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd',
+             'csi_band4_bf16']
     tag = '// kernels: ' + ' '.join(names)
-    if os.path.exists(inc) and os.path.getmtime(inc) >= os.path.getmtime(gen):
+    if os.path.exists(inc) and os.path.getmtime(inc) >= max(os.path.getmtime(gen), os.path.getmtime(gen8)):
         with open(inc) as f:
             if f.readline().strip() == tag:           # same generator, same kernel list
                 return inc
@@ -145,7 +147,7 @@ def build_band_kernel(verbose=False):
     rows = [', '.join('0x%02x' % b for b in blob[i:i + 24]) for i in range(0, len(blob), 24)]
     with open(inc + '.tmp', 'w') as f:
         f.write(tag + '\n')
-        f.write('// generated by _lib.build_band_kernel from band_kernel_gen.py - gfx950 code object of csi_band8 (%d bytes)\n' % len(blob))
+        f.write('// generated by _lib.build_band_kernel from band_kernel_gen.py + band4_kernel_gen.py - gfx950 code object of the band kernels (%d bytes)\n' % len(blob))
         f.write('alignas(4096) static const unsigned char band8_hsaco[] = {\n' + ',\n'.join(rows) + '};\n')
     os.replace(inc + '.tmp', inc)
     return inc

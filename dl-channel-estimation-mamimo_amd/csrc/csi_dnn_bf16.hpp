@@ -300,10 +300,12 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 const double bytes = 4.0 * ((double)M2 / nt * h1 + (double)nt * h1) + 2.0 * ((double)l1.out * h1 + (double)cf.n_out * l1.out) + 4.0 * (double)M2 * cf.n_out;
                 // small calls: the column-split launch (csi_dnn_hs.hpp); its partial outputs live in the h1 / activation buffers this path leaves unused
                 const bool staged_fn = fn == c->band_fn_bf16;
+                // round 6: the register-blocked form (4 waves x 512 registers) serves the same staged shapes with the same operand buffers
+                if (staged_fn && c->band4 && c->band_fn4_bf16 && !ba.stamps) fn = c->band_fn4_bf16;
                 const int Sb = (staged_fn && ba.ldo == ba.n2 && (ba.N1 * (long)ba.ldb1 * 2 < 0x7fffffffL)) ?
                                    band8_splits(c, ba, ((size_t)M2 * h1 + (size_t)M2 * maxh) / 2, true) : 1;
                 if (Sb > 1) rc = band8_launch_split(c, ba, Sb, reinterpret_cast<float*>(h1b), flops, bytes, true);
-                else if (fused_ok || Sb == 1) rc = band8_launch(c, fn, ba, flops, bytes);
+                else rc = band8_launch(c, fn, ba, flops, bytes);
                 done = true;
             } else if (fused_ok) {
                 rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);

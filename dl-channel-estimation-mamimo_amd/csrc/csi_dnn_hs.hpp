@@ -280,6 +280,11 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             (void)hipGetLastError();
             c->band_fn_bf16_cs = nullptr;
         }
+        if (hipModuleGetFunction(&c->band_fn4_bf16, c->band_mod, "csi_band4_bf16") != hipSuccess) {
+            (void)hipGetLastError();
+            c->band_fn4_bf16 = nullptr;
+        }
+        c->band_bf16_threads = (ext && n_bf && std::strncmp(n_bf, "csi_band4", 9) == 0) ? 256 : BAND8_THREADS;
     }
     *fn = bf16 ? (staged ? c->band_fn_bf16 : c->band_fn_bf16_ns) : (staged ? c->band_fn : c->band_fn_ns);
 #endif
@@ -308,7 +313,9 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
     Band8Args a8 = band8_args(ba);
     size_t sz = sizeof(a8);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+    // the register-blocked form is a workgroup of 4 waves (band4_kernel_gen.py), the others of 8
+    const unsigned threads = fn == c->band_fn4_bf16 ? 256u : (fn == c->band_fn_bf16 ? (unsigned)c->band_bf16_threads : (unsigned)BAND8_THREADS);
+    HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, threads, 1, 1, 0, c->stream, nullptr, extra));
     return CSI_OK;
 }
 

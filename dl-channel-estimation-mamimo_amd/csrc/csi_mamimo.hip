@@ -1207,6 +1207,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "small_rows_band") *value = c->small_rows_band;
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_band") *value = c->hs_band;
+    else if (n == "band4") *value = c->band4;
+    else if (n == "band4_available") *value = c->band_fn4_bf16 != nullptr;
     else if (n == "band_launches") *value = c->band_launches;
     else if (n == "band_split") *value = c->band_split;
     else if (n == "aux_fork_early") *value = c->aux_fork_early;
@@ -1318,6 +1320,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
                                                 "2 (bf16 contexts: also the form with per-lane loads, any nt) or 3 (fp32 contexts: only that form; A/B runs)");
         drop_graphs(c);
         c->hs_band = (int)value;
+    } else if (n == "band4") {
+        drop_graphs(c);
+        c->band4 = value != 0;
     } else if (n == "l0_stream") {
         drop_graphs(c);
         c->l0_stream = value != 0;
