@@ -59,7 +59,7 @@ GV, BQ, CV = 50, 58, 74             # fp32 sums (8) / bias quads [2 sets] x 8 / 
 V_RD0, V_RD1, V_AX1, V_AX2 = 86, 87, 88, 89
 V_TL0, V_TL1, V_LL = 90, 92, 94     # [r]
 V_LOFF, V_TOFF = 96, 97             # V_TOFF [2]
-V_VO1, V_VO2 = 99, 103              # [4] each
+V_VO = 99                           # LDS-DMA offset of this lane inside a weight sub-tile: 4096 w + 16 lane
 V_BADDR, V_B2ADDR, V_OUTOFF, V_M, V_4HI, V_HI, V_L31 = 107, 108, 109, 111, 113, 114, 115
 V_T = 18                            # scratch of prologue / epilogue / stamps: aliases the slab values (dead there)
 ACC1 = 128                          # arch VGPRs v128 .. v255: [r][jj] x 16
@@ -122,15 +122,18 @@ class Role4:
         return [['  ds_read_b128 %s, %s offset:%d' % (self.w(s, jj), vreg(V_RD1 if s else V_RD0), slot * RING_SLOT + jj * 2048)] for jj in range(4)]
 
     def u_pieces(self, kind, slot, pre=None):
-        """this wave's 4 LDS-DMA pieces (1 KiB each) of the next sub-tile of stream `kind` into ring slot `slot`, then the pointer step"""
-        ptr, vo = (S_W1P, V_VO1) if kind == 's1' else (S_W2P, V_VO2)
+        """this wave's 4 LDS-DMA pieces (1 KiB each) of the next sub-tile of stream `kind` into ring slot `slot`.  The weights come PRE-TILED
+        (band4_tile_kernel: every 16-KiB sub-tile contiguous, in stream order, already in the ring's swizzled image): a piece is 1 KiB of
+        whole 128-byte lines, and since the instruction's immediate offset moves the LDS destination together with the source
+        (tools/ldsdma_offset_probe.hip) the four pieces share one m0 and one offset register"""
+        ptr = S_W1P if kind == 's1' else S_W2P
         units = []
-        if pre:
-            units.append(['  ' + ln for ln in pre])
         if 'nodma' not in self.dbg:
             for p in range(4):
-                units.append(['  s_add_u32 m0, %s, %d' % (sreg(S_DMA), slot * RING_SLOT + p * 1024), '  s_nop 0',
-                              '  global_load_lds_dwordx4 %s, %s' % (vreg(vo + p), sreg(ptr, 2)), ('vm', 'P%d' % slot)])
+                u = ['  s_add_u32 m0, %s, %d' % (sreg(S_DMA), slot * RING_SLOT), '  s_nop 0'] if p == 0 else []
+                u += ['  global_load_lds_dwordx4 %s, %s%s' % (vreg(V_VO), sreg(ptr, 2), ' offset:%d' % (1024 * p) if p else ''), ('vm', 'P%d' % slot)]
+                units.append(u)
+        units.append(['  s_add_u32 %s, %s, %d' % (sreg(ptr), sreg(ptr), RING_SLOT), '  s_addc_u32 %s, %s, 0' % (sreg(ptr + 1), sreg(ptr + 1))])
         return units
 
     def u_step(self, ptr, delta):
@@ -275,7 +278,7 @@ class Role4:
             b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
             b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
         for t in range(4):
-            flat(b, self.u_pieces('s1', t) + self.u_step(S_W1P, 64))
+            flat(b, self.u_pieces('s1', t))
         for t in range(4):
             flat(b, self.u_stage_issue(t, reset=(t == 0)))
         b.wait_vm({'T0', 'L0'})
@@ -300,20 +303,15 @@ class Role4:
             pre = self.u_read_w(0, slot)
             if produce_ok:
                 pre += self.u_convert1(par ^ 1)
-            if issue_ok and 'slabpost' not in self.dbg:
+            if issue_ok:
                 pre += self.u_stage_issue(i & 3)
             post = self.u_read_w(1, nslot)
             if produce_ok:
                 post += self.u_read_f1(par ^ 1)
             if stage_ok:
                 post += self.u_stage_read((i + 2) & 3)
-            if piece == 's1':
-                dma = self.u_pieces('s1', slot) + self.u_step(S_W1P, 64)
-            else:                                           # the regressor's sub-tiles 0 .. 3 of this column step (fragment order 0, 1, 2, 3 = tiles 0, 4, 1, 5)
-                dma = self.u_pieces('s2', slot) + self.u_step(S_W2P, 256 if (i & 1) == 0 else -192)
-            if issue_ok and 'slabpost' in self.dbg:         # (A/B: the slab request behind the barrier, one sub-step later than slab u + 4 could go)
-                dma += self.u_stage_issue(i & 3)
-            post = dma + post if 'dmafirst' in self.dbg else post + dma
+            # (piece 's2': the regressor's sub-tiles 0 .. 3 of this column step, in fragment order = tiles 0, 4, 1, 5)
+            post += self.u_pieces(piece, slot)
             needs = {'P%d' % nslot}
             if stage_ok:
                 needs |= {'T%d' % ((i + 2) & 3), 'L%d' % ((i + 2) & 3)}
@@ -386,7 +384,6 @@ class Role4:
                 units += self.u_bias(f, k & 1, (sec + 1) & 1)
             return units
 
-        W2_STEP = [256, -192, 256, -192, 256, -192, 256, 64]          # sub-tile q -> q + 1 of the regressor stream (k ranges of tiles 0, 4, 1, 5, 2, 6, 3, 7)
         for q in range(NQ):
             slot, par, nslot = q & 3, q & 1, (q + 1) & 3
             pre = self.u_read_w(0, slot) + conv_units(2 * q)
@@ -406,18 +403,9 @@ class Role4:
                 post += self.u_read_f1(0) + self.u_stage_read(1)
                 needs |= {'T1', 'L1'}
             post += conv_units(2 * q + 1)
-            if q < NQ - 4:
-                post += self.u_pieces('s2', slot) + self.u_step(S_W2P, W2_STEP[q + 4])
-            else:
-                prep = None
-                if q == NQ - 4:                             # the stage-1 weight pointer moves to the next column step (wraps at the end)
-                    prep = ['s_add_u32 %s, %s, 1' % (sreg(S_T), sreg(S_COL)),
-                            's_cmp_ge_u32 %s, %s' % (sreg(S_T), sreg(S_NCOL)),
-                            's_cselect_b32 %s, 0, %s' % (sreg(S_T), sreg(S_T)),
-                            's_mul_i32 %s, %s, %s' % (sreg(S_T + 1), sreg(S_T), sreg(S_COLBYTES)),
-                            's_add_u32 %s, %s, %s' % (sreg(S_W1P), sreg(S_W1), sreg(S_T + 1)),
-                            's_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1 + 1))]
-                post += self.u_pieces('s1', slot, pre=prep) + self.u_step(S_W1P, 64)
+            # sub-tiles 4 .. 7 of the regressor stream, then sub-tiles 0 .. 3 of the next column step's pair-layer stream (the tiled copy is
+            # in stream order: the pointer just runs on; behind the last column step it runs into the copy's four spare tiles)
+            post += self.u_pieces('s2' if q < NQ - 4 else 's1', slot)
             self.substep(st2, 2, slot, par, pre, post, needs)
         tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
         tail.e('s_add_u32 %s, %s, 1' % (sreg(S_COL), sreg(S_COL)))
@@ -570,20 +558,9 @@ def common_prologue(b, dbg=()):
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_AX1), sreg(S_T), vreg(V_AX1)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_AX2), AX2_OFF, vreg(V_AX1)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_AX1), AX1_OFF, vreg(V_AX1)))
-    # ---- LDS-DMA pieces: image row 64 w + 16 p + (lane >> 2), chunk (lane & 3) ^ ((lane >> 4) & 3)
-    b.e('v_and_b32_e32 %s, 3, %s' % (vreg(V_T + 1), vreg(V_LANE)))
-    b.e('v_bfe_u32 %s, %s, 4, 2' % (vreg(V_T + 2), vreg(V_LANE)))
-    b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 2)))
-    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_T + 1), vreg(V_T + 1)))
-    b.e('v_lshrrev_b32_e32 %s, 2, %s' % (vreg(V_T), vreg(V_LANE)))
-    b.e('s_lshl_b32 %s, %s, 6' % (sreg(S_T), sreg(S_WAVE)))
-    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(V_T)))
-    for vo, ld in ((V_VO1, S_LDB1), (V_VO2, S_LDB2)):
-        b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T), sreg(ld)))
-        b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(vo), vreg(V_T + 3), vreg(V_T + 1)))
-        b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T), sreg(ld)))                               # 16 rows x ld halves x 2 B
-        for p in range(1, 4):
-            b.e('v_add_u32_e32 %s, %s, %s' % (vreg(vo + p), sreg(S_T), vreg(vo + p - 1)))
+    # ---- LDS-DMA pieces: byte 4096 w + 1024 p + 16 lane of the (pre-tiled) sub-tile = of the ring slot
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_VO), vreg(V_LANE)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_VO), sreg(S_DMA), vreg(V_VO)))
     # ---- bias reads
     b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_BADDR), vreg(V_HI)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_BADDR), BIAS1_OFF, vreg(V_BADDR)))
@@ -773,7 +750,7 @@ VARIANTS = [('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('cs
             ('csi_band4_bf16_nobarrier', ('nobarrier',)), ('csi_band4_bf16_nointerleave', ('nointerleave',)),
             ('csi_band4_bf16_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band4_bf16_noaside_noread', ('noconv', 'noreq', 'noread')),
             ('csi_band4_bf16_skeleton_nobarrier', ('noconv', 'noreq', 'nodma', 'noread', 'nobarrier')),
-            ('csi_band4_bf16_pk', ('pk',)), ('csi_band4_bf16_rowstores', ('rowstores',)), ('csi_band4_bf16_slabpost', ('slabpost',)), ('csi_band4_bf16_dmafirst', ('dmafirst',)),
+            ('csi_band4_bf16_pk', ('pk',)), ('csi_band4_bf16_rowstores', ('rowstores',)), 
             ('csi_band4_bf16_nostore', ('nostore',)), ('csi_band4_bf16_skeleton_nostore', ('noconv', 'noreq', 'nodma', 'noread', 'nostore'))]
 
 

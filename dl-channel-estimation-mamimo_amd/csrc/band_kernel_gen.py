@@ -932,6 +932,97 @@ def common_prologue(b, dbg=(), mode='hs'):
     b.e('s_cbranch_scc0 L_r1_start')
 
 
+def epilogue_staged(b, h, slow_label):
+    """Round 6.  With ldo == n2 (the library's layout) the output of a band is ONE contiguous block of 128 x ldo floats, but a lane owns a
+    ROW: the direct stores of the accumulators are 64 scattered 8-byte pieces per instruction - measured on the register-blocked bf16 form
+    (band4_kernel_gen.py) at 0.46 ms of a 3.33 ms launch.  Here the block is assembled in LDS (ring, exchange area and slabs are dead; the
+    bias quads go to registers first) and leaves as a linear stream of 16-byte pieces, 1 KiB per wave-instruction.  Taken when the band is
+    full, ldo == n2, n2 is even (8-byte LDS writes) and the block is 16-byte aligned; anything else branches to the row-per-lane stores."""
+    BQ2, ST, D, GOFF, U, NW = 2, V_T + 12, 2, 30, 5, 8
+    b.e('s_add_u32 %s, %s, 128' % (sreg(S_T), sreg(S_M0)))
+    b.e('s_cmp_le_u32 %s, %s' % (sreg(S_T), sreg(S_M)))
+    b.e('s_cbranch_scc0 %s' % slow_label)
+    b.e('s_cmp_eq_u32 %s, %s' % (sreg(S_LDO), sreg(S_N2)))
+    b.e('s_cbranch_scc0 %s' % slow_label)
+    b.e('s_and_b32 %s, %s, 1' % (sreg(S_T), sreg(S_N2)))
+    b.e('s_cmp_eq_u32 %s, 0' % sreg(S_T))
+    b.e('s_cbranch_scc0 %s' % slow_label)
+    b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T + 4), sreg(S_M0), sreg(S_LDO)))
+    b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T + 4), sreg(S_T + 4)))                       # (M * ldo * 4 < 2^32: band8_serves)
+    b.e('s_add_u32 %s, %s, %s' % (sreg(S_T + 4), sreg(S_OUT), sreg(S_T + 4)))
+    b.e('s_addc_u32 %s, %s, 0' % (sreg(S_T + 5), sreg(S_OUT + 1)))
+    b.e('s_and_b32 %s, %s, 15' % (sreg(S_T), sreg(S_T + 4)))
+    b.e('s_cmp_eq_u32 %s, 0' % sreg(S_T))
+    b.e('s_cbranch_scc0 %s' % slow_label)
+    for jj in range(4):                       # bias2 quads of this half's 16 column chunks
+        for rq in range(4):
+            b.e('ds_read_b128 %s, %s offset:%d' % (vreg(BQ2 + 4 * (4 * jj + rq), 4), vreg(V_B2ADDR), (32 * jj + 8 * rq) * 4))
+    # LDS address of this lane's row, its first column: ((32 rg + l31) * ldo + 128 h + 4 hi) * 4
+    b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T), sreg(S_RG)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(ST), sreg(S_T), vreg(V_L31)))
+    b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(ST), vreg(ST), sreg(S_LDO)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(ST), vreg(ST), vreg(V_4HI)))
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(ST), 128 * h, vreg(ST)))
+    b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(ST), vreg(ST)))
+    b.e('s_waitcnt lgkmcnt(0)')
+    b.e('s_barrier')                          # every wave has left the main loop and holds its bias quads: the LDS is the staging area now
+    for jj in range(4):
+        for rq in range(4):
+            c0 = 128 * h + 32 * jj + 8 * rq
+            imm = (32 * jj + 8 * rq) * 4
+            uid = 'L_s%d_%d_%d' % (h, jj, rq)
+            bq = BQ2 + 4 * (4 * jj + rq)
+            for e in range(4):
+                b.e('v_accvgpr_read_b32 %s, %s' % (vreg(V_T + e), areg(ACC2 + 16 * jj + 4 * rq + e)))
+            for e in range(4):
+                b.e('v_fma_f32 %s, %s, %s, %s' % (vreg(V_T + e), vreg(V_T + e), sreg(S_AS2), vreg(bq + e)))
+            b.e('s_cmp_ge_u32 %s, %d' % (sreg(S_N2), c0 + 8))
+            b.e('s_cbranch_scc0 %s_m' % uid)
+            b.e('ds_write_b64 %s, %s offset:%d' % (vreg(ST), vreg(V_T, 2), imm))
+            b.e('ds_write_b64 %s, %s offset:%d' % (vreg(ST), vreg(V_T + 2, 2), imm + 8))
+            b.e('s_branch %s_d' % uid)
+            b.label('%s_m' % uid)
+            for pr in range(2):                                                         # column pair valid <=> 4 hi + 2 pr < n2 - c0 (n2 even)
+                b.e('s_sub_i32 %s, %s, %d' % (sreg(S_T), sreg(S_N2), c0 + 2 * pr))
+                b.e('v_cmp_gt_i32_e32 vcc, %s, %s' % (sreg(S_T), vreg(V_4HI)))
+                b.e('s_mov_b64 exec, vcc')
+                b.e('ds_write_b64 %s, %s offset:%d' % (vreg(ST), vreg(V_T + 2 * pr, 2), imm + 8 * pr))
+            b.e('s_mov_b64 exec, -1')
+            b.label('%s_d' % uid)
+    b.e('s_waitcnt lgkmcnt(0)')
+    b.e('s_barrier')
+    # ---- the block leaves: piece i (16 bytes) of 32 * ldo; wave w takes pieces 64 w + lane + 512 j
+    b.e('s_lshl_b32 %s, %s, 6' % (sreg(S_T), sreg(S_WAVE)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), sreg(S_T), vreg(V_LANE)))          # piece index of round 0
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_T + 9), vreg(V_T + 8)))                 # its LDS address; advances by U rounds per iteration
+    for k in range(U):
+        b.e('v_add_u32_e32 %s, %d, %s' % (vreg(GOFF + k), 1024 * NW * k, vreg(V_T + 9)))    # global offsets of the U rounds (the base advances)
+    b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T + 2), sreg(S_LDO)))                          # pieces
+    b.e('s_mov_b32 %s, 0' % sreg(S_T + 3))
+    b.label('L_copy_%d' % h)
+    for k in range(U):
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 10), sreg(S_T + 3), vreg(V_T + 8)))
+        if k:
+            b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 10), 64 * NW * k, vreg(V_T + 10)))
+        b.e('v_cmp_gt_u32_e32 vcc, %s, %s' % (sreg(S_T + 2), vreg(V_T + 10)))
+        b.e('s_mov_b64 %s, vcc' % sreg(78 + 2 * k, 2))
+        b.e('s_mov_b64 exec, vcc')
+        b.e('ds_read_b128 %s, %s offset:%d' % (vreg(D + 4 * k, 4), vreg(V_T + 9), 1024 * NW * k))
+    b.e('s_mov_b64 exec, -1')
+    b.e('s_waitcnt lgkmcnt(0)')
+    for k in range(U):
+        b.e('s_mov_b64 exec, %s' % sreg(78 + 2 * k, 2))
+        b.e('global_store_dwordx4 %s, %s, %s' % (vreg(GOFF + k), vreg(D + 4 * k, 4), sreg(S_T + 4, 2)))
+    b.e('s_mov_b64 exec, -1')
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 9), 1024 * NW * U, vreg(V_T + 9)))
+    b.e('s_add_u32 %s, %s, %d' % (sreg(S_T + 4), sreg(S_T + 4), 1024 * NW * U))
+    b.e('s_addc_u32 %s, %s, 0' % (sreg(S_T + 5), sreg(S_T + 5)))
+    b.e('s_add_u32 %s, %s, %d' % (sreg(S_T + 3), sreg(S_T + 3), 64 * NW * U))
+    b.e('s_cmp_lt_u32 %s, %s' % (sreg(S_T + 3), sreg(S_T + 2)))
+    b.e('s_cbranch_scc1 L_copy_%d' % h)
+    b.e('s_branch L_end')
+
+
 def epilogue(b, h, dbg=()):
     b.label('L_epilogue_%d' % h)
     b.e('s_waitcnt vmcnt(0)')                 # the re-fetched head of the stream has landed: the ring may go
@@ -965,6 +1056,9 @@ def epilogue(b, h, dbg=()):
     b.label('L_noguard_%d' % h)
     if 'nostore' in dbg:
         b.e('s_branch L_end')
+    if 'rowstores' not in dbg:
+        epilogue_staged(b, h, 'L_rowstores_%d' % h)
+    b.label('L_rowstores_%d' % h)
     # ---- output: lane = row, register quad = 4 consecutive outputs (columns 128 h + 32 jj + 8 rq + 4 hi + e)
     b.e('s_mov_b64 exec, %s' % sreg(S_ROWMASK, 2))
     for jj in range(4):
@@ -1075,7 +1169,7 @@ VARIANTS = [('csi_band8', ()), ('csi_band8_cs', ('colsplit',)), ('csi_band8_bf16
             ('csi_band8_bf16_nobarrier', ('bf16', 'nobarrier')), ('csi_band8_bf16_noread', ('bf16', 'noread')), ('csi_band8_bf16_nodma', ('bf16', 'nodma')),
             ('csi_band8_bf16_skeleton_nobarrier', ('bf16', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band8_bf16_skeleton_rnd', ('bf16', 'noconv', 'noreq', 'nodma', 'noread', 'rnd')),
             ('csi_band8_bf16_noaside_noread', ('bf16', 'noconv', 'noreq', 'noread')), ('csi_band8_bf16_noaside_nodma', ('bf16', 'noconv', 'noreq', 'nodma')),
-            ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
+            ('csi_band8_rowstores', ('rowstores',)), ('csi_band8_exit2', ('exit2',)), ('csi_band8_exit2_noguard', ('exit2', 'noguard')), ('csi_band8_exit2_nostore', ('exit2', 'nostore')), ('csi_band8_dump', ('dump',)), ('csi_band8_dump0', ('dump0',))]
 
 
 def main():

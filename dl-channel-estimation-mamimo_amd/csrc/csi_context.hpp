@@ -85,6 +85,9 @@ struct Model {
     int T_hs_shift = HS_SHIFT_AUTO;   // HS_SHIFT_AUTO = not built
     float* T_sw = nullptr;       // T (bf16 contexts) / T_hs (split engine) in the slab order of the staged band kernels (band_tsw_kernel); rebuilt with the table
     bool T_sw_ok = false;
+    uint16_t* Wt1 = nullptr;     // bf16 contexts: the pair layer's and the regressor's weights pre-tiled for the register-blocked band kernel
+    uint16_t* Wt2 = nullptr;     // (band4_tile_kernel, built on first use from layers[1].Wb / layers[2].Wb_p)
+    bool tiled_ok = false;
     float* l0_rowmax = nullptr;  // [4096] row maxima of a mid-size call's preambles (l0_row_max_kernel -> l0_hs_stream_kernel)
     bool loaded = false;
     bool table_ok = false;
@@ -435,6 +438,10 @@ void free_model(Model& m) {
     if (m.T) hipFree(m.T);
     if (m.T_hs) hipFree(m.T_hs);
     if (m.T_sw) hipFree(m.T_sw);
+    if (m.Wt1) hipFree(m.Wt1);
+    if (m.Wt2) hipFree(m.Wt2);
+    m.Wt1 = m.Wt2 = nullptr;
+    m.tiled_ok = false;
     if (m.l0_rowmax) hipFree(m.l0_rowmax);
     m.W0p = m.T = m.T_hs = m.T_sw = m.l0_rowmax = nullptr;
     m.T_sw_ok = false;

@@ -137,6 +137,29 @@ __global__ void band_tsw_kernel(const float* __restrict__ T, int ldt, int nt, in
         *reinterpret_cast<float4*>(dst + i * 4) = v;
     }
 }
+// The weight streams of the register-blocked band kernel (band4_kernel_gen.py) PRE-TILED: every 16-KiB sub-tile [256 rows][32 k] bf16 stored
+// contiguously, in the order the kernel streams them, in the swizzled image the ring slot holds (unit pos of row r = k-columns
+// 8 (pos ^ ((r >> 2) & 3)) .. + 7 of the sub-tile) - so that an LDS-DMA piece is 1 KiB of whole 128-byte lines (the K-major matrix gives it
+// sixteen 64-byte row segments) and the four pieces of a sub-tile differ by an immediate.
+//   mode 0, pair layer W1 [N1][ld]: tile (c, u) = rows 256 c .., k-columns 32 u ..; tiles c-major; `spare` zero tiles behind the last.
+//   mode 1, regressor W2p [256][ld]: tile (c, q) = all 256 rows, k-columns 256 c + 128 (q & 1) + 32 (q >> 1) .. (fragment order of the kernel:
+//   the h2 fragments alternate between the halves).
+__global__ void band4_tile_kernel(const uint16_t* __restrict__ src, int ld, int ncol, int nsub, int mode, int spare, uint16_t* __restrict__ dst) {
+    const size_t units = (size_t)(ncol * nsub + spare) * 1024;            // 16-byte units
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
+        const int pos = (int)(i & 3), r = (int)((i >> 2) & 255);
+        const size_t t = i >> 10;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t < (size_t)ncol * nsub) {
+            const int c = (int)(t / nsub), u = (int)(t % nsub);
+            const int row = mode == 0 ? 256 * c + r : r;
+            const int k = (mode == 0 ? 32 * u : 256 * c + 128 * (u & 1) + 32 * (u >> 1)) + 8 * (pos ^ ((r >> 2) & 3));
+            v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + k);
+        }
+        *reinterpret_cast<uint4*>(dst + i * 8) = v;
+    }
+}
+
 // which form serves a call: the staged ones need the band's L0 rows in one 1-KiB slab (8 rows of 32 k / 16 rows of 16 k) and the T slab in 8 KiB
 inline bool band8_staged(const BandArgs& g, bool bf16 = true) { return bf16 ? (g.nt >= 32 && g.nt <= 64) : (g.nt >= 16 && g.nt <= 128); }
 

@@ -10,7 +10,7 @@ CTR="${CTR:-SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
 for v in ${@:-csi_band8_bf16 csi_band8_bf16_noconv csi_band8_bf16_noaside csi_band8_bf16_skeleton}; do
   D=gpurun_out/bf16pmc/$v
   rm -rf $D; mkdir -p $D
-  CSI_BAND8_BF16_NAME=$v rocprofv3 --pmc $CTR --output-format csv -d $D -o pmc -- python bench.py --dtype bf16 --nt 64 --nr 4 --packets 5000 --steps 3 --warmup 2 --check 0 --no-cpu-baseline --no-latency --no-other-configs --no-regimes --host-path 0 --option hs_band=2 > $D/bench.json 2> $D/err.txt
+  CSI_BAND8_BF16_NAME=$v rocprofv3 --pmc $CTR --output-format csv -d $D -o pmc -- python bench.py --dtype bf16 --nt 64 --nr 4 --packets 5000 --steps 3 --warmup 2 --check 0 --no-cpu-baseline --no-latency --no-other-configs --no-regimes --host-path 0 --option hs_band=2 --option band4=0 --no-next-rows --full-line > $D/bench.json 2> $D/err.txt
   python - $v $D <<'PY'
 import csv, sys, collections, glob, json
 v, d = sys.argv[1], sys.argv[2]
@@ -19,7 +19,7 @@ if not f:
     print(v, 'no counter file;', open(d + '/err.txt').read()[-300:]); sys.exit(0)
 agg, dur, seen = collections.defaultdict(list), [], set()
 for r in csv.DictReader(open(f[0])):
-    if 'band8' not in r['Kernel_Name']:
+    if 'csi_band' not in r['Kernel_Name']:
         continue
     agg[r['Counter_Name']].append(float(r['Counter_Value']))
     if r['Dispatch_Id'] not in seen:
