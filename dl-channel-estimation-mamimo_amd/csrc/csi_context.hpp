@@ -159,6 +159,11 @@ struct csi_ctx {
     size_t aux_ws_bytes = 0, aux_l0skinny_bytes = 0, aux_skbuf_bytes = 0, aux_fuse_ws_bytes = 0;
     int small_call_overlap = 1;  // "small_call_overlap" option
     // the one-packet regime (csi_dnn_small.hpp): both models of a call of <= 8 rx preambles in 1 + n_hidden launches
+    int small_ls_fused = 1;      // "small_ls_fused": a one-packet csi_estimate_device call runs its LS estimate inside the layer-0 launch (small_l0_ls_kernel)
+    float* small_ls_h_re = nullptr;   // set by csi_estimate_device around its predict call, consumed by predict_small
+    float* small_ls_h_im = nullptr;
+    int64_t small_ls_launches = 0;
+    int debug_small_tile16 = 0;  // CSI_DEBUG_HOOKS=1 CSI_SMALL_TILE16=1, read once at csi_create (A/B runs)
     int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
     int small_rows = 1024;       // "small_rows": pair rows up to which a call takes it (and at most 64 preambles).  Measured (profiles/r05_regime_probe.txt):
                                  // 4 packets 117 us against 143 on the general kernels, 8 packets 162 / 170, 12 packets 251 / 246, 16 packets 283 / 252

@@ -31,6 +31,25 @@ bool small_call_ok(csi_ctx* c, int64_t npkt) {
     return true;
 }
 
+// (defined in csi_mamimo.hip behind the LS plan) the LS kernel of this context is the Walsh-Hadamard one in its default shape: its LDS bytes
+bool ls_default_fwht2(const csi_ctx* c, size_t* lds_bytes);
+LsArgs ls_args(const csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, float* d_h_re, float* d_h_im);
+
+// csi_estimate_device: may the LS estimate of this call ride in the layer-0 launch?  The weight-streaming layer 0 (at most 8 preambles), the
+// Walsh-Hadamard LS kernel in its default one-thread-per-bin shape on the Sylvester order itself (Nt = 16 / 32 / 64)
+bool small_ls_fusable(csi_ctx* c, int64_t npkt) {
+    const csi_config& cf = c->cfg;
+    const int nt = cf.nt;
+    if (!c->small_ls_fused || !(nt == 16 || nt == 32 || nt == 64) || cf.dtype != CSI_DTYPE_F32) return false;
+    size_t lds = 0;
+    if (!ls_default_fwht2(c, &lds)) return false;
+    // ONLY beside the weight-streaming layer 0 of the one-packet path (plain v_fma_f32, no matrix instructions).  The same arrangement beside the
+    // mid-size path's l0_hs_stream_kernel (f16 MFMAs) was built and measured this round: LS results wrong and different run to run at 3 and 8
+    // packets (profiles/r06_small_calls.txt) - the signature round 4 saw with LS waves beside another workgroup's MFMAs on one SIMD
+    // (profiles/r04_ls_ringb_variants.txt); and it bought nothing there (97.3 us either way: the second stream's chain is the longer one)
+    return small_call_ok(c, npkt) && npkt * cf.nr <= SC_MAX_ROWS0;
+}
+
 int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int64_t npkt, float* d_out_re, float* d_out_im) {
     const csi_config& cf = c->cfg;
     const int nt = cf.nt, h1 = cf.hidden[0], nh = cf.n_hidden;
@@ -79,7 +98,29 @@ int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int6
         // 4 columns per workgroup, 2 k steps of 1024 in flight: every shape tried (4 / 8 columns, 2 ... 5 steps) lands at 16.2-17.0 us
         // for the 84 MB of the shipped model = 5.2 TB/s - the memory system's rate, not the kernel's (profiles/r05_small_call_trace.txt)
         const dim3 grid((unsigned)((h1 + 3) / 4), 2);
-        if (M1 > 4) hipLaunchKernelGGL((small_l0_gemv_kernel<8, 4, 2>), grid, dim3(256), 0, c->stream, a);
+        if (c->small_ls_h_re && c->small_ls_h_im) {
+            // csi_estimate_device: the LS estimate of the call inside this launch (small_l0_ls_kernel), one boundary and 8.9 us less per call
+            LsArgs la = ls_args(c, d_ltf_re, d_ltf_im, c->small_ls_h_re, c->small_ls_h_im);
+            size_t ls_lds = 0;
+            if (!ls_default_fwht2(c, &ls_lds)) return fail(c, CSI_ERR_NOT_READY, "one-packet call: the LS kernel changed under the call");
+            int nblk = M1, ls_blocks = M1;
+            const dim3 fgrid(grid.x + (unsigned)ls_blocks, 2);
+            const void* fn = nullptr;
+#define SC_LS(NTV) (M1 > 4 ? (const void*)small_l0_ls_kernel<NTV, 8> : (const void*)small_l0_ls_kernel<NTV, 4>)
+            fn = nt == 16 ? SC_LS(16) : (nt == 32 ? SC_LS(32) : SC_LS(64));
+#undef SC_LS
+            static thread_local const void* attr_fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            bool seen = false;
+            for (const void* f : attr_fn) seen = seen || f == fn;
+            if (!seen) {
+                HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
+                for (auto& f : attr_fn) if (!f) { f = fn; break; }
+            }
+            void* kargs[] = {(void*)&a, (void*)&la, (void*)&nblk, (void*)&ls_blocks};
+            HIP_TRY(c, hipLaunchKernel(fn, fgrid, dim3(256), kargs, ls_lds, c->stream));
+            c->small_ls_h_re = c->small_ls_h_im = nullptr;      // consumed
+            ++c->small_ls_launches;
+        } else if (M1 > 4) hipLaunchKernelGGL((small_l0_gemv_kernel<8, 4, 2>), grid, dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL((small_l0_gemv_kernel<4, 4, 2>), grid, dim3(256), 0, c->stream, a);
         HIP_TRY(c, hipGetLastError());
     }
@@ -103,8 +144,7 @@ int predict_small(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im, int6
         g.M = M2; g.N = l.out; g.K = l.in; g.ldb = l.ldw;
         g.lda = li == 1 ? h1 : l.in;
         g.ldc = last ? cf.n_out : l.out;
-        bool force16 = false;                     // A/B runs: CSI_DEBUG_HOOKS=1 CSI_SMALL_TILE16=1 keeps every layer on the 16 x 16 tiles
-        if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_SMALL_TILE16")) force16 = d[0] == '1';
+        const bool force16 = c->debug_small_tile16 != 0;      // A/B runs: CSI_DEBUG_HOOKS=1 CSI_SMALL_TILE16=1 (read once, at csi_create) keeps every layer on the 16 x 16 tiles
         ProfScope ps(c, last ? K_REGRESSOR : (li == 1 ? K_PAIR_DENSE : K_DENSE_HIDDEN), 2.0 * 2.0 * (double)M2 * g.N * g.K,
                      2.0 * 4.0 * ((double)g.N * g.K + (double)M2 * g.N + (double)M2 * g.K));
         // 32 x 32 tiles (half the operand traffic per flop) where they still make ~256 workgroups, 16 x 16 tiles where the layer is

@@ -831,8 +831,10 @@ __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* t
 __device__ __forceinline__ void ls_store_sbase(float* base_uniform, uint32_t byte_off, float v) {
     asm volatile("global_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
 }
-template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1), bool PERM = false, bool SST = PERM>
-__global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
+// The body is a device function of (workgroup index, workgroup count) so that the one-packet path can run it in the SAME launch as layer 0
+// of the DNN (small_call.hip.h: small_l0_ls_kernel - the LS workgroups beside the weight-streaming ones, round 6)
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF, bool PERM, bool SST>
+__device__ __forceinline__ void ls_fwht2_body(const LsArgs& a, const int nblk, const unsigned wg_x, const unsigned wg_n) {
     static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
     static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
     static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning one half of every output block)");
@@ -860,10 +862,10 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     __syncthreads();                            // tables visible; drains the table loads before any DMA is counted
 
     const uint32_t s_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)S);
-    const int nitems = blockIdx.x < (unsigned)nblk ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nitems = wg_x < (unsigned)nblk ? (nblk - 1 - (int)wg_x) / (int)wg_n + 1 : 0;
     const int T = nitems * NCH;                 // chunks this workgroup walks
     int ti = 0, ich = 0;                        // next chunk to request
-    size_t iblk = blockIdx.x;
+    size_t iblk = wg_x;
     typedef const __attribute__((address_space(4))) int* ctab_t;
     typedef int ls_i32x8 __attribute__((ext_vector_type(8)));
     typedef const __attribute__((address_space(4))) ls_i32x8* ctab8_t;        // eight consecutive table entries = one s_load_dwordx8 (32-byte aligned:
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             }
         }
         ++ti;
-        if (++ich == NCH) { ich = 0; iblk += gridDim.x; }
+        if (++ich == NCH) { ich = 0; iblk += wg_n; }
     };
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) issue_next();
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
     for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
 
     int t = 0;
-    for (size_t blk = blockIdx.x; blk < (size_t)nblk; blk += gridDim.x) {
+    for (size_t blk = wg_x; blk < (size_t)nblk; blk += wg_n) {
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch, ++t) {
             // PERM: this chunk's butterfly coefficients (the input signs, multiplied out on the host: see the despread), requested here -
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             // slot rows consumed -> their successors (chunk t + NSTG) start streaming
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_next();
-            if (ch == 0 && t > 0) store_item(blk - gridDim.x);
+            if (ch == 0 && t > 0) store_item(blk - wg_n);
             // DBF: two spectra images alternate, so the image written now was last read two chunks ago - every wave
             // finished that despread before it arrived at the previous "spectra complete" barrier
             f32x2* Fb = Fc + (DBF ? (t & 1) * CH * LSC_ROW : 0);
@@ -1050,7 +1052,12 @@ __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(co
             }
         }
     }
-    if (nitems > 0) store_item(blockIdx.x + (size_t)(nitems - 1) * gridDim.x);
+    if (nitems > 0) store_item(wg_x + (size_t)(nitems - 1) * wg_n);
+}
+
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1), bool PERM = false, bool SST = PERM>
+__global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
+    ls_fwht2_body<NT, SPLIT, CH, NSTG, DBF, PERM, SST>(a, nblk, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_f32.hip.h"
+#include "ls_estimate.hip.h"
 
 namespace csi {
 
@@ -44,11 +45,11 @@ struct SmallL0Args {
 
 // grid (ceil(h1 / COLS), 2), 256 threads; COLS output columns per workgroup (a multiple of 4), UN k steps of 1024 in flight
 template <int MR, int SC_GEMV_COLS, int UN>
-__global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
+__device__ __forceinline__ void small_l0_gemv_body(const SmallL0Args& a, const int wg_x, const int z) {
     __shared__ float red[4][64][MR * SC_GEMV_COLS + 1];
     __shared__ float part[4][MR * SC_GEMV_COLS];
-    const int z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * SC_GEMV_COLS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = wg_x * SC_GEMV_COLS;
     const float* __restrict__ x = a.x[z];
     const float* __restrict__ W = a.Wt[z];
     f32x4 acc[MR][SC_GEMV_COLS];
@@ -122,6 +123,24 @@ __global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
         for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(l0s[m][4 * qd + e] + tv[e], 0.f), sc[e], sh[e]);
         *reinterpret_cast<f32x4*>(a.h1out[z] + (size_t)r * a.h1 + n) = v;
     }
+}
+
+template <int MR, int SC_GEMV_COLS, int UN>
+__global__ __launch_bounds__(256) void small_l0_gemv_kernel(SmallL0Args a) {
+    small_l0_gemv_body<MR, SC_GEMV_COLS, UN>(a, blockIdx.x, blockIdx.y);
+}
+
+// Round 6: the LS estimate of a one-packet call IN THE SAME LAUNCH as layer 0.  The two are independent (the same preambles feed both,
+// generate_maMIMO_LTF.m:336-349), the LS kernel of such a call is 4 workgroups of latency (8.9 us) and the weight stream leaves the CUs
+// idle enough: workgroups (x < ls_blocks, y = 0) run the Walsh-Hadamard LS body (ls_estimate.hip.h), the others layer 0 of component model y.
+// One launch and one boundary less per call; both bodies are the functions the separate kernels call, so the results are the same bits.
+template <int NT, int MR>
+__global__ __launch_bounds__(256) void small_l0_ls_kernel(SmallL0Args a, LsArgs la, int nblk, int ls_blocks) {
+    if ((int)blockIdx.x < ls_blocks) {
+        if (blockIdx.y == 0) ls_fwht2_body<NT, 1, 8, (NT == 64 ? 3 : 1), false, false, true>(la, nblk, blockIdx.x, (unsigned)ls_blocks);
+        return;
+    }
+    small_l0_gemv_body<MR, 4, 2>(a, (int)blockIdx.x - ls_blocks, blockIdx.y);
 }
 
 struct SmallGemmArgs {
