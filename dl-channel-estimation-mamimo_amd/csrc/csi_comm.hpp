@@ -12,7 +12,7 @@
 //   csi_broadcast_weights  - RCCL: record and buffers by ncclBroadcast, one ncclAllReduce(min) of a status word between
 //                            them so that a rank that refuses the record takes every rank out BEFORE the grouped broadcast
 //   csi_clone_weights      - one process: record by value, buffers by hipMemcpy[Peer]Async from the source context
-// run.  The second one exists so that a single-GPU box executes every line of the receiver side (tests/test_gpu_round4.py).
+// run.  The second one exists so that a single-GPU box executes every line of the receiver side (tests/test_gpu_*.py).
 //
 // RCCL is loaded with dlopen at csi_comm_init (librccl.so.1, the library `torch.distributed` backend "nccl" wraps on ROCm):
 // a single-GPU user of libcsi_mamimo.so needs no RCCL installed, and a process that already carries torch's copy shares it.

@@ -831,233 +831,24 @@ __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* t
 __device__ __forceinline__ void ls_store_sbase(float* base_uniform, uint32_t byte_off, float v) {
     asm volatile("global_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
 }
-// The body is a device function of (workgroup index, workgroup count) so that the one-packet path can run it in the SAME launch as layer 0
-// of the DNN (small_call.hip.h: small_l0_ls_kernel - the LS workgroups beside the weight-streaming ones, round 6)
-template <int NT, int SPLIT, int CH, int NSTG, bool DBF, bool PERM, bool SST>
-__device__ __forceinline__ void ls_fwht2_body(const LsArgs& a, const int nblk, const unsigned wg_x, const unsigned wg_n) {
-    static_assert(NT == 16 || NT == 32 || NT == 64 || NT == 128, "power-of-two antenna counts up to 128");
-    static_assert(CH == 8 || CH == 16, "chunk of 8 or 16 symbols");
-    static_assert(SPLIT == 1 || SPLIT == 2, "one thread per bin, or two (each owning one half of every output block)");
-    constexpr int NW = 4 * SPLIT, SPW = CH / NW, NCH = NT / CH, R = 2 * SPW;
-    // SPLIT = 2: thread half g owns antennas g CH/2 .. of every block of CH.  H_CH = H_2 (x) H_{CH/2} in the Sylvester
-    // order, so its CH/2 transform outputs are the FWHT_{CH/2} of x[s] + (-1)^g x[s + CH/2]: half the butterflies of
-    // the full transform instead of all of them in both threads.
-    constexpr int CHH = CH / SPLIT;
-    static_assert(SPW >= 1 && NSTG >= 1 && NSTG <= 4 && (NSTG - 1) * R <= 63, "shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x2* twc = reinterpret_cast<f32x2*>(smem);                       // [LSC_NTW] per-stage twiddles
-    f32x2* Fc = twc + LSC_NTW;                                         // [CH][LSC_ROW] spectra image (re, im)
-    float* S = reinterpret_cast<float*>(Fc + (DBF ? 2 : 1) * CH * LSC_ROW);   // [NSTG][CH][2][256] raw samples, LDS-DMA target
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
-    lsc_build_twiddles(twc, a.tw, tid, 256 * SPLIT);
-    const int q = tid & 255;                    // this thread's data bin
-    const int g = SPLIT == 2 ? (tid >> 8) : 0;  // which half of every output block this thread accumulates
-    const bool qok = q < LS_NDATA;
-    const int pos = lsc_phys(a.bin_pos[qok ? q : 0]);
-    const float rden = 1.0f / a.denom[qok ? q : 0];          // +-1/NT, exact
-    __syncthreads();                            // tables visible; drains the table loads before any DMA is counted
-
-    const uint32_t s_off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)S);
-    const int nitems = wg_x < (unsigned)nblk ? (nblk - 1 - (int)wg_x) / (int)wg_n + 1 : 0;
-    const int T = nitems * NCH;                 // chunks this workgroup walks
-    int ti = 0, ich = 0;                        // next chunk to request
-    size_t iblk = wg_x;
-    typedef const __attribute__((address_space(4))) int* ctab_t;
-    typedef int ls_i32x8 __attribute__((ext_vector_type(8)));
-    typedef const __attribute__((address_space(4))) ls_i32x8* ctab8_t;        // eight consecutive table entries = one s_load_dwordx8 (32-byte aligned:
-                                                                              // the table starts on a 256-byte boundary, every run starts at a multiple of 8)
-    static_assert(!PERM || CHH == 8, "the table-driven form reads its tables in runs of eight");
-    const ctab_t tab = PERM ? (ctab_t)(uintptr_t)a.perm : nullptr;
-    int nsrc[SPW];                              // PERM: source symbols of the chunk issue_next() issues next
-#pragma unroll
-    for (int u = 0; u < SPW; ++u) nsrc[u] = PERM ? tab[wave + u * NW] : 0;
-    auto issue_next = [&]() {
-        if (ti >= T) return;
-        const uint32_t d = s_off + (uint32_t)((((ti % NSTG) * CH + wave) * 2) * LS_FFT * sizeof(float));
-        if (PERM) {
-            // the source symbols of this chunk were looked up one chunk ago (nsrc): a scalar load in front of the DMA issue would put
-            // its latency on the ring's critical path (measured: +5 % at Nt = 128 whatever the permutation was)
-            const size_t o = iblk * a.len_ltf + LS_CP + 4 * lane;
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) {
-                ls_dma16(a.ltf_re + o + (size_t)nsrc[u] * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
-                ls_dma16(a.ltf_im + o + (size_t)nsrc[u] * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
-            }
-            const int nich = ich + 1 == NCH ? 0 : ich + 1;
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) nsrc[u] = tab[nich * CH + wave + u * NW];
-        } else {
-            const size_t o = iblk * a.len_ltf + (size_t)(ich * CH + wave) * LS_SYM + LS_CP + 4 * lane;
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) {
-                ls_dma16(a.ltf_re + o + (size_t)u * NW * LS_SYM, d + u * NW * 2 * LS_FFT * sizeof(float));
-                ls_dma16(a.ltf_im + o + (size_t)u * NW * LS_SYM, d + (u * NW * 2 + 1) * LS_FFT * sizeof(float));
-            }
-        }
-        ++ti;
-        if (++ich == NCH) { ich = 0; iblk += wg_n; }
-    };
-#pragma unroll
-    for (int k = 0; k < NSTG; ++k) issue_next();
-
-    // The finished item is stored one step late: after the next chunk's samples are in registers and the ring slot
-    // is refilled (vmcnt counts stores too: a landing wait right behind the stores would drain them with the ring idle).
-    f32x2 h[NCH * CHH];                         // (re, im) of the owned antennas: block ab, antenna ab CH + g CHH + j
-    const int gu = __builtin_amdgcn_readfirstlane(g);
-    auto store_item = [&](size_t blk) {
-        if (qok && !(a.dbg & 4)) {
-            if (PERM) {
-                // transform row r = ab CH + g CHH + j goes to antenna tab[2 NT + r], times the sign tab[3 NT + r]; the row base is
-                // wave-uniform (scalar address arithmetic), the lane adds its bin
-                char* const item_re = reinterpret_cast<char*>(a.h_re + blk * NT * LS_NDATA);
-                char* const item_im = reinterpret_cast<char*>(a.h_im + blk * NT * LS_NDATA);
-#pragma unroll
-                for (int ab = 0; ab < NCH; ++ab) {
-                    const ls_i32x8 orow = *(ctab8_t)(tab + 2 * NT + ab * CH + gu * CHH), osgn = *(ctab8_t)(tab + 3 * NT + ab * CH + gu * CHH);
-#pragma unroll
-                    for (int j = 0; j < CHH; ++j) {
-                        const unsigned rowb = (unsigned)orow[j];     // the table holds the row's byte offset inside the item: one 64-bit scalar add per plane
-                        const int sbits = osgn[j];          // (a scalar copy first: __builtin_bit_cast on the element expression itself reads element 0 - clang, ROCm 7.2)
-                        const float rs = rden * __builtin_bit_cast(float, sbits);
-                        const f32x2 v = h[ab * CHH + j] * f32x2{rs, rs};
-                        ls_store_sbase(reinterpret_cast<float*>(item_re + rowb), 4u * (unsigned)q, v[0]);
-                        ls_store_sbase(reinterpret_cast<float*>(item_im + rowb), 4u * (unsigned)q, v[1]);
-                    }
-                }
-            } else if (SST) {
-                const size_t row0 = (blk * NT + (size_t)gu * CHH) * LS_NDATA;
-#pragma unroll
-                for (int ab = 0; ab < NCH; ++ab)
-#pragma unroll
-                    for (int j = 0; j < CHH; ++j) {
-                        const f32x2 v = h[ab * CHH + j] * f32x2{rden, rden};          // one packed multiply for both planes
-                        ls_store_sbase(a.h_re + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, v[0]);
-                        ls_store_sbase(a.h_im + row0 + (size_t)(ab * CH + j) * LS_NDATA, 4u * (unsigned)q, v[1]);
-                    }
-            } else {
-                float* pre = a.h_re + (blk * NT + g * CHH) * LS_NDATA + q;
-                float* pim = a.h_im + (blk * NT + g * CHH) * LS_NDATA + q;
-#pragma unroll
-                for (int ab = 0; ab < NCH; ++ab)
-#pragma unroll
-                    for (int j = 0; j < CHH; ++j) {
-                        const f32x2 v = h[ab * CHH + j] * f32x2{rden, rden};
-                        pre[(ab * CH + j) * LS_NDATA] = v[0];
-                        pim[(ab * CH + j) * LS_NDATA] = v[1];
-                    }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
-    };
-#pragma unroll
-    for (int j = 0; j < NCH * CHH; ++j) h[j] = f32x2{0.f, 0.f};
-
-    int t = 0;
-    for (size_t blk = wg_x; blk < (size_t)nblk; blk += wg_n) {
-#pragma unroll 1
-        for (int ch = 0; ch < NCH; ++ch, ++t) {
-            // PERM: this chunk's butterfly coefficients (the input signs, multiplied out on the host: see the despread), requested here -
-            // a whole chunk of work ahead of their use
-            int cfb[CH];
-            if (PERM) {
-#pragma unroll
-                for (int r8 = 0; r8 < CH; r8 += 8) {
-                    ls_i32x8 sg8 = *(ctab8_t)(tab + NT + ch * CH + r8);
-                    asm volatile("" : "+s"(sg8));               // materialise now (the scheduler would sink the scalar load to its use)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) cfb[r8 + r] = sg8[r];
-                }
-            }
-            // ---- this wave's rows of chunk t have landed?
-            const int younger = ti - t - 1;
-            if (NSTG == 1 || younger <= 0) ls_wait_vm<0>();
-            else if (NSTG == 2 || younger == 1) ls_wait_vm<R>();
-            else if (NSTG == 3 || younger == 2) ls_wait_vm<2 * R>();
-            else ls_wait_vm<3 * R>();
-            // ---- stage 0 straight from the raw rows
-            f32x2 y0[SPW][4];
-            lsc_stage0_read<SPW, NW>(S + (size_t)(((t % NSTG) * CH + wave) * 2) * LS_FFT, rev3, y0);
-            // slot rows consumed -> their successors (chunk t + NSTG) start streaming
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_next();
-            if (ch == 0 && t > 0) store_item(blk - wg_n);
-            // DBF: two spectra images alternate, so the image written now was last read two chunks ago - every wave
-            // finished that despread before it arrived at the previous "spectra complete" barrier
-            f32x2* Fb = Fc + (DBF ? (t & 1) * CH * LSC_ROW : 0);
-            if (!DBF && t > 0) ls_lds_barrier();  // spectra of chunk t - 1 consumed by every thread
-            lsc_stage0_write<SPW, NW>(Fb, wave, lane, y0);
-            if (!(a.dbg & 1)) lsc_fft_rows<SPW, NW, true>(Fb, wave, twc, lane);
-            ls_lds_barrier();                     // spectra complete
-            // ---- this bin's CH spectra -> registers, FWHT over the symbol index, signed add into the owned blocks
-            if (!(a.dbg & 2)) {
-                f32x2 w[CHH];
-                // PERM: input s carries the sign S_s.  No multiply is spent on it: a butterfly (S_a A) +- (S_b B) = S_a (A +- (S_a S_b) B)
-                // is an fma with the scalar coefficient S_a S_b (from the table) and leaves BOTH outputs with the pending sign S_a; after
-                // the level of stride hh element j is pending S_{j with its low bits cleared}, after the last one every element is pending
-                // S_0 - which joins the sign of the cross-chunk stage, an fma coefficient already.  The instruction count is the
-                // Sylvester kernel's.  Table row 1, per chunk: [the CHH fold coefficients (SPLIT = 2)], S_0, then CHH/2 + CHH/4 + .. + 1
-                // level coefficients.
-                constexpr int L0 = CH - CHH;
-                if (SPLIT == 2) {
-                    const float gs = g ? -1.f : 1.f;
-                    if (PERM) {
-                        const int gneg = gu << 31;
-#pragma unroll
-                        for (int r = 0; r < CHH; ++r) {
-                            const int kb = cfb[r] ^ gneg;
-                            const float k = __builtin_bit_cast(float, kb);
-                            w[r] = __builtin_elementwise_fma(f32x2{k, k}, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
-                        }
-                    } else {
-                        const f32x2 gs2 = {gs, gs};
-#pragma unroll
-                        for (int r = 0; r < CHH; ++r)
-                            w[r] = __builtin_elementwise_fma(gs2, Fb[(size_t)(r + CHH) * LSC_ROW + pos], Fb[(size_t)r * LSC_ROW + pos]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < CHH; ++r) w[r] = Fb[(size_t)r * LSC_ROW + pos];
-                }
-#pragma unroll
-                for (int hh = 1; hh < CHH; hh <<= 1)
-#pragma unroll
-                    for (int i = 0; i < CHH; ++i)
-                        if (!(i & hh)) {
-                            if (PERM) {
-                                const int cb = cfb[L0 + 1 + CHH - CHH / hh + i / (2 * hh)];
-                                const float cp = __builtin_bit_cast(float, cb), cn = -cp;
-                                const f32x2 x = w[i], y = w[i + hh];
-                                w[i] = __builtin_elementwise_fma(f32x2{cp, cp}, y, x);
-                                w[i + hh] = __builtin_elementwise_fma(f32x2{cn, cn}, y, x);
-                                continue;
-                            }
-                            const f32x2 x = w[i], y = w[i + hh];
-                            w[i] = x + y;
-                            w[i + hh] = x - y;
-                        }
-                // cross-chunk stages: output block ab takes +-w by the sign of H_{NT/CH}[ab][ch]
-#pragma unroll
-                for (int ab = 0; ab < NCH; ++ab) {
-                    const int sgb = ((__builtin_popcount(ab & ch) & 1) << 31) ^ (PERM ? cfb[L0] : 0x3f800000);     // PERM: times the chunk's pending sign
-                    const float sg = __builtin_bit_cast(float, sgb);
-                    const f32x2 sgn = {sg, sg};
-#pragma unroll
-                    for (int j = 0; j < CHH; ++j) h[ab * CHH + j] = __builtin_elementwise_fma(sgn, w[j], h[ab * CHH + j]);
-                }
-            }
-        }
-    }
-    if (nitems > 0) store_item(wg_x + (size_t)(nitems - 1) * wg_n);
-}
-
 template <int NT, int SPLIT, int CH, int NSTG, bool DBF = false, int MINB = (SPLIT == 1 ? 2 : 1), bool PERM = false, bool SST = PERM>
 __global__ __launch_bounds__(256 * SPLIT, MINB) void ls_estimate_fwht2_kernel(const LsArgs a, int nblk) {
-    ls_fwht2_body<NT, SPLIT, CH, NSTG, DBF, PERM, SST>(a, nblk, blockIdx.x, gridDim.x);
+#define LS_WG_X blockIdx.x
+#define LS_WG_N gridDim.x
+#include "ls_fwht2_body.inc"
+#undef LS_WG_X
+#undef LS_WG_N
+}
+
+// The same body as a device function of (workgroup index, workgroup count): the one-packet path runs it in the SAME launch as layer 0 of the
+// DNN (small_call.hip.h: small_l0_ls_kernel - the LS workgroups beside the weight-streaming ones, round 6), one item per workgroup
+template <int NT, int SPLIT, int CH, int NSTG, bool DBF, bool PERM, bool SST>
+__device__ __forceinline__ void ls_fwht2_body(const LsArgs& a, const int nblk, const unsigned wg_x, const unsigned wg_n) {
+#define LS_WG_X wg_x
+#define LS_WG_N wg_n
+#include "ls_fwht2_body.inc"
+#undef LS_WG_X
+#undef LS_WG_N
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1455,7 +1246,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const 
             // chunk t after a fast wave had passed the next barrier and started to overwrite them: the reads must be retired before
             // the wave's own arrival at that barrier, which "all operands first" guarantees by construction).  The kernel as it stands is
             // bit-for-bit reproducible without the drain: 72 configurations x 12 runs, every item compared
-            // (profiles/r04_ls_generic_stress_nodrain.txt; tests/stress_ls_generic.py, bounded form in tests/test_gpu_round4.py).
+            // (profiles/r04_ls_generic_stress_nodrain.txt; tests/stress_ls_generic.py, bounded form in tests/test_gpu_*.py).
             // ls_debug 64 puts the drain back for A/B runs.
             // End of round 4 (profiles/r04_ls_ringb_variants.txt): what IS seen, rarely and on some boxes only, with the
             // two-workgroups-per-CU instantiation <1, 4, 1, NPP, 2> (no longer selected: ls_ringb_min) is not a race at all - every bad

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random LS shapes against the oracle (GPU box):  python tests/fuzz_ls.py [cases] [seed]; a seeded, bounded run of the same
-cases is part of the gpu test suite (tests/test_gpu_round3.py::test_fuzz_ls_cases).
+cases is part of the gpu test suite (tests/test_gpu_ls.py::test_fuzz_ls_cases).
 
 Every case: antenna count, rx count and packet count at random (item counts below, at and far above the resident grid of
 the persistent kernels), the Sylvester Hadamard pilot matrix or a generic one, the automatic kernel and every kernel

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised shape sweep (GPU box: python tests/fuzz_shapes.py [cases] [seed]; a seeded, bounded run of the same cases is part
-of the gpu test suite, tests/test_gpu_round3.py::test_fuzz_shape_cases):
+of the gpu test suite, tests/test_gpu_dnn_f32.py::test_fuzz_shape_cases):
 random Nt / Nr / packet counts / hidden widths / depth / BatchNormalization on-off / dtype / GEMM engine, the shared
 layer-0 path, the literal path and the LS estimate against the oracle."""
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE test function of the GPU suite without pytest's collection of the whole tests/ tree - for the last GPU seconds of a
 round, when a fresh box's `python -m pytest tests ...` start-up alone would eat them.
-    python tools/run_one_gpu_test.py tests/test_gpu_round4.py test_estimate_c128_into_pinned_result_arrays
+    python tools/run_one_gpu_test.py tests/test_gpu_*.py test_estimate_c128_into_pinned_result_arrays
 Fixtures served: pkg, oracle (as tests/conftest.py builds them).  Prints PASSED / the traceback, exit code 0 / 1."""
 import importlib.util
 import inspect
