@@ -256,6 +256,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         "small_rows_band" (default 256 = 2 packets of that shape; calls of at most 8 preambles are not subject to it): the limit where the column-split band kernel serves
  *                         the model ("band_split": two hidden layers, 16 <= Nt <= 128, hidden[1] a multiple of 512) - from there
  *                         on the general path (weight-streaming layer 0 + that kernel) is the faster one
+ *   "small_ls_fused"   1 (default): a csi_estimate_device call of at most 8 rx preambles runs its LS estimate INSIDE the layer-0 launch of the
+ *                         one-packet path (csrc/small_call.hip.h: small_l0_ls_kernel - LS workgroups beside the weight-streaming ones;
+ *                         Sylvester-ordered pilot, Nt = 16 / 32 / 64): one launch and 8 us less per call, same bits; 0: the LS kernel
+ *                         in front (A/B runs).  Read-only: "small_ls_launches".
  *   "l0_stream"        1 (default): layer 0 of a call of 9 ... "l0_stream_max_rows" (default 1280) rx preambles runs on the weight-streaming split-f16 kernel
  *                         (csrc/l0_hs_stream.hip.h: every preamble row scaled by its own power of two, no range guard needed);
  *                         0: the general kernels.  "l0_stream_ks": its k ranges (0 = automatic); "l0_stream_prepass_rows": beyond
@@ -310,6 +314,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         32 <= nt <= 64 (streamed form); 0: the separate kernels (A/B runs); 2: bf16 contexts take the per-lane form
  *                         at any other nt as well (measured slower than the separate kernels); 3: only the per-lane forms (A/B runs).
  *                         Read-only: "band_launches".
+ *   "band4"            1 (default): bf16 contexts take the REGISTER-BLOCKED form of that kernel where its streamed form applies (32 <= nt <= 64;
+ *                         csrc/band4_kernel_gen.py "csi_band4_bf16": 4 waves x 512 registers, every weight fragment against two row
+ *                         groups, weights pre-tiled at first use); 0: the 8-wave form "csi_band8_bf16" (A/B runs; same bf16 roundings,
+ *                         fp32 sums in another order).  Read-only: "band4_available".
  *   "band_split"       -1 (default): a call with fewer bands of 128 pair rows than the part has CUs (24 ... 64 packets of the shipped
  *                         shape) splits every band's hidden features over 2 or 4 workgroups ("csi_band8_cs") and adds their regressor
  *                         sums in split order - same arithmetic, the final fp32 sums associate differently (1 ulp class);
