@@ -319,7 +319,8 @@ def main():
     band_any = eng.get_option('band_launches') > 0                                   # first per-pair layer + regressor as one kernel (hs_band)
     band_kernel = args.dtype == 'f32' and band_any
     # bf16 contexts: the register-blocked form (csrc/band4_kernel_gen.py) where it serves the call
-    band_name = 'csi_band8' if band_kernel else ('csi_band4_bf16' if (band_any and eng.get_option('band4') and eng.get_option('band4_available')) else 'csi_band8_bf16')
+    band4 = band_any and eng.get_option('band4') and eng.get_option('band4_available')
+    band_name = ('csi_band4' if band4 else 'csi_band8') + ('' if band_kernel else '_bf16')
     # range guard of the split-f16 engine over the timed steps: a hit would have made eng.synchronize() raise
     # (CSI_ERR_RANGE) above; the counters go into the line
     guard = {'hs_launches': eng.get_option('hs_launches'), 'hs_range_fallbacks': eng.get_option('hs_range_fallbacks'),
@@ -579,8 +580,10 @@ def main():
 
     def hbm_per_launch(*prefixes):
         for pre in prefixes:
+            if isinstance(traffic.get(pre), dict):               # the kernel's own name first (csi_band4 is also a prefix of csi_band4_bf16)
+                return traffic[pre].get('hbm_bytes_per_launch')
             for k, v in traffic.items():
-                if k.startswith(pre):
+                if k.startswith(pre) and isinstance(v, dict):
                     return v.get('hbm_bytes_per_launch')
         return None
 
@@ -645,7 +648,7 @@ def main():
                      'unit': 'TFLOP/s', 'frac': achieved / mfma_peak, 'peak_note': peak_note,
                      'executed_mfma_tflops': achieved * (SPLIT_PRODUCTS if split_engine else 1),
                      'vs_fp32_mfma_peak': achieved / FP32_MATRIX_PEAK_TFLOPS if args.dtype == 'f32' else None,
-                     'traffic': (hbm_per_launch(('csi_band8' if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32'
+                     'traffic': (hbm_per_launch((band_name if band_kernel else 'gemm_hs_pp_pair_kernel<2') if split_engine else 'pair_gemm') if args.dtype == 'f32'
                                  else hbm_per_launch(band_name if band_any else 'gemm_bf16_pp_pair_kernel<1')), 'traffic_unit': 'HBM bytes per launch (PMC)',
                      'traffic_source': traffic.get('_file'), 'profile_files': prof_files or None,
                      'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),

@@ -32,7 +32,7 @@ import sys
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from band_kernel_gen import (Block, Wait, simulate, sreg, vreg, areg, DESCRIPTOR, S_AS2, META_KERNEL, KARG_BYTES,     # noqa: E402
+from band_kernel_gen import (Block, Wait, simulate, sreg, vreg, areg, DESCRIPTOR, S_AS2, S_INSC, S_AS1OS, S_OUTSC, META_KERNEL, KARG_BYTES,     # noqa: E402
                              S_L0, S_TS, S_W1, S_B1, S_W2, S_B2, S_OUT, S_PEAK, S_STAMPS, S_LDL, S_NT, S_LDB1, S_M, S_K1, S_N1, S_LDB2, S_N2,
                              S_LDO, S_MAGIC, S_WAVE, S_H, S_M0, S_W1P, S_W2P, S_L0P, S_TSP, S_TRIP, S_COL, S_NCOL, S_NSUB1, S_DMA, S_T,
                              S_ROWMASK, S_SAVE, S_COLBYTES, S_BIAS2OFF, S_TSLABB)
@@ -423,7 +423,278 @@ class Role4:
         return [pro, head, loop, last, bub, st2, tail]
 
 
-def common_prologue(b, dbg=()):
+# =============================================================================================== split-f16 form ("csi_band4": fp32 contexts)
+# Same blocking for the split engine of fp32 contexts (gemm_hs.hip.h operands: every value as hi + lo f16 halves, three MFMAs per product:
+# w_lo x a_hi, w_hi x a_hi, w_hi x a_lo).  Sub-step = 16 k: the weight sub-tile [256 rows][16 k as hi | lo] has the bf16 form's geometry
+# (plane 0 = hi, plane 1 = lo); an activation fragment is (hi, lo) of 32 rows x 16 k.  Wave (h, rp) CONVERTS the fragments of row group
+# r = h of its row pair (both halves, the whole 16 k) and reads the partner's from the exchange; 24 MFMAs per sub-step and wave.
+# Stage 2: 16 fragments per column step (tile x half g of its 16-feature groups), owner q & 1, order (tile jt = q >> 2, g = (q >> 1) & 1).
+H_OWNF = 2                           # own stage-1 fragment: [parity][hi | lo] x 4
+H_SLT, H_SLL, H_GV, H_BQ, H_CV = 18, 26, 34, 42, 50     # slab values T / L0 (8 each), fp32 temporaries (8), bias quads (8), converted h2 units [2][hi | lo] x 4
+V_PK1, V_PK2 = 66, 67                # packed maxima of the hi halves (range guard)
+H_AF = 160                           # AGPRs: the partner's stage-1 fragment [parity][hi | lo] x 4
+H_F2 = 176                           # AGPRs: h2 fragments [parity][r][hi | lo] x 4
+
+
+class RoleH(Role4):
+    """split-f16 form: straight-line program of the waves of one feature half"""
+
+    def wh(self, plane, jj):
+        return areg(AW + 16 * plane + 4 * jj, 4)
+
+    def a1(self, par, r, plane):
+        return vreg(H_OWNF + 8 * par + 4 * plane, 4) if r == self.h else areg(H_AF + 8 * par + 4 * plane, 4)
+
+    def a2(self, par, r, plane):
+        return areg(H_F2 + 16 * par + 8 * r + 4 * plane, 4)
+
+    def mf(self, kind, r, jj, wplane, aplane, par, zero_c=False):
+        if kind == 1:
+            d, f = vreg(ACC1 + 16 * (4 * r + jj), 16), self.a1(par, r, aplane)
+        else:
+            d, f = areg(ACC2 + 16 * (4 * r + jj), 16), self.a2(par, r, aplane)
+        return ['  v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (d, self.wh(wplane, jj), f, '0' if zero_c else d)]
+
+    def u_read_w(self, plane, slot):
+        if 'noread' in self.dbg:
+            return []
+        return [['  ds_read_b128 %s, %s offset:%d' % (self.wh(plane, jj), vreg(V_RD1 if plane else V_RD0), slot * RING_SLOT + jj * 2048)] for jj in range(4)]
+
+    def u_stage_issue(self, slot, reset=False):
+        units = []
+        if reset:
+            units.append(['  s_mov_b32 %s, %s' % (sreg(S_L0P), sreg(S_L0)), '  s_mov_b32 %s, %s' % (sreg(S_L0P + 1), sreg(S_L0 + 1)),
+                          '  s_mov_b32 %s, %s' % (sreg(S_TSP), sreg(S_TS)), '  s_mov_b32 %s, %s' % (sreg(S_TSP + 1), sreg(S_TS + 1))])
+        if 'noreq' not in self.dbg:
+            for i, tch in enumerate((S_TCH0, S_TCH1)):
+                units.append(['  s_add_u32 m0, %s, %d' % (sreg(tch), TS_OFF + slot * TSLAB), '  s_nop 0',
+                              '  global_load_lds_dwordx4 %s, %s' % (vreg(V_TOFF + i), sreg(S_TSP, 2)), ('vm', 'T%d' % slot)])
+            if self.h == 0:
+                self.uid += 1
+                skip = 'L_r0_l0skip_%d' % self.uid
+                units.append(['  s_cmp_lg_u32 %s, 0' % sreg(S_WAVE), '  s_cbranch_scc1 %s' % skip, '  s_mov_b32 m0, %d' % (L0S_OFF + slot * 1024), '  s_nop 0',
+                              '  global_load_lds_dwordx4 %s, %s' % (vreg(V_LOFF), sreg(S_L0P, 2)), ('vmopt', 'L%d' % slot), skip + ':'])
+        units.append(['  s_add_u32 %s, %s, %s' % (sreg(S_TSP), sreg(S_TSP), sreg(S_TSLABB)), '  s_addc_u32 %s, %s, 0' % (sreg(S_TSP + 1), sreg(S_TSP + 1)),
+                      '  s_add_u32 %s, %s, 64' % (sreg(S_L0P), sreg(S_L0P)), '  s_addc_u32 %s, %s, 0' % (sreg(S_L0P + 1), sreg(S_L0P + 1))])
+        return units
+
+    def u_stage_read(self, slot):
+        """this lane's 8 T and 8 L0 values (k = 8 hi .. + 7 of the sub-step's 16) of ITS row of row group r = h"""
+        if 'noreq' in self.dbg:
+            return []
+        return [['  ds_read_b128 %s, %s offset:%d' % (vreg(H_SLT, 4), vreg(V_TL0), slot * TSLAB)],
+                ['  ds_read_b128 %s, %s offset:%d' % (vreg(H_SLT + 4, 4), vreg(V_TL1), slot * TSLAB)],
+                ['  ds_read_b128 %s, %s offset:%d' % (vreg(H_SLL, 4), vreg(V_LL), slot * 1024)],
+                ['  ds_read_b128 %s, %s offset:%d' % (vreg(H_SLL + 4, 4), vreg(V_LL), slot * 1024 + 16)]]
+
+    def split_units(self, hi, lo, pk):
+        """GV (8 fp32, relu applied) -> hi halves, lo = f16(x - hi) through v_fma_mix (gemm_hs.hip.h hs_lo_pair), packed maximum of the hi halves"""
+        u = []
+        for p in range(4):
+            u.append(['  v_cvt_pk_f16_f32 %s, %s, %s' % (vreg(hi + p), vreg(H_GV + 2 * p), vreg(H_GV + 2 * p + 1))])
+        for p in range(4):
+            u.append(['  v_fma_mixlo_f16 %s, %s, -1.0, %s op_sel_hi:[1,0,0]' % (vreg(lo + p), vreg(hi + p), vreg(H_GV + 2 * p))])
+            u.append(['  v_pk_max_u16 %s, %s, %s' % (vreg(pk), vreg(pk), vreg(hi + p))])
+        for p in range(4):
+            u.append(['  v_fma_mixhi_f16 %s, %s, -1.0, %s op_sel:[1,0,0] op_sel_hi:[1,0,0]' % (vreg(lo + p), vreg(hi + p), vreg(H_GV + 2 * p + 1))])
+        return u
+
+    def u_convert1(self, par_next):
+        hi, lo = H_OWNF + 8 * par_next, H_OWNF + 8 * par_next + 4
+        units = []
+        if 'noconv' not in self.dbg:
+            for e in range(8):
+                units.append(['  v_fma_f32 %s, %s, %s, %s' % (vreg(H_GV + e), vreg(H_SLL + e), sreg(S_INSC), vreg(H_SLT + e))])
+            for e in range(8):
+                units.append(['  v_max_f32_e32 %s, 0, %s' % (vreg(H_GV + e), vreg(H_GV + e))])
+            units += self.split_units(hi, lo, V_PK1)
+        units.append(['  ds_write_b128 %s, %s offset:%d' % (vreg(V_AX1), vreg(hi, 4), par_next * 4096 + self.h * 2048)])
+        units.append(['  ds_write_b128 %s, %s offset:%d' % (vreg(V_AX1), vreg(lo, 4), par_next * 4096 + self.h * 2048 + 1024)])
+        return units
+
+    def u_read_f1(self, par_next):
+        o = 1 - self.h
+        return [['  ds_read_b128 %s, %s offset:%d' % (areg(H_AF + 8 * par_next + 4 * pl, 4), vreg(V_AX1), par_next * 4096 + o * 2048 + pl * 1024)] for pl in range(2)]
+
+    def u_read_f2(self, par_next):
+        return [['  ds_read_b128 %s, %s offset:%d' % (self.a2(par_next, r, pl), vreg(V_AX2), par_next * 4096 + r * 2048 + pl * 1024)] for r in range(2) for pl in range(2)]
+
+    @staticmethod
+    def frag(q):
+        """fragment q of a column step -> (tile of its owner, half g of the tile's 16-feature groups)"""
+        return q >> 2, (q >> 1) & 1
+
+    def u_bias(self, q):
+        jt, g = self.frag(q)
+        imm = (128 * self.h + 32 * jt + 16 * g) * 4
+        return [['  ds_read_b128 %s, %s offset:%d' % (vreg(H_BQ, 4), vreg(V_BADDR), imm)],
+                ['  ds_read_b128 %s, %s offset:%d' % (vreg(H_BQ + 4, 4), vreg(V_BADDR), imm + 32)]]
+
+    def u_unit(self, q, r, cset):
+        """h2 unit (fragment q, row group r): accumulator registers 8 g .. of tile jt -> (hi, lo) in CV set cset"""
+        if 'noconv' in self.dbg:
+            return []
+        jt, g = self.frag(q)
+        acc = ACC1 + 16 * (4 * r + jt) + 8 * g
+        u = []
+        for e in range(8):
+            u.append(['  v_fma_f32 %s, %s, %s, %s' % (vreg(H_GV + e), vreg(acc + e), sreg(S_AS1OS), vreg(H_BQ + e))])
+        for e in range(8):
+            u.append(['  v_max_f32_e32 %s, 0, %s' % (vreg(H_GV + e), vreg(H_GV + e))])
+        return u + self.split_units(H_CV + 8 * cset, H_CV + 8 * cset + 4, V_PK2)
+
+    def u_write_unit(self, q, r, cset):
+        return [['  ds_write_b128 %s, %s offset:%d' % (vreg(V_AX2), vreg(H_CV + 8 * cset + 4 * pl, 4), (q & 1) * 4096 + r * 2048 + pl * 1024)] for pl in range(2)]
+
+    def substep(self, b, kind, slot, par, pre, post, needs, first=False):
+        """P0 = w_lo x a_hi (w_lo was read behind the previous barrier), P1 = w_hi x a_hi, barrier, P2 = w_hi x a_lo"""
+        b.e('s_waitcnt lgkmcnt(0)')
+        order = [(jj, r) for jj in range(4) for r in range(2)]
+        p0 = [self.mf(kind, r, jj, 1, 0, par, zero_c=first) for jj, r in order]
+        p1 = [self.mf(kind, r, jj, 0, 0, par) for jj, r in order]
+        p2 = [self.mf(kind, r, jj, 0, 1, par) for jj, r in order]
+        # the plane-0 (hi) weight reads lead the list: they go out among P0's first MFMAs and are waited for in front of P1
+        cut = min(len(pre), max(4, (len(pre) + 1) // 2))
+        self.deal(b, p0, pre[:cut])
+        b.e('s_waitcnt lgkmcnt(0)')
+        self.deal(b, p1, pre[cut:])
+        b.e('s_waitcnt lgkmcnt(0)')
+        b.wait_vm(needs)
+        self.barrier(b)
+        self.deal(b, p2, post)
+
+    def build(self):
+        h = self.h
+        L = lambda s: 'L_r%d_%s' % (h, s)
+        pro, head, loop, last, bub, st2, tail = (Block(n) for n in ('pro', 'head', 'loop', 'last', 'bub', 'st2', 'tail'))
+
+        def flat(b, units):
+            for u in units:
+                b.items.extend(u)
+
+        b = pro
+        b.label(L('start'))
+        for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
+            b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
+            b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
+        for t in range(4):
+            flat(b, self.u_pieces('s1', t))
+        for t in range(4):
+            flat(b, self.u_stage_issue(t, reset=(t == 0)))
+        b.wait_vm({'T0', 'L0'})
+        b.e('s_waitcnt lgkmcnt(0)')
+        self.barrier(b)
+        flat(b, self.u_stage_read(0))
+        b.e('s_waitcnt lgkmcnt(0)')
+        flat(b, self.u_convert1(0))
+        b.wait_vm({'P0', 'T1', 'L1'})
+        b.e('s_waitcnt lgkmcnt(0)')
+        self.barrier(b)
+        flat(b, self.u_read_f1(0))
+        flat(b, self.u_read_w(1, 0))
+        flat(b, self.u_stage_read(1))
+        b.e('s_mov_b32 %s, 0' % sreg(S_COL))
+
+        def s1_substep(b, i, first=False, produce_ok=True, piece='s1', stage_ok=True, issue_ok=True):
+            slot, par, nslot = i & 3, i & 1, (i + 1) & 3
+            pre = self.u_read_w(0, slot)
+            if produce_ok:
+                pre += self.u_convert1(par ^ 1)
+            if issue_ok:
+                pre += self.u_stage_issue(i & 3)
+            post = self.u_read_w(1, nslot)
+            if produce_ok:
+                post += self.u_read_f1(par ^ 1)
+            if stage_ok:
+                post += self.u_stage_read((i + 2) & 3)
+            post += self.u_pieces(piece, slot)
+            needs = {'P%d' % nslot}
+            if stage_ok:
+                needs |= {'T%d' % ((i + 2) & 3), 'L%d' % ((i + 2) & 3)}
+            self.substep(b, 1, slot, par, pre, post, needs, first=first)
+
+        head.label(L('col'))
+        for i in range(4):
+            s1_substep(head, i, first=(i == 0))
+        head.e('s_lshr_b32 %s, %s, 2' % (sreg(S_TRIP), sreg(S_NSUB1)))
+        head.e('s_sub_u32 %s, %s, 2' % (sreg(S_TRIP), sreg(S_TRIP)))
+        head.e('s_cmp_eq_u32 %s, 0' % sreg(S_TRIP))
+        head.e('s_cbranch_scc1 %s' % L('last'))
+        loop.items.append('  .p2align 6')
+        loop.label(L('loop'))
+        for i in range(4):
+            s1_substep(loop, i)
+        loop.e('s_sub_u32 %s, %s, 1' % (sreg(S_TRIP), sreg(S_TRIP)))
+        loop.e('s_cmp_lg_u32 %s, 0' % sreg(S_TRIP))
+        loop.e('s_cbranch_scc1 %s' % L('loop'))
+        last.label(L('last'))
+        for i in range(4):
+            s1_substep(last, i, produce_ok=(i < 3), piece='s2', stage_ok=(i < 2), issue_ok=False)
+
+        # ---- between the stages: half h converts fragment h (its tile 0, g 0) for both row groups
+        b = bub
+        b.e('s_nop 15')
+        b.e('s_nop 15')
+        if 'noconv' not in self.dbg:
+            flat(b, self.u_bias(h))
+        b.e('s_waitcnt lgkmcnt(0)')
+        for r in range(2):
+            flat(b, self.u_unit(h, r, 0))
+            flat(b, self.u_write_unit(h, r, 0))
+        if h == 0 and 'noconv' not in self.dbg:
+            flat(b, self.u_bias(2))                          # fragment 2's units: pre 0 (r 0), pre 1 (r 1)
+        b.e('s_waitcnt lgkmcnt(0)')
+        self.barrier(b)
+        flat(b, self.u_read_f2(0))
+
+        # ---- stage 2: 16 sub-steps.  Fragment f >= 2 (owner f & 1): unit r 0 converted before barrier f - 2 and written behind it (the buffer's
+        # previous fragment f - 2 has been read by every wave then), unit r 1 converted and written before barrier f - 1; the bias quads of a
+        # fragment are read behind barrier f - 3 (one set: both units use them)
+        NQ = 16
+        for q in range(NQ):
+            slot, par, nslot = q & 3, q & 1, (q + 1) & 3
+            pre = self.u_read_w(0, slot)
+            post = self.u_read_w(1, nslot)
+            needs = {'P%d' % nslot}
+            if q < NQ - 1:
+                post += self.u_read_f2(par ^ 1)
+            fa, fb = q + 2, q + 1                            # fragments whose unit r 0 / r 1 this half may own in this sub-step
+            if fa < NQ and (fa & 1) == h and fa >= 2:
+                pre += self.u_unit(fa, 0, 0)
+                post += self.u_write_unit(fa, 0, 0)
+            if fb < NQ and (fb & 1) == h and fb >= 2:
+                pre += self.u_unit(fb, 1, 1) + self.u_write_unit(fb, 1, 1)
+            fn = q + 3                                       # bias quads of the fragment whose first unit comes in the next sub-step
+            if fn < NQ and (fn & 1) == h and 'noconv' not in self.dbg:
+                post += self.u_bias(fn)
+            if NQ - 5 <= q <= NQ - 2:
+                pre += self.u_stage_issue(q - (NQ - 5), reset=(q == NQ - 5))
+            if q == NQ - 2:
+                post += self.u_stage_read(0)
+                needs |= {'T0', 'L0'}
+            if q == NQ - 1:
+                pre += self.u_convert1(0)
+                post += self.u_read_f1(0) + self.u_stage_read(1)
+                needs |= {'T1', 'L1'}
+            post += self.u_pieces('s2' if q < NQ - 4 else 's1', slot)
+            self.substep(st2, 2, slot, par, pre, post, needs)
+        tail.e('v_add_u32_e32 %s, 1024, %s' % (vreg(V_BADDR), vreg(V_BADDR)))
+        tail.e('s_add_u32 %s, %s, 1' % (sreg(S_COL), sreg(S_COL)))
+        tail.e('s_cmp_lt_u32 %s, %s' % (sreg(S_COL), sreg(S_NCOL)))
+        tail.e('s_cbranch_scc1 %s' % L('col'))
+        tail.e('s_branch L_epilogue_%d' % h)
+
+        col0 = [head, last, bub, st2, tail]
+        col1 = [head, loop, last, bub, st2, tail]
+        col2 = [head, loop, loop, last, bub, st2, tail]
+        for first_col in (col0, col1, col2):
+            for second_col in (col0, col1, col2):
+                for with_opt in (True, False):
+                    simulate([pro] + first_col + second_col + second_col, with_opt=with_opt)
+        return [pro, head, loop, last, bub, st2, tail]
+
+
+def common_prologue(b, dbg=(), hs=False):
     b.e('s_load_dwordx16 %s, s[0:1], 0x0' % sreg(4, 16))
     b.e('s_load_dwordx16 %s, s[0:1], 0x40' % sreg(20, 16))
     b.e('s_waitcnt lgkmcnt(0)')
@@ -437,7 +708,7 @@ def common_prologue(b, dbg=()):
     b.e('s_cmp_ge_i32 %s, %s' % (sreg(S_M0), sreg(S_M)))
     b.e('s_cbranch_scc1 L_end')
     stamp(b, 0, 0)
-    b.e('s_lshr_b32 %s, %s, 5' % (sreg(S_NSUB1), sreg(S_K1)))               # sub-tiles of 32 k
+    b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_NSUB1), sreg(S_K1), 4 if hs else 5))               # sub-tiles of 32 k (bf16) / 16 k (split-f16)
     b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_NCOL), sreg(S_N1)))
     b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_COLBYTES), sreg(S_LDB1)))          # 256 rows x ldb1 halves x 2 B
     b.e('s_lshl_b32 %s, %s, 12' % (sreg(S_DMA), sreg(S_WAVE)))              # this wave's 4 pieces: image rows 64 w ..
@@ -450,6 +721,8 @@ def common_prologue(b, dbg=()):
     b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 1), vreg(V_T)))
     b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B1, 2)))
     b.e('s_waitcnt vmcnt(0)')
+    if hs:                                                                   # h2 is carried as out_scale * relu(z1): the bias in the same scale
+        b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_OUTSC), vreg(V_T + 2)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 1), BIAS1_OFF, vreg(V_T + 1)))
     b.e('ds_write_b32 %s, %s' % (vreg(V_T + 1), vreg(V_T + 2)))
     b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
@@ -470,8 +743,11 @@ def common_prologue(b, dbg=()):
     # ---- lane constants
     b.e('v_and_b32_e32 %s, 31, %s' % (vreg(V_L31), vreg(V_LANE)))
     b.e('v_lshrrev_b32_e32 %s, 5, %s' % (vreg(V_HI), vreg(V_LANE)))
-    b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T + 4), sreg(S_H)))
-    b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI), sreg(S_T + 4)))     # unit 4 h + 2 hi: this half's k-step of a slab row
+    if hs:
+        b.e('v_lshlrev_b32_e32 %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI)))                     # unit 2 hi of the 4 units (16 k) of a slab row
+    else:
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T + 4), sreg(S_H)))
+        b.e('v_lshl_add_u32 %s, %s, 1, %s' % (vreg(V_T + 6), vreg(V_HI), sreg(S_T + 4)))     # unit 4 h + 2 hi: this half's k-step of a slab row
     # pr0 = m0 / nt and prmax = (M - 1) / nt (uniform; exact division by multiplication + one correction)
     for k, src in ((0, sreg(S_M0)), (1, None)):
         if src is None:
@@ -484,15 +760,22 @@ def common_prologue(b, dbg=()):
         b.e('v_cmp_le_u32_e32 vcc, %s, %s' % (sreg(S_NT), vreg(V_T + 10)))
         b.e('v_addc_co_u32_e32 %s, vcc, 0, %s, vcc' % (vreg(V_T + 11 + k), vreg(V_T + 9)))    # q + (r >= nt)
     # ---- this lane's two rows: m = m0 + 64 rp + 32 r + l31 (clamped for the loads), pr = m / nt, t = m - pr nt
-    for r in range(2):
+    rsh = 6 if hs else 7                                     # log2 of the bytes of a slab row (16 / 32 k fp32)
+
+    def row_of(r_off_sgpr_or_imm, dst_m):
         b.e('s_lshl_b32 %s, %s, 6' % (sreg(S_T), sreg(S_RP)))
-        b.e('s_add_u32 %s, %s, %d' % (sreg(S_T), sreg(S_T), 32 * r))
+        if isinstance(r_off_sgpr_or_imm, int):
+            b.e('s_add_u32 %s, %s, %d' % (sreg(S_T), sreg(S_T), r_off_sgpr_or_imm))
+        else:
+            b.e('s_lshl_b32 %s, %s, 5' % (sreg(S_T + 1), r_off_sgpr_or_imm))
+            b.e('s_add_u32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_T + 1)))
         b.e('s_add_u32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_M0)))
-        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_M + r), sreg(S_T), vreg(V_L31)))
-        b.e('v_cmp_gt_i32_e32 vcc, %s, %s' % (sreg(S_M), vreg(V_M + r)))
-        b.e('s_mov_b64 %s, vcc' % sreg(S_ROWMASK1 if r else S_ROWMASK, 2))
+        b.e('v_add_u32_e32 %s, %s, %s' % (vreg(dst_m), sreg(S_T), vreg(V_L31)))
+
+    def slab_addresses(m_reg, k):
+        """pr, t of row m (clamped) -> the LDS addresses of this lane's T units and L0 units: V_TL0 + k, V_TL1 + k, V_LL + k"""
         b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_M)))
-        b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(V_M + r)))
+        b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T), sreg(S_T), vreg(m_reg)))
         b.e('v_mul_hi_u32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T), sreg(S_MAGIC)))
         b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_NT)))
         b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T), vreg(V_T + 2)))
@@ -501,39 +784,52 @@ def common_prologue(b, dbg=()):
         b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), vreg(V_T + 1), vreg(V_T + 4)))      # pr
         b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 4), vreg(V_T + 4), sreg(S_NT)))
         b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 3), vreg(V_T + 3), vreg(V_T + 4)))      # t
-        # T slab reads: unit u of row t sits at t * 128 + ((u ^ ((t >> 1) & 7)) << 4)
-        b.e('v_bfe_u32 %s, %s, 1, 3' % (vreg(V_T + 5), vreg(V_T + 3)))
-        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 7), vreg(V_T + 3)))
+        # T slab: unit u of row t sits at t * rowbytes + ((u ^ swizzle(t)) << 4); swizzle (t >> 1) & 7 for 8 units, (t >> 2) & 3 for 4
+        if hs:
+            b.e('v_bfe_u32 %s, %s, 2, 2' % (vreg(V_T + 5), vreg(V_T + 3)))
+        else:
+            b.e('v_bfe_u32 %s, %s, 1, 3' % (vreg(V_T + 5), vreg(V_T + 3)))
+        b.e('v_lshlrev_b32_e32 %s, %d, %s' % (vreg(V_T + 7), rsh, vreg(V_T + 3)))
         b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 7), TS_OFF, vreg(V_T + 7)))
         b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 6), vreg(V_T + 5)))
-        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL0 + r), vreg(V_T + 2), vreg(V_T + 7)))
+        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL0 + k), vreg(V_T + 2), vreg(V_T + 7)))
         b.e('v_or_b32_e32 %s, 1, %s' % (vreg(V_T + 2), vreg(V_T + 6)))
         b.e('v_xor_b32_e32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 2), vreg(V_T + 5)))
-        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL1 + r), vreg(V_T + 2), vreg(V_T + 7)))
-        # L0 slab read: row pr - pr0, units 4 h + 2 hi, + 1 (contiguous)
+        b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_TL1 + k), vreg(V_T + 2), vreg(V_T + 7)))
+        # L0 slab: row pr - pr0, this lane's two units (contiguous)
         b.e('v_sub_u32_e32 %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), vreg(V_T + 11)))
-        b.e('v_lshlrev_b32_e32 %s, 7, %s' % (vreg(V_T + 2), vreg(V_T + 2)))
+        b.e('v_lshlrev_b32_e32 %s, %d, %s' % (vreg(V_T + 2), rsh, vreg(V_T + 2)))
         b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_T + 2), vreg(V_T + 6), vreg(V_T + 2)))
-        b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_LL + r), L0S_OFF, vreg(V_T + 2)))
+        b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_LL + k), L0S_OFF, vreg(V_T + 2)))
+
+    for r in range(2):
+        row_of(32 * r, V_M + r)
+        b.e('v_cmp_gt_i32_e32 vcc, %s, %s' % (sreg(S_M), vreg(V_M + r)))
+        b.e('s_mov_b64 %s, vcc' % sreg(S_ROWMASK1 if r else S_ROWMASK, 2))
+        if not hs:
+            slab_addresses(V_M + r, r)                       # bf16: a wave converts its k-step of BOTH row groups
         # output addressing of the row
         b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_T), sreg(S_H)))                                 # 128 h floats = 512 h bytes
         b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_OUTOFF + r), vreg(V_M + r), sreg(S_LDO)))
         b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_OUTOFF + r), vreg(V_OUTOFF + r)))
         b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_OUTOFF + r), vreg(V_HI), vreg(V_OUTOFF + r)))
         b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_OUTOFF + r), sreg(S_T), vreg(V_OUTOFF + r)))
+    if hs:                                                   # split-f16: a wave converts the whole fragment of row group r = h
+        row_of(sreg(S_H), V_T + 13)
+        slab_addresses(V_T + 13, 0)
     # L0 slab DMA (wave 0): lane -> row min(pr0 + (lane >> 3), prmax), 16-byte unit lane & 7
-    b.e('v_lshrrev_b32_e32 %s, 3, %s' % (vreg(V_T + 8), vreg(V_LANE)))
+    b.e('v_lshrrev_b32_e32 %s, %d, %s' % (vreg(V_T + 8), 2 if hs else 3, vreg(V_LANE)))
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 11)))
     b.e('v_min_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 12)))
     b.e('v_mul_lo_u32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), sreg(S_LDL)))
-    b.e('v_and_b32_e32 %s, 7, %s' % (vreg(V_T + 9), vreg(V_LANE)))
+    b.e('v_and_b32_e32 %s, %d, %s' % (vreg(V_T + 9), 3 if hs else 7, vreg(V_LANE)))
     b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 9), vreg(V_T + 9)))
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 8), vreg(V_T + 8), vreg(V_T + 9)))
     b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_LOFF), vreg(V_T + 8)))
     # T slab DMA: this wave's chunks min(2 w + i, nch - 1) of the nt * 128 bytes (nch = ceil(nt / 8) <= 8 chunks of 1 KiB)
-    b.e('s_lshl_b32 %s, %s, 7' % (sreg(S_TSLABB), sreg(S_NT)))
-    b.e('s_add_u32 %s, %s, 7' % (sreg(S_T), sreg(S_NT)))
-    b.e('s_lshr_b32 %s, %s, 3' % (sreg(S_T), sreg(S_T)))
+    b.e('s_lshl_b32 %s, %s, %d' % (sreg(S_TSLABB), sreg(S_NT), rsh))
+    b.e('s_add_u32 %s, %s, %d' % (sreg(S_T), sreg(S_NT), 15 if hs else 7))
+    b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_T), sreg(S_T), 4 if hs else 3))
     b.e('s_sub_u32 %s, %s, 1' % (sreg(S_T), sreg(S_T)))                                  # nch - 1
     b.e('s_lshl_b32 %s, %s, 1' % (sreg(S_T + 1), sreg(S_WAVE)))
     for i, tch in enumerate((S_TCH0, S_TCH1)):
@@ -568,6 +864,9 @@ def common_prologue(b, dbg=()):
     b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_T), sreg(S_H)))
     b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_B2ADDR), vreg(V_HI), sreg(S_BIAS2OFF)))
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_B2ADDR), sreg(S_T), vreg(V_B2ADDR)))
+    if hs:
+        b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK1))
+        b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK2))
     for i in range(128):
         b.e('v_accvgpr_write_b32 %s, 0' % areg(ACC2 + i))
     b.e('s_waitcnt lgkmcnt(0)')
@@ -674,12 +973,36 @@ def epilogue_staged(b, h, slow_label, nwaves=4):
     b.e('s_branch L_end')
 
 
-def epilogue(b, h, dbg=()):
+def epilogue(b, h, dbg=(), hs=False):
     b.label('L_epilogue_%d' % h)
     b.e('s_waitcnt vmcnt(0)')                 # the re-fetched head of the stream has landed: the ring may go
     b.e('s_nop 15')
     b.e('s_nop 15')
     stamp(b, 2, 10 + h)
+    if hs:
+        # range guard (gemm_hs.hip.h hs_report_peak): pk1 = this lane's maximum of the |h1| hi halves, pk2 = of the |h2| hi halves
+        b.e('s_cmp_eq_u64 %s, 0' % sreg(S_PEAK, 2))
+        b.e('s_cbranch_scc1 L_noguard_%d' % h)
+        for pk, row_max in ((V_PK1, True), (V_PK2, False)):
+            b.e('v_lshrrev_b32_e32 %s, 16, %s' % (vreg(V_T), vreg(pk)))
+            b.e('v_and_b32_e32 %s, 0xffff, %s' % (vreg(V_T + 1), vreg(pk)))
+            b.e('v_max_u32_e32 %s, %s, %s' % (vreg(V_T), vreg(V_T), vreg(V_T + 1)))
+            b.e('v_min_u32_e32 %s, 0x7c00, %s' % (vreg(V_T), vreg(V_T)))
+            b.e('v_cvt_f32_f16_e32 %s, %s' % (vreg(V_T + 1), vreg(V_T)))
+            b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
+            b.e('v_cmp_lt_f32_e32 vcc, 0x476a6000, %s' % vreg(V_T + 1))                 # 60000.0 < m
+            b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+            b.e('global_atomic_umax %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_PEAK, 2)))
+            b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+            if row_max:
+                b.e('v_cmp_lt_f32_e32 vcc, 0, %s' % vreg(V_T + 1))
+                b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
+                b.e('v_cmp_gt_f32_e32 vcc, 0x3d800000, %s' % vreg(V_T + 1))              # m < 0.0625
+                b.e('s_and_b64 exec, exec, vcc')
+                b.e('v_mov_b32_e32 %s, 1' % vreg(V_T + 3))
+                b.e('global_atomic_or %s, %s, %s offset:4' % (vreg(V_T + 2), vreg(V_T + 3), sreg(S_PEAK, 2)))
+                b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
+        b.label('L_noguard_%d' % h)
     if 'nostore' in dbg:
         b.e('s_branch L_end')
     if 'rowstores' not in dbg:
@@ -719,15 +1042,17 @@ def epilogue(b, h, dbg=()):
 
 
 def kernel(name, dbg=()):
+    hs = 'hs' in dbg
     out = ['.globl %s' % name, '.p2align 8', '.type %s,@function' % name, '%s:' % name]
     pre = Block('common')
-    common_prologue(pre, dbg)
+    common_prologue(pre, dbg, hs)
     blocks = [pre]
-    r0 = Role4(0, dbg).build()
-    r1 = Role4(1, dbg).build()
+    role = RoleH if hs else Role4
+    r0 = role(0, dbg).build()
+    r1 = role(1, dbg).build()
     e0, e1 = Block('ep0'), Block('ep1')
-    epilogue(e0, 0, dbg)
-    epilogue(e1, 1, dbg)
+    epilogue(e0, 0, dbg, hs)
+    epilogue(e1, 1, dbg, hs)
     blocks += r0 + [e0] + r1 + [e1]
     end = Block('end')
     end.label('L_end')
@@ -745,7 +1070,9 @@ def kernel(name, dbg=()):
 DESCRIPTOR4 = DESCRIPTOR.replace('.amdhsa_next_free_vgpr 256', '.amdhsa_next_free_vgpr 512').replace('.amdhsa_accum_offset 128', '.amdhsa_accum_offset 256')
 META4 = META_KERNEL.replace('.vgpr_count: 256', '.vgpr_count: 512').replace('.agpr_count: 128', '.agpr_count: 256').replace('.max_flat_workgroup_size: 512', '.max_flat_workgroup_size: 256')
 
-VARIANTS = [('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
+VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
+            ('csi_band4_nodma', ('hs', 'nodma')), ('csi_band4_nostore', ('hs', 'nostore')), ('csi_band4_noconv', ('hs', 'noconv')),
+            ('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
             ('csi_band4_bf16_skeleton', ('noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_bf16_nodma', ('nodma',)), ('csi_band4_bf16_noread', ('noread',)),
             ('csi_band4_bf16_nobarrier', ('nobarrier',)), ('csi_band4_bf16_nointerleave', ('nointerleave',)),
             ('csi_band4_bf16_noaside_nodma', ('noconv', 'noreq', 'nodma')), ('csi_band4_bf16_noaside_noread', ('noconv', 'noreq', 'noread')),

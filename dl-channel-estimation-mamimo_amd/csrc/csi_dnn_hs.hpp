@@ -280,6 +280,11 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             (void)hipGetLastError();
             c->band_fn_bf16_cs = nullptr;
         }
+        if (hipModuleGetFunction(&c->band_fn4, c->band_mod, "csi_band4") != hipSuccess) {
+            (void)hipGetLastError();
+            c->band_fn4 = nullptr;
+        }
+        c->band_hs_threads = (ext && n_hs && std::strncmp(n_hs, "csi_band4", 9) == 0) ? 256 : BAND8_THREADS;
         if (hipModuleGetFunction(&c->band_fn4_bf16, c->band_mod, "csi_band4_bf16") != hipSuccess) {
             (void)hipGetLastError();
             c->band_fn4_bf16 = nullptr;
@@ -314,7 +319,8 @@ int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops,
     size_t sz = sizeof(a8);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     // the register-blocked form is a workgroup of 4 waves (band4_kernel_gen.py), the others of 8
-    const unsigned threads = fn == c->band_fn4_bf16 ? 256u : (fn == c->band_fn_bf16 ? (unsigned)c->band_bf16_threads : (unsigned)BAND8_THREADS);
+    const unsigned threads = (fn == c->band_fn4_bf16 || fn == c->band_fn4) ? 256u : (fn == c->band_fn_bf16 ? (unsigned)c->band_bf16_threads :
+                             (fn == c->band_fn ? (unsigned)c->band_hs_threads : (unsigned)BAND8_THREADS));
     HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, threads, 1, 1, 0, c->stream, nullptr, extra));
     return CSI_OK;
 }
@@ -490,6 +496,24 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
             // (the band path leaves the activation buffers unused: hbuf0 - M2 x 1024 floats here - holds the partial outputs)
             const int S = (fn == c->band_fn && staged && ba.ldo == ba.n2) ? band8_splits(c, ba, (size_t)M2 * l1.out) : 1;
             if (S > 1) return band8_launch_split(c, ba, S, hbuf0, flops, bytes);
+            // round 6: the register-blocked form (band4_kernel_gen.py "csi_band4": 4 waves x 512 registers, every weight fragment against two
+            // row groups) on the same operands, its weight streams pre-tiled once per model (band4_tile_kernel)
+            const bool hooked4 = c->band_hs_threads == 256;
+            if (fn == c->band_fn && staged && ((c->band4 && c->band_fn4) || hooked4) && !ba.stamps) {
+                if (!m.tiled_ok) {
+                    const int ncol = l1.out / 256, nsub = h1 / 16;
+                    const size_t b1 = (size_t)(ncol * nsub + 4) * BAND_SLOT_BYTES, b2 = (size_t)ncol * 16 * BAND_SLOT_BYTES;
+                    if ((!m.Wt1 && hipMalloc((void**)&m.Wt1, b1) != hipSuccess) || (!m.Wt2 && hipMalloc((void**)&m.Wt2, b2) != hipSuccess))
+                        return fail(c, CSI_ERR_NOMEM, "device allocation of the tiled band weights failed");
+                    hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W1, ba.ldb1, ncol, nsub, 0, 4, m.Wt1);
+                    hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W2p, ba.ldb2, ncol, 16, 2, 0, m.Wt2);
+                    HIP_TRY(c, hipGetLastError());
+                    m.tiled_ok = true;
+                }
+                if (c->band4 && c->band_fn4) fn = c->band_fn4;
+                ba.W1 = m.Wt1;
+                ba.W2p = m.Wt2;
+            }
             return band8_launch(c, fn, ba, flops, bytes);
         }
     }

@@ -1231,7 +1231,7 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "f32_engine") *value = c->f32_engine;
     else if (n == "hs_band") *value = c->hs_band;
     else if (n == "band4") *value = c->band4;
-    else if (n == "band4_available") *value = c->band_fn4_bf16 != nullptr;
+    else if (n == "band4_available") *value = (c->cfg.dtype == CSI_DTYPE_BF16 ? c->band_fn4_bf16 : c->band_fn4) != nullptr;
     else if (n == "band_launches") *value = c->band_launches;
     else if (n == "band_split") *value = c->band_split;
     else if (n == "aux_fork_early") *value = c->aux_fork_early;

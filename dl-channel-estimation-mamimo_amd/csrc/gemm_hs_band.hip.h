@@ -144,6 +144,8 @@ __global__ void band_tsw_kernel(const float* __restrict__ T, int ldt, int nt, in
 //   mode 0, pair layer W1 [N1][ld]: tile (c, u) = rows 256 c .., k-columns 32 u ..; tiles c-major; `spare` zero tiles behind the last.
 //   mode 1, regressor W2p [256][ld]: tile (c, q) = all 256 rows, k-columns 256 c + 128 (q & 1) + 32 (q >> 1) .. (fragment order of the kernel:
 //   the h2 fragments alternate between the halves).
+//   mode 2, the split-f16 form's regressor (hs [256][ld halves], 16 k = 32 halves as hi | lo per group): tile (c, q), q = 0 .. 15, = the group of
+//   k-columns 256 c + 128 (q & 1) + 32 (q >> 2) + 16 ((q >> 1) & 1) ..; its pair layer is mode 0 with nsub = K1 / 16 (32 halves per sub-tile row too).
 __global__ void band4_tile_kernel(const uint16_t* __restrict__ src, int ld, int ncol, int nsub, int mode, int spare, uint16_t* __restrict__ dst) {
     const size_t units = (size_t)(ncol * nsub + spare) * 1024;            // 16-byte units
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
@@ -153,7 +155,8 @@ __global__ void band4_tile_kernel(const uint16_t* __restrict__ src, int ld, int 
         if (t < (size_t)ncol * nsub) {
             const int c = (int)(t / nsub), u = (int)(t % nsub);
             const int row = mode == 0 ? 256 * c + r : r;
-            const int k = (mode == 0 ? 32 * u : 256 * c + 128 * (u & 1) + 32 * (u >> 1)) + 8 * (pos ^ ((r >> 2) & 3));
+            const int k0 = mode == 0 ? 32 * u : (mode == 1 ? 256 * c + 128 * (u & 1) + 32 * (u >> 1) : 512 * c + 256 * (u & 1) + 64 * (u >> 2) + 32 * ((u >> 1) & 1));
+            const int k = k0 + 8 * (pos ^ ((r >> 2) & 3));      // (in 2-byte elements: bf16 values / f16 halves)
             v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + k);
         }
         *reinterpret_cast<uint4*>(dst + i * 8) = v;

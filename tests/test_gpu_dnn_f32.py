@@ -805,13 +805,25 @@ def test_band_kernel_matches_oracle_and_separate_kernels(pkg, oracle, nt, nr, np
     assert rel_rows(b_re[sel], r_re) < TOL and rel_rows(b_im[sel], r_im) < TOL
     b2_re, _ = e.predict(ltf)
     assert np.array_equal(b_re, b2_re)
-    e.set_option('hs_band', 3)                                # the form with per-lane global loads of L0 / T: the same arithmetic
-    p_re, p_im = e.predict(ltf)
+    # round 6: where the LDS-staged form applies (16 <= Nt <= 128) the default is the REGISTER-BLOCKED kernel (csi_band4, band4_kernel_gen.py: 4 waves x
+    # 512 registers); "band4" = 0 is the 8-wave kernel - same split operands, the h2 fragments in another order (fp32 sums associate differently)
+    staged = 16 <= nt <= 128
+    assert e.get_option('band4') == 1 and e.get_option('band4_available') == 1
+    e.set_option('band4', 0)
+    a_re, a_im = e.predict(ltf)
     assert e.get_option('band_launches') == n0 + 6
-    assert np.array_equal(b_re, p_re) and np.array_equal(b_im, p_im)
+    if staged:
+        assert rel_rows(b_re, a_re) < 2e-6 and rel_rows(b_im, a_im) < 2e-6 and not np.array_equal(b_re, a_re)
+        assert rel_rows(a_re[sel], r_re) < TOL and rel_rows(a_im[sel], r_im) < TOL
+    else:
+        assert np.array_equal(b_re, a_re) and np.array_equal(b_im, a_im)
+    e.set_option('hs_band', 3)                                # the 8-wave form with per-lane global loads of L0 / T: the same arithmetic as the staged 8-wave form
+    p_re, p_im = e.predict(ltf)
+    assert e.get_option('band_launches') == n0 + 8
+    assert np.array_equal(a_re, p_re) and np.array_equal(a_im, p_im)
     e.set_option('hs_band', 0)
     s_re, s_im = e.predict(ltf)
-    assert e.get_option('band_launches') == n0 + 6
+    assert e.get_option('band_launches') == n0 + 8
     assert rel_rows(b_re, s_re) < 5e-6 and rel_rows(b_im, s_im) < 5e-6
 
 
