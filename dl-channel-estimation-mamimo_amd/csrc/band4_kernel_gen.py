@@ -53,18 +53,22 @@ S_TCH0, S_TCH1 = 73, 71             # byte offsets of this wave's two 1-KiB chun
 S_ROWMASK1 = 76
 
 V_TID, V_LANE = 0, 1
-OWNF = 2                            # own k-step of the stage-1 fragments: [parity][r] x 4
-SLT, SLL = 18, 26                   # slab values of the fragment being converted: T [r] x 8 at 18 + 16 r, L0 at 26 + 16 r
-GV, BQ, CV = 50, 58, 74             # fp32 sums (8) / bias quads [2 sets] x 8 / converted h2 quarters [3] x 4
-V_RD0, V_RD1, V_AX1, V_AX2 = 86, 87, 88, 89
-V_TL0, V_TL1, V_LL = 90, 92, 94     # [r]
-V_LOFF, V_TOFF = 96, 97             # V_TOFF [2]
-V_VO = 99                           # LDS-DMA offset of this lane inside a weight sub-tile: 4096 w + 16 lane
-V_BADDR, V_B2ADDR, V_OUTOFF, V_M, V_4HI, V_HI, V_L31 = 107, 108, 109, 111, 113, 114, 115
-V_T = 18                            # scratch of prologue / epilogue / stamps: aliases the slab values (dead there)
-ACC1 = 128                          # arch VGPRs v128 .. v255: [r][jj] x 16
-ACC2 = 0                            # AGPRs a0 .. a127: [r][jj] x 16
-AW, AF, F2 = 128, 160, 176          # AGPRs: weight fragments [k-step][jj] x 4; partner's stage-1 fragments [parity][r] x 4; h2 fragments [parity][r][k-step] x 4
+# Register plan.  Accumulators in AGPRs (a0 .. a127 the regressor's, a128 .. a255 stage 1's), MFMA A / B operands in LOW arch VGPRs, everything the
+# VALU / LDS / DMA instructions touch in arch VGPRs from v128 up.  Two things about the MFMA operand fetch were measured on the skeleton
+# (profiles/r06_band_probe.txt): (1) C / D in arch VGPRs with A / B in AGPRs issues ~15 % slower than any other combination (the first form of this
+# kernel kept the stage-1 accumulators in arch VGPRs so that the h2 conversion could read them without v_accvgpr_read); (2) so do A / B operands in
+# v128 .. v207 beside accumulators in a128 .. a255 - the operand registers want to sit below the accumulators' index range.
+AW, OWNF, AF, F2 = 2, 34, 50, 66    # weight fragments [k-step][jj] x 4 | own stage-1 fragments [parity][r] x 4 | the partner's [parity][r] x 4 | h2 fragments [parity][r][k-step] x 4
+SLT, SLL = 128, 136                 # slab values of the fragment being converted: T [r] x 8 at 128 + 16 r, L0 at 136 + 16 r
+GV, BQ, CV = 160, 168, 184          # fp32 sums (8) / bias quads [2 sets] x 8 / converted h2 quarters [3] x 4
+V_RD0, V_RD1, V_AX1, V_AX2 = 196, 197, 198, 199
+V_TL0, V_TL1, V_LL = 200, 202, 204  # [r]
+V_LOFF, V_TOFF = 206, 207           # V_TOFF [2]
+V_VO = 209                          # LDS-DMA offset of this lane inside a weight sub-tile: 4096 w + 16 lane
+V_BADDR, V_B2ADDR, V_OUTOFF, V_M, V_4HI, V_HI, V_L31 = 210, 211, 212, 214, 216, 217, 218
+V_T = 128                           # scratch of prologue / epilogue / stamps: aliases the slab values (dead there)
+ACC1 = 128                          # AGPRs a128 .. a255: stage-1 accumulators [r][jj] x 16
+ACC2 = 0                            # AGPRs a0 .. a127: the regressor's [r][jj] x 16
 
 
 def stamp(b, i, uid):
@@ -98,17 +102,17 @@ class Role4:
 
     # ---------------------------------------------------------------- operands
     def w(self, s, jj):
-        return areg(AW + 16 * s + 4 * jj, 4)
+        return vreg(AW + 16 * s + 4 * jj, 4)
 
     def f1(self, par, r, s):
-        return vreg(OWNF + 8 * par + 4 * r, 4) if s == self.h else areg(AF + 8 * par + 4 * r, 4)
+        return vreg(OWNF + 8 * par + 4 * r, 4) if s == self.h else vreg(AF + 8 * par + 4 * r, 4)
 
     def f2(self, par, r, s):
-        return areg(F2 + 16 * par + 8 * r + 4 * s, 4)
+        return vreg(F2 + 16 * par + 8 * r + 4 * s, 4)
 
     def mfma(self, kind, r, jj, s, par, zero_c=False):
         if kind == 1:
-            d = vreg(ACC1 + 16 * (4 * r + jj), 16)
+            d = areg(ACC1 + 16 * (4 * r + jj), 16)
             f = self.f1(par, r, s)
         else:
             d = areg(ACC2 + 16 * (4 * r + jj), 16)
@@ -192,7 +196,7 @@ class Role4:
 
     def u_read_f1(self, par_next):
         """the partner half's k-step of the next stage-1 fragment"""
-        return [['  ds_read_b128 %s, %s offset:%d' % (areg(AF + 8 * par_next + 4 * r, 4), vreg(V_AX1), par_next * 4096 + r * 2048 + (1 - self.h) * 1024)] for r in range(2)]
+        return [['  ds_read_b128 %s, %s offset:%d' % (vreg(AF + 8 * par_next + 4 * r, 4), vreg(V_AX1), par_next * 4096 + r * 2048 + (1 - self.h) * 1024)] for r in range(2)]
 
     def u_read_f2(self, par_next):
         return [['  ds_read_b128 %s, %s offset:%d' % (self.f2(par_next, r, s), vreg(V_AX2), par_next * 4096 + r * 2048 + s * 1024)] for r in range(2) for s in range(2)]
@@ -208,11 +212,13 @@ class Role4:
             return []
         acc = ACC1 + 16 * (4 * r + (q >> 1)) + 8 * s
         units = []
+        for p in range(8):
+            units.append(['  v_accvgpr_read_b32 %s, %s' % (vreg(GV + p), areg(acc + p))])
         if 'pk' not in self.dbg:
             for p in range(8):
-                units.append(['  v_add_f32_e32 %s, %s, %s' % (vreg(GV + p), vreg(acc + p), vreg(BQ + 8 * bset + p))])
+                units.append(['  v_add_f32_e32 %s, %s, %s' % (vreg(GV + p), vreg(GV + p), vreg(BQ + 8 * bset + p))])
         for p in range(4 if 'pk' in self.dbg else 0):
-            units.append(['  v_pk_add_f32 %s, %s, %s' % (vreg(GV + 2 * p, 2), vreg(acc + 2 * p, 2), vreg(BQ + 8 * bset + 2 * p, 2))])
+            units.append(['  v_pk_add_f32 %s, %s, %s' % (vreg(GV + 2 * p, 2), vreg(GV + 2 * p, 2), vreg(BQ + 8 * bset + 2 * p, 2))])
         for p in range(4):
             units.append(['  v_cvt_pk_bf16_f32 %s, %s, %s' % (vreg(CV + 4 * cset + p), vreg(GV + 2 * p), vreg(GV + 2 * p + 1))])
         for p in range(4):
@@ -429,28 +435,28 @@ class Role4:
 # (plane 0 = hi, plane 1 = lo); an activation fragment is (hi, lo) of 32 rows x 16 k.  Wave (h, rp) CONVERTS the fragments of row group
 # r = h of its row pair (both halves, the whole 16 k) and reads the partner's from the exchange; 24 MFMAs per sub-step and wave.
 # Stage 2: 16 fragments per column step (tile x half g of its 16-feature groups), owner q & 1, order (tile jt = q >> 2, g = (q >> 1) & 1).
-H_OWNF = 2                           # own stage-1 fragment: [parity][hi | lo] x 4
-H_SLT, H_SLL, H_GV, H_BQ, H_CV = 18, 26, 34, 42, 50     # slab values T / L0 (8 each), fp32 temporaries (8), bias quads (8), converted h2 units [2][hi | lo] x 4
-V_PK1, V_PK2 = 66, 67                # packed maxima of the hi halves (range guard)
-H_AF = 160                           # AGPRs: the partner's stage-1 fragment [parity][hi | lo] x 4
-H_F2 = 176                           # AGPRs: h2 fragments [parity][r][hi | lo] x 4
+H_OWNF = OWNF                        # own stage-1 fragment: [parity][hi | lo] x 4
+H_SLT, H_SLL, H_GV, H_BQ, H_CV = 128, 136, 144, 152, 160     # slab values T / L0 (8 each), fp32 temporaries (8), bias quads (8), converted h2 units [2][hi | lo] x 4
+V_PK1, V_PK2 = 176, 177              # packed maxima of the hi halves (range guard)
+H_AF = AF                            # the partner's stage-1 fragment [parity][hi | lo] x 4
+H_F2 = F2                            # h2 fragments [parity][r][hi | lo] x 4
 
 
 class RoleH(Role4):
     """split-f16 form: straight-line program of the waves of one feature half"""
 
     def wh(self, plane, jj):
-        return areg(AW + 16 * plane + 4 * jj, 4)
+        return vreg(AW + 16 * plane + 4 * jj, 4)
 
     def a1(self, par, r, plane):
-        return vreg(H_OWNF + 8 * par + 4 * plane, 4) if r == self.h else areg(H_AF + 8 * par + 4 * plane, 4)
+        return vreg(H_OWNF + 8 * par + 4 * plane, 4) if r == self.h else vreg(H_AF + 8 * par + 4 * plane, 4)
 
     def a2(self, par, r, plane):
-        return areg(H_F2 + 16 * par + 8 * r + 4 * plane, 4)
+        return vreg(H_F2 + 16 * par + 8 * r + 4 * plane, 4)
 
     def mf(self, kind, r, jj, wplane, aplane, par, zero_c=False):
         if kind == 1:
-            d, f = vreg(ACC1 + 16 * (4 * r + jj), 16), self.a1(par, r, aplane)
+            d, f = areg(ACC1 + 16 * (4 * r + jj), 16), self.a1(par, r, aplane)
         else:
             d, f = areg(ACC2 + 16 * (4 * r + jj), 16), self.a2(par, r, aplane)
         return ['  v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (d, self.wh(wplane, jj), f, '0' if zero_c else d)]
@@ -514,7 +520,7 @@ class RoleH(Role4):
 
     def u_read_f1(self, par_next):
         o = 1 - self.h
-        return [['  ds_read_b128 %s, %s offset:%d' % (areg(H_AF + 8 * par_next + 4 * pl, 4), vreg(V_AX1), par_next * 4096 + o * 2048 + pl * 1024)] for pl in range(2)]
+        return [['  ds_read_b128 %s, %s offset:%d' % (vreg(H_AF + 8 * par_next + 4 * pl, 4), vreg(V_AX1), par_next * 4096 + o * 2048 + pl * 1024)] for pl in range(2)]
 
     def u_read_f2(self, par_next):
         return [['  ds_read_b128 %s, %s offset:%d' % (self.a2(par_next, r, pl), vreg(V_AX2), par_next * 4096 + r * 2048 + pl * 1024)] for r in range(2) for pl in range(2)]
@@ -538,7 +544,9 @@ class RoleH(Role4):
         acc = ACC1 + 16 * (4 * r + jt) + 8 * g
         u = []
         for e in range(8):
-            u.append(['  v_fma_f32 %s, %s, %s, %s' % (vreg(H_GV + e), vreg(acc + e), sreg(S_AS1OS), vreg(H_BQ + e))])
+            u.append(['  v_accvgpr_read_b32 %s, %s' % (vreg(H_GV + e), areg(acc + e))])
+        for e in range(8):
+            u.append(['  v_fma_f32 %s, %s, %s, %s' % (vreg(H_GV + e), vreg(H_GV + e), sreg(S_AS1OS), vreg(H_BQ + e))])
         for e in range(8):
             u.append(['  v_max_f32_e32 %s, 0, %s' % (vreg(H_GV + e), vreg(H_GV + e))])
         return u + self.split_units(H_CV + 8 * cset, H_CV + 8 * cset + 4, V_PK2)
@@ -1070,7 +1078,7 @@ def kernel(name, dbg=()):
 DESCRIPTOR4 = DESCRIPTOR.replace('.amdhsa_next_free_vgpr 256', '.amdhsa_next_free_vgpr 512').replace('.amdhsa_accum_offset 128', '.amdhsa_accum_offset 256')
 META4 = META_KERNEL.replace('.vgpr_count: 256', '.vgpr_count: 512').replace('.agpr_count: 128', '.agpr_count: 256').replace('.max_flat_workgroup_size: 512', '.max_flat_workgroup_size: 256')
 
-VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
+VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
             ('csi_band4_nodma', ('hs', 'nodma')), ('csi_band4_nostore', ('hs', 'nostore')), ('csi_band4_noconv', ('hs', 'noconv')),
             ('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
             ('csi_band4_bf16_skeleton', ('noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_bf16_nodma', ('nodma',)), ('csi_band4_bf16_noread', ('noread',)),
