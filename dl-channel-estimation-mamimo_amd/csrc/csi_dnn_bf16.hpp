@@ -190,7 +190,8 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
     const size_t per_pkt = (size_t)nr * cf.len_ltf * 2 + (size_t)nr * h1 * 4 * (BF16_L0_MAX_SPLITS + 1) + (size_t)nr * nt * h1 * 2 +
                            (size_t)nr * nt * maxh * 2 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
     // default 8 GiB: a whole config-3 step (5000 packets) in one chunk, so that layer 0 sees M1 = 20000 rows
-    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)8 << 30);
+    // (two component models in flight on two streams hold a workspace each: the cap is shared between them - ADVICE round 5)
+    const size_t budget = (cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)8 << 30)) / (size_t)std::max(c->models_in_flight, 1);
     int64_t cap = std::max<int64_t>(1, (int64_t)(budget / per_pkt));
     cap = std::min(cap, (int64_t)0x7fffffff / ((int64_t)nr * nt * 2));
     const int64_t nchunks = (npkt + cap - 1) / cap;
@@ -257,14 +258,15 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
         bool done = false;
         if (fused_ok || band_small) {
             // h1 is generated inside the first per-pair GEMM from the (slab-summed) layer-0 product
-            float* l0sum = l0;
-            if (S > 1) {
-                l0sum = l0 + (size_t)S * M1 * h1;
+            float* l0sum = S > 1 ? l0 + (size_t)S * M1 * h1 : l0;
+            auto sum_slabs = [&]() -> int {          // the k-range slabs of layer 0 -> l0sum, once a kernel that reads it is known to run
+                if (S <= 1) return CSI_OK;
                 ProfScope ps(c, K_SPLITK_REDUCE, (double)S * M1 * h1, 4.0 * (S + 1) * (double)M1 * h1);
                 const size_t n4 = (size_t)M1 * h1 / 4;
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, c->stream, l0, l0sum, n4, S);
                 HIP_TRY(c, hipGetLastError());
-            }
+                return CSI_OK;
+            };
             PairSrc src{l0sum, m.T, h1, nt};
             const Layer& lr = m.layers[nh];
             hipFunction_t fn = nullptr;
@@ -296,6 +298,8 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 }
             }
             if (fn) {
+                rc = sum_slabs();
+                if (rc) return rc;
                 const double flops = 2.0 * (double)M2 * l1.out * h1 + 2.0 * (double)M2 * cf.n_out * l1.out;
                 const double bytes = 4.0 * ((double)M2 / nt * h1 + (double)nt * h1) + 2.0 * ((double)l1.out * h1 + (double)cf.n_out * l1.out) + 4.0 * (double)M2 * cf.n_out;
                 // small calls: the column-split launch (csi_dnn_hs.hpp); its partial outputs live in the h1 / activation buffers this path leaves unused
@@ -323,6 +327,8 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 else rc = band8_launch(c, fn, ba, flops, bytes);
                 done = true;
             } else if (fused_ok) {
+                rc = sum_slabs();
+                if (rc) return rc;
                 rc = bf16_tail(c, m, nullptr, M2, hb0, hb1, d_out + (size_t)p0 * nr * nt * cf.n_out, 1, &src);
                 done = true;
             }

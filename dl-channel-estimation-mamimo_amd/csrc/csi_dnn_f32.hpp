@@ -180,7 +180,8 @@ int predict_plane(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, float*
     // is on - the factor depends on the chunk size, hence the loop) and the ping-pong buffers of
     // the hidden activations.
     const size_t hid_pkt = (size_t)nr * nt * maxh * 4 * (nh >= 3 ? 2 : (nh >= 2 ? 1 : 0));
-    const size_t budget = cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)4 << 30);   // 4 GiB: a config-2 step is one chunk
+    // 4 GiB: a config-2 step is one chunk.  Two component models in flight on two streams hold a workspace each: the cap is shared between them
+    const size_t budget = (cf.workspace_bytes > 0 ? (size_t)cf.workspace_bytes : ((size_t)4 << 30)) / (size_t)std::max(c->models_in_flight, 1);
     const int64_t max_rows = (int64_t)0x7fffffff / ((int64_t)nr * nt * 2);     // M2 must fit an int
     int64_t nchunks = 1, chunk = npkt;
     int splits_max = 1;

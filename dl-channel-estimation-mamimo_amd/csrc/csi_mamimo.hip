@@ -1031,7 +1031,11 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
             // runs 16.8 us beside the weight stream.  profiles/r05_small_call_trace.txt)
             // The second stream of a two-stream call is forked HERE, in front of the LS kernel: the imag model's chain needs the
             // preambles, not the LS result, and the cross-queue wait (6-7 us before its first kernel starts) passes under the LS kernel
-            if (c->aux_fork_early && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
+            // NOT in bf16 contexts (round 6): there the second stream's first kernels are bf16 MFMA GEMMs, and an LS wave that shares a SIMD with another
+            // workgroup's v_mfma_f32_32x32x16_bf16 waves computes wrong values - 19 of 20 calls of 500 ... 1000 packets at Nt = 64 came back with 7 ... 51 wrong
+            // (packet, rx) items in the LS planes, max abs 0.14-0.27 (tools/ls_two_stream_check.py, profiles/r06_small_calls.txt; the signature of
+            // profiles/r04_ls_ringb_variants.txt).  fp32 contexts (f16 MFMAs beside the LS kernel) are clean over every size, every call.
+            if (c->aux_fork_early && c->cfg.dtype != CSI_DTYPE_BF16 && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
                 hipError_t e = hipEventRecord(c->aux_fork, c->stream);
                 if (e == hipSuccess) e = hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0);
                 if (e != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: forking the second stream failed: %s", hipGetErrorString(e));

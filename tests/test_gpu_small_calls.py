@@ -351,3 +351,41 @@ def test_ls_inside_the_layer0_launch_of_a_one_packet_call(pkg, oracle, nt, nr, n
         e.synchronize()
         assert e.get_option('small_ls_launches') == n1
     e.close()
+
+
+@pytest.mark.parametrize('dtype,nt,sizes', [('bf16', 64, (256, 500, 600)), ('f32', 32, (24, 256, 700))])
+def test_ls_planes_of_two_stream_calls_equal_the_one_stream_call(pkg, oracle, dtype, nt, sizes):
+    """Round 6.  csi_estimate_device runs the two component models of a mid-size call on two streams; fp32 contexts fork the second one in FRONT of the
+    LS kernel.  In bf16 contexts that put bf16-MFMA waves of the imag model's layer 0 beside the LS waves and the LS planes came back with wrong items
+    (19 of 20 calls at 500 ... 1000 packets, profiles/r06_small_calls.txt): there the fork sits behind the LS kernel now.  Every call of every size: LS
+    planes bit-identical with the one-stream call, DNN planes run-to-run identical, a sampled packet against the oracle."""
+    nr, hidden = 4, (256, 256)
+    rng = np.random.default_rng(5)
+    w = [oracle.make_weights(rng, 320 * nt + nt, list(hidden), 234) for _ in range(2)]
+    P = oracle.hadamard(nt)
+    e = pkg.CsiEngine(nt, nr, hidden=hidden, dtype=dtype)
+    e.load_weights('real', w[0])
+    e.load_weights('imag', w[1])
+    e.set_pilot(P)
+    for n in sizes:
+        d_re, d_im = e.empty((n, nr, e.len_ltf)), e.empty((n, nr, e.len_ltf))
+        e.synth_white(11, 0, n, d_re, d_im)
+        o = [e.empty((n, nr, nt, 234)) for _ in range(4)]
+        e.set_option('small_call_overlap', 0)
+        e.estimate_device(d_re, d_im, n, *o)
+        e.synchronize()
+        ref = [a.download() for a in o[2:]]
+        ltf = d_re.download(n - 1, 1) + 1j * d_im.download(n - 1, 1)
+        r_ls = oracle.ls_estimate(ltf, P)
+        assert rel_rows(ref[0][-1:], r_ls.real) < 1e-5 and rel_rows(ref[1][-1:], r_ls.imag) < 1e-5
+        e.set_option('small_call_overlap', 1)
+        dnn0 = None
+        for it in range(12):
+            e.estimate_device(d_re, d_im, n, *o)
+            e.synchronize()
+            got = [a.download() for a in o]
+            assert np.array_equal(got[2], ref[0]) and np.array_equal(got[3], ref[1]), '%s %d packets, call %d: LS planes differ from the one-stream call' % (dtype, n, it)
+            dnn0 = dnn0 or got[:2]
+            assert np.array_equal(got[0], dnn0[0]) and np.array_equal(got[1], dnn0[1])
+        del d_re, d_im, o
+    e.close()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""ls_two_stream_check.py - the LS planes of csi_estimate_device calls that run the two component models on two streams (the second forked in FRONT of
+the LS kernel, "aux_fork_early") against the same call on one stream: every call, every size.  usage: ls_two_stream_check.py f32|bf16 [calls]"""
+import os, sys, zlib
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dl_channel_estimation_mamimo_amd as pkg
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+nt, nr, hidden = (64, 4, (1024, 1024)) if dtype == 'bf16' else (32, 4, (1024, 1024))
+rng = np.random.default_rng(1)
+eng = pkg.CsiEngine(nt, nr, hidden=hidden, dtype=dtype)
+eng.load_weights('real', pkg.synth.make_weights(rng, nt, hidden)); eng.load_weights('imag', pkg.synth.make_weights(rng, nt, hidden))
+eng.set_pilot(pkg.synth.hadamard(nt))
+bad = 0
+for n in (3, 24, 64, 128, 256, 500, 600, 1000):
+    d_re, d_im = eng.empty((n, nr, eng.len_ltf)), eng.empty((n, nr, eng.len_ltf))
+    eng.synth_white(11, 0, n, d_re, d_im)
+    o = [eng.empty((n, nr, nt, 234)) for _ in range(4)]
+    eng.set_option('small_call_overlap', 0)
+    eng.estimate_device(d_re, d_im, n, *o); eng.synchronize()
+    ref = [a.download() for a in o]
+    eng.set_option('small_call_overlap', 1)
+    wrong = 0
+    for it in range(calls):
+        eng.estimate_device(d_re, d_im, n, *o); eng.synchronize()
+        got = [a.download() for a in o]
+        if not (np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])):
+            wrong += 1
+            if wrong == 1:
+                d = np.abs(got[2] - ref[2]); idx = np.argwhere(d > 0)
+                print('   first bad call: %d LS values differ, max abs %.3g, items (packet, rx) touched: %d' % (len(idx), d.max(), len({(i[0], i[1]) for i in idx.tolist()})))
+        if it == 0:
+            dnn0 = got[:2]           # (the DNN planes may take other kernels on two streams - column splits count the models in flight -: compared run to run)
+        assert np.array_equal(got[0], dnn0[0]) and np.array_equal(got[1], dnn0[1]), 'DNN planes differ from run to run'
+    bad += wrong
+    print('%s Nt=%d packets %4d: %d of %d two-stream calls with LS planes different from the one-stream call (aux_fork_early %d)' % (dtype, nt, n, wrong, calls, eng.get_option('aux_fork_early')), flush=True)
+print('RESULT', 'FAILED' if bad else 'ok')
