@@ -779,6 +779,17 @@ def test_fuzz_shape_cases(seed, cases):
     assert not bad, '\n'.join(log[i] for i in bad)
 
 
+@pytest.mark.parametrize('seed,cases', [(3, 14), (11, 14)])
+def test_fuzz_band4_cases(seed, cases):
+    """tests/fuzz_band4.py inside the suite: random shapes the register-blocked band kernels serve (both arithmetic modes; ragged bands, odd output counts,
+    one to four column steps) against the 8-wave kernels and the oracle."""
+    import fuzz_band4
+    rng = np.random.default_rng(seed)
+    log = []
+    bad = [i for i in range(cases) if not fuzz_band4.run_case(rng, i, log.append)]
+    assert not bad, '\n'.join(log[i] for i in bad)
+
+
 @pytest.mark.parametrize('nt,nr,npkt,hidden', BAND_CASES)
 def test_band_kernel_matches_oracle_and_separate_kernels(pkg, oracle, nt, nr, npkt, hidden):
     """First per-pair layer + regressor as ONE kernel (band_kernel_gen.py, option hs_band): against the fp64 oracle, against
