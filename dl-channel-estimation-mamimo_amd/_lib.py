@@ -124,7 +124,7 @@ def build_band_kernel(verbose=False):
     csrc = os.path.join(_PKG_DIR, 'csrc')
     gen8, gen, inc = os.path.join(csrc, 'band_kernel_gen.py'), os.path.join(csrc, 'band4_kernel_gen.py'), os.path.join(csrc, 'band8_hsaco.inc')
     names = ['csi_band8', 'csi_band8_cs', 'csi_band8_bf16_cs', 'csi_band8_nostage', 'csi_band8_bf16', 'csi_band8_bf16_nostage', 'csi_band8_skeleton_rnd',
-             'csi_band4_bf16', 'csi_band4']
+             'csi_band4_bf16', 'csi_band4', 'csi_band4_cs', 'csi_band4_bf16_cs']
     tag = '// kernels: ' + ' '.join(names)
     if os.path.exists(inc) and os.path.getmtime(inc) >= max(os.path.getmtime(gen), os.path.getmtime(gen8)):
         with open(inc) as f:

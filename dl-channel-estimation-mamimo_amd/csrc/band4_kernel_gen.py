@@ -32,7 +32,7 @@ import sys
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from band_kernel_gen import (Block, Wait, simulate, sreg, vreg, areg, DESCRIPTOR, S_AS2, S_INSC, S_AS1OS, S_OUTSC, META_KERNEL, KARG_BYTES,     # noqa: E402
+from band_kernel_gen import (Block, Wait, simulate, sreg, vreg, areg, DESCRIPTOR, S_AS2, S_INSC, S_AS1OS, S_OUTSC, META_KERNEL, KARG_BYTES, KARG_BYTES_CS, S_PART,     # noqa: E402
                              S_L0, S_TS, S_W1, S_B1, S_W2, S_B2, S_OUT, S_PEAK, S_STAMPS, S_LDL, S_NT, S_LDB1, S_M, S_K1, S_N1, S_LDB2, S_N2,
                              S_LDO, S_MAGIC, S_WAVE, S_H, S_M0, S_W1P, S_W2P, S_L0P, S_TSP, S_TRIP, S_COL, S_NCOL, S_NSUB1, S_DMA, S_T,
                              S_ROWMASK, S_SAVE, S_COLBYTES, S_BIAS2OFF, S_TSLABB)
@@ -715,6 +715,37 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('s_lshl_b32 %s, s2, 7' % sreg(S_M0))
     b.e('s_cmp_ge_i32 %s, %s' % (sreg(S_M0), sreg(S_M)))
     b.e('s_cbranch_scc1 L_end')
+    if 'colsplit' in dbg:
+        # column-split form (small calls: fewer bands than CUs, as csi_band8_cs): workgroup (x, y) computes band x over the N1 hidden features
+        # [y N1, (y + 1) N1) of a layer gridDim.y * N1 wide.  The arguments describe split 0; split y moves the (pre-tiled, stream-ordered) pair-layer
+        # weights by its N1 / 256 column steps of K1 / SK sub-tiles, the regressor's by N1 / 256 x NQ sub-tiles, bias1 by y N1 entries, reads a zero bias2
+        # and writes its partial outputs to part + (y - 1) * M * ldo * 4; the host adds the partials to split 0's output in y order
+        b.e('s_load_dwordx2 %s, s[0:1], 0x80' % sreg(S_PART, 2))
+        b.e('s_waitcnt lgkmcnt(0)')
+        b.e('s_cmp_eq_u32 s3, 0')
+        b.e('s_cbranch_scc1 L_cs_done')
+        b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_T), sreg(S_N1)))                            # column steps of one split
+        b.e('s_mul_i32 %s, %s, s3' % (sreg(S_T), sreg(S_T)))                              # ... in front of this split
+        b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_T + 1), sreg(S_K1), 4 if hs else 5))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T + 1), sreg(S_T + 1), sreg(S_T)))
+        b.e('s_lshl_b32 %s, %s, 14' % (sreg(S_T + 1), sreg(S_T + 1)))                    # 16-KiB sub-tiles (the tiled copy of a layer is < 2^31 bytes: host)
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_W1), sreg(S_W1), sreg(S_T + 1)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1 + 1), sreg(S_W1 + 1)))
+        b.e('s_lshl_b32 %s, %s, %d' % (sreg(S_T + 1), sreg(S_T), 14 + (4 if hs else 3)))  # NQ = 16 / 8 regressor sub-tiles per column step
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_W2), sreg(S_W2), sreg(S_T + 1)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W2 + 1), sreg(S_W2 + 1)))
+        b.e('s_mul_i32 %s, %s, s3' % (sreg(S_T), sreg(S_N1)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_B1), sreg(S_B1), sreg(S_T)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_B1 + 1), sreg(S_B1 + 1)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_M), sreg(S_LDO)))
+        b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_T), sreg(S_T)))
+        b.e('s_sub_u32 %s, s3, 1' % sreg(S_T + 1))
+        b.e('s_mul_hi_u32 %s, %s, %s' % (sreg(S_T + 2), sreg(S_T), sreg(S_T + 1)))
+        b.e('s_mul_i32 %s, %s, %s' % (sreg(S_T), sreg(S_T), sreg(S_T + 1)))
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_OUT), sreg(S_PART), sreg(S_T)))
+        b.e('s_addc_u32 %s, %s, %s' % (sreg(S_OUT + 1), sreg(S_PART + 1), sreg(S_T + 2)))
+        b.label('L_cs_done')
     stamp(b, 0, 0)
     b.e('s_lshr_b32 %s, %s, %d' % (sreg(S_NSUB1), sreg(S_K1), 4 if hs else 5))               # sub-tiles of 32 k (bf16) / 16 k (split-f16)
     b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_NCOL), sreg(S_N1)))
@@ -742,6 +773,10 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
     b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))
     b.e('v_cmp_gt_u32_e32 vcc, %s, v0' % sreg(S_N2))
+    if 'colsplit' in dbg:                                  # splits 1 .. carry no bias2 (the host adds their outputs to split 0's)
+        b.e('s_cmp_eq_u32 s3, 0')
+        b.e('s_cselect_b64 %s, -1, 0' % sreg(S_T, 2))
+        b.e('s_and_b64 vcc, vcc, %s' % sreg(S_T, 2))
     b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
     b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B2, 2)))
     b.e('s_waitcnt vmcnt(0)')
@@ -1078,7 +1113,7 @@ def kernel(name, dbg=()):
 DESCRIPTOR4 = DESCRIPTOR.replace('.amdhsa_next_free_vgpr 256', '.amdhsa_next_free_vgpr 512').replace('.amdhsa_accum_offset 128', '.amdhsa_accum_offset 256')
 META4 = META_KERNEL.replace('.vgpr_count: 256', '.vgpr_count: 512').replace('.agpr_count: 128', '.agpr_count: 256').replace('.max_flat_workgroup_size: 512', '.max_flat_workgroup_size: 256')
 
-VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
+VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_cs', ('hs', 'colsplit')), ('csi_band4_bf16_cs', ('colsplit',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
             ('csi_band4_nodma', ('hs', 'nodma')), ('csi_band4_nostore', ('hs', 'nostore')), ('csi_band4_noconv', ('hs', 'noconv')),
             ('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
             ('csi_band4_bf16_skeleton', ('noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_bf16_nodma', ('nodma',)), ('csi_band4_bf16_noread', ('noread',)),
@@ -1094,9 +1129,11 @@ def parts(only=None):
     for name, dbg in VARIANTS:
         if only and name not in only:
             continue
+        cs = 'colsplit' in dbg
+        karg = KARG_BYTES_CS if cs else KARG_BYTES
         text.append(kernel(name, dbg))
-        text.append(DESCRIPTOR4.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES, idy=0))
-        meta.append(META4.format(name=name, karg=KARG_BYTES, lds=LDS_BYTES))
+        text.append(DESCRIPTOR4.format(name=name, karg=karg, lds=LDS_BYTES, idy=1 if cs else 0))
+        meta.append(META4.format(name=name, karg=karg, lds=LDS_BYTES))
     return text, meta
 
 

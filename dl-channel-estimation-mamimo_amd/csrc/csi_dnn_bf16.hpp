@@ -308,23 +308,18 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                                    band8_splits(c, ba, ((size_t)M2 * h1 + (size_t)M2 * maxh) / 2, true) : 1;
                 // round 6: the register-blocked form (4 waves x 512 registers) serves the same staged shapes with the same operand buffers
                 const bool hooked4 = c->band_bf16_threads == 256;          // (CSI_DEBUG_HOOKS: a csi_band4* variant named in place of csi_band8_bf16)
-                if (staged_fn && ((c->band4 && c->band_fn4_bf16) || hooked4) && !ba.stamps && Sb == 1) {
-                    if (!m.tiled_ok) {                   // its weight streams, pre-tiled (gemm_hs_band.hip.h: band4_tile_kernel), once per model
-                        const int ncol = l1.out / 256, nsub = h1 / 32;
-                        const size_t b1 = (size_t)(ncol * nsub + 4) * BAND_SLOT_BYTES, b2 = (size_t)ncol * 8 * BAND_SLOT_BYTES;
-                        if ((!m.Wt1 && hipMalloc((void**)&m.Wt1, b1) != hipSuccess) || (!m.Wt2 && hipMalloc((void**)&m.Wt2, b2) != hipSuccess))
-                            return fail(c, CSI_ERR_NOMEM, "device allocation of the tiled band weights failed");
-                        hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W1, ba.ldb1, ncol, nsub, 0, 4, m.Wt1);
-                        hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W2p, ba.ldb2, ncol, 8, 1, 0, m.Wt2);
-                        HIP_TRY(c, hipGetLastError());
-                        m.tiled_ok = true;
+                const bool blocked = staged_fn && c->band4 && c->band_fn4_bf16 && !ba.stamps;
+                if (Sb > 1) {
+                    const bool b4 = blocked && c->band_fn4_bf16_cs && Sb == 2;      // (4 splits: the 8-wave form, as in fp32 contexts - csi_dnn_hs.hpp)
+                    if (b4) rc = band4_prepare(c, m, ba, true);
+                    if (!rc) rc = band8_launch_split(c, ba, Sb, reinterpret_cast<float*>(h1b), flops, bytes, true, b4);
+                } else {
+                    if (blocked || (staged_fn && hooked4 && !ba.stamps)) {
+                        rc = band4_prepare(c, m, ba, true);
+                        if (blocked) fn = c->band_fn4_bf16;
                     }
-                    if (c->band4 && c->band_fn4_bf16) fn = c->band_fn4_bf16;
-                    ba.W1 = m.Wt1;
-                    ba.W2p = m.Wt2;
+                    if (!rc) rc = band8_launch(c, fn, ba, flops, bytes);
                 }
-                if (Sb > 1) rc = band8_launch_split(c, ba, Sb, reinterpret_cast<float*>(h1b), flops, bytes, true);
-                else rc = band8_launch(c, fn, ba, flops, bytes);
                 done = true;
             } else if (fused_ok) {
                 rc = sum_slabs();

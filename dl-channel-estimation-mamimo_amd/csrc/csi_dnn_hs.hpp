@@ -285,6 +285,8 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             c->band_fn4 = nullptr;
         }
         c->band_hs_threads = (ext && n_hs && std::strncmp(n_hs, "csi_band4", 9) == 0) ? 256 : BAND8_THREADS;
+        if (hipModuleGetFunction(&c->band_fn4_cs, c->band_mod, "csi_band4_cs") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_cs = nullptr; }
+        if (hipModuleGetFunction(&c->band_fn4_bf16_cs, c->band_mod, "csi_band4_bf16_cs") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_bf16_cs = nullptr; }
         if (hipModuleGetFunction(&c->band_fn4_bf16, c->band_mod, "csi_band4_bf16") != hipSuccess) {
             (void)hipGetLastError();
             c->band_fn4_bf16 = nullptr;
@@ -310,6 +312,25 @@ bool band_split_static_ok(csi_ctx* c, const Model& m) {
     hipFunction_t fn = nullptr;
     if (band8_function(c, &fn, false, true) != CSI_OK || !fn) return false;
     return c->band_fn_cs != nullptr;
+}
+
+// The register-blocked band kernels (band4_kernel_gen.py) stream PRE-TILED weights: built once per model at first use (band4_tile_kernel), then the
+// argument record's W1 / W2p point at the tiled copies.  bf16: sub-tiles of 32 k, 8 regressor fragments per column step; split-f16: 16 k, 16 fragments.
+int band4_prepare(csi_ctx* c, Model& m, BandArgs& ba, bool bf16) {
+    if (!m.tiled_ok) {
+        const int ncol = ba.N1 / 256, nsub = ba.K1 / (bf16 ? 32 : 16), nq = bf16 ? 8 : 16;
+        const size_t b1 = (size_t)(ncol * nsub + 4) * BAND_SLOT_BYTES, b2 = (size_t)ncol * nq * BAND_SLOT_BYTES;
+        if (b1 >= 0x7fffffffull) return fail(c, CSI_ERR_INVALID_ARG, "band weights of %zu bytes: beyond what the tiled copy addresses", b1);
+        if ((!m.Wt1 && hipMalloc((void**)&m.Wt1, b1) != hipSuccess) || (!m.Wt2 && hipMalloc((void**)&m.Wt2, b2) != hipSuccess))
+            return fail(c, CSI_ERR_NOMEM, "device allocation of the tiled band weights failed");
+        hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W1, ba.ldb1, ncol, nsub, 0, 4, m.Wt1);
+        hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W2p, ba.ldb2, ncol, nq, bf16 ? 1 : 2, 0, m.Wt2);
+        HIP_TRY(c, hipGetLastError());
+        m.tiled_ok = true;
+    }
+    ba.W1 = m.Wt1;
+    ba.W2p = m.Wt2;
+    return CSI_OK;
 }
 
 int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops, double bytes) {
@@ -348,7 +369,7 @@ int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floa
 }
 
 // the column-split launch: partial outputs of splits 1 .. in `part`, added to split 0's output in split order
-int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes, bool bf16 = false) {
+int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes, bool bf16 = false, bool blocked = false) {
     ++c->band_launches;
     ++c->band_split_launches;
     BandArgs one = ba;
@@ -360,7 +381,9 @@ int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, doubl
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     {
         ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
-        HIP_TRY(c, hipModuleLaunchKernel(bf16 ? c->band_fn_bf16_cs : c->band_fn_cs, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
+        // blocked: the register-blocked form (4 waves; ba.W1 / W2p are the tiled copies of the WHOLE layer: split y starts at its own column steps)
+        const hipFunction_t fn = blocked ? (bf16 ? c->band_fn4_bf16_cs : c->band_fn4_cs) : (bf16 ? c->band_fn_bf16_cs : c->band_fn_cs);
+        HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, blocked ? 256u : (unsigned)BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
     }
     const size_t n = (size_t)ba.M * ba.ldo;
     ProfScope ps(c, K_SPLITK_REDUCE, (double)(S - 1) * n, 4.0 * (S + 1) * (double)n);
@@ -495,24 +518,21 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
             const double bytes = 4.0 * ((double)M2 / cf.nt * h1 + (double)cf.nt * h1 + (double)l1.out * h1 + (double)cf.n_out * l1.out + (double)M2 * cf.n_out);
             // (the band path leaves the activation buffers unused: hbuf0 - M2 x 1024 floats here - holds the partial outputs)
             const int S = (fn == c->band_fn && staged && ba.ldo == ba.n2) ? band8_splits(c, ba, (size_t)M2 * l1.out) : 1;
-            if (S > 1) return band8_launch_split(c, ba, S, hbuf0, flops, bytes);
-            // round 6: the register-blocked form (band4_kernel_gen.py "csi_band4": 4 waves x 512 registers, every weight fragment against two
-            // row groups) on the same operands, its weight streams pre-tiled once per model (band4_tile_kernel)
+            // round 6: the register-blocked forms (band4_kernel_gen.py "csi_band4" / "csi_band4_cs": 4 waves x 512 registers, every weight fragment against two
+            // row groups) on the same operands, their weight streams pre-tiled once per model
             const bool hooked4 = c->band_hs_threads == 256;
-            if (fn == c->band_fn && staged && ((c->band4 && c->band_fn4) || hooked4) && !ba.stamps) {
-                if (!m.tiled_ok) {
-                    const int ncol = l1.out / 256, nsub = h1 / 16;
-                    const size_t b1 = (size_t)(ncol * nsub + 4) * BAND_SLOT_BYTES, b2 = (size_t)ncol * 16 * BAND_SLOT_BYTES;
-                    if ((!m.Wt1 && hipMalloc((void**)&m.Wt1, b1) != hipSuccess) || (!m.Wt2 && hipMalloc((void**)&m.Wt2, b2) != hipSuccess))
-                        return fail(c, CSI_ERR_NOMEM, "device allocation of the tiled band weights failed");
-                    hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W1, ba.ldb1, ncol, nsub, 0, 4, m.Wt1);
-                    hipLaunchKernelGGL(band4_tile_kernel, dim3(512), dim3(256), 0, c->stream, ba.W2p, ba.ldb2, ncol, 16, 2, 0, m.Wt2);
-                    HIP_TRY(c, hipGetLastError());
-                    m.tiled_ok = true;
-                }
-                if (c->band4 && c->band_fn4) fn = c->band_fn4;
-                ba.W1 = m.Wt1;
-                ba.W2p = m.Wt2;
+            const bool blocked = fn == c->band_fn && staged && c->band4 && c->band_fn4 && !ba.stamps;
+            if (S > 1) {
+                // (measured, tools/regime_probe.py band4=1 / 0 alternating: 2 splits - 64 packets - 192 against 195 us, 128 packets unsplit 304 against 315; 4 splits -
+                // 24 packets - 120 against 117 us: a quarter band on four waves has less to hide its waits behind)
+                const bool b4 = blocked && c->band_fn4_cs && S == 2;
+                if (b4) { const int rc = band4_prepare(c, m, ba, false); if (rc) return rc; }
+                return band8_launch_split(c, ba, S, hbuf0, flops, bytes, false, b4);
+            }
+            if (blocked || (fn == c->band_fn && staged && hooked4 && !ba.stamps)) {
+                const int rc = band4_prepare(c, m, ba, false);
+                if (rc) return rc;
+                if (blocked) fn = c->band_fn4;
             }
             return band8_launch(c, fn, ba, flops, bytes);
         }
