@@ -280,11 +280,11 @@ class Role4:
         # ---- prologue
         b = pro
         b.label(L('start'))
-        for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
-            b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
-            b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
-        for t in range(4):
-            flat(b, self.u_pieces('s1', t))
+        b.e('s_mov_b32 %s, %s' % (sreg(S_W2P), sreg(S_W2)))
+        b.e('s_mov_b32 %s, %s' % (sreg(S_W2P + 1), sreg(S_W2 + 1)))
+        if 'nodma' not in self.dbg:                          # (the common prologue issued this wave's pieces of sub-tiles 0 .. 3 behind the table loads)
+            for t in range(4):
+                b.items.extend([('vm', 'P%d' % t)] * 4)
         for t in range(4):
             flat(b, self.u_stage_issue(t, reset=(t == 0)))
         b.wait_vm({'T0', 'L0'})
@@ -582,11 +582,11 @@ class RoleH(Role4):
 
         b = pro
         b.label(L('start'))
-        for p, src in ((S_W1P, S_W1), (S_W2P, S_W2)):
-            b.e('s_mov_b32 %s, %s' % (sreg(p), sreg(src)))
-            b.e('s_mov_b32 %s, %s' % (sreg(p + 1), sreg(src + 1)))
-        for t in range(4):
-            flat(b, self.u_pieces('s1', t))
+        b.e('s_mov_b32 %s, %s' % (sreg(S_W2P), sreg(S_W2)))
+        b.e('s_mov_b32 %s, %s' % (sreg(S_W2P + 1), sreg(S_W2 + 1)))
+        if 'nodma' not in self.dbg:                          # (the common prologue issued this wave's pieces of sub-tiles 0 .. 3 behind the table loads)
+            for t in range(4):
+                b.items.extend([('vm', 'P%d' % t)] * 4)
         for t in range(4):
             flat(b, self.u_stage_issue(t, reset=(t == 0)))
         b.wait_vm({'T0', 'L0'})
@@ -751,38 +751,60 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('s_lshr_b32 %s, %s, 8' % (sreg(S_NCOL), sreg(S_N1)))
     b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_COLBYTES), sreg(S_LDB1)))          # 256 rows x ldb1 halves x 2 B
     b.e('s_lshl_b32 %s, %s, 12' % (sreg(S_DMA), sreg(S_WAVE)))              # this wave's 4 pieces: image rows 64 w ..
-    # ---- bias tables: bias1s[i] = out_scale * bias1[i] (i < N1), bias2s[i] = bias2[i] (i < n2, else 0; 256 entries)
-    b.e('s_mov_b32 %s, 0' % sreg(S_T))
-    b.label('L_b1')
-    b.e('v_add_u32_e32 %s, %s, v0' % (vreg(V_T), sreg(S_T)))
-    b.e('v_cmp_gt_u32_e32 vcc, %s, %s' % (sreg(S_N1), vreg(V_T)))
-    b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
-    b.e('v_lshlrev_b32_e32 %s, 2, %s' % (vreg(V_T + 1), vreg(V_T)))
-    b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B1, 2)))
-    b.e('s_waitcnt vmcnt(0)')
-    if hs:                                                                   # h2 is carried as out_scale * relu(z1): the bias in the same scale
-        b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_OUTSC), vreg(V_T + 2)))
-    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 1), BIAS1_OFF, vreg(V_T + 1)))
-    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 1), vreg(V_T + 2)))
-    b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
-    b.e('s_add_u32 %s, %s, 256' % (sreg(S_T), sreg(S_T)))
-    b.e('s_cmp_lt_u32 %s, %s' % (sreg(S_T), sreg(S_N1)))
-    b.e('s_cbranch_scc1 L_b1')
+    # ---- bias tables: bias1s[i] = out_scale * bias1[i] (i < N1), bias2s[i] = bias2[i] (i < n2, else 0; 256 entries).
+    # One workgroup per CU: nothing overlaps a band's prologue.  So every load of the tables is requested at once (N1 / 256 <= 16 per thread + one
+    # for bias2) and, behind them, this wave's LDS-DMA pieces of the first four weight sub-tiles; ONE counted wait (the 16 pieces stay in flight) releases
+    # the table values.  (First form: load - wait - write per 256 entries, then the pieces from the role's prologue: five memory round trips in a row.)
+    BL = 142                                                                 # v142 .. v157: bias1 values, v158: bias2
+    b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))                                   # byte offset of entry tid
+    for it in range(MAX_N1 // 256):
+        b.e('s_cmp_gt_u32 %s, %d' % (sreg(S_N1), 256 * it))
+        b.e('s_cbranch_scc0 L_b1_issued')
+        b.e('global_load_dword %s, %s, %s offset:%d' % (vreg(BL + it), vreg(V_T + 1), sreg(S_B1, 2), 1024 * it) if 1024 * it < 4096 else
+            'global_load_dword %s, %s, %s' % (vreg(BL + it), vreg(V_T + 2), sreg(S_B1, 2)))
+        if 1024 * (it + 1) >= 4096 and it + 1 < MAX_N1 // 256:                           # (13-bit immediates: the byte offset moves on in a register)
+            b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 2), 1024 * (it + 1), vreg(V_T + 1)))
+    b.label('L_b1_issued')
     b.e('s_lshl_b32 %s, %s, 2' % (sreg(S_BIAS2OFF), sreg(S_N1)))
     b.e('s_add_u32 %s, %s, %d' % (sreg(S_BIAS2OFF), sreg(S_BIAS2OFF), BIAS1_OFF))
-    b.e('v_mov_b32_e32 %s, 0' % vreg(V_T + 2))
-    b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))
+    b.e('v_mov_b32_e32 %s, 0' % vreg(BL + 16))
     b.e('v_cmp_gt_u32_e32 vcc, %s, v0' % sreg(S_N2))
     if 'colsplit' in dbg:                                  # splits 1 .. carry no bias2 (the host adds their outputs to split 0's)
         b.e('s_cmp_eq_u32 s3, 0')
         b.e('s_cselect_b64 %s, -1, 0' % sreg(S_T, 2))
         b.e('s_and_b64 vcc, vcc, %s' % sreg(S_T, 2))
     b.e('s_and_saveexec_b64 %s, vcc' % sreg(S_SAVE, 2))
-    b.e('global_load_dword %s, %s, %s' % (vreg(V_T + 2), vreg(V_T + 1), sreg(S_B2, 2)))
-    b.e('s_waitcnt vmcnt(0)')
+    b.e('global_load_dword %s, %s, %s' % (vreg(BL + 16), vreg(V_T + 1), sreg(S_B2, 2)))
     b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
-    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 1), sreg(S_BIAS2OFF), vreg(V_T + 1)))
-    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 1), vreg(V_T + 2)))            # 256 threads = the 256 entries
+    # the first four sub-tiles of the pair layer's weight stream (the roles' prologues count them as in flight)
+    b.e('s_mov_b32 %s, %s' % (sreg(S_W1P), sreg(S_W1)))
+    b.e('s_mov_b32 %s, %s' % (sreg(S_W1P + 1), sreg(S_W1 + 1)))
+    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_VO), vreg(V_LANE)))
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_VO), sreg(S_DMA), vreg(V_VO)))
+    npieces = 0
+    if 'nodma' not in dbg:
+        for t in range(4):
+            b.e('s_add_u32 m0, %s, %d' % (sreg(S_DMA), t * RING_SLOT))
+            b.e('s_nop 0')
+            for pc in range(4):
+                b.e('global_load_lds_dwordx4 %s, %s%s' % (vreg(V_VO), sreg(S_W1P, 2), ' offset:%d' % (1024 * pc) if pc else ''))
+                npieces += 1
+            b.e('s_add_u32 %s, %s, %d' % (sreg(S_W1P), sreg(S_W1P), RING_SLOT))
+            b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1P + 1)))
+    else:
+        b.e('s_add_u32 %s, %s, %d' % (sreg(S_W1P), sreg(S_W1P), 4 * RING_SLOT))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1P + 1)))
+    b.e('s_waitcnt vmcnt(%d)' % npieces)                                                 # the table values are in (loads return in order); the pieces fly on
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 2), BIAS1_OFF, vreg(V_T + 1)))
+    for it in range(MAX_N1 // 256):
+        b.e('s_cmp_gt_u32 %s, %d' % (sreg(S_N1), 256 * it))
+        b.e('s_cbranch_scc0 L_b1_written')
+        if hs:                                                                           # h2 is carried as out_scale * relu(z1): the bias in the same scale
+            b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(BL + it), sreg(S_OUTSC), vreg(BL + it)))
+        b.e('ds_write_b32 %s, %s offset:%d' % (vreg(V_T + 2), vreg(BL + it), 1024 * it))
+    b.label('L_b1_written')
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_BIAS2OFF), vreg(V_T + 1)))
+    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 2), vreg(BL + 16)))                          # 256 threads = the 256 entries
     # ---- lane constants
     b.e('v_and_b32_e32 %s, 31, %s' % (vreg(V_L31), vreg(V_LANE)))
     b.e('v_lshrrev_b32_e32 %s, 5, %s' % (vreg(V_HI), vreg(V_LANE)))
@@ -897,9 +919,7 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_AX1), sreg(S_T), vreg(V_AX1)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_AX2), AX2_OFF, vreg(V_AX1)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_AX1), AX1_OFF, vreg(V_AX1)))
-    # ---- LDS-DMA pieces: byte 4096 w + 1024 p + 16 lane of the (pre-tiled) sub-tile = of the ring slot
-    b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_VO), vreg(V_LANE)))
-    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_VO), sreg(S_DMA), vreg(V_VO)))
+    # (V_VO - byte 4096 w + 16 lane of the pre-tiled sub-tile = of the ring slot - was set with the first pieces above)
     # ---- bias reads
     b.e('v_lshlrev_b32_e32 %s, 4, %s' % (vreg(V_BADDR), vreg(V_HI)))
     b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_BADDR), BIAS1_OFF, vreg(V_BADDR)))
