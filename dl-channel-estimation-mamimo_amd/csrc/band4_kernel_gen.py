@@ -285,8 +285,12 @@ class Role4:
         if 'nodma' not in self.dbg:                          # (the common prologue issued this wave's pieces of sub-tiles 0 .. 3 behind the table loads)
             for t in range(4):
                 b.items.extend([('vm', 'P%d' % t)] * 4)
-        for t in range(4):
-            flat(b, self.u_stage_issue(t, reset=(t == 0)))
+        if 'roleslabs' in self.dbg:                          # (A/B: the first four slabs requested here instead of in the common prologue)
+            for t in range(4):
+                flat(b, self.u_stage_issue(t, reset=(t == 0)))
+        elif 'noreq' not in self.dbg:                        # (... and the first four T / L0 slabs)
+            for t in range(4):
+                b.items.extend([('vm', 'T%d' % t), ('vm', 'T%d' % t)] + ([('vmopt', 'L%d' % t)] if h == 0 else []))
         b.wait_vm({'T0', 'L0'})
         b.e('s_waitcnt lgkmcnt(0)')
         self.barrier(b)
@@ -587,8 +591,12 @@ class RoleH(Role4):
         if 'nodma' not in self.dbg:                          # (the common prologue issued this wave's pieces of sub-tiles 0 .. 3 behind the table loads)
             for t in range(4):
                 b.items.extend([('vm', 'P%d' % t)] * 4)
-        for t in range(4):
-            flat(b, self.u_stage_issue(t, reset=(t == 0)))
+        if 'roleslabs' in self.dbg:                          # (A/B: the first four slabs requested here instead of in the common prologue)
+            for t in range(4):
+                flat(b, self.u_stage_issue(t, reset=(t == 0)))
+        elif 'noreq' not in self.dbg:                        # (... and the first four T / L0 slabs)
+            for t in range(4):
+                b.items.extend([('vm', 'T%d' % t), ('vm', 'T%d' % t)] + ([('vmopt', 'L%d' % t)] if h == 0 else []))
         b.wait_vm({'T0', 'L0'})
         b.e('s_waitcnt lgkmcnt(0)')
         self.barrier(b)
@@ -794,17 +802,6 @@ def common_prologue(b, dbg=(), hs=False):
     else:
         b.e('s_add_u32 %s, %s, %d' % (sreg(S_W1P), sreg(S_W1P), 4 * RING_SLOT))
         b.e('s_addc_u32 %s, %s, 0' % (sreg(S_W1P + 1), sreg(S_W1P + 1)))
-    b.e('s_waitcnt vmcnt(%d)' % npieces)                                                 # the table values are in (loads return in order); the pieces fly on
-    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 2), BIAS1_OFF, vreg(V_T + 1)))
-    for it in range(MAX_N1 // 256):
-        b.e('s_cmp_gt_u32 %s, %d' % (sreg(S_N1), 256 * it))
-        b.e('s_cbranch_scc0 L_b1_written')
-        if hs:                                                                           # h2 is carried as out_scale * relu(z1): the bias in the same scale
-            b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(BL + it), sreg(S_OUTSC), vreg(BL + it)))
-        b.e('ds_write_b32 %s, %s offset:%d' % (vreg(V_T + 2), vreg(BL + it), 1024 * it))
-    b.label('L_b1_written')
-    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_BIAS2OFF), vreg(V_T + 1)))
-    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 2), vreg(BL + 16)))                          # 256 threads = the 256 entries
     # ---- lane constants
     b.e('v_and_b32_e32 %s, 31, %s' % (vreg(V_L31), vreg(V_LANE)))
     b.e('v_lshrrev_b32_e32 %s, 5, %s' % (vreg(V_HI), vreg(V_LANE)))
@@ -927,6 +924,42 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('s_lshl_b32 %s, %s, 9' % (sreg(S_T), sreg(S_H)))
     b.e('v_lshl_add_u32 %s, %s, 4, %s' % (vreg(V_B2ADDR), vreg(V_HI), sreg(S_BIAS2OFF)))
     b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_B2ADDR), sreg(S_T), vreg(V_B2ADDR)))
+    # ---- the first four T / L0 slabs (every wave its two 1-KiB chunks of a T slab, wave 0 the band's L0 rows), then the table values: they were requested
+    # first and loads return in order, so one counted wait that leaves this wave's LDS-DMA in flight (16 weight pieces + 8 slab chunks; wave 0 has 4 more) releases them
+    nslab = 0
+    b.e('s_mov_b32 %s, %s' % (sreg(S_L0P), sreg(S_L0)))
+    b.e('s_mov_b32 %s, %s' % (sreg(S_L0P + 1), sreg(S_L0 + 1)))
+    b.e('s_mov_b32 %s, %s' % (sreg(S_TSP), sreg(S_TS)))
+    b.e('s_mov_b32 %s, %s' % (sreg(S_TSP + 1), sreg(S_TS + 1)))
+    for t in range(0 if 'roleslabs' in dbg else 4):
+        if 'noreq' not in dbg:
+            for i, tch in enumerate((S_TCH0, S_TCH1)):
+                b.e('s_add_u32 m0, %s, %d' % (sreg(tch), TS_OFF + t * TSLAB))
+                b.e('s_nop 0')
+                b.e('global_load_lds_dwordx4 %s, %s' % (vreg(V_TOFF + i), sreg(S_TSP, 2)))
+                nslab += 1
+            b.e('s_cmp_lg_u32 %s, 0' % sreg(S_WAVE))
+            b.e('s_cbranch_scc1 L_pro_l0skip_%d' % t)
+            b.e('s_mov_b32 m0, %d' % (L0S_OFF + t * 1024))
+            b.e('s_nop 0')
+            b.e('global_load_lds_dwordx4 %s, %s' % (vreg(V_LOFF), sreg(S_L0P, 2)))
+            b.label('L_pro_l0skip_%d' % t)
+        b.e('s_add_u32 %s, %s, %s' % (sreg(S_TSP), sreg(S_TSP), sreg(S_TSLABB)))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_TSP + 1), sreg(S_TSP + 1)))
+        b.e('s_add_u32 %s, %s, %d' % (sreg(S_L0P), sreg(S_L0P), 64 if hs else 128))
+        b.e('s_addc_u32 %s, %s, 0' % (sreg(S_L0P + 1), sreg(S_L0P + 1)))
+    b.e('s_waitcnt vmcnt(%d)' % (npieces + nslab))                                                 # the table values are in (loads return in order); the pieces fly on
+    b.e('v_lshlrev_b32_e32 %s, 2, v0' % vreg(V_T + 1))                                   # (byte offset of entry tid again: the scratch registers were reused)
+    b.e('v_add_u32_e32 %s, %d, %s' % (vreg(V_T + 2), BIAS1_OFF, vreg(V_T + 1)))
+    for it in range(MAX_N1 // 256):
+        b.e('s_cmp_gt_u32 %s, %d' % (sreg(S_N1), 256 * it))
+        b.e('s_cbranch_scc0 L_b1_written')
+        if hs:                                                                           # h2 is carried as out_scale * relu(z1): the bias in the same scale
+            b.e('v_mul_f32_e32 %s, %s, %s' % (vreg(BL + it), sreg(S_OUTSC), vreg(BL + it)))
+        b.e('ds_write_b32 %s, %s offset:%d' % (vreg(V_T + 2), vreg(BL + it), 1024 * it))
+    b.label('L_b1_written')
+    b.e('v_add_u32_e32 %s, %s, %s' % (vreg(V_T + 2), sreg(S_BIAS2OFF), vreg(V_T + 1)))
+    b.e('ds_write_b32 %s, %s' % (vreg(V_T + 2), vreg(BL + 16)))                          # 256 threads = the 256 entries
     if hs:
         b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK1))
         b.e('v_mov_b32_e32 %s, 0' % vreg(V_PK2))
@@ -1133,7 +1166,7 @@ def kernel(name, dbg=()):
 DESCRIPTOR4 = DESCRIPTOR.replace('.amdhsa_next_free_vgpr 256', '.amdhsa_next_free_vgpr 512').replace('.amdhsa_accum_offset 128', '.amdhsa_accum_offset 256')
 META4 = META_KERNEL.replace('.vgpr_count: 256', '.vgpr_count: 512').replace('.agpr_count: 128', '.agpr_count: 256').replace('.max_flat_workgroup_size: 512', '.max_flat_workgroup_size: 256')
 
-VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_cs', ('hs', 'colsplit')), ('csi_band4_bf16_cs', ('colsplit',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
+VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_cs', ('hs', 'colsplit')), ('csi_band4_bf16_cs', ('colsplit',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_roleslabs', ('hs', 'roleslabs')), ('csi_band4_bf16_roleslabs', ('roleslabs',)), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
             ('csi_band4_nodma', ('hs', 'nodma')), ('csi_band4_nostore', ('hs', 'nostore')), ('csi_band4_noconv', ('hs', 'noconv')),
             ('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
             ('csi_band4_bf16_skeleton', ('noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_bf16_nodma', ('nodma',)), ('csi_band4_bf16_noread', ('noread',)),
