@@ -430,6 +430,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
 
     csi_ctx* c = new csi_ctx();
     if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_SMALL_TILE16")) c->debug_small_tile16 = d[0] == '1';   // (once: not in the call path)
+    if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_BF16_FORK_EARLY")) c->debug_bf16_fork_early = d[0] == '1';   // the round-6 repro (tools/ls_wrong_block_probe.py)
     c->cfg = *cfg;
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     c->d_in = cfg->len_ltf + cfg->nt;
@@ -1035,7 +1036,7 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
             // workgroup's v_mfma_f32_32x32x16_bf16 waves computes wrong values - 19 of 20 calls of 500 ... 1000 packets at Nt = 64 came back with 7 ... 51 wrong
             // (packet, rx) items in the LS planes, max abs 0.14-0.27 (tools/ls_two_stream_check.py, profiles/r06_small_calls.txt; the signature of
             // profiles/r04_ls_ringb_variants.txt).  fp32 contexts (f16 MFMAs beside the LS kernel) are clean over every size, every call.
-            if (c->aux_fork_early && c->cfg.dtype != CSI_DTYPE_BF16 && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
+            if (c->aux_fork_early && (c->cfg.dtype != CSI_DTYPE_BF16 || c->debug_bf16_fork_early) && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
                 hipError_t e = hipEventRecord(c->aux_fork, c->stream);
                 if (e == hipSuccess) e = hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0);
                 if (e != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: forking the second stream failed: %s", hipGetErrorString(e));
@@ -2047,5 +2048,15 @@ int csi_profile_query(csi_ctx* c, int id, double* total_ms, int64_t* launches, d
     if (bytes) *bytes = c->prof_bytes[id];
     return CSI_OK;
 }
+
+#if (CSI_LS_VAR_DEFAULT) & 512
+// race-hunt build only (tools/ls_opsel_hunt.sh): the log of packed +-i rotations that differed from the scalar form
+int csi_debug_opsel_log(unsigned* host, int n_dwords, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && host) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(csi::g_opsel_log), (size_t)n_dwords * 4);
+    if (e == hipSuccess && reset) { const unsigned z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(csi::g_opsel_log), &z, 4); }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

@@ -587,6 +587,11 @@ __device__ __forceinline__ void ls_lds_barrier() {
 // runs on the packed-fp32 pipe: v_pk_add_f32 for the butterflies (the +-i rotations are op_sel / neg modifiers),
 // v_pk_mul_f32 + v_pk_fma_f32 per twiddle product - half the VALU and LDS instructions of the planar transform
 // (ls_fft256_wave), which is what these kernels are bound by once the ring hides the HBM latency.
+// the form of the transform's packed operations when nothing else is asked for: 0 in the product; tools/ls_opsel_hunt.sh builds the library with other values
+// (the VAR bits listed at lsc_stage0_write) to test them on the reproducible case of profiles/r06_small_calls.txt (4)
+#ifndef CSI_LS_VAR_DEFAULT
+#define CSI_LS_VAR_DEFAULT 128
+#endif
 constexpr int LSC_ROW = LS_FFT + LS_FFT / 4;            // 320 complex elements per padded row
 constexpr int LSC_NTW = 256;                            // twiddle table: stage 1 [3][4], stage 2 [3][16], stage 3 [3][64] (252 used)
 __device__ __forceinline__ int lsc_phys(int e) { return e + ((e >> 4) << 2); }
@@ -686,18 +691,53 @@ __device__ __forceinline__ f32x2 sc_cmul_np(f32x2 x, f32x2 w) {
     asm volatile("v_fma_f32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(dy) : "v"(x[0]), "v"(w[1]), "v"(t1));
     return f32x2{dx, dy};
 }
+#if (CSI_LS_VAR_DEFAULT) & 512
+// 512 (tools/ls_opsel_hunt.sh, never in the product): every +-i rotation computed BOTH ways; a packed result that differs from the scalar one is logged
+// (operands, result, thread, workgroup) into a device buffer that csi_debug_opsel_log() copies out
+__device__ unsigned g_opsel_log[4 + 8 * 4096];
+__device__ __forceinline__ void opsel_log(unsigned kind, f32x2 a, f32x2 b, f32x2 p) {
+    const unsigned i = atomicAdd(&g_opsel_log[0], 1u);
+    if (i < 4096) {
+        unsigned* e = g_opsel_log + 4 + 8 * i;
+        e[0] = kind | (threadIdx.x << 8);
+        e[1] = __builtin_bit_cast(unsigned, a[0]); e[2] = __builtin_bit_cast(unsigned, a[1]);
+        e[3] = __builtin_bit_cast(unsigned, b[0]); e[4] = __builtin_bit_cast(unsigned, b[1]);
+        e[5] = __builtin_bit_cast(unsigned, p[0]); e[6] = __builtin_bit_cast(unsigned, p[1]);
+        e[7] = blockIdx.x;
+    }
+}
+__device__ __forceinline__ f32x2 opsel_both(unsigned kind, f32x2 a, f32x2 b) {
+    // the packed form on COPIES of the operands that stay live behind it, so that the log holds what the instruction was given
+    f32x2 p;
+    if (kind == 0) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=&v"(p) : "v"(a), "v"(b));
+    else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(p) : "v"(a), "v"(b));
+    const f32x2 s = kind == 0 ? f32x2{a[0] + b[1], a[1] - b[0]} : f32x2{a[0] - b[1], a[1] + b[0]};
+    if (__builtin_bit_cast(unsigned, p[0]) != __builtin_bit_cast(unsigned, s[0]) || __builtin_bit_cast(unsigned, p[1]) != __builtin_bit_cast(unsigned, s[1]))
+        opsel_log(kind, a, b, p);
+    return p;
+}
+#endif
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_cmul_v(f32x2 x, f32x2 w) {
+    if (VAR & 256) return sc_cmul(x, w);          // 256: only the twiddle products in scalar operations
     if ((VAR & 96) == 96) return sc_cmul_np(x, w);
     return (VAR & 64) ? sc_cmul(x, w) : ((VAR & 32) ? pk_cmul_np(x, w) : ((VAR & 2) ? pk_cmul_ec(x, w) : pk_cmul(x, w)));
 }
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_add_mi_v(f32x2 a, f32x2 b) {
+#if (CSI_LS_VAR_DEFAULT) & 512
+    if (VAR & 512) return opsel_both(0, a, b);
+#endif
+    if (VAR & 128) return sc_add_mi(a, b);        // 128: only the +-i rotations (outputs 1 and 3 of a butterfly) in scalar operations
     if ((VAR & 96) == 96) return sc_add_mi_np(a, b);
     return (VAR & 64) ? sc_add_mi(a, b) : ((VAR & 32) ? pk_add_mi_np(a, b) : ((VAR & 2) ? pk_add_mi_ec(a, b) : pk_add_mi(a, b)));
 }
 template <int VAR>
 __device__ __forceinline__ f32x2 lsc_add_pi_v(f32x2 a, f32x2 b) {
+#if (CSI_LS_VAR_DEFAULT) & 512
+    if (VAR & 512) return opsel_both(1, a, b);
+#endif
+    if (VAR & 128) return sc_add_pi(a, b);
     if ((VAR & 96) == 96) return sc_add_pi_np(a, b);
     return (VAR & 64) ? sc_add_pi(a, b) : ((VAR & 32) ? pk_add_pi_np(a, b) : ((VAR & 2) ? pk_add_pi_ec(a, b) : pk_add_pi(a, b)));
 }
@@ -716,7 +756,7 @@ __device__ __forceinline__ void lsc_build_twiddles(f32x2* twc, const float* tw, 
 
 // stage 0 of the DIT transform for this wave's SPW rows of a raw (planar, natural-order) chunk slot: butterfly `lane`
 // takes samples rev3(lane) + 64 m; no twiddles
-template <int SPW, int NW, int VAR = 0>
+template <int SPW, int NW, int VAR = CSI_LS_VAR_DEFAULT>
 __device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32x2 (&y)[SPW][4]) {
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
@@ -736,7 +776,7 @@ __device__ __forceinline__ void lsc_stage0_read(const float* srow, int rev3, f32
 // places them between the stage's VALU operations: a schedule perturbation, measured to RAISE the event rate ~70 x), 8 (kernel) =
 // every LDS-DMA of the wave landed before the "spectra complete" barrier, 16 = the sources of the op_sel adds stay live until the
 // stage's writes are out, 32 = two idle cycles behind every op_sel operation, 64 = no op_sel / packed operation at all (scalar forms)
-template <int SPW, int NW, int VAR = 0>
+template <int SPW, int NW, int VAR = CSI_LS_VAR_DEFAULT>
 __device__ __forceinline__ void lsc_stage0_write(f32x2* Fc, int wave, int lane, const f32x2 (&y)[SPW][4]) {
     const int p0 = 4 * lane + 4 * (lane >> 2);           // lsc_phys(4 lane): elements 4 lane .. 4 lane + 3, 32-byte aligned
     if (VAR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -752,7 +792,7 @@ __device__ __forceinline__ void lsc_stage0_write(f32x2* Fc, int wave, int lane, 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // stages 1-3, NS rows interleaved in one instruction stream
-template <int NS, int VAR = 0>
+template <int NS, int VAR = CSI_LS_VAR_DEFAULT>
 __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32x2* twc, int lane) {
 #pragma unroll
     for (int st = 1; st < 4; ++st) {
@@ -798,7 +838,7 @@ __device__ __forceinline__ void lsc_fft_stages(f32x2* const (&fr)[NS], const f32
     }
 }
 // stages 1-3 of this wave's rows wave, wave + NW, ...: pairs interleaved when PAIR
-template <int SPW, int NW, bool PAIR, int VAR = 0>
+template <int SPW, int NW, bool PAIR, int VAR = CSI_LS_VAR_DEFAULT>
 __device__ __forceinline__ void lsc_fft_rows(f32x2* Fc, int wave, const f32x2* twc, int lane) {
     if (PAIR && SPW >= 2) {
 #pragma unroll
@@ -1042,7 +1082,7 @@ __device__ __forceinline__ void ls_bf_split2(float x0, float x1, uint32_t& p1, u
 
 constexpr int LSB_BLOCK = 512;      // bf16 elements of one (chunk, piece, antenna tile) block: [2 k-halves][32 rows][8 symbols]
 
-template <int JT, int NW, int NSTG, int NPP, int MINB = 1, bool DBF = false, int VAR = 0>
+template <int JT, int NW, int NSTG, int NPP, int MINB = 1, bool DBF = false, int VAR = CSI_LS_VAR_DEFAULT>
 __global__ __launch_bounds__(64 * NW, MINB) void ls_estimate_ringb_kernel(const LsArgs a, int nblk) {
     constexpr int CH = 16, SPW = CH / NW, QW = 8 / NW;
     constexpr int NB = NPP * JT, NPD = (NB + NW - 1) / NW;      // P blocks per chunk, LDS-DMAs per wave for them
