@@ -163,7 +163,8 @@ struct csi_ctx {
     float* small_ls_h_re = nullptr;   // set by csi_estimate_device around its predict call, consumed by predict_small
     float* small_ls_h_im = nullptr;
     int64_t small_ls_launches = 0;
-    int debug_bf16_fork_early = 0;   // CSI_DEBUG_HOOKS=1 CSI_BF16_FORK_EARLY=1: bf16 contexts fork the second stream in front of the LS kernel again (the repro of profiles/r06_small_calls.txt (4))
+    int debug_ls_lds_pad = 0;        // CSI_DEBUG_HOOKS=1 CSI_LS_LDS_PAD=<bytes>: the Walsh-Hadamard LS kernel asks for that much more LDS than it uses
+    int debug_bf16_fork_late = 0;    // CSI_DEBUG_HOOKS=1 CSI_BF16_FORK_LATE=1: bf16 contexts fork the second stream of a two-stream call behind the LS kernel (A/B runs)
     int debug_small_tile16 = 0;  // CSI_DEBUG_HOOKS=1 CSI_SMALL_TILE16=1, read once at csi_create (A/B runs)
     int small_fused = 1;         // "small_fused" option: 0 = the general kernels (six launches per model on two streams)
     int small_rows = 1024;       // "small_rows": pair rows up to which a call takes it (and at most 64 preambles).  Measured (profiles/r05_regime_probe.txt):

@@ -138,6 +138,7 @@ LsPlan ls_plan(const csi_ctx* c) {
         }
         p.lds = (size_t)(2 * LSC_NTW + nf * ch * 2 * LSC_ROW + nstg * ch * 2 * LS_FFT) * sizeof(float);
         p.threads = 256 * split;
+        p.lds += (size_t)c->debug_ls_lds_pad;              // CSI_DEBUG_HOOKS=1 CSI_LS_LDS_PAD=<bytes>: unused LDS, i.e. fewer workgroups per CU (A/B runs)
         p.per_cu = std::max(1, std::min(split == 1 ? maxcu : 1, (int)((160 * 1024) / p.lds)));
     } else if (mode == LS_RING) {
         const int jt = (nt + 31) / 32, ldp = jt * 32;
@@ -430,7 +431,8 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
 
     csi_ctx* c = new csi_ctx();
     if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_SMALL_TILE16")) c->debug_small_tile16 = d[0] == '1';   // (once: not in the call path)
-    if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_BF16_FORK_EARLY")) c->debug_bf16_fork_early = d[0] == '1';   // the round-6 repro (tools/ls_wrong_block_probe.py)
+    if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_LS_LDS_PAD")) c->debug_ls_lds_pad = std::atoi(d);
+    if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_BF16_FORK_LATE")) c->debug_bf16_fork_late = d[0] == '1';   // A/B: bf16 contexts fork the second stream behind the LS kernel
     c->cfg = *cfg;
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     c->d_in = cfg->len_ltf + cfg->nt;
@@ -1032,11 +1034,13 @@ int csi_estimate_device(csi_ctx* c, const float* d_ltf_re, const float* d_ltf_im
             // runs 16.8 us beside the weight stream.  profiles/r05_small_call_trace.txt)
             // The second stream of a two-stream call is forked HERE, in front of the LS kernel: the imag model's chain needs the
             // preambles, not the LS result, and the cross-queue wait (6-7 us before its first kernel starts) passes under the LS kernel
-            // NOT in bf16 contexts (round 6): there the second stream's first kernels are bf16 MFMA GEMMs, and an LS wave that shares a SIMD with another
-            // workgroup's v_mfma_f32_32x32x16_bf16 waves computes wrong values - 19 of 20 calls of 500 ... 1000 packets at Nt = 64 came back with 7 ... 51 wrong
-            // (packet, rx) items in the LS planes, max abs 0.14-0.27 (tools/ls_two_stream_check.py, profiles/r06_small_calls.txt; the signature of
-            // profiles/r04_ls_ringb_variants.txt).  fp32 contexts (f16 MFMAs beside the LS kernel) are clean over every size, every call.
-            if (c->aux_fork_early && (c->cfg.dtype != CSI_DTYPE_BF16 || c->debug_bf16_fork_early) && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
+            // (Round 6, first: bf16 contexts forked BEHIND the LS kernel, because 19 of 20 calls of 500 ... 1000 packets at Nt = 64 came back with wrong LS items when
+            // the imag model's layer 0 - gemm_bf16_kernel, 64 KiB of LDS: its MFMA waves fit on an LS workgroup's CU - ran beside the LS kernel.  Root cause found
+            // later in the round (tools/pk_opsel_probe.hip, profiles/r06_pk_opsel_probe.txt): a packed-fp32 instruction whose SECOND source takes its
+            // low half from the high register (the transform's +-i rotations were v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]) loses that operand in lanes 48-63 while
+            // another wave of the SIMD issues MFMAs.  The rotations are single adds now (ls_estimate.hip.h, CSI_LS_VAR_DEFAULT) and every context forks here again;
+            // CSI_DEBUG_HOOKS=1 CSI_BF16_FORK_LATE=1 brings the late fork back for A/B runs.)
+            if (c->aux_fork_early && !(c->cfg.dtype == CSI_DTYPE_BF16 && c->debug_bf16_fork_late) && !small_call_ok(c, npkt) && two_stream_call(c, npkt) && aux_stream_ensure(c) == CSI_OK) {
                 hipError_t e = hipEventRecord(c->aux_fork, c->stream);
                 if (e == hipSuccess) e = hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0);
                 if (e != hipSuccess) r = fail(c, CSI_ERR_HIP, "csi_estimate_device: forking the second stream failed: %s", hipGetErrorString(e));

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""ls_opsel_count.py - how many bf16 two-stream calls (second stream forked in FRONT of the LS kernel: CSI_DEBUG_HOOKS=1 CSI_BF16_FORK_EARLY=1) come back with
+"""ls_opsel_count.py - how many bf16 two-stream calls (second stream forked in FRONT of the LS kernel, the default again) come back with
 LS planes that differ from the one-stream call, and which transform outputs the wrong bins trace back to.  The library under test comes from
 CSI_LIBRARY_PATH (tools/ls_opsel_hunt.sh).  usage: ls_opsel_count.py [calls]"""
 import os, sys, time
 os.environ['CSI_DEBUG_HOOKS'] = '1'
-os.environ['CSI_BF16_FORK_EARLY'] = '1'
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dl_channel_estimation_mamimo_amd as pkg

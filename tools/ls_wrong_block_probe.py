@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """ls_wrong_block_probe.py - WHAT is wrong in the LS planes of a bf16 call whose second stream is forked in front of the LS kernel (the repro of
-profiles/r06_small_calls.txt (4); CSI_DEBUG_HOOKS=1 CSI_BF16_FORK_EARLY=1 brings the round-5 order back).  For every wrong (packet, rx) item of the
+profiles/r06_small_calls.txt (4); the order every context uses again since the rotations are single adds; build the old form with tools/ls_opsel_hunt.sh build 0).  For every wrong (packet, rx) item of the
 first bad calls: which antennas / bins / planes differ, and whether the difference is one chunk's contribution to one output block (missing, doubled,
 sign), another item's values, or a stale previous value.  usage: ls_wrong_block_probe.py [packets] [calls]"""
 import os, sys
 os.environ['CSI_DEBUG_HOOKS'] = '1'
-os.environ['CSI_BF16_FORK_EARLY'] = '1'
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dl_channel_estimation_mamimo_amd as pkg
