@@ -16,7 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-constexpr int NFORM = 34;
+constexpr int NFORM = 44;
 // forms: 0 v_pk_add op_sel swap + neg_hi (a - i b)   1 v_pk_add op_sel swap + neg_lo (a + i b)   2 v_pk_add op_sel swap, no neg
 //        3 v_pk_mul op_sel:[0,0] op_sel_hi:[1,0] (broadcast lo)   4 v_pk_fma op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]
 //        5 v_pk_mov_b32 op_sel:[1,0] (swap halves)   6 v_pk_add plain (no op_sel: control)   7 v_pk_add neg_lo/neg_hi only (control)
@@ -124,6 +124,55 @@ __global__ __launch_bounds__(256, 2) void victim(unsigned* counts, unsigned* sam
             asm volatile("v_mul_f32 %0, %1, %2" : "=&v"(r0) : "v"(a[1]), "v"(b[0]));
             asm volatile("v_mul_f32 %0, %1, %2" : "=&v"(r1) : "v"(a[0]), "v"(b[1]));
             if (bits(p[0]) != bits(r0) || bits(p[1]) != bits(r1)) ++bad[33];
+        }
+        // 34-43: 16-bit packed forms, the mix instructions and the compiler's 64-bit copy.  References: the same instruction WITHOUT the select on a
+        // pre-arranged operand (v_perm / v_alignbit build the swapped register in single operations).
+        {
+            const unsigned ua = bits(a[0]) ^ (bits(b[1]) << 3), ub = bits(b[0]) ^ (bits(a[1]) >> 5);      // two f16 pairs (any bit pattern: compare bits)
+            unsigned ub_sw, up, ur;
+            asm volatile("v_alignbit_b32 %0, %1, %1, 16" : "=&v"(ub_sw) : "v"(ub));                          // halves of ub swapped
+            // 34 v_pk_add_f16 src1 swapped
+            asm volatile("v_pk_add_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(up) : "v"(ua), "v"(ub));
+            asm volatile("v_pk_add_f16 %0, %1, %2" : "=&v"(ur) : "v"(ua), "v"(ub_sw));
+            if (up != ur) ++bad[34];
+            // 35 v_pk_mul_f16 src1 swapped
+            asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(up) : "v"(ua), "v"(ub));
+            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=&v"(ur) : "v"(ua), "v"(ub_sw));
+            if (up != ur) ++bad[35];
+            // 36 v_pk_fma_f16 src1 swapped
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=&v"(up) : "v"(ua), "v"(ub), "v"(ua));
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=&v"(ur) : "v"(ua), "v"(ub_sw), "v"(ua));
+            if (up != ur) ++bad[36];
+            // 37 v_pk_add_u16 src1 swapped
+            asm volatile("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(up) : "v"(ua), "v"(ub));
+            asm volatile("v_pk_add_u16 %0, %1, %2" : "=&v"(ur) : "v"(ua), "v"(ub_sw));
+            if (up != ur) ++bad[37];
+            // 38 v_pk_max_i16 src1 swapped
+            asm volatile("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(up) : "v"(ua), "v"(ub));
+            asm volatile("v_pk_max_i16 %0, %1, %2" : "=&v"(ur) : "v"(ua), "v"(ub_sw));
+            if (up != ur) ++bad[38];
+            // 39 v_fma_mix_f32: src1 = the HIGH f16 of ub  against  src1 = the low f16 of the swapped register
+            float fm, fr;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=&v"(fm) : "v"(a[0]), "v"(ub), "v"(b[0]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=&v"(fr) : "v"(a[0]), "v"(ub_sw), "v"(b[0]));
+            if (bits(fm) != bits(fr)) ++bad[39];
+            // 40 v_fma_mixlo_f16 with the high f16 of src1
+            unsigned m0 = 0, m1 = 0;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(m0) : "v"(a[0]), "v"(ub), "v"(b[0]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "+v"(m1) : "v"(a[0]), "v"(ub_sw), "v"(b[0]));
+            if (m0 != m1) ++bad[40];
+            // 41 the compiler's 64-bit copy: v_pk_mov_b32 d, s, s op_sel:[0,1]  (D.lo = src0.lo, D.hi = src1.hi)
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=&v"(p) : "v"(a), "v"(b));
+            if (bits(p[0]) != bits(a[0]) || bits(p[1]) != bits(b[1])) ++bad[41];
+            // 42 v_pk_add_f32 with op_sel on src0 AND src1 (both halves swapped)
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=&v"(p) : "v"(a), "v"(b));
+            asm volatile("v_add_f32 %0, %1, %2" : "=&v"(r0) : "v"(a[1]), "v"(b[1]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=&v"(r1) : "v"(a[0]), "v"(b[0]));
+            if (bits(p[0]) != bits(r0) || bits(p[1]) != bits(r1)) ++bad[42];
+            // 43 v_pk_add_f32 with the SAME register pair as both sources, second one swapped ( (x + y, y + x) )
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(p) : "v"(a));
+            asm volatile("v_add_f32 %0, %1, %2" : "=&v"(r0) : "v"(a[0]), "v"(a[1]));
+            if (bits(p[0]) != bits(r0) || bits(p[1]) != bits(r0)) ++bad[43];
         }
         // 8-11: the butterfly's dependent chain in ONE asm statement - two packed differences (the producers), then the op_sel rotation that reads them,
         // with 0 / 1 / 2 / 4 idle issue slots in between; the reference from single operations
@@ -325,7 +374,10 @@ int main(int argc, char** argv) {
                                 "16 stores in flight, 32 rotations", "32 stores in flight, 32 rotations", "32 stores, 32 cycles, rotations", "32 stores, 96 cycles, rotations",
                                 "LDS-DMA interleaved with rotations", "4 LDS-DMA, then 64 rotations",
                                 "v_pk_add_f32 src0 swapped (op_sel:[1,0] op_sel_hi:[0,1])", "v_pk_add_f32 src1 hi for both halves", "v_pk_add_f32 src1 lo for both halves",
-                                "v_pk_mul_f32 src1 swapped", "v_pk_fma_f32 src1 swapped", "v_pk_fma_f32 src2 swapped", "v_pk_add_f32 src0 swapped + constant", "v_pk_mul_f32 src0 swapped"};
+                                "v_pk_mul_f32 src1 swapped", "v_pk_fma_f32 src1 swapped", "v_pk_fma_f32 src2 swapped", "v_pk_add_f32 src0 swapped + constant", "v_pk_mul_f32 src0 swapped",
+                                "v_pk_add_f16 src1 halves swapped", "v_pk_mul_f16 src1 halves swapped", "v_pk_fma_f16 src1 halves swapped", "v_pk_add_u16 src1 halves swapped",
+                                "v_pk_max_i16 src1 halves swapped", "v_fma_mix_f32 src1 = high f16", "v_fma_mixlo_f16 src1 = high f16", "v_pk_mov_b32 op_sel:[0,1] (64-bit copy)",
+                                "v_pk_add_f32 src0 AND src1 swapped", "v_pk_add_f32 d, a, a with the second swapped"};
     printf("rounds %d, victim LDS %d KiB, mode %d: wrong packed results per 16-lane quarter (lanes 0-15, 16-31, 32-47, 48-63) of %.3g per form\n", rounds, lds_kib, mode,
            (double)rounds * 2000 * 256 * viters);
     for (int f = 0; f < NFORM; ++f) printf("  %-58s %10u %10u %10u %10u\n", names[f], h[f * 4], h[f * 4 + 1], h[f * 4 + 2], h[f * 4 + 3]);
