@@ -711,6 +711,13 @@ class RoleH(Role4):
 
 
 def common_prologue(b, dbg=(), hs=False):
+    if 'persist' in dbg:
+        # persistent form ("csi_band4_p" / "csi_band4_bf16_p"): a launch of P workgroups, workgroup x computes bands x, x + P, x + 2 P, ...: behind a band's
+        # stores it comes back HERE with s2 += P (the argument record is read again: the body moves some of its pointers).  The record is the column-split
+        # one (144 bytes); its last quadword holds P.  Outstanding stores at the restart are older than every new operation, so the counted vmcnt waits
+        # of the body only become conservative by them.
+        b.label('L_restart')
+        b.e('s_load_dwordx2 %s, s[0:1], 0x88' % sreg(S_PART, 2))
     b.e('s_load_dwordx16 %s, s[0:1], 0x0' % sreg(4, 16))
     b.e('s_load_dwordx16 %s, s[0:1], 0x40' % sreg(20, 16))
     b.e('s_waitcnt lgkmcnt(0)')
@@ -971,6 +978,9 @@ def common_prologue(b, dbg=(), hs=False):
     b.e('s_cbranch_scc0 L_r1_start')
 
 
+END_LABEL = ['L_end']           # where a finished band goes: 'L_next' in the persistent form (set by kernel())
+
+
 def epilogue_staged(b, h, slow_label, nwaves=4):
     """Round 6.  The band's output is ONE contiguous block of 128 x ldo floats when ldo == n2 (the library's layout) - but a lane owns a ROW,
     so the direct stores of the accumulators are 64 scattered 8-byte pieces per instruction: 0.46 ms of the 3.33 ms launch at configs[2]
@@ -1066,7 +1076,7 @@ def epilogue_staged(b, h, slow_label, nwaves=4):
     b.e('s_add_u32 %s, %s, %d' % (sreg(S_T + 3), sreg(S_T + 3), 64 * nwaves * U))
     b.e('s_cmp_lt_u32 %s, %s' % (sreg(S_T + 3), sreg(S_T + 2)))
     b.e('s_cbranch_scc1 L_copy_%d' % h)
-    b.e('s_branch L_end')
+    b.e('s_branch %s' % END_LABEL[0])
 
 
 def epilogue(b, h, dbg=(), hs=False):
@@ -1100,7 +1110,7 @@ def epilogue(b, h, dbg=(), hs=False):
                 b.e('s_mov_b64 exec, %s' % sreg(S_SAVE, 2))
         b.label('L_noguard_%d' % h)
     if 'nostore' in dbg:
-        b.e('s_branch L_end')
+        b.e('s_branch %s' % END_LABEL[0])
     if 'rowstores' not in dbg:
         epilogue_staged(b, h, 'L_rowstores_%d' % h)
     b.label('L_rowstores_%d' % h)
@@ -1134,12 +1144,13 @@ def epilogue(b, h, dbg=(), hs=False):
                 b.label('%s_d' % uid)
     b.e('s_mov_b64 exec, -1')
     stamp(b, 3, 20 + h)
-    b.e('s_branch L_end')
+    b.e('s_branch %s' % END_LABEL[0])
 
 
 def kernel(name, dbg=()):
     hs = 'hs' in dbg
     out = ['.globl %s' % name, '.p2align 8', '.type %s,@function' % name, '%s:' % name]
+    END_LABEL[0] = 'L_next' if 'persist' in dbg else 'L_end'
     pre = Block('common')
     common_prologue(pre, dbg, hs)
     blocks = [pre]
@@ -1151,6 +1162,12 @@ def kernel(name, dbg=()):
     epilogue(e1, 1, dbg, hs)
     blocks += r0 + [e0] + r1 + [e1]
     end = Block('end')
+    if 'persist' in dbg:
+        end.label('L_next')
+        end.e('s_waitcnt lgkmcnt(0)')       # every wave's reads of the staged output block are back before any wave's next prologue writes LDS
+        end.e('s_barrier')
+        end.e('s_add_u32 s2, s2, %s' % sreg(S_PART))
+        end.e('s_branch L_restart')
     end.label('L_end')
     end.e('s_endpgm')
     blocks.append(end)
@@ -1166,7 +1183,7 @@ def kernel(name, dbg=()):
 DESCRIPTOR4 = DESCRIPTOR.replace('.amdhsa_next_free_vgpr 256', '.amdhsa_next_free_vgpr 512').replace('.amdhsa_accum_offset 128', '.amdhsa_accum_offset 256')
 META4 = META_KERNEL.replace('.vgpr_count: 256', '.vgpr_count: 512').replace('.agpr_count: 128', '.agpr_count: 256').replace('.max_flat_workgroup_size: 512', '.max_flat_workgroup_size: 256')
 
-VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_cs', ('hs', 'colsplit')), ('csi_band4_bf16_cs', ('colsplit',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_roleslabs', ('hs', 'roleslabs')), ('csi_band4_bf16_roleslabs', ('roleslabs',)), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
+VARIANTS = [('csi_band4', ('hs',)), ('csi_band4_p', ('hs', 'persist')), ('csi_band4_bf16_p', ('persist',)), ('csi_band4_cs', ('hs', 'colsplit')), ('csi_band4_bf16_cs', ('colsplit',)), ('csi_band4_rowstores', ('hs', 'rowstores')), ('csi_band4_roleslabs', ('hs', 'roleslabs')), ('csi_band4_bf16_roleslabs', ('roleslabs',)), ('csi_band4_skeleton', ('hs', 'noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_skeleton_nobarrier', ('hs', 'noconv', 'noreq', 'nodma', 'noread', 'nobarrier')), ('csi_band4_noaside', ('hs', 'noconv', 'noreq')),
             ('csi_band4_nodma', ('hs', 'nodma')), ('csi_band4_nostore', ('hs', 'nostore')), ('csi_band4_noconv', ('hs', 'noconv')),
             ('csi_band4_bf16', ()), ('csi_band4_bf16_noconv', ('noconv',)), ('csi_band4_bf16_noaside', ('noconv', 'noreq')),
             ('csi_band4_bf16_skeleton', ('noconv', 'noreq', 'nodma', 'noread')), ('csi_band4_bf16_nodma', ('nodma',)), ('csi_band4_bf16_noread', ('noread',)),
@@ -1183,7 +1200,7 @@ def parts(only=None):
         if only and name not in only:
             continue
         cs = 'colsplit' in dbg
-        karg = KARG_BYTES_CS if cs else KARG_BYTES
+        karg = KARG_BYTES_CS if (cs or 'persist' in dbg) else KARG_BYTES
         text.append(kernel(name, dbg))
         text.append(DESCRIPTOR4.format(name=name, karg=karg, lds=LDS_BYTES, idy=1 if cs else 0))
         meta.append(META4.format(name=name, karg=karg, lds=LDS_BYTES))

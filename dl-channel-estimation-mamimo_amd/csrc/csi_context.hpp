@@ -232,6 +232,9 @@ struct csi_ctx {
     hipFunction_t band_fn_cs = nullptr;        // column-split form: grid (bands, splits), split y computes N1 / splits of the hidden features
     hipFunction_t band_fn4_cs = nullptr;       // column-split launches of the register-blocked forms (csi_band4_cs / csi_band4_bf16_cs)
     hipFunction_t band_fn4_bf16_cs = nullptr;
+    hipFunction_t band_fn4_p = nullptr, band_fn4_bf16_p = nullptr;      // persistent forms (one workgroup per CU walks the bands)
+    bool band_hs_persist = false, band_bf16_persist = false;            // hooked A/B runs: CSI_BAND8_NAME / CSI_BAND8_BF16_NAME name a persistent form
+    int n_cu = 256;                                                      // compute units of the device (csi_create)
     hipFunction_t band_fn4 = nullptr;          // register-blocked split-f16 form (band4_kernel_gen.py "csi_band4"), staged, 16 <= nt <= 128
     int band_hs_threads = 512;                 // workgroup size of band_fn (a CSI_BAND8_NAME variant named csi_band4* has 256)
     hipFunction_t band_fn4_bf16 = nullptr;     // register-blocked bf16 form (band4_kernel_gen.py: 4 waves x 512 registers, 256 threads), staged, 32 <= nt <= 64

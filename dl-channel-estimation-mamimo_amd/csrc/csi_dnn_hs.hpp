@@ -285,6 +285,11 @@ int band8_function(csi_ctx* c, hipFunction_t* fn, bool bf16 = false, bool staged
             c->band_fn4 = nullptr;
         }
         c->band_hs_threads = (ext && n_hs && std::strncmp(n_hs, "csi_band4", 9) == 0) ? 256 : BAND8_THREADS;
+        const auto ends_p = [](const char* n) { const size_t l = n ? std::strlen(n) : 0; return l > 2 && n[l - 2] == '_' && n[l - 1] == 'p'; };
+        c->band_hs_persist = ext && ends_p(n_hs);          // hooked A/B runs of the persistent forms (csi_band4_p / csi_band4_bf16_p)
+        c->band_bf16_persist = ext && ends_p(n_bf);
+        if (hipModuleGetFunction(&c->band_fn4_p, c->band_mod, "csi_band4_p") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_p = nullptr; }
+        if (hipModuleGetFunction(&c->band_fn4_bf16_p, c->band_mod, "csi_band4_bf16_p") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_bf16_p = nullptr; }
         if (hipModuleGetFunction(&c->band_fn4_cs, c->band_mod, "csi_band4_cs") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_cs = nullptr; }
         if (hipModuleGetFunction(&c->band_fn4_bf16_cs, c->band_mod, "csi_band4_bf16_cs") != hipSuccess) { (void)hipGetLastError(); c->band_fn4_bf16_cs = nullptr; }
         if (hipModuleGetFunction(&c->band_fn4_bf16, c->band_mod, "csi_band4_bf16") != hipSuccess) {
@@ -336,13 +341,18 @@ int band4_prepare(csi_ctx* c, Model& m, BandArgs& ba, bool bf16) {
 int band8_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& ba, double flops, double bytes) {
     ++c->band_launches;
     ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
-    Band8Args a8 = band8_args(ba);
-    size_t sz = sizeof(a8);
+    Band8ArgsCs a8{band8_args(ba), nullptr, 0};
+    const unsigned bands = (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS);
+    // the persistent forms (round 6: csi_band4_p / csi_band4_bf16_p): one workgroup per CU walks bands x, x + P, ...; P travels in the record's last quadword
+    const bool persist = fn == c->band_fn4_p || fn == c->band_fn4_bf16_p || (fn == c->band_fn && c->band_hs_persist) || (fn == c->band_fn_bf16 && c->band_bf16_persist);
+    const unsigned grid = persist ? std::min(bands, (unsigned)std::max(c->n_cu, 1)) : bands;
+    a8.pad = grid;
+    size_t sz = persist ? sizeof(a8) : sizeof(a8.a);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     // the register-blocked form is a workgroup of 4 waves (band4_kernel_gen.py), the others of 8
-    const unsigned threads = (fn == c->band_fn4_bf16 || fn == c->band_fn4) ? 256u : (fn == c->band_fn_bf16 ? (unsigned)c->band_bf16_threads :
-                             (fn == c->band_fn ? (unsigned)c->band_hs_threads : (unsigned)BAND8_THREADS));
-    HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), 1, 1, threads, 1, 1, 0, c->stream, nullptr, extra));
+    const unsigned threads = (fn == c->band_fn4_bf16 || fn == c->band_fn4 || fn == c->band_fn4_p || fn == c->band_fn4_bf16_p) ? 256u :
+                             (fn == c->band_fn_bf16 ? (unsigned)c->band_bf16_threads : (fn == c->band_fn ? (unsigned)c->band_hs_threads : (unsigned)BAND8_THREADS));
+    HIP_TRY(c, hipModuleLaunchKernel(fn, grid, 1, 1, threads, 1, 1, 0, c->stream, nullptr, extra));
     return CSI_OK;
 }
 

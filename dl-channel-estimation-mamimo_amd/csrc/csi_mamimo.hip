@@ -434,6 +434,7 @@ int csi_create(const csi_config* cfg, csi_ctx** out) {
     if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_LS_LDS_PAD")) c->debug_ls_lds_pad = std::atoi(d);
     if (const char* h = std::getenv("CSI_DEBUG_HOOKS")) if (h[0] == '1') if (const char* d = std::getenv("CSI_BF16_FORK_LATE")) c->debug_bf16_fork_late = d[0] == '1';   // A/B: bf16 contexts fork the second stream behind the LS kernel
     c->cfg = *cfg;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     c->d_in = cfg->len_ltf + cfg->nt;
     if (const char* e = std::getenv("CSI_FORCE_PAIR_TILE")) c->force_pair_tile = std::atoi(e);
