@@ -253,6 +253,8 @@ struct csi_ctx {
                                  // ("hs_min_blocks"; measured crossover at Nt=32, 1024x1024 with the two component models on two
                                  // streams: 24 packets - profiles/r05_regime_probe.txt; 80 = 40 packets before round 5); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
+    long long bf16_l0_fused_split_launches = 0;   // layer-0 products that took the fused kernel with K ranges because of "bf16_l0_fused_split" (get only)
+    int bf16_l0_fused_split = 1; // "bf16_l0_fused_split": bf16 layer 0 of calls between the streaming kernel's range and 256 tiles on the fused kernel with K ranges (round 6); 0 = cast pass + 128 x 128 kernel
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats
     int ls_ringb_min = 33;       // "ls_ringb_min": from this Nt on a non-Hadamard pilot takes the bf16-split despread (ls_estimate_ringb_kernel).

@@ -39,7 +39,7 @@ int launch_gemm_bf16(csi_ctx* c, int kid, GemmBf16Args g, int splits) {
 // Split-K of the bf16 layer-0 product ([M1 x len_ltf] x [len_ltf x h1], M1 = packets x rx): with one
 // 256x256 workgroup per CU the row tiles alone rarely fill whole rounds of 256 CUs (config 3:
 // 79 x 4 tiles = 1.23 rounds); choose the split count whose last round is fullest.
-constexpr int BF16_L0_MAX_SPLITS = 6;
+constexpr int BF16_L0_MAX_SPLITS = 8;
 int bf16_layer0_splits(int M1, int h1, int K) {
     const long tiles = (long)((M1 + PP_BM - 1) / PP_BM + 7) / 8 * 8 * ((h1 + PP_BN - 1) / PP_BN);      // as launched (pp_grid)
     if (tiles < 256) return 1;
@@ -226,11 +226,38 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                 g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
             }
         }
+        // round 6: between the streaming kernel's range and 256 tiles of the fused kernel (321 ... 4095 packets at Nt = 64, Nr = 4) layer 0 took a cast pass
+        // plus the 128 x 128 kernel (1000 packets: 100-130 us + 450 us per model, 0.15 of the bf16 peak; tools/ls_overlap_trace.sh shows it).  The fused
+        // 256 x 256 kernel with its K cut so that tiles x ranges fill the CUs does the same product without the cast pass ("bf16_l0_fused_split" = 0: before)
+        int kps_hint = 0;
+        const int stream_splits_hint = bf16_l0_stream_splits(c, M1, h1, cf.len_ltf, &kps_hint);       // (the streaming kernel takes the call: nothing to choose)
+        if (!stream_splits_hint && c->bf16_l0_fused_split && c->bf16_fused_h1 != 0 && c->force_pair_tile == 0 && (cf.len_ltf & 3) == 0) {
+            const long launched = (long)(((M1 + PP_BM - 1) / PP_BM + 7) / 8 * 8) * ((h1 + PP_BN - 1) / PP_BN);      // as pp_grid launches them
+            if (launched < 256) {
+                // K ranges: rounds of 256 workgroups x the k extent of one range, plus the slabs written and read back (a 256 x 256 x k workgroup at the
+                // kernel's measured rate ~40 ns per k; a slab of M1 x h1 floats at ~4 TB/s both ways).  1500 packets: 3 ranges = 288 workgroups = two rounds
+                // (3079 us per call), 5 ranges = 480 of 512
+                int s3 = 1;
+                double best = 1e30;
+                for (int sx = 1; sx <= BF16_L0_MAX_SPLITS; ++sx) {
+                    const int kps = ((cf.len_ltf + sx - 1) / sx + B_BK - 1) / B_BK * B_BK;
+                    if (sx > 1 && (cf.len_ltf / sx < 1024 || kps / PP_BK < 3)) break;
+                    const double cost = (double)((launched * sx + 255) / 256) * kps * 40e-9 + (sx > 1 ? (double)sx * M1 * h1 * 8.0 / 4e12 : 0.0);
+                    if (cost < best) { best = cost; s3 = sx; }
+                }
+                if (launched * s3 >= 128) {
+                    ++c->bf16_l0_fused_split_launches;
+                    S = s3;
+                    g.k_per_split = ((cf.len_ltf + S - 1) / S + B_BK - 1) / B_BK * B_BK;
+                }
+            }
+        }
         float* l0 = l0_ws;
         int kps_stream = 0;
         const int stream_splits = bf16_l0_stream_splits(c, M1, h1, cf.len_ltf, &kps_stream);
         const long l0_tiles = (long)((M1 + PP_BM - 1) / PP_BM) * ((h1 + PP_BN - 1) / PP_BN) * S;
-        const bool l0_fused = c->bf16_fused_h1 != 0 && c->force_pair_tile != 128 && (l0_tiles >= 256 || c->force_pair_tile == 256) &&
+        const long l0_launched = (long)(((M1 + PP_BM - 1) / PP_BM + 7) / 8 * 8) * ((h1 + PP_BN - 1) / PP_BN) * S;
+        const bool l0_fused = c->bf16_fused_h1 != 0 && c->force_pair_tile != 128 && (l0_tiles >= 256 || c->force_pair_tile == 256 || (c->bf16_l0_fused_split && l0_launched >= 128)) &&
                               g.k_per_split / PP_BK >= 3 && (cf.len_ltf & 3) == 0;
         if (stream_splits) {
             // small and mid-size calls: the weight-streaming kernel, its k-range slabs in the split-K scratch of the context

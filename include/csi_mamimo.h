@@ -290,6 +290,10 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         without BN); -8..14: fixed.  Operands that leave the f16 range at either end are
  *                         detected on the device: csi_predict repeats the call on the fp32 MFMA kernels by
  *                         itself, after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
+ *   "bf16_l0_fused_split" bf16 mode: 1 (default, round 6) runs layer 0 of calls between the weight-streaming kernel's range and 256 tiles
+ *                      of the fused 256 x 256 kernel (321 ... 4095 packets at Nt = 64, Nr = 4) on that kernel with its K cut into ranges;
+ *                      0 = a cast pass plus the 128 x 128 kernel, as before.
+ *                      "bf16_l0_fused_split_launches" (get only) counts the layer-0 products that took that form.
  *   "bf16_fused_h1"    bf16 mode: 1 (default) generates the first per-pair activations inside the GEMM,
  *                         0 materialises them in HBM first (tests / A-B)
  *   "host_threads"     threads that copy between the caller's (pageable) buffers and the pinned

@@ -314,3 +314,31 @@ def test_register_blocked_band_kernel_bf16(pkg, oracle, nt, nr, npkt, hidden, n_
     c_re, c_im = e.predict(ltf)
     assert np.array_equal(c_re, b_re) and np.array_equal(c_im, b_im)
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nt,nr,npkt,hidden', [(16, 4, 400, (1024, 64)),       # 1600 preambles, K = 5120: 8 x 4 launched tiles, five K ranges
+                                               (32, 2, 700, (1024, 128))])     # 1400 preambles, K = 10240: eight ranges
+def test_bf16_layer0_fused_kernel_with_k_ranges(pkg, oracle, nt, nr, npkt, hidden):
+    """Round 6: between the weight-streaming kernel's range and 256 tiles of the fused 256 x 256 kernel, layer 0 of a bf16 context runs on the fused kernel
+    with its K cut into ranges ("bf16_l0_fused_split", default) instead of a cast pass plus the 128 x 128 kernel: against the oracle's bf16-operand
+    emulation at the tolerance of every bf16 kernel, against the form it replaces, run to run bit-identical."""
+    rng = np.random.default_rng(9100 + nt + npkt)
+    w_re, w_im = _weights(oracle, 710 + nt, nt, hidden)
+    P = oracle.hadamard(nt)
+    ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=6.0)[0].astype(np.complex64)
+    e = _engine(pkg, nt, nr, hidden, w_re, w_im, P, dtype='bf16')
+    n0, s0 = e.get_option('bf16_l0_fused_split_launches'), e.get_option('l0_stream_launches')
+    o_re, o_im = e.predict(ltf)
+    assert e.get_option('bf16_l0_fused_split_launches') == n0 + 2 and e.get_option('l0_stream_launches') == s0
+    sel = sorted(set([0, npkt // 2, npkt - 1]))
+    b_re, b_im = oracle.predict_packets_bf16(ltf[sel], P, w_re, w_im)
+    assert rel_rows(o_re[sel], b_re) < BF16_TOL_IMPL_round5 and rel_rows(o_im[sel], b_im) < BF16_TOL_IMPL_round5
+    p_re, p_im = e.predict(ltf)
+    assert np.array_equal(o_re, p_re) and np.array_equal(o_im, p_im)
+    e.set_option('bf16_l0_fused_split', 0)
+    g_re, g_im = e.predict(ltf)
+    assert e.get_option('bf16_l0_fused_split_launches') == n0 + 4
+    assert rel_rows(g_re[sel], b_re) < BF16_TOL_IMPL_round5
+    assert rel_rows(o_re, g_re) < BF16_TOL_IMPL_round5 and rel_rows(o_im, g_im) < BF16_TOL_IMPL_round5
+    e.close()
