@@ -41,12 +41,13 @@ enum KernelId {
     K_TRAIN_GEMM,        // forward / dgrad / wgrad products of csi_train_step
     K_TRAIN_ELEMWISE,    // BatchNormalization, dropout, loss, Adam of csi_train_step
     K_NMSE,              // per-link NMSE metric
+    K_PAIR_DENSE_TAIL,   // the last, partly filled round of band workgroups launched in column splits ("band_tail_split", round 6)
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "layer0_ltf_gemm", "splitk_reduce", "pair_dense_gemm", "dense_hidden_gemm", "regressor_gemm",
     "ls_estimate", "naive_dense0_gemm", "synth_white", "pilot_table", "cast_bf16", "pair_h1_bf16", "lmmse_levinson",
-    "train_gemm", "train_elementwise", "nmse_links"};
+    "train_gemm", "train_elementwise", "nmse_links", "pair_dense_tail"};
 
 thread_local std::string g_create_error;
 
@@ -254,6 +255,9 @@ struct csi_ctx {
                                  // streams: 24 packets - profiles/r05_regime_probe.txt; 80 = 40 packets before round 5); layer 0 from max(this, 128)
     int hs_in_shift = HS_SHIFT_AUTO;         // split-f16: the preamble samples times 2^hs_in_shift
     long long bf16_l0_fused_split_launches = 0;   // layer-0 products that took the fused kernel with K ranges because of "bf16_l0_fused_split" (get only)
+    int band_tail_split = 1;     // "band_tail_split": a call of more bands than CUs whose last round of band workgroups would leave >= half of the CUs idle launches
+                                 // that round in 2 or 4 column splits (one-stream calls; round 6); 0 = one launch
+    long long band_tail_launches = 0;
     int bf16_l0_fused_split = 1; // "bf16_l0_fused_split": bf16 layer 0 of calls between the streaming kernel's range and 256 tiles on the fused kernel with K ranges (round 6); 0 = cast pass + 128 x 128 kernel
     int bf16_fused_h1 = 1;       // "bf16_fused_h1" option: 0 = materialise h1 (pair_h1_bf16_kernel) instead of generating it in the GEMM
     int p_pieces = 3;            // bf16 pieces (8 significand bits each) the entries of P need: 1 for +-1 pilots, 3 for arbitrary floats

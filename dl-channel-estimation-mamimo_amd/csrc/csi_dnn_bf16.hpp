@@ -341,11 +341,18 @@ int predict_plane_bf16(csi_ctx* c, Model& m, const float* d_ltf, int64_t npkt, f
                     if (b4) rc = band4_prepare(c, m, ba, true);
                     if (!rc) rc = band8_launch_split(c, ba, Sb, reinterpret_cast<float*>(h1b), flops, bytes, true, b4);
                 } else {
+                    const BandArgs ba_plain = ba;          // (band4_prepare puts the tiled weight copies into ba)
                     if (blocked || (staged_fn && hooked4 && !ba.stamps)) {
                         rc = band4_prepare(c, m, ba, true);
                         if (blocked) fn = c->band_fn4_bf16;
                     }
-                    if (!rc) rc = band8_launch(c, fn, ba, flops, bytes);
+                    long r0 = 0;
+                    const int St = (!rc && staged_fn && (ba.N1 * (long)ba.ldb1 * 2 < 0x7fffffffL)) ?
+                                       band_tail_plan(c, ba, ((size_t)M2 * h1 + (size_t)M2 * maxh) / 2, true, &r0) : 0;
+                    if (St) {
+                        const bool b4 = blocked && c->band_fn4_bf16_cs && St == 2;
+                        rc = band_tail_launch(c, fn, ba, b4 ? ba : ba_plain, b4, St, r0, reinterpret_cast<float*>(h1b), flops, bytes, true);
+                    } else if (!rc) rc = band8_launch(c, fn, ba, flops, bytes);
                 }
                 done = true;
             } else if (fused_ok) {

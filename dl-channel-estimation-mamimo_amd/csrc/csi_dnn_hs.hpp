@@ -379,7 +379,8 @@ int band8_splits(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floa
 }
 
 // the column-split launch: partial outputs of splits 1 .. in `part`, added to split 0's output in split order
-int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes, bool bf16 = false, bool blocked = false) {
+int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, double flops, double bytes, bool bf16 = false, bool blocked = false,
+                       int kid = K_PAIR_DENSE) {
     ++c->band_launches;
     ++c->band_split_launches;
     BandArgs one = ba;
@@ -390,7 +391,7 @@ int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, doubl
     size_t sz = sizeof(a);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     {
-        ProfScope ps(c, K_PAIR_DENSE, flops, bytes);
+        ProfScope ps(c, kid, flops, bytes);
         // blocked: the register-blocked form (4 waves; ba.W1 / W2p are the tiled copies of the WHOLE layer: split y starts at its own column steps)
         const hipFunction_t fn = blocked ? (bf16 ? c->band_fn4_bf16_cs : c->band_fn4_cs) : (bf16 ? c->band_fn_bf16_cs : c->band_fn_cs);
         HIP_TRY(c, hipModuleLaunchKernel(fn, (unsigned)((ba.M + BAND_ROWS - 1) / BAND_ROWS), (unsigned)S, 1, blocked ? 256u : (unsigned)BAND8_THREADS, 1, 1, 0, c->stream, nullptr, extra));
@@ -400,6 +401,46 @@ int band8_launch_split(csi_ctx* c, const BandArgs& ba, int S, float* part, doubl
     hipLaunchKernelGGL(band_split_sum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, ba.out, part, n, n, S - 1);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
+}
+
+// "band_tail_split" (round 6): one workgroup per CU computes a band for 75-190 us, so a call of `bands` bands runs in ceil(bands / CUs) rounds and a last
+// round of a few bands costs a whole one (configs[2]: 10 000 bands = 39 rounds + 16 bands = 2.5 % of the kernel's time for 0.16 % of the work).  When that
+// round holds at most half (a quarter) of the CUs' worth of bands it is launched separately in 2 (4) column splits - the rows of the full rounds through
+// the unsplit kernel, the rest through the column-split one on shifted operand pointers.  Returns the split count of the tail (0: one launch) and its first row.
+inline int band_tail_plan(const csi_ctx* c, const BandArgs& ba, size_t part_capacity_floats, bool bf16, long* row0) {
+    // measured (tools/band_tail_ab.py, profiles/r06_band_probe.txt (G)): fp32 contexts -2.8 ... -3.2 % per call where it applies (2100 / 2600 / 3100 / 4150 packets of the
+    // shipped shape); bf16 contexts 0 ... +1 % (bands of 75 us backfill the last round well enough; the 8-wave split kernels and the extra sum eat the rest): fp32 only
+    if (bf16) return 0;
+    if (!c->band_tail_split || c->models_in_flight > 1 || ba.stamps || c->band_split == 0 || c->band_split == 1) return 0;
+    if (!(bf16 ? c->band_fn_bf16_cs : c->band_fn_cs) || ba.ldo != ba.n2) return 0;
+    const long ncu = std::max(c->n_cu, 1), bands = (ba.M + BAND_ROWS - 1) / BAND_ROWS;
+    const long full = bands / ncu * ncu, tail = bands - full;
+    if (full < ncu || tail == 0) return 0;
+    int S = 0;
+    for (int s = 4; s >= 2; s >>= 1)
+        if (tail * s <= ncu && (ba.N1 % (256 * s)) == 0) { S = s; break; }
+    const long r0 = full * BAND_ROWS;
+    if (!S || ba.nt < 1 || (r0 % ba.nt) != 0) return 0;
+    const unsigned long long part = (unsigned long long)(S - 1) * (unsigned long long)(ba.M - r0) * (unsigned long long)ba.ldo;
+    if (part > part_capacity_floats || (unsigned long long)ba.N1 * ba.ldb1 * 2ull >= 0x7fffffffull) return 0;
+    *row0 = r0;
+    return S;
+}
+// the two launches of a tail-split call: `full` = the arguments the unsplit kernel `fn` takes (tiled weights if it is a register-blocked form), `cs` = the
+// arguments of the column-split launch (tiled weights iff cs_blocked)
+inline int band_tail_launch(csi_ctx* c, hipFunction_t fn, const BandArgs& full, const BandArgs& cs, bool cs_blocked, int S, long r0, float* part, double flops,
+                            double bytes, bool bf16) {
+    const double f0 = (double)r0 / (double)full.M;
+    BandArgs a0 = full;
+    a0.M = (int)r0;
+    int rc = band8_launch(c, fn, a0, flops * f0, bytes * f0);
+    if (rc) return rc;
+    BandArgs a1 = cs;
+    a1.M = cs.M - (int)r0;
+    a1.L0 = cs.L0 + (size_t)(r0 / cs.nt) * cs.ldl;
+    a1.out = cs.out + (size_t)r0 * cs.ldo;
+    ++c->band_tail_launches;
+    return band8_launch_split(c, a1, S, part, flops * (1.0 - f0), bytes * (1.0 - f0), bf16, cs_blocked, K_PAIR_DENSE_TAIL);
 }
 
 // csi_profile_band_skeleton: the band kernel's MFMA + barrier skeleton (band_kernel_gen.py 'skeleton_rnd': no operand conversion, no
@@ -539,10 +580,17 @@ int hs_tail(csi_ctx* c, Model& m, const float* l0sum, int M2, float* hbuf0, floa
                 if (b4) { const int rc = band4_prepare(c, m, ba, false); if (rc) return rc; }
                 return band8_launch_split(c, ba, S, hbuf0, flops, bytes, false, b4);
             }
+            const BandArgs ba_plain = ba;          // (band4_prepare puts the tiled weight copies into ba)
             if (blocked || (fn == c->band_fn && staged && hooked4 && !ba.stamps)) {
                 const int rc = band4_prepare(c, m, ba, false);
                 if (rc) return rc;
                 if (blocked) fn = c->band_fn4;
+            }
+            long r0 = 0;
+            const int St = (fn == c->band_fn4 || (fn == c->band_fn && staged)) ? band_tail_plan(c, ba, (size_t)M2 * l1.out, false, &r0) : 0;
+            if (St) {
+                const bool b4 = blocked && c->band_fn4_cs && St == 2;
+                return band_tail_launch(c, fn, ba, b4 ? ba : ba_plain, b4, St, r0, hbuf0, flops, bytes, false);
             }
             return band8_launch(c, fn, ba, flops, bytes);
         }

@@ -1261,6 +1261,8 @@ int csi_get_option(csi_ctx* c, const char* name, int64_t* value) {
     else if (n == "hs_blocked") *value = c->hs_blocked;
     else if (n == "hs_in_shift") *value = c->hs_in_shift;
     else if (n == "bf16_fused_h1") *value = c->bf16_fused_h1;
+    else if (n == "band_tail_split") *value = c->band_tail_split;
+    else if (n == "band_tail_launches") *value = c->band_tail_launches;
     else if (n == "bf16_l0_fused_split") *value = c->bf16_l0_fused_split;
     else if (n == "bf16_l0_fused_split_launches") *value = c->bf16_l0_fused_split_launches;
     else if (n == "host_threads") *value = c->host_threads;
@@ -1392,6 +1394,9 @@ int csi_set_option(csi_ctx* c, const char* name, int64_t value) {
         if (value != HS_SHIFT_AUTO && (value < -8 || value > 14)) return fail(c, CSI_ERR_INVALID_ARG, "%s must be -8..14 or 99 (automatic)", name);
         drop_graphs(c);
         (n == "hs_act_shift" ? c->hs_act_shift : c->hs_in_shift) = (int)value;
+    } else if (n == "band_tail_split") {
+        drop_graphs(c);
+        c->band_tail_split = value != 0;
     } else if (n == "bf16_l0_fused_split") {
         drop_graphs(c);
         c->bf16_l0_fused_split = value != 0;

@@ -290,6 +290,9 @@ int  csi_synchronize(csi_ctx* ctx);
  *                         without BN); -8..14: fixed.  Operands that leave the f16 range at either end are
  *                         detected on the device: csi_predict repeats the call on the fp32 MFMA kernels by
  *                         itself, after device-pointer calls csi_synchronize returns CSI_ERR_RANGE
+ *   "band_tail_split"  fp32 contexts, 1 (default, round 6): a one-stream call of more bands (128 pair rows) than compute units whose LAST round of band workgroups would
+ *                      fill at most half (a quarter) of them launches that round in 2 (4) column splits; 0 = one launch.  "band_tail_launches" (get only)
+ *                      counts the calls that did.
  *   "bf16_l0_fused_split" bf16 mode: 1 (default, round 6) runs layer 0 of calls between the weight-streaming kernel's range and 256 tiles
  *                      of the fused 256 x 256 kernel (321 ... 4095 packets at Nt = 64, Nr = 4) on that kernel with its K cut into ranges;
  *                      0 = a cast pass plus the 128 x 128 kernel, as before.

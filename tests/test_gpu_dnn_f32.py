@@ -1073,3 +1073,39 @@ def test_register_blocked_band_kernel_in_a_graph_and_at_full_size(pkg, oracle):
     e.synchronize()
     assert rel_rows(take(o[0]), g_re) < 2e-6 and rel_rows(take(o[1]), g_im) < 2e-6
     e.close()
+
+
+def test_band_tail_split_matches_the_single_launch_and_the_oracle(pkg, oracle):
+    """Round 6 ("band_tail_split"): a one-stream fp32 call of more bands than CUs whose last round of band workgroups is nearly empty runs that round in column
+    splits on shifted operand pointers.  552 bands (512 + 40 -> four splits) and 340 bands (256 + 84 -> two): every output row against the single launch at the
+    split engine's rounding, rows of both parts against the fp64 oracle inside the contract, run to run bit-identical.  (257 ... 320 bands: the whole call
+    runs in two column splits - band8_splits - and there is no tail launch.)"""
+    for (nt, nr, npkt, hidden) in ((16, 2, 2208, (128, 512)), (32, 1, 1360, (256, 1024))):
+        rng = np.random.default_rng(4200 + npkt)
+        w_re, w_im = _weights(oracle, 900 + nt, nt, hidden)
+        P = oracle.hadamard(nt)
+        ltf = oracle.make_structured_packets(rng, npkt, nr, P, snr_db=7.0)[0].astype(np.complex64)
+        e = _engine(pkg, nt, nr, hidden, w_re, w_im, P)
+        e.set_option('f32_engine', 1)
+        e.set_option('small_call_overlap', 0)       # one stream (calls of up to 262 144 pair rows run their two models on two streams: the other model fills the round)
+        d_re, d_im = e.to_device(np.ascontiguousarray(ltf.real)), e.to_device(np.ascontiguousarray(ltf.imag))
+        outs = [e.empty((npkt, nr, nt, 234)) for _ in range(2)]
+
+        def run():
+            e.predict_device(d_re, d_im, npkt, *outs); e.synchronize()
+            return [x.download() for x in outs]
+        n0 = e.get_option('band_tail_launches')
+        a = run()
+        assert e.get_option('band_tail_launches') == n0 + 2, 'both models of the call take the tail launch'
+        a2 = run()
+        assert np.array_equal(a[0], a2[0]) and np.array_equal(a[1], a2[1])
+        e.set_option('band_tail_split', 0)
+        b = run()
+        assert e.get_option('band_tail_launches') == n0 + 4
+        assert rel_rows(a[0], b[0]) < 2e-6 and rel_rows(a[1], b[1]) < 2e-6
+        first_tail = (npkt * nr * nt // 128) // 256 * 256 * 128 // (nr * nt)      # the packet the tail's rows start in
+        assert np.array_equal(a[0][:first_tail - 1], b[0][:first_tail - 1]), 'the rows of the full rounds come from the same kernel on the same operands'
+        sel = [0, first_tail + 1, npkt - 1]
+        r_re, r_im = oracle.predict_packets(ltf[sel], P, w_re, w_im, np.float64, pkt_batch=3)
+        assert rel_rows(a[0][sel], r_re) < 1e-5 and rel_rows(a[1][sel], r_im) < 1e-5
+        e.close()
