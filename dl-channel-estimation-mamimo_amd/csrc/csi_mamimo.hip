@@ -933,7 +933,10 @@ namespace {
 bool two_stream_call(csi_ctx* c, int64_t npkt) {
     const bool bf16 = c->cfg.dtype == CSI_DTYPE_BF16;
     return c->small_call_overlap && !c->prof_on && !c->use_graph && !c->in_graph_call && !c->in_host_pipeline &&
-           (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 131072) || c->small_call_overlap == 2);
+           (npkt * c->cfg.nr * std::max(c->cfg.nt, 1) <= (bf16 ? 262144 : 327680) || c->small_call_overlap == 2);
+    // (fp32 contexts, round 6: 131 072 -> 327 680 pair rows.  With the register-blocked band kernels two streams win up to 2560 packets of the shipped shape -
+    // 1025 packets 2396 -> 2239 us per call, 1408: 2997 -> 2893, 2048: 4117 -> 4047, 2560: 5293 -> 5252 - and lose from 3000 on (+1.8 %, 4000: +3 %);
+    // bf16 contexts: even at 1280 packets, worse beyond.  tools/regime_probe.py small_call_overlap=1 small_call_overlap=2, profiles/r06_band_probe.txt (H))
 }
 int aux_stream_ensure(csi_ctx* c) {
     if (!c->aux_stream) {

@@ -241,7 +241,7 @@ int  csi_synchronize(csi_ctx* ctx);
  *   "xcd_order"        1 | 0: force the XCD super-tile / the linear tile order of the plain GEMMs
  *                         (-1 = automatic)
  *   "ls_fft_first_max" largest Nt served by the FFT-first LS kernel (default 15, max 64)
- *   "small_call_overlap" 1 (default): calls of at most 131 072 pair rows (1024 packets at Nt = 32, Nr = 4) run the real and the imag
+ *   "small_call_overlap" 1 (default): calls of at most 327 680 pair rows (2560 packets at Nt = 32, Nr = 4; 131 072 until round 6) run the real and the imag
  *                         model on two streams side by side - a mid-size call's kernels fill a fraction of the chip (24 ... 128 packets:
  *                         1.25-1.55x, 500 packets +1.4 %; device-pointer calls only: inside the host-buffer entry points' pipeline the
  *                         chunks stay on one stream, where the fork measured 6 % slower); 0: one after the other; 2: any size (A/B runs).
