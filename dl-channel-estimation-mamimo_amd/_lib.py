@@ -155,7 +155,23 @@ def build_band_kernel(verbose=False):
 
 def build_library(force=False, verbose=False):
     """Compile csrc/csi_mamimo.hip for gfx950 into the in-tree shared object (hipcc
-    cross-compiles without a GPU); the assembly band kernel is generated, assembled and embedded first.  Returns the path."""
+    cross-compiles without a GPU); the assembly band kernel is generated, assembled and embedded first.  Returns the path.
+    Several processes may arrive here at once (the ranks of one `torch.distributed.run` launch on a tree without a built library): one of them builds
+    under an exclusive file lock, into a temporary name that replaces the library atomically; the others wait and find it up to date."""
+    import fcntl
+    try:
+        lock = open(_SO + '.lock', 'w')
+    except OSError:                      # a read-only tree: nothing can be built there anyway; the up-to-date check below still answers
+        return _build_library_locked(force, verbose)
+    with lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_library_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_library_locked(force, verbose):
     build_band_kernel(verbose)
     srcs = [_SRC] + [os.path.join(_PKG_DIR, 'csrc', f) for f in os.listdir(os.path.join(_PKG_DIR, 'csrc'))]
     srcs.append(os.path.join(_REPO, 'include', 'csi_mamimo.h'))
@@ -166,7 +182,8 @@ def build_library(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # host side: baseline x86-64; the three AVX2 staging loops of the host pipeline carry their own target attribute and a
     # run-time CPU check (csi_hostpipe.hpp)
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', _SRC, '-o', _SO]
+    tmp_so = '%s.tmp.%d' % (_SO, os.getpid())
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', _SRC, '-o', tmp_so]
     # CSI_BUILD_DEFINES="NAME ..." adds -DNAME: CSI_LS_RACE_VARIANTS compiles the race-hunt instantiations of the LS kernel
     # (tools/ls_race_box*.sh); the product build carries none of them
     cmd[1:1] = ['-D' + d for d in os.environ.get('CSI_BUILD_DEFINES', '').split()]
@@ -174,7 +191,10 @@ def build_library(force=False, verbose=False):
         print(' '.join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     if res.returncode != 0:
+        if os.path.exists(tmp_so):
+            os.remove(tmp_so)
         raise RuntimeError('hipcc failed:\n' + res.stdout)
+    os.replace(tmp_so, _SO)
     return _SO
 
 
