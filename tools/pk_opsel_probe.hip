@@ -327,6 +327,28 @@ __global__ __launch_bounds__(256) void aggressor2(float* sink, const float4* gsr
     if (s == 123.456f) sink[0] = s + sh[threadIdx.x].x;
 }
 
+// modes 5 / 6: the same tight loop of four independent MFMAs, written in asm so that ONLY the register file of the accumulators differs:
+// 5 = accumulators in AGPRs (a[..]: what the product's GEMM kernels and hipcc's large kernels use), 6 = accumulators in arch VGPRs (v[..])
+template <bool AGPR>
+__global__ __launch_bounds__(256) void aggressor3(float* sink, int iters) {
+    __shared__ float pad[4096];          // 16 KiB: one workgroup per CU beside the victims (one MFMA wave per SIMD)
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x ^ i)); }
+    f32x16 c0, c1, c2, c3;
+    for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        if (AGPR)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %2, %4, %5, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %5, %3" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a), "v"(b));
+        else
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %2, %4, %5, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %5, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    if (s == 123.456f) { pad[threadIdx.x] = s; sink[0] = s + pad[(threadIdx.x + 1) & 4095]; }
+}
+
 // memory aggressor (mode 3 / 4): a streaming copy with the GEMM's LDS footprint (it cannot share a CU with a victim workgroup either)
 __global__ __launch_bounds__(512, 1) void mem_aggressor(const float4* src, float4* dst, size_t n4, int reps) {
     extern __shared__ float lds[];
@@ -359,6 +381,8 @@ int main(int argc, char** argv) {
         if (mode == 0) hipLaunchKernelGGL(aggressor, dim3(256), dim3(512), 128 * 1024, sb, sink, aiters, 1);
         // mode 4: the same MFMA loop WITHOUT an LDS footprint: its waves share CUs (and SIMDs) with the victim's
         if (mode == 4) hipLaunchKernelGGL(aggressor, dim3(2048), dim3(256), 0, sb, sink, aiters / 8, 0);
+        if (mode == 5) hipLaunchKernelGGL(aggressor3<true>, dim3(2048), dim3(256), 0, sb, sink, aiters / 16);
+        if (mode == 6) hipLaunchKernelGGL(aggressor3<false>, dim3(2048), dim3(256), 0, sb, sink, aiters / 16);
         if (mode >= 10) hipLaunchKernelGGL(aggressor2, dim3(2048), dim3(256), 0, sb, sink, (const float4*)big, aiters / 16, mode - 10);
         if (mode == 3) hipLaunchKernelGGL(mem_aggressor, dim3(256), dim3(512), 128 * 1024, sb, (const float4*)big, (float4*)(big + (size_t)(256 << 20) / 4), (size_t)(256 << 20) / 16, 4);
         CHECK(hipGetLastError());
