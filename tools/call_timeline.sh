@@ -10,7 +10,7 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/kt_kernel_trace.csv', recursive=True)[0]
 rows = sorted(({'k': r['Kernel_Name'].split('(')[0].replace('void csi::', '').replace('void ', '')[:44], 's': int(r['Start_Timestamp']), 'e': int(r['End_Timestamp']),
                 'q': r.get('Queue_Id', '?'), 'g': r.get('Grid_Size', '?'), 'w': r.get('Workgroup_Size', '?')} for r in csv.DictReader(open(f))), key=lambda r: r['s'])
-ls = [i for i, r in enumerate(rows) if r['k'].startswith('ls_')]
+ls = [i for i, r in enumerate(rows) if r['k'].startswith('ls_') or r['k'].startswith('small_l0_ls')]      # (a one-packet call starts with the fused LS + layer-0 launch)
 first = ls[-2] if len(ls) >= 2 else 0          # the call before the last one: complete
 last = ls[-1]
 t0 = rows[first]['s']
