@@ -13,7 +13,7 @@ eng = pkg.CsiEngine(nt, nr, hidden=hidden, dtype=dtype)
 eng.load_weights('real', pkg.synth.make_weights(rng, nt, hidden)); eng.load_weights('imag', pkg.synth.make_weights(rng, nt, hidden))
 eng.set_pilot(pkg.synth.hadamard(nt))
 bad = 0
-for n in (3, 24, 64, 128, 256, 500, 600, 1000):
+for n in ([int(x) for x in os.environ['SIZES'].split(',')] if os.environ.get('SIZES') else (3, 24, 64, 128, 256, 500, 600, 1000)):
     d_re, d_im = eng.empty((n, nr, eng.len_ltf)), eng.empty((n, nr, eng.len_ltf))
     eng.synth_white(11, 0, n, d_re, d_im)
     o = [eng.empty((n, nr, nt, 234)) for _ in range(4)]
